@@ -1,0 +1,84 @@
+"""ctypes binding of libembnet_hip.so (the C ABI in include/embnet.h).
+
+The library is the product: if it is missing or does not load this module
+raises — there is no CPU or eager-PyTorch fallback anywhere in the package.
+Argument and return types are taken from the prototypes in include/embnet.h,
+so the header is the single source of truth for the boundary.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libembnet_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "embnet.h")
+
+_lib = None
+
+_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
+           "uint64_t": ctypes.c_uint64, "void": None}
+
+
+class EmbnetError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every prototype the header declares."""
+    text = re.sub(r"/\*.*?\*/", " ", open(path).read(), flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|size_t|const char\*)\s+(embnet_\w+)\s*\(([^)]*)\)\s*;", text):
+        argtypes = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                argtypes.append(ctypes.c_void_p)
+            else:
+                argtypes.append(_CTYPES[a.replace("const ", "").split()[0]])
+        res = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+        protos[name] = (res, argtypes)
+    return protos
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EmbnetError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C embeddingnet_amd/csrc`).  embeddingnet_amd has no fallback path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, argtypes) in parse_header().items():
+            fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, argtypes
+        if l.embnet_abi_version() != 1:
+            raise EmbnetError("libembnet_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EmbnetError(f"embnet error {rc}: {lib().embnet_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EmbnetError("embeddingnet_amd ops run on the GPU only (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise EmbnetError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32(x):
+    return float(x)

@@ -1,0 +1,269 @@
+"""Drop-in for embedding_net/backbones.py: get_backbone() with the reference's
+signature, names and return value, built from embeddingnet_amd.layers (HIP).
+
+  'simple'            reference backbones.py:19-41
+  'simple2'           reference backbones.py:42-81   (conv -> ReLU -> BN order)
+  'resnet18/34/50'    reference backbones.py:99-104  (image-classifiers pre-activation ResNet)
+  head                reference backbones.py:110-121 (GAP -> Dense(E//2) -> Dense(E) -> l2norm)
+
+Parameter names follow oracle/backbones.py (`<layer>/<weight>`), see
+keras_weights().
+"""
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import layers as L
+from . import ops
+
+
+def default_device():
+    import os
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+
+class Model(nn.Module):
+    """Small Keras-Model facade: callable on NHWC tensors, .predict() on NumPy batches."""
+
+    def __init__(self, net, name="model"):
+        super().__init__()
+        self.net = net
+        self.name = name
+
+    def forward(self, x):
+        return self.net(x)
+
+    @property
+    def layers(self):
+        return [m for m in self.net.modules() if not list(m.children())]
+
+    @torch.no_grad()
+    def predict(self, images, batch_size=32):
+        """NumPy NHWC in [0,1] -> NumPy; inference mode (moving BN statistics, no dropout),
+        as Keras Model.predict (used by the mining generator, datagenerators.py:214)."""
+        was = self.training
+        self.eval()
+        dev = next(self.parameters()).device
+        out = []
+        x = np.asarray(images, dtype=np.float32)
+        for i in range(0, len(x), batch_size):
+            out.append(self(torch.from_numpy(x[i:i + batch_size]).to(dev)).cpu().numpy())
+        self.train(was)
+        return np.concatenate(out, axis=0)
+
+    def summary(self):
+        n = sum(p.numel() for p in self.parameters())
+        print(f"Model: {self.name}\n{self.net}\nTotal params: {n:,}")
+
+
+class L2Norm(nn.Module):
+    def forward(self, x):
+        return ops.l2_normalize(x)
+
+
+class Seq(nn.Module):
+    """Ordered container keeping attribute names (they are the weight names)."""
+
+    def __init__(self, **mods):
+        super().__init__()
+        self._order = list(mods)
+        for k, m in mods.items():
+            setattr(self, k, m)
+
+    def forward(self, x):
+        for k in self._order:
+            x = getattr(self, k)(x)
+        return x
+
+
+def _simple(gen):
+    return Seq(
+        conv1=L.Conv2D(3, 64, 10, activation="relu", l2=2e-4, gen=gen), pool1=L.MaxPool2D(),
+        conv2=L.Conv2D(64, 128, 7, activation="relu", l2=2e-4, gen=gen), pool2=L.MaxPool2D(),
+        conv3=L.Conv2D(128, 128, 4, activation="relu", l2=2e-4, gen=gen), pool3=L.MaxPool2D(),
+        conv4=L.Conv2D(128, 256, 4, activation="relu", l2=2e-4, gen=gen), flatten=L.Flatten())
+
+
+def _simple2(gen):
+    def cbr(i, cin, c, k, s=1, pad="valid"):
+        return {f"conv{i}": L.Conv2D(cin, c, k, strides=s, padding=pad, activation="relu", l2=2e-4, gen=gen),
+                f"bn{i}": L.BatchNormalization(c)}
+    mods = {}
+    mods.update(cbr(1, 3, 32, 3)); mods.update(cbr(2, 32, 32, 3)); mods.update(cbr(3, 32, 32, 5, 2, "same"))
+    mods["drop1"] = L.Dropout(0.4, seed=1)
+    mods.update(cbr(4, 32, 64, 3)); mods.update(cbr(5, 64, 64, 3)); mods.update(cbr(6, 64, 64, 5, 2, "same"))
+    mods["drop2"] = L.Dropout(0.4, seed=2)
+    mods.update(cbr(7, 64, 128, 4))
+    return Seq(**mods)
+
+
+RN_EPS = 2e-5
+RESNET = {"resnet18": ("basic", (2, 2, 2, 2)), "resnet34": ("basic", (3, 4, 6, 3)),
+          "resnet50": ("bottleneck", (3, 4, 6, 3))}
+
+
+def _rn_conv(cin, c, k, stride, pad, gen):
+    return L.Conv2D(cin, c, k, strides=stride, padding=pad if pad else "valid", use_bias=False,
+                    kernel_initializer="he_uniform", gen=gen)
+
+
+class ResidualUnit(nn.Module):
+    """image-classifiers residual_conv_block / residual_bottleneck_block (pre-activation)."""
+
+    def __init__(self, cin, filters, stride, post, kind, gen):
+        super().__init__()
+        self.kind, self.post = kind, post
+        cout = filters if kind == "basic" else filters * 4
+        self.bn1 = L.BatchNormalization(cin, epsilon=RN_EPS, relu=True)
+        if post:
+            self.sc = _rn_conv(cin, cout, 1, stride, 0, gen)
+        if kind == "basic":
+            self.conv1 = _rn_conv(cin, filters, 3, stride, 1, gen)
+            self.bn2 = L.BatchNormalization(filters, epsilon=RN_EPS, relu=True)
+            self.conv2 = _rn_conv(filters, filters, 3, 1, 1, gen)
+        else:
+            self.conv1 = _rn_conv(cin, filters, 1, 1, 0, gen)
+            self.bn2 = L.BatchNormalization(filters, epsilon=RN_EPS, relu=True)
+            self.conv2 = _rn_conv(filters, filters, 3, stride, 1, gen)
+            self.bn3 = L.BatchNormalization(filters, epsilon=RN_EPS, relu=True)
+            self.conv3 = _rn_conv(filters, cout, 1, 1, 0, gen)
+        self.out_channels = cout
+
+    def forward(self, x):
+        a = self.bn1(x)
+        sc = self.sc(a) if self.post else x
+        y = self.conv2(self.bn2(self.conv1(a)))
+        if self.kind != "basic":
+            y = self.conv3(self.bn3(y))
+        return L.add(y, sc)
+
+
+class ResNet(nn.Module):
+    def __init__(self, name, gen):
+        super().__init__()
+        kind, reps = RESNET[name]
+        self.bn_data = L.BatchNormalization(3, epsilon=RN_EPS, scale=False)
+        self.conv0 = _rn_conv(3, 64, 7, 2, 3, gen)
+        self.bn0 = L.BatchNormalization(64, epsilon=RN_EPS, relu=True)
+        self.pooling0 = L.MaxPool2D(3, 2, zero_pad=1)
+        self._units = []
+        cin = 64
+        for stage, rep in enumerate(reps):
+            f = 64 * 2 ** stage
+            for blk in range(rep):
+                u = ResidualUnit(cin, f, 2 if (blk == 0 and stage > 0) else 1, blk == 0, kind, gen)
+                nm = f"stage{stage + 1}_unit{blk + 1}"
+                setattr(self, nm, u)
+                self._units.append(nm)
+                cin = u.out_channels
+        self.bn1 = L.BatchNormalization(cin, epsilon=RN_EPS, relu=True)
+        self.out_channels = cin
+
+    def forward(self, x):
+        x = self.pooling0(self.bn0(self.conv0(self.bn_data(x))))
+        for nm in self._units:
+            x = getattr(self, nm)(x)
+        return self.bn1(x)
+
+
+def _spatial_out(net, input_shape, device):
+    """Feature-map shape by a dry geometry walk (no kernel launch): run on the meta device is not
+    possible for HIP ops, so compute from layer geometry."""
+    h, w, c = input_shape
+    for m in net.modules():
+        if isinstance(m, L.Conv2D):
+            _, _, _, h, w = m.geometry(h, w)
+            c = m.kernel.shape[-1]
+        elif isinstance(m, L.MaxPool2D):
+            h, w = (h + 2 * m.p - m.k) // m.s + 1, (w + 2 * m.p - m.k) // m.s + 1
+    return h, w, c
+
+
+class BaseModel(nn.Module):
+    """images -> embeddings: backbone + head (+ l2_norm)."""
+
+    def __init__(self, backbone, head):
+        super().__init__()
+        self.backbone, self.head = backbone, head
+
+    def forward(self, x):
+        return self.head(self.backbone(x))
+
+
+def get_backbone(input_shape,
+                 encodings_len=4096,
+                 backbone_name='simple',
+                 embeddings_normalization=True,
+                 backbone_weights='imagenet',
+                 freeze_backbone=False,
+                 **kwargs):
+    """Same contract as the reference: returns (base_model, backbone_model); extra MODEL keys
+    (mode, distance_type, ...) are swallowed.  Build-side extras: seed=<int>, device=<torch.device>."""
+    seed = int(kwargs.get("seed", 0))
+    device = kwargs.get("device") or default_device()
+    gen = torch.Generator().manual_seed(seed)
+    input_shape = tuple(input_shape)
+    if backbone_name == 'simple':
+        backbone = _simple(gen)
+        h, w, c = _spatial_out(backbone, input_shape, device)
+        head = Seq(dense=L.Dense(h * w * c, encodings_len, activation="relu", l2=1e-3, gen=gen))
+    elif backbone_name == 'simple2':
+        backbone = _simple2(gen)
+        h, w, c = _spatial_out(backbone, input_shape, device)
+        head = Seq(flatten=L.Flatten(), dense1=L.Dense(h * w * c, 512, activation="relu", gen=gen),
+                   drop=L.Dropout(0.5, seed=3),
+                   dense2=L.Dense(512, encodings_len, activation="relu", l2=1e-3, gen=gen))
+    else:
+        if backbone_name.startswith('efficientnet'):
+            from .efficientnet import EfficientNet
+            backbone = EfficientNet(backbone_name, gen)
+        elif backbone_name in RESNET:
+            backbone = ResNet(backbone_name, gen)
+        else:
+            raise KeyError(f"backbone '{backbone_name}' is not implemented in embeddingnet_amd "
+                           f"(available: simple, simple2, {', '.join(RESNET)}, efficientnet-b0)")
+        if backbone_weights is not None:
+            if isinstance(backbone_weights, str) and backbone_weights.endswith(".npz"):
+                load_keras_weights(backbone, np.load(backbone_weights), strict=False)
+            else:
+                warnings.warn(f"backbone_weights='{backbone_weights}': pretrained weight sets are not bundled "
+                              "(no network); the backbone is randomly initialised")
+        if freeze_backbone:
+            # reference freezes backbone_model.layers[:-2]; the last two layers (final BN + ReLU) stay trainable
+            tail = {id(p) for p in backbone.bn1.parameters()} if hasattr(backbone, "bn1") else set()
+            for p in backbone.parameters():
+                if id(p) not in tail:
+                    p.requires_grad_(False)
+        head = Seq(gap=L.GlobalAveragePooling2D(),
+                   dense1=L.Dense(backbone.out_channels, encodings_len // 2, activation="relu", gen=gen),
+                   dense2=L.Dense(encodings_len // 2, encodings_len, activation="relu", gen=gen))
+    if embeddings_normalization:
+        head.l2_norm = L2Norm()
+        head._order.append("l2_norm")
+    backbone_model = Model(backbone, name="backbone_model").to(device)
+    base_model = Model(BaseModel(backbone, head), name="base_model").to(device)
+    base_model.frozen_backbone = bool(freeze_backbone)
+    return base_model, backbone_model
+
+
+# ---------------------------------------------------------------------------- weight naming
+def keras_weights(module):
+    """{'<layer>/<weight>': tensor} with the layer path joined by '_' and container prefixes
+    (net/backbone/head) dropped — the naming oracle/backbones.py uses."""
+    out = {}
+    for k, v in list(module.named_parameters()) + list(module.named_buffers()):
+        parts = [p for p in k.split(".") if p not in ("net", "backbone", "head")]
+        out["_".join(parts[:-1]) + "/" + parts[-1]] = v
+    return out
+
+
+@torch.no_grad()
+def load_keras_weights(module, weights, strict=True):
+    mine = keras_weights(module)
+    for k, t in mine.items():
+        if k in weights:
+            t.copy_(torch.as_tensor(np.asarray(weights[k]), dtype=t.dtype).reshape(t.shape))
+        elif strict:
+            raise KeyError(f"missing weight {k}")

@@ -1,0 +1,68 @@
+// Shared host/device helpers for libembnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+namespace embnet {
+
+// ---- error reporting (embnet_last_error) ---------------------------------
+char* last_error_buf();                      // thread-local, 512 bytes
+int fail(int code, const char* fmt, ...);    // formats into last_error_buf, returns code
+
+enum : int {
+  EMBNET_OK = 0,
+  EMBNET_EINVAL = -1,      // bad argument (null pointer, size <= 0, unsupported shape)
+  EMBNET_ELAUNCH = -2,     // hipLaunch / hipGetLastError failure
+  EMBNET_EWORKSPACE = -3,  // caller's workspace too small
+};
+
+#define EMBNET_CHECK_ARG(cond, ...) \
+  do { if (!(cond)) return ::embnet::fail(::embnet::EMBNET_EINVAL, __VA_ARGS__); } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return EMBNET_OK;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ------------------------------------------------------
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based RNG: one 64-bit mix (splitmix64 finaliser) of (seed, a, b).
+// Used for the two random negative-selection rules and for dropout masks.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t a, uint64_t b) {
+  return (uint32_t)(mix64(mix64(seed ^ (a * 0xD6E8FEB86659FD93ull)) + b) >> 32);
+}
+
+}  // namespace embnet

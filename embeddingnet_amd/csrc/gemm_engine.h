@@ -1,0 +1,211 @@
+// fp32 MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32, exact f32).
+//
+// One 256-thread workgroup (4 wave64) computes a BM x BN output tile; each wave
+// owns a (BM/WAVES_M) x (BN/WAVES_N) sub-tile as TM x TN accumulators of 32x32.
+// The K loop runs in tiles of BK = 32: every thread prefetches its float4 pieces
+// of the NEXT A/B tiles from HBM/L2 into registers while the MFMAs consume the
+// current tiles from LDS (one LDS buffer + register prefetch, two barriers per
+// tile; 36.9 KB LDS at 128x128 so three workgroups share a CU and fill each
+// other's barrier gaps — f32 MFMA issues once per 64 cycles per SIMD, so operand
+// delivery is cheap next to the matrix pipe).
+//
+// Operands come in two LDS layouts, chosen per operand by the op:
+//   TileKC<ROWS>: [ROWS][BK+4]  k contiguous  (activations gathered NHWC, rows of X)
+//   TileKM<ROWS>: [BK][ROWS]    row contiguous (weights [k][cout], dY for wgrad)
+// MFMA 32x32x2 wants lane (i = lane&31, h = lane>>5) to supply A[i][k] for the two
+// k of a step.  We fix ONE k schedule for both operands: at step (j,t), j in 0..3,
+// t in 0..3, lane-half h multiplies k = 8j + 4h + t.  A KC tile then feeds four
+// steps from a single ds_read_b128 (conflict-free with the +4 pad), a KM tile
+// from four ds_read_b32 of 32 consecutive floats.  Summation order inside a
+// tile differs from plain k order; results are f32-rounding-equivalent.
+#pragma once
+#include "common.h"
+
+namespace embnet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+template <int ROWS>
+struct TileKC {
+  static constexpr int LD = BK + 4;
+  static constexpr int FLOATS = ROWS * LD;
+  static constexpr int PASSES = ROWS * (BK / 4) / NTHREADS;
+  static_assert(PASSES >= 1, "tile too small for 256 threads");
+  // pass p of thread tid covers row row_of(tid,p), k = k_of(tid) .. +3
+  __device__ static __forceinline__ int row_of(int tid, int p) { return (p * NTHREADS + tid) >> 3; }
+  __device__ static __forceinline__ int k_of(int tid) { return (tid & 7) * 4; }
+  __device__ static __forceinline__ void store(float* s, const float4 (&r)[PASSES], int tid) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+      *reinterpret_cast<float4*>(&s[row_of(tid, p) * LD + k_of(tid)]) = r[p];
+  }
+  __device__ static __forceinline__ void frag(const float* s, int r0, int j, int lane, float (&v)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(&s[(r0 + (lane & 31)) * LD + 8 * j + 4 * (lane >> 5)]);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+};
+
+template <int ROWS>
+struct TileKM {
+  static constexpr int LD = ROWS;
+  static constexpr int FLOATS = BK * LD;
+  static constexpr int PASSES = BK * (ROWS / 4) / NTHREADS;
+  static_assert(PASSES >= 1, "tile too small for 256 threads");
+  // pass p of thread tid covers k = k_of(tid,p), rows row_of(tid,p) .. +3
+  __device__ static __forceinline__ int k_of(int tid, int p) { return (p * NTHREADS + tid) / (ROWS / 4); }
+  __device__ static __forceinline__ int row_of(int tid, int p) { return ((p * NTHREADS + tid) % (ROWS / 4)) * 4; }
+  __device__ static __forceinline__ void store(float* s, const float4 (&r)[PASSES], int tid) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+      *reinterpret_cast<float4*>(&s[k_of(tid, p) * LD + row_of(tid, p)]) = r[p];
+  }
+  __device__ static __forceinline__ void frag(const float* s, int r0, int j, int lane, float (&v)[4]) {
+    const float* b = &s[(8 * j + 4 * (lane >> 5)) * LD + r0 + (lane & 31)];
+    v[0] = b[0]; v[1] = b[LD]; v[2] = b[2 * LD]; v[3] = b[3 * LD];
+  }
+};
+
+// ---- generic dense-matrix loaders ----------------------------------------
+// Matrix whose k index is contiguous: elem(row,k) = base[row*ld + k].
+template <int ROWS>
+struct LoadRowsKC {
+  using Tile = TileKC<ROWS>;
+  const float* base; long ld; int rows, K; bool vec;
+  int row0, tid;
+  __device__ void init(const float* b, long ld_, int rows_, int K_, int row0_, int tid_) {
+    base = b; ld = ld_; rows = rows_; K = K_; row0 = row0_; tid = tid_;
+    vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  }
+  __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
+    const int k = kt * BK + Tile::k_of(tid);
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) {
+      const int row = row0 + Tile::row_of(tid, p);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows) {
+        const float* src = base + (long)row * ld + k;
+        if (vec && k + 3 < K) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k < K) v.x = src[0];
+          if (k + 1 < K) v.y = src[1];
+          if (k + 2 < K) v.z = src[2];
+          if (k + 3 < K) v.w = src[3];
+        }
+      }
+      r[p] = v;
+    }
+  }
+};
+
+// Matrix whose row index is contiguous: elem(k,row) = base[k*ld + row].
+template <int ROWS>
+struct LoadRowsKM {
+  using Tile = TileKM<ROWS>;
+  const float* base; long ld; int rows, K; bool vec;
+  int row0, tid;
+  __device__ void init(const float* b, long ld_, int rows_, int K_, int row0_, int tid_) {
+    base = b; ld = ld_; rows = rows_; K = K_; row0 = row0_; tid = tid_;
+    vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  }
+  __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) {
+      const int k = kt * BK + Tile::k_of(tid, p);
+      const int row = row0 + Tile::row_of(tid, p);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K) {
+        const float* src = base + (long)k * ld + row;
+        if (vec && row + 3 < rows) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (row < rows) v.x = src[0];
+          if (row + 1 < rows) v.y = src[1];
+          if (row + 2 < rows) v.z = src[2];
+          if (row + 3 < rows) v.w = src[3];
+        }
+      }
+      r[p] = v;
+    }
+  }
+};
+
+// ---- tile geometry ----------------------------------------------------------
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+struct Geom {
+  static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+  static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  static constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile below one MFMA");
+};
+
+// Main loop.  LA/LB: loaders with .load(kt, regs); TA/TB: their LDS tile types.
+template <class G, class TA, class TB, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end,
+                                              float* smem, f32x16 (&acc)[G::TM][G::TN]) {
+  float* sA = smem;
+  float* sB = smem + TA::FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+
+#pragma unroll
+  for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[TA::PASSES], rb[TB::PASSES];
+  if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); }
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();                       // everyone finished reading the previous tile
+    TA::store(sA, ra, tid);
+    TB::store(sB, rb, tid);
+    __syncthreads();
+    if (kt + 1 < kt_end) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }   // in flight under the MFMAs
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      float a[G::TM][4], b[G::TN][4];
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i) TA::frag(sA, wm + 32 * i, j, lane, a[i]);
+#pragma unroll
+      for (int i = 0; i < G::TN; ++i) TB::frag(sB, wn + 32 * i, j, lane, b[i]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+          for (int in = 0; in < G::TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][t], b[in][t], acc[im][in], 0, 0, 0);
+    }
+  }
+}
+
+// Walk the accumulators: f(row_in_tile, col_in_tile, value) for this lane's elements.
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[G::TM][G::TN], F&& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+#pragma unroll
+  for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < G::TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        f(wm + 32 * im + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wn + 32 * in + (lane & 31), acc[im][in][r]);
+}
+
+// blockIdx.x -> (tile_m, tile_n) keeping the workgroups that share an XCD (ids equal mod 8)
+// on neighbouring tiles so they reuse operand panels in that XCD's L2.  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+}  // namespace embnet

@@ -1,0 +1,203 @@
+// Online triplet mining on the distance matrix: mine-and-select.
+//
+// Replaces the Python double loop of TripletsDataGenerator.get_batch_triplets_mining
+// (/root/reference/embedding_net/datagenerators.py:225-250) and its three selection
+// rules (:188-199).  Rows are class-contiguous: class c owns rows [cK,(c+1)K).
+// For every ordered positive pair (i<j) of a class, in the order combinations() yields,
+//   loss[q] = (D[i,j] - D[i,neg_q]) + margin      (two f32 roundings, like NumPy)
+// over the N-K out-of-class columns neg_q in ascending order, then
+//   hardest      first arg-max, kept iff loss > 0
+//   random_hard  uniform pick among {loss > 0}
+//   semihard     uniform pick among {0 < loss < margin}
+// One wavefront scans one pair (ballot/popcount rank-select for the random rules,
+// shuffle arg-max for hardest); a single-workgroup pass then compacts the active pairs
+// into the (a,p,n) list in pair order and applies the reference's fallback triplet.
+// HBM-bound integer/compare work: 4*N*(N-K)*(K-1)/2.. bytes read from an L2-resident matrix.
+#include "common.h"
+#include "../../include/embnet.h"
+
+namespace embnet {
+
+__device__ __forceinline__ void decode_pair(int q, int k, int& ii, int& jj) {
+  // q-th pair of combinations(range(k), 2)
+  int i = 0, rem = q;
+  while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+  ii = i; jj = i + 1 + rem;
+}
+
+__global__ __launch_bounds__(256) void mine_select_kernel(
+    const float* __restrict__ D, int n, int p, int k, float margin, int mode, uint64_t seed,
+    int* __restrict__ selected, uint32_t* __restrict__ cand_mask, int mask_words) {
+  const int ppc = k * (k - 1) / 2;
+  const int npairs = p * ppc;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pair >= npairs) return;
+  const int c = pair / ppc;
+  int ii, jj;
+  decode_pair(pair % ppc, k, ii, jj);
+  const int lo = c * k, nneg = n - k;
+  const int i = lo + ii, j = lo + jj;
+  const float* row = D + (long)i * n;
+  const float dap = row[j];
+
+  auto loss_at = [&](int q) -> float {
+    const int col = q < lo ? q : q + k;
+    return __fadd_rn(__fsub_rn(dap, row[col]), margin);
+  };
+
+  int result = -1;
+  if (mode == EMBNET_MINE_HARDEST) {
+    float best = -INFINITY; int bq = 0x7fffffff;
+    for (int q = lane; q < nneg; q += 64) {
+      const float v = loss_at(q);
+      if (v > best) { best = v; bq = q; }           // ascending q per lane: first max kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oq = __shfl_xor(bq, o, 64);
+      if (ov > best || (ov == best && oq < bq)) { best = ov; bq = oq; }
+    }
+    if (bq != 0x7fffffff && best > 0.f) result = bq;
+    if (cand_mask && lane == 0 && result >= 0)
+      atomicOr(&cand_mask[(long)pair * mask_words + (result >> 5)], 1u << (result & 31));
+  } else {
+    const bool semi = mode == EMBNET_MINE_SEMIHARD;
+    int total = 0;
+    for (int q0 = 0; q0 < nneg; q0 += 64) {
+      const int q = q0 + lane;
+      bool pred = false;
+      if (q < nneg) { const float v = loss_at(q); pred = v > 0.f && (!semi || v < margin); }
+      const unsigned long long m = __ballot(pred);
+      total += __popcll(m);
+      if (cand_mask && lane < 2 && q0 + 32 * lane < nneg)
+        cand_mask[(long)pair * mask_words + (q0 >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+    }
+    if (total > 0) {
+      const uint32_t u = rng_u32(seed, (uint64_t)pair, 0);
+      const int want = (int)(((uint64_t)u * (uint64_t)total) >> 32);   // uniform in [0,total)
+      int cum = 0;
+      for (int q0 = 0; q0 < nneg; q0 += 64) {
+        const int q = q0 + lane;
+        bool pred = false;
+        if (q < nneg) { const float v = loss_at(q); pred = v > 0.f && (!semi || v < margin); }
+        const unsigned long long m = __ballot(pred);
+        const int cnt = __popcll(m);
+        if (want < cum + cnt) {
+          const int rank = __popcll(m & ((1ull << lane) - 1ull));
+          const unsigned long long hit = __ballot(pred && rank == want - cum);
+          result = q0 + __ffsll((long long)hit) - 1;
+          break;
+        }
+        cum += cnt;
+      }
+    }
+  }
+  if (lane == 0) selected[pair] = result < 0 ? -1 : (result < lo ? result : result + k);
+}
+
+// Single workgroup: stable compaction of the active pairs into triplets[T][3], T -> *count.
+__global__ __launch_bounds__(1024) void mine_compact_kernel(const int* __restrict__ selected, int n, int p,
+                                                            int k, int* __restrict__ triplets,
+                                                            int* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int ppc = k * (k - 1) / 2, npairs = p * ppc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < npairs; q0 += 1024) {
+    const int pair = q0 + tid;
+    const int sel = pair < npairs ? selected[pair] : -1;
+    const bool act = sel >= 0;
+    const unsigned long long m = __ballot(act);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (act) {
+      int ii, jj;
+      decode_pair(pair % ppc, k, ii, jj);
+      const int lo = (pair / ppc) * k;
+      int* t = triplets + 3 * (long)(off + rank);
+      t[0] = lo + ii; t[1] = lo + jj; t[2] = sel;
+    }
+    __syncthreads();
+    if (tid == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_tot[w]; base_s += s; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int total = base_s;
+    if (total == 0) {                 // datagenerators.py:246-250 — last pair of the last class, first negative
+      triplets[0] = n - 2; triplets[1] = n - 1; triplets[2] = 0;
+      total = 1;
+    }
+    *count = total;
+  }
+}
+
+// Hermans batch-hard (build-defined, not in the reference): one wave per anchor.
+__global__ __launch_bounds__(256) void batch_hard_kernel(const float* __restrict__ D, int n, int k,
+                                                         int* __restrict__ triplets, int* __restrict__ count) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (a == 0 && lane == 0 && count) *count = n;
+  if (a >= n) return;
+  const int lo = (a / k) * k, hi = lo + k;
+  const float* row = D + (long)a * n;
+  float bp = -INFINITY, bn = INFINITY; int ip = 0x7fffffff, in_ = 0x7fffffff;
+  for (int c = lane; c < n; c += 64) {
+    const float v = row[c];
+    if (c >= lo && c < hi) { if (c != a && v > bp) { bp = v; ip = c; } }
+    else if (v < bn) { bn = v; in_ = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bp, o, 64); const int oi = __shfl_xor(ip, o, 64);
+    if (ov > bp || (ov == bp && oi < ip)) { bp = ov; ip = oi; }
+    const float nv = __shfl_xor(bn, o, 64); const int ni = __shfl_xor(in_, o, 64);
+    if (nv < bn || (nv == bn && ni < in_)) { bn = nv; in_ = ni; }
+  }
+  if (lane == 0) { int* t = triplets + 3 * (long)a; t[0] = a; t[1] = ip; t[2] = in_; }
+}
+
+}  // namespace embnet
+
+using namespace embnet;
+
+extern "C" int embnet_mine_max_triplets(int p, int k) {
+  if (p <= 0 || k <= 0) return 0;
+  const long t = (long)p * k * (k - 1) / 2;
+  return (int)(t > 0 ? t : 1);
+}
+
+extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margin, int mode,
+                                    uint64_t seed, int32_t* triplets, int32_t* count,
+                                    int32_t* selected, uint32_t* cand_mask, void* stream) {
+  EMBNET_CHECK_ARG(dist && triplets && count && selected, "mine_triplets: null pointer");
+  EMBNET_CHECK_ARG(p >= 2 && k >= 2, "mine_triplets: need k_classes>=2 and k_samples>=2 (got %d,%d)", p, k);
+  EMBNET_CHECK_ARG(mode == EMBNET_MINE_SEMIHARD || mode == EMBNET_MINE_HARDEST || mode == EMBNET_MINE_RANDOM_HARD,
+                   "mine_triplets: unknown mode %d", mode);
+  hipStream_t s = (hipStream_t)stream;
+  const int n = p * k, npairs = p * (k * (k - 1) / 2);
+  const int mask_words = (n - k + 31) / 32;
+  if (cand_mask) {
+    hipError_t e = hipMemsetAsync(cand_mask, 0, (size_t)npairs * mask_words * 4, s);
+    if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "mine_triplets: memset: %s", hipGetErrorString(e));
+  }
+  mine_select_kernel<<<cdiv(npairs, 4), 256, 0, s>>>(dist, n, p, k, margin, mode, seed, selected, cand_mask,
+                                                     mask_words);
+  mine_compact_kernel<<<1, 1024, 0, s>>>(selected, n, p, k, triplets, count);
+  return check_launch("mine_triplets");
+}
+
+extern "C" int embnet_batch_hard(const float* dist, int p, int k, int32_t* triplets, int32_t* count,
+                                 void* stream) {
+  EMBNET_CHECK_ARG(dist && triplets, "batch_hard: null pointer");
+  EMBNET_CHECK_ARG(p >= 2 && k >= 2, "batch_hard: need k_classes>=2 and k_samples>=2 (got %d,%d)", p, k);
+  const int n = p * k;
+  batch_hard_kernel<<<cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(dist, n, k, triplets, count);
+  return check_launch("batch_hard");
+}

@@ -1,0 +1,445 @@
+// HBM-bound layers around the convolutions, NHWC fp32: BatchNorm (train / inference, optional
+// fused ReLU), max pooling, global average pooling, ReLU/bias backward, residual add, dropout,
+// L2 kernel regulariser.  Stand-ins for the Keras layers used at
+// /root/reference/embedding_net/backbones.py:21-36 (MaxPool2D, Flatten/Dense bias+ReLU),
+// :44-75 (BatchNormalization, Dropout), :110-116 (GlobalAveragePooling2D) and the zoo ResNet blocks.
+// Roofline: HBM.  Algorithmic bytes per element are noted at each kernel.
+#include "common.h"
+#include "../../include/embnet.h"
+
+namespace embnet {
+
+// ---------------------------------------------------------------- column reductions over [M, C]
+// Layout of a 256-thread workgroup: cl channel lanes x rl row lanes (cl*rl = 256, cl a power of 2),
+// consecutive threads on consecutive channels -> coalesced rows.  Each workgroup reduces a slab of
+// rows and writes partial[block][2][C]; a finalize kernel adds the partials in double, fixed order.
+struct ColGeom { int cl, rl, blocks, rows_per_block; };
+
+static ColGeom col_geom(long m, int c) {
+  ColGeom g;
+  int cl = 1; while (cl < c && cl < 256) cl <<= 1;
+  g.cl = cl; g.rl = 256 / cl;
+  long blocks = (m + (long)g.rl * 16 - 1) / ((long)g.rl * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  g.blocks = (int)blocks;
+  g.rows_per_block = (int)((m + blocks - 1) / blocks);
+  return g;
+}
+
+template <class F>   // F(row, col, &v0, &v1) accumulates two sums for element (row, col)
+__device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __restrict__ partial, F f) {
+  __shared__ float sh[2][256];
+  const int ci = threadIdx.x % g.cl, ri = threadIdx.x / g.cl;
+  const long r0 = (long)blockIdx.x * g.rows_per_block;
+  const long r1 = min(r0 + g.rows_per_block, m);
+  for (int c0 = 0; c0 < c; c0 += g.cl) {
+    const int col = c0 + ci;
+    float a = 0.f, b = 0.f;
+    if (col < c)
+      for (long r = r0 + ri; r < r1; r += g.rl) f(r, col, a, b);
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if (ri == 0 && col < c) {
+      for (int k = 1; k < g.rl; ++k) { a += sh[0][k * g.cl + ci]; b += sh[1][k * g.cl + ci]; }
+      partial[((long)blockIdx.x * 2 + 0) * c + col] = a;
+      partial[((long)blockIdx.x * 2 + 1) * c + col] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm
+// stats pass: reads x once (4 B/elem)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long m, int c, ColGeom g,
+                                                       float* __restrict__ partial) {
+  col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
+    const float v = x[r * c + col]; a += v; b = fmaf(v, v, b);
+  });
+}
+
+// mean/var -> scale = gamma*rstd, shift = beta - mean*scale; moving stats updated in place.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, long m, int c,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ moving_mean,
+                                                          float* __restrict__ moving_var) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < blocks; ++b) { s += partial[((long)b * 2) * c + col]; ss += partial[((long)b * 2 + 1) * c + col]; }
+  const double mean = s / (double)m;
+  double var = ss / (double)m - mean * mean;            // biased, as Keras uses in training
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = (gamma ? gamma[col] : 1.f) * rstd;
+  mean_out[col] = (float)mean; rstd_out[col] = rstd;
+  scale[col] = sc; shift[col] = (beta ? beta[col] : 0.f) - (float)mean * sc;
+  if (moving_mean) moving_mean[col] = momentum * moving_mean[col] + (1.f - momentum) * (float)mean;
+  if (moving_var) moving_var[col] = momentum * moving_var[col] + (1.f - momentum) * (float)var;
+}
+
+// inference: scale/shift from the moving statistics
+__global__ __launch_bounds__(256) void bn_infer_prepare_kernel(int c, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ moving_mean,
+                                                               const float* __restrict__ moving_var, float eps,
+                                                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  const float sc = (gamma ? gamma[col] : 1.f) * rsqrtf(moving_var[col] + eps);
+  scale[col] = sc; shift[col] = (beta ? beta[col] : 0.f) - moving_mean[col] * sc;
+}
+
+// y = [relu](x*scale[c] + shift[c])   (8 B/elem)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, long total, int c,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int relu, float* __restrict__ y) {
+  const long stride = (long)gridDim.x * 256;
+  if ((c & 3) == 0) {
+    const long n4 = total >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const int col = (int)((i * 4) % c);
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 sc = *reinterpret_cast<const float4*>(scale + col);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + col);
+      float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      reinterpret_cast<float4*>(y)[i] = o;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+      const int col = (int)(i % c);
+      float o = fmaf(x[i], scale[col], shift[col]);
+      y[i] = relu ? fmaxf(o, 0.f) : o;
+    }
+  }
+}
+
+// backward reductions: dbeta = sum dz, dgamma = sum dz*xhat, dz = dy * [x*scale+shift > 0]   (8 B/elem)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            long m, int c, ColGeom g, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            float* __restrict__ partial) {
+  col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
+    const float xv = x[r * c + col];
+    float dz = dy[r * c + col];
+    if (relu && fmaf(xv, scale[col], shift[col]) <= 0.f) dz = 0.f;
+    a += dz; b = fmaf(dz, (xv - mean[col]) * rstd[col], b);
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
+                                                              float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < blocks; ++b) { s += partial[((long)b * 2) * c + col]; ss += partial[((long)b * 2 + 1) * c + col]; }
+  dbeta[col] = (float)s; dgamma[col] = (float)ss;
+}
+
+// dx = scale * (dz - dbeta/M - xhat*dgamma/M)     (12 B/elem)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           long total, int c, float inv_m, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, int relu, int training,
+                                                           float* __restrict__ dx) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int col = (int)(i % c);
+    const float xv = x[i];
+    float dz = dy[i];
+    if (relu && fmaf(xv, scale[col], shift[col]) <= 0.f) dz = 0.f;
+    if (training) {
+      const float xh = (xv - mean[col]) * rstd[col];
+      dx[i] = scale[col] * (dz - dbeta[col] * inv_m - xh * dgamma[col] * inv_m);
+    } else {
+      dx[i] = scale[col] * dz;       // frozen statistics: plain affine
+    }
+  }
+}
+
+// ---------------------------------------------------------------- pooling
+// y = max over the window; taps outside the image read as 0 (ZeroPadding2D semantics) and carry no
+// gradient; first maximum in row-major tap order wins.  argmax: tap index or 255.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                                          int k, int stride, int pad, int oh, int ow,
+                                                          float* __restrict__ y, uint8_t* __restrict__ argmax) {
+  const long total = (long)n * oh * ow * c;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c);
+  long t = i / c;
+  const int x_o = (int)(t % ow); t /= ow;
+  const int y_o = (int)(t % oh);
+  const int b = (int)(t / oh);
+  float best = -INFINITY; int bi = 255;
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
+      const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+      const float v = in ? x[(((long)b * h + ih) * w + iw) * c + col] : 0.f;
+      if (v > best) { best = v; bi = in ? dy * k + dx : 255; }
+    }
+  y[i] = best; argmax[i] = (uint8_t)bi;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                          int n, int h, int w, int c, int k, int stride, int pad,
+                                                          int oh, int ow, float* __restrict__ dx) {
+  const long total = (long)n * h * w * c;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c);
+  long t = i / c;
+  const int iw = (int)(t % w); t /= w;
+  const int ih = (int)(t % h);
+  const int b = (int)(t / h);
+  float g = 0.f;
+  // windows (y_o,x_o) with y_o*stride - pad <= ih < y_o*stride - pad + k
+  const int y_hi = min((ih + pad) / stride, oh - 1), x_hi = min((iw + pad) / stride, ow - 1);
+  for (int y_o = y_hi; y_o >= 0 && y_o * stride - pad + k > ih; --y_o)
+    for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
+      const int tap = (ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad));
+      const long o = (((long)b * oh + y_o) * ow + x_o) * c + col;
+      if (argmax[o] == tap) g += dy[o];
+    }
+  dx[i] = g;
+}
+
+// y[n,c] = mean over hw
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int n, int hw, int c,
+                                                      float* __restrict__ y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * c) return;
+  const int col = i % c, b = i / c;
+  float s = 0.f;
+  for (int p = 0; p < hw; ++p) s += x[((long)b * hw + p) * c + col];
+  y[i] = s / (float)hw;
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, int n, int hw, int c,
+                                                      float* __restrict__ dx) {
+  const long total = (long)n * hw * c;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c);
+  const int b = (int)(i / ((long)hw * c));
+  dx[i] = dy[b * c + col] / (float)hw;
+}
+
+// ---------------------------------------------------------------- elementwise
+// dz = dy * [y > 0];  optional column sums of dz -> bias gradient partials
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       long total, float* __restrict__ dz) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long m, int c, ColGeom g,
+                                                     float* __restrict__ partial) {
+  col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) { a += x[r * c + col]; });
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long total,
+                                                  float* __restrict__ y) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) y[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, long total, float alpha,
+                                                    const float* __restrict__ alpha_dev, float* __restrict__ y) {
+  const float a = alpha * (alpha_dev ? *alpha_dev : 1.f);
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) y[i] = a * x[i];
+}
+
+// inverted dropout with a counter-based mask: y = x * keep / (1-rate); the same (seed, index) gives
+// the same mask in backward.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long total, float rate,
+                                                      uint64_t seed, float* __restrict__ y) {
+  const float keep_scale = 1.f / (1.f - rate);
+  const uint32_t thr = (uint32_t)((double)rate * 4294967296.0);
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+    y[i] = rng_u32(seed, (uint64_t)i, 1) >= thr ? x[i] * keep_scale : 0.f;
+}
+
+// sum of squares -> partial per block (double finalize on one thread)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long total,
+                                                            float* __restrict__ partial) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) s = fmaf(x[i], x[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += partial[i];
+  *out = (float)(alpha * s);
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
+                                                              float* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  double s = 0.0;
+  for (int b = 0; b < blocks; ++b) s += partial[((long)b * 2) * c + col];
+  out[col] = (float)s;
+}
+
+}  // namespace embnet
+
+using namespace embnet;
+#define S(stream) ((hipStream_t)(stream))
+static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+extern "C" size_t embnet_bn_workspace_bytes(long m, int c) {
+  if (m <= 0 || c <= 0) return 0;
+  return (size_t)col_geom(m, c).blocks * 2 * c * sizeof(float);
+}
+
+extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                                   float momentum, int relu, float* y, float* save_mean, float* save_rstd,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(x && y && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_train_fwd: m=%ld c=%d", m, c);
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "bn_train_fwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  const ColGeom g = col_geom(m, c);
+  float* partial = (float*)workspace;
+  bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, partial);
+  bn_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(partial, g.blocks, m, c, gamma, beta, eps, momentum, save_mean,
+                                                          save_rstd, scale, shift, moving_mean, moving_var);
+  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+  return check_launch("bn_train_fwd");
+}
+
+extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
+                                   const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
+                                   float* scale, float* shift, void* stream) {
+  EMBNET_CHECK_ARG(x && y && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_infer_fwd: m=%ld c=%d", m, c);
+  bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
+  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+  return check_launch("bn_infer_fwd");
+}
+
+extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
+                             const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                             float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  EMBNET_CHECK_ARG(dy && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd: training needs saved statistics");
+  EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_bwd: m=%ld c=%d", m, c);
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "bn_bwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  const ColGeom g = col_geom(m, c);
+  float* partial = (float*)workspace;
+  // inference-mode statistics: xhat uses the moving stats folded in scale/shift; dgamma then needs them too.
+  // We only support parameter gradients in training mode; frozen BN returns dgamma = dbeta sums with xhat from
+  // save_mean/save_rstd when given, else zeros.
+  if (save_mean && save_rstd) {
+    bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial);
+    bn_bwd_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
+  } else {
+    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
+    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+  }
+  bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
+                                                               scale, shift, dbeta, dgamma, relu, training, dx);
+  return check_launch("bn_bwd");
+}
+
+extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,
+                                  int ow, float* y, uint8_t* argmax, void* stream) {
+  EMBNET_CHECK_ARG(x && y && argmax, "maxpool_fwd: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k <= 15 && stride > 0 && pad >= 0 && oh > 0 && ow > 0,
+                   "maxpool_fwd: bad geometry");
+  EMBNET_CHECK_ARG((oh - 1) * stride - pad + k <= h + pad && (ow - 1) * stride - pad + k <= w + pad,
+                   "maxpool_fwd: window leaves the padded image");
+  const long total = (long)n * oh * ow * c;
+  maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k,
+                                  int stride, int pad, int oh, int ow, float* dx, void* stream) {
+  EMBNET_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "maxpool_bwd: bad geometry");
+  const long total = (long)n * h * w * c;
+  maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx);
+  return check_launch("maxpool_bwd");
+}
+
+extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream) {
+  EMBNET_CHECK_ARG(x && y && n > 0 && hw > 0 && c > 0, "gap_fwd: bad argument");
+  gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y);
+  return check_launch("gap_fwd");
+}
+
+extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream) {
+  EMBNET_CHECK_ARG(dy && dx && n > 0 && hw > 0 && c > 0, "gap_bwd: bad argument");
+  gap_bwd_kernel<<<cdiv((long)n * hw * c, 256), 256, 0, S(stream)>>>(dy, n, hw, c, dx);
+  return check_launch("gap_bwd");
+}
+
+extern "C" int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void* stream) {
+  EMBNET_CHECK_ARG(dy && y && dz && total > 0, "relu_bwd: bad argument");
+  relu_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(dy, y, total, dz);
+  return check_launch("relu_bwd");
+}
+
+extern "C" size_t embnet_colsum_workspace_bytes(long m, int c) { return embnet_bn_workspace_bytes(m, c); }
+
+extern "C" int embnet_colsum(const float* x, long m, int c, float* out, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  EMBNET_CHECK_ARG(x && out && workspace && m > 0 && c > 0, "colsum: bad argument");
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  const ColGeom g = col_geom(m, c);
+  colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace);
+  colsum_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, out);
+  return check_launch("colsum");
+}
+
+extern "C" int embnet_add(const float* a, const float* b, long total, float* y, void* stream) {
+  EMBNET_CHECK_ARG(a && b && y && total > 0, "add: bad argument");
+  add_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y);
+  return check_launch("add");
+}
+
+extern "C" int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev, float* y, void* stream) {
+  EMBNET_CHECK_ARG(x && y && total > 0, "scale: bad argument");
+  scale_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, alpha, alpha_dev, y);
+  return check_launch("scale");
+}
+
+extern "C" int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream) {
+  EMBNET_CHECK_ARG(x && y && total > 0, "dropout: bad argument");
+  EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "dropout: rate %f outside [0,1)", rate);
+  dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, y);
+  return check_launch("dropout");
+}
+
+extern "C" size_t embnet_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+extern "C" int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(x && out && workspace && total > 0, "sumsq: bad argument");
+  if (workspace_bytes < embnet_sumsq_workspace_bytes()) return fail(EMBNET_EWORKSPACE, "sumsq: workspace too small");
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  sumsq_partial_kernel<<<blocks, 256, 0, S(stream)>>>(x, total, (float*)workspace);
+  sum_finalize_kernel<<<1, 64, 0, S(stream)>>>((const float*)workspace, blocks, alpha, out);
+  return check_launch("sumsq");
+}

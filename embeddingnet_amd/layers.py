@@ -1,0 +1,448 @@
+"""Keras-semantics layers on the HIP kernels (NHWC fp32).
+
+Each layer is a torch.nn.Module that owns its parameters in Keras layout and
+name (`kernel` [R,S,Cin,Cout] / [in,out], `bias`, `gamma`, `beta`,
+`moving_mean`, `moving_variance`) and whose forward/backward are launches of
+libembnet_hip.so entry points through torch.autograd.Function — PyTorch is the
+tape, the allocator and the optimizer, not the compute.
+
+Semantics restated from the layers /root/reference/embedding_net/backbones.py
+instantiates: Conv2D default stride 1, 'valid', bias,
+glorot_uniform; 'same' pads extra on the bottom/right; BatchNormalization
+momentum .99, eps 1e-3, biased batch variance in training; MaxPool2D() 2x2/2;
+Dropout inverted scaling; l2(lambda) = lambda * sum(w^2) on kernels.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+_WS = {}
+
+
+class KernelTimer:
+    """Optional HIP-event brackets around the conv launches (bench.py's roofline leg).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []          # (kernel name, flops, start event, end event)
+
+    def summary(self):
+        """{kernel: dict(launches, ms_total, flops_total)} — call after a device synchronize."""
+        out = {}
+        for name, flops, s, e in self.records:
+            d = out.setdefault(name, dict(launches=0, ms_total=0.0, flops_total=0.0))
+            d["launches"] += 1
+            d["ms_total"] += s.elapsed_time(e)
+            d["flops_total"] += flops
+        return out
+
+
+TIMER = None       # set to a KernelTimer to time conv kernels
+
+
+def _conv_timed(kind, dims, call):
+    if TIMER is None:
+        return call()
+    n, h, wd, c, r, s, k, oh, ow = dims
+    name = _lib.lib().embnet_conv2d_kernel_name(kind, n, h, wd, c, r, s, k, oh, ow).decode()
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    out = call()
+    s1.record()
+    TIMER.records.append((name, 2.0 * n * oh * ow * k * r * s * c, s0, s1))
+    return out
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (kernels on one stream run in order, so reuse is safe)."""
+    n = max((int(nbytes) + 3) // 4, 256)
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def same_pad(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+# ----------------------------------------------------------------------------- conv
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, geom, relu):
+        x, w = _c(x), _c(w)
+        n, h, wd, c = x.shape
+        r, s, c2, k = w.shape
+        if c2 != c:
+            raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
+        stride, pt, pl, oh, ow = geom
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(_lib.lib().embnet_conv2d_fwd_f32(
+            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), stream())))
+        ctx.geom, ctx.relu, ctx.has_bias = geom, relu, bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        lib = _lib.lib()
+        n, h, wd, c = x.shape
+        r, s, _, k = w.shape
+        stride, pt, pl, oh, ow = ctx.geom
+        dy = _c(dy)
+        if ctx.relu:
+            dz = torch.empty_like(dy)
+            check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv_timed(1, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_dgrad_f32(
+                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, stream())))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            need = lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow)
+            ws = workspace(need, x.device)
+            _conv_timed(2, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+                ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
+                stream())))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dz.view(-1, k))
+        return dx, dw, db, None, None
+
+
+def _colsum(x2d):
+    lib = _lib.lib()
+    m, c = x2d.shape
+    out = torch.empty((c,), device=x2d.device, dtype=torch.float32)
+    ws = workspace(lib.embnet_colsum_workspace_bytes(m, c), x2d.device)
+    check(lib.embnet_colsum(ptr(x2d), m, c, ptr(out), ptr(ws), ws.numel() * 4, stream()))
+    return out
+
+
+def glorot_uniform_(t, gen):
+    shape = t.shape
+    rf = int(math.prod(shape[:-2])) if len(shape) > 2 else 1
+    fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return t.uniform_(-lim, lim, generator=gen)
+
+
+def he_uniform_(t, gen):
+    shape = t.shape
+    rf = int(math.prod(shape[:-2])) if len(shape) > 2 else 1
+    lim = math.sqrt(6.0 / (shape[-2] * rf))
+    return t.uniform_(-lim, lim, generator=gen)
+
+
+class Conv2D(nn.Module):
+    """Keras Conv2D.  padding: 'valid' | 'same' | int (a ZeroPadding2D(p) in front of a valid conv)."""
+
+    def __init__(self, in_channels, filters, kernel_size, strides=1, padding="valid", activation=None,
+                 use_bias=True, kernel_initializer="glorot_uniform", l2=0.0, gen=None):
+        super().__init__()
+        if activation not in (None, "relu"):
+            raise ValueError("Conv2D supports activation None or 'relu'")
+        self.k, self.stride, self.padding, self.relu, self.l2 = kernel_size, strides, padding, activation == "relu", l2
+        w = torch.empty(kernel_size, kernel_size, in_channels, filters)
+        (he_uniform_ if kernel_initializer == "he_uniform" else glorot_uniform_)(w, gen)
+        self.kernel = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(filters)) if use_bias else None
+
+    def geometry(self, h, w):
+        k, s = self.k, self.stride
+        if self.padding == "same":
+            oh, pt = same_pad(h, k, s)
+            ow, pl = same_pad(w, k, s)
+        else:
+            p = 0 if self.padding == "valid" else int(self.padding)
+            pt = pl = p
+            oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        if oh <= 0 or ow <= 0:
+            raise _lib.EmbnetError(f"Conv2D {k}x{k}/{s} '{self.padding}' does not fit a {h}x{w} input")
+        return (s, pt, pl, oh, ow)
+
+    def forward(self, x):
+        return _Conv2dFn.apply(x, self.kernel, self.bias, self.geometry(x.shape[1], x.shape[2]), self.relu)
+
+
+# ----------------------------------------------------------------------------- dense
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        x, w = _c(x), _c(w)
+        m, i = x.shape
+        i2, o = w.shape
+        if i != i2:
+            raise _lib.EmbnetError(f"dense: input width {i} != kernel rows {i2}")
+        y = torch.empty((m, o), device=x.device, dtype=torch.float32)
+        check(_lib.lib().embnet_dense_fwd_f32(ptr(x), ptr(w), ptr(bias), ptr(y), m, i, o, int(relu), stream()))
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        lib = _lib.lib()
+        m, i = x.shape
+        o = w.shape[1]
+        dy = _c(dy)
+        if ctx.relu:
+            dz = torch.empty_like(dy)
+            check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.embnet_dense_dgrad_f32(ptr(dz), ptr(w), ptr(dx), m, i, o, stream()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            check(lib.embnet_dense_wgrad_f32(ptr(x), ptr(dz), ptr(dw), m, i, o, stream()))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dz)
+        return dx, dw, db, None
+
+
+class Dense(nn.Module):
+    def __init__(self, in_features, units, activation=None, l2=0.0, gen=None):
+        super().__init__()
+        if activation not in (None, "relu"):
+            raise ValueError("Dense supports activation None or 'relu'")
+        self.relu, self.l2 = activation == "relu", l2
+        self.kernel = nn.Parameter(glorot_uniform_(torch.empty(in_features, units), gen))
+        self.bias = nn.Parameter(torch.zeros(units))
+
+    def forward(self, x):
+        return _DenseFn.apply(x, self.kernel, self.bias, self.relu)
+
+
+# ----------------------------------------------------------------------------- batch norm
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training):
+        x = _c(x)
+        lib = _lib.lib()
+        c = x.shape[-1]
+        m = x.numel() // c
+        y = torch.empty_like(x)
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        if training:
+            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(relu), ptr(y),
+                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
+                                          ws.numel() * 4, stream()))
+        else:
+            check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
+                                          int(relu), ptr(y), stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+        ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        lib = _lib.lib()
+        c = x.shape[-1]
+        m = x.numel() // c
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+        mean = stats[0].data_ptr() if ctx.training else None
+        rstd = stats[1].data_ptr() if ctx.training else None
+        check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, stats[2].data_ptr(), stats[3].data_ptr(),
+                                int(ctx.relu), int(ctx.training), ptr(dx), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                ptr(ws), ws.numel() * 4, stream()))
+        dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
+        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class BatchNormalization(nn.Module):
+    """Keras BatchNormalization on the last axis; `relu=True` fuses a following Activation('relu')."""
+
+    def __init__(self, channels, epsilon=1e-3, momentum=0.99, scale=True, relu=False):
+        super().__init__()
+        self.eps, self.momentum, self.relu = epsilon, momentum, relu
+        self.gamma = nn.Parameter(torch.ones(channels)) if scale else None
+        self.beta = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("moving_mean", torch.zeros(channels))
+        self.register_buffer("moving_variance", torch.ones(channels))
+
+    def forward(self, x):
+        return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                  self.momentum, self.relu, self.training)
+
+
+# ----------------------------------------------------------------------------- pooling
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        x = _c(x)
+        n, h, w, c = x.shape
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        if oh <= 0 or ow <= 0:
+            raise _lib.EmbnetError(f"MaxPool {k}x{k}/{stride} does not fit a {h}x{w} input")
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        check(_lib.lib().embnet_maxpool_fwd(ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(y), ptr(arg), stream()))
+        ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        n, h, w, c, k, stride, pad, oh, ow = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32)
+        check(_lib.lib().embnet_maxpool_bwd(ptr(dy), ptr(arg), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), stream()))
+        return dx, None, None, None
+
+
+class MaxPool2D(nn.Module):
+    """Keras MaxPool2D(); zero_pad=p reproduces ZeroPadding2D(p) + 'valid' pooling (pads with 0)."""
+
+    def __init__(self, pool_size=2, strides=None, zero_pad=0):
+        super().__init__()
+        self.k, self.s, self.p = pool_size, strides or pool_size, zero_pad
+
+    def forward(self, x):
+        return _MaxPoolFn.apply(x, self.k, self.s, self.p)
+
+
+class _GapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        check(_lib.lib().embnet_gap_fwd(ptr(x), n, h * w, c, ptr(y), stream()))
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        check(_lib.lib().embnet_gap_bwd(ptr(dy), n, h * w, c, ptr(dx), stream()))
+        return dx
+
+
+class GlobalAveragePooling2D(nn.Module):
+    def forward(self, x):
+        return _GapFn.apply(x)
+
+
+class Flatten(nn.Module):
+    """(h, w, c) order — a view on NHWC, no kernel."""
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)
+
+
+# ----------------------------------------------------------------------------- elementwise
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        check(_lib.lib().embnet_add(ptr(a), ptr(b), a.numel(), ptr(y), stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise _lib.EmbnetError(f"Add: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    return _AddFn.apply(a, b)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().embnet_dropout(ptr(x), x.numel(), rate, seed, ptr(y), stream()))
+        ctx.rate, ctx.seed = rate, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(_lib.lib().embnet_dropout(ptr(dy), dy.numel(), ctx.rate, ctx.seed, ptr(dx), stream()))
+        return dx, None, None
+
+
+class Dropout(nn.Module):
+    """Keras Dropout (inverted scaling, training only).  `enabled=False` turns it off for parity runs."""
+
+    def __init__(self, rate, seed=0):
+        super().__init__()
+        self.rate, self.seed, self.enabled, self._step = rate, seed, True, 0
+
+    def forward(self, x):
+        if not (self.training and self.enabled and self.rate > 0):
+            return x
+        self._step += 1
+        return _DropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)
+
+
+class _L2PenaltyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, lam):
+        w = _c(w)
+        lib = _lib.lib()
+        out = torch.empty((), device=w.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_sumsq_workspace_bytes(), w.device)
+        check(lib.embnet_sumsq(ptr(w), w.numel(), lam, ptr(out), ptr(ws), ws.numel() * 4, stream()))
+        ctx.lam = lam
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        dw = torch.empty_like(w)
+        check(_lib.lib().embnet_scale(ptr(w), w.numel(), 2.0 * ctx.lam, ptr(_c(dout)), ptr(dw), stream()))
+        return dw, None
+
+
+def l2_penalty(w, lam):
+    """Keras regularizers.l2(lam)(w) = lam * sum(w^2)."""
+    return _L2PenaltyFn.apply(w, float(lam))
+
+
+def regularization_loss(module):
+    """Sum of the l2 kernel regularisers declared on Conv2D/Dense layers (Keras adds it to the loss)."""
+    total = None
+    for m in module.modules():
+        lam = getattr(m, "l2", 0.0)
+        if lam and isinstance(m, (Conv2D, Dense)) and m.kernel.requires_grad:
+            term = l2_penalty(m.kernel, lam)
+            total = term if total is None else total + term
+    return total

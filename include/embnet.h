@@ -1,0 +1,178 @@
+/* libembnet_hip.so — C ABI of the MI355X (gfx950) metric-learning hot path.
+ *
+ * The reference (RocketFlash/EmbeddingNet) is pure Python on Keras: it has no FFI
+ * or operator-plugin interface.  Its boundary for this path is the Python call
+ * surface that tools/train.py uses; embeddingnet_amd/ mirrors that
+ * surface and lowers it onto the entry points below.  Each entry point names the
+ * reference code it stands in for (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (HBM) unless marked "host";
+ *     tensors are dense fp32, images/feature maps NHWC, conv kernels [R,S,Cin,Cout]
+ *     (Keras HWIO), dense kernels [in,out];
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     nothing synchronises, nothing allocates: the caller owns outputs and workspaces
+ *     (sizes from the matching *_workspace_bytes call);
+ *   - return 0 on success; <0 on error (EMBNET_E*), message via embnet_last_error()
+ *     (thread-local).  Invalid arguments are rejected before anything is launched;
+ *   - safe to call from several host threads on distinct streams/workspaces.
+ */
+#ifndef EMBNET_H
+#define EMBNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMBNET_ABI_VERSION 1
+
+enum {
+  EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
+  EMBNET_MINE_HARDEST = 1,     /* datagenerators.py:188-190 */
+  EMBNET_MINE_RANDOM_HARD = 2  /* datagenerators.py:192-194 */
+};
+
+int embnet_abi_version(void);
+const char* embnet_last_error(void);
+
+/* ------------------------------------------------------------------ loss path */
+
+/* datagenerators.py:219 `pairwise_distances(all_embeddings)` (scikit-learn euclidean):
+ * dist[n,n] = sqrt(max(|x_i|^2 + |x_j|^2 - 2 x_i.x_j, 0)), diagonal 0; squared!=0 skips the sqrt.
+ * x[n,e].  workspace >= embnet_pairwise_workspace_bytes(n). */
+size_t embnet_pairwise_workspace_bytes(int n);
+int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dist, int squared,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* datagenerators.py:225-250 (+ selection rules :188-199): mine (anchor,positive,negative) row
+ * indices from dist[n,n], n = p*k, class c = rows [c*k,(c+1)*k).  Pairs are visited in the
+ * reference's order; triplets[T,3] is written in that order, T -> *count (>=1: the reference's
+ * fallback triplet (n-2,n-1,0) when nothing qualifies).  triplets must hold
+ * embnet_mine_max_triplets(p,k) rows; selected[pairs] receives the chosen negative row or -1;
+ * cand_mask (optional, [pairs][ceil((n-k)/32)] words) receives the candidate set of each pair as
+ * a bitmask over the ascending out-of-class columns.  seed drives the two random rules. */
+int embnet_mine_max_triplets(int p, int k);
+int embnet_mine_triplets(const float* dist, int p, int k, float margin, int mode, uint64_t seed,
+                         int32_t* triplets, int32_t* count, int32_t* selected, uint32_t* cand_mask,
+                         void* stream);
+
+/* Hermans batch-hard selection (README.md:112 cites it; no reference code): per anchor the
+ * farthest same-class and the closest other-class row.  triplets[n,3]; *count = n (optional). */
+int embnet_batch_hard(const float* dist, int p, int k, int32_t* triplets, int32_t* count, void* stream);
+
+/* losses_and_accuracies.py:26-42 loss_function(y_true, y_pred): y_pred[t,3e] = concat(a,p,n);
+ * loss[t] = max(|a-p|^2 - |a-n|^2 + margin, 0).  bwd: dy[t,3e] from dloss[t]. */
+int embnet_triplet_hinge_fwd(const float* y_pred, int t, int e, float margin, float* loss, void* stream);
+int embnet_triplet_hinge_bwd(const float* y_pred, const float* dloss, int t, int e, float margin,
+                             float* dy, void* stream);
+
+/* Same hinge on rows gathered from emb[n,e] by triplets[.,3] (fused train step; replaces the
+ * three-branch concat of models.py:181-185 + the loss).  *count triplets are live (device
+ * scalar, no host sync); loss[max_t], active[max_t] (1 where the hinge passes gradient);
+ * *mean_loss = mean over the live triplets (Keras' reduction).  bwd: demb[n,e] =
+ * (*upstream / count) * d(sum loss)/d emb, upstream NULL = 1. */
+int embnet_triplet_gather_fwd(const float* emb, int n, int e, const int32_t* triplets,
+                              const int32_t* count, int max_t, float margin, float* loss,
+                              float* active, float* mean_loss, void* stream);
+int embnet_triplet_gather_bwd(const float* emb, int n, int e, const int32_t* triplets,
+                              const int32_t* count, int max_t, const float* active,
+                              const float* upstream, float* demb, void* stream);
+
+/* losses_and_accuracies.py:4-11 contrastive_loss (margin 1, y=1 same class): *loss = mean(...).
+ * bwd: ddist[b] = *upstream * d loss / d dist. */
+int embnet_contrastive_fwd(const float* y_true, const float* dist, int b, float* loss, void* stream);
+int embnet_contrastive_bwd(const float* y_true, const float* dist, int b, const float* upstream,
+                           float* ddist, void* stream);
+
+/* losses_and_accuracies.py:47-50 accuracy: *acc = mean((dist < 0.5) == y_true). */
+int embnet_accuracy(const float* y_true, const float* dist, int b, float* acc, void* stream);
+
+/* backbones.py:38/:77/:118 K.l2_normalize(x, axis=1): y = x * rsqrt(max(sum x^2, 1e-12)).
+ * rnorm[n] is saved for backward. */
+int embnet_l2norm_fwd(const float* x, int n, int e, float* y, float* rnorm, void* stream);
+int embnet_l2norm_bwd(const float* y, const float* rnorm, const float* dy, int n, int e, float* dx,
+                      void* stream);
+
+/* models.py:225 siamese 'l2' head: dist[b] = sqrt(max(sum (e1-e2)^2, 1e-7)). */
+int embnet_pair_distance_fwd(const float* e1, const float* e2, int b, int e, float* dist, void* stream);
+int embnet_pair_distance_bwd(const float* e1, const float* e2, const float* dist, const float* ddist,
+                             int b, int e, float* de1, float* de2, void* stream);
+
+/* ------------------------------------------------------------------ backbone layers
+ * Stand-ins for the Keras layers that backbones.py:19-121 instantiates (TensorFlow kernels in the
+ * reference).  All NHWC fp32. */
+
+/* Conv2D (backbones.py:21-31, :44-68, zoo ResNet/EfficientNet convs): implicit GEMM on fp32 MFMA.
+ * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
+ * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its
+ * bottom/right asymmetry, or an explicit ZeroPadding2D).  bias may be NULL; relu!=0 fuses the activation. */
+int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
+                          int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
+                          void* stream);
+/* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input). */
+int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
+                            int k, int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
+/* dw[r,s,c,k]; split-K slabs live in `workspace` (>= embnet_conv2d_wgrad_workspace_bytes). */
+size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
+int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                            int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                            int oh, int ow, void* stream);
+
+/* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
+ * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
+const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
+
+/* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out]. */
+int embnet_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y, int m, int in, int out,
+                         int relu, void* stream);
+int embnet_dense_dgrad_f32(const float* dy, const float* w, float* dx, int m, int in, int out, void* stream);
+int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw, int m, int in, int out, void* stream);
+
+/* BatchNormalization over the last axis of x[m,c] (backbones.py:46-69; zoo ResNet BN with eps 2e-5).
+ * train: biased batch variance; moving <- momentum*moving + (1-momentum)*batch (updated in place, may
+ * be NULL); gamma NULL = scale=False; relu!=0 fuses the following ReLU.  save_mean/save_rstd/scale/shift
+ * ([c] each) are kept by the caller for backward. */
+size_t embnet_bn_workspace_bytes(long m, int c);
+int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                        float momentum, int relu, float* y, float* save_mean, float* save_rstd, float* scale,
+                        float* shift, float* moving_mean, float* moving_var, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
+                        const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
+                        float* scale, float* shift, void* stream);
+int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                  const float* scale, const float* shift, int relu, int training, float* dx, float* dgamma,
+                  float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* MaxPool2D (backbones.py:23,26,29: 2x2/2; zoo ResNet: ZeroPadding2D(1) + 3x3/2).  Taps outside the
+ * image read 0 and take no gradient.  argmax[n,oh,ow,c] (uint8) is kept for backward. */
+int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh, int ow,
+                       float* y, uint8_t* argmax, void* stream);
+int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
+                       int pad, int oh, int ow, float* dx, void* stream);
+
+/* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
+int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);
+int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream);
+
+/* Elementwise helpers of the backward pass and the residual blocks. */
+int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void* stream);   /* dz = dy*[y>0] */
+size_t embnet_colsum_workspace_bytes(long m, int c);
+int embnet_colsum(const float* x, long m, int c, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);                                                                /* bias grads */
+int embnet_add(const float* a, const float* b, long total, float* y, void* stream);           /* Add() */
+int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev, float* y, void* stream);
+/* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
+int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream);
+/* kernel_regularizer=l2(lambda) (backbones.py:22-36): *out = alpha * sum x^2. */
+size_t embnet_sumsq_workspace_bytes(void);
+int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMBNET_H */

@@ -1,0 +1,280 @@
+"""GPU parity of the backbone layers, the backbones and the fused step against the
+oracle (oracle/backbones.py on PyTorch-CPU, float64 where cheap).  Tolerances stated per test;
+they are fp32-accumulation bounds, the oracle being the same arithmetic in a different order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import recipes as R
+from oracle import backbones as OB
+from oracle import losses as olosses
+from oracle import mining as omining
+from oracle import pairwise as opair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def g(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+
+
+def close(got, want, rtol, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = want.detach().double().numpy() if torch.is_tensor(want) else np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert err <= rtol, f"{what}: max err / max|ref| = {err:.3e} > {rtol:.1e}"
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, padding, bias, relu
+    (2, 20, 20, 3, 64, 7, 2, 3, False, False),        # resnet conv0 (C=3 scalar gather)
+    (2, 16, 16, 64, 64, 3, 1, 1, False, False),       # resnet 3x3
+    (3, 15, 17, 64, 128, 3, 2, 1, False, False),      # stride-2 3x3, odd sizes
+    (2, 14, 14, 64, 128, 1, 2, "valid", False, False),  # projection shortcut
+    (2, 30, 30, 32, 32, 5, 2, "same", True, True),    # simple2 'same' stride 2 (asymmetric pad)
+    (2, 31, 29, 32, 64, 5, 2, "same", True, True),
+    (1, 24, 24, 3, 64, 10, 1, "valid", True, True),   # simple conv1
+    (2, 12, 12, 20, 24, 3, 1, "valid", True, False),  # channels not multiples of 32
+    (2, 9, 9, 6, 10, 2, 1, "valid", True, True),      # non-vector channel counts
+    (4, 7, 7, 512, 512, 3, 1, 1, False, False),       # deep K (4608)
+    (2, 8, 8, 256, 64, 1, 1, "valid", False, False),  # bottleneck 1x1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_fwd_bwd(dev, case):
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout, k, stride, padding, bias, relu = case
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(repr(case).encode()) % 2 ** 31)
+    layer = L.Conv2D(cin, cout, k, strides=stride, padding=padding, use_bias=bias,
+                     activation="relu" if relu else None).to(dev)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    kern = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) * 0.1
+    with torch.no_grad():
+        layer.kernel.copy_(g(kern, dev))
+        if bias:
+            layer.bias.copy_(g(b, dev))
+    xt = g(x, dev).requires_grad_(True)
+    y = layer(xt)
+    # oracle in float64
+    ctx = OB.Ctx({"c/kernel": torch.tensor(kern, dtype=torch.float64, requires_grad=True),
+                  "c/bias": torch.tensor(b, dtype=torch.float64, requires_grad=True)})
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = OB.conv2d(ctx, "c", xr, cout, k, stride=stride, padding=padding, bias=bias, relu=relu)
+    close(y, yr, 2e-5, "fwd")
+    dy = rs.randn(*yr.shape).astype(np.float32)
+    y.backward(g(dy, dev))
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    close(xt.grad, xr.grad, 2e-5, "dgrad")
+    close(layer.kernel.grad, ctx.params["c/kernel"].grad, 2e-5, "wgrad")
+    if bias:
+        close(layer.bias.grad, ctx.params["c/bias"].grad, 2e-5, "bias grad")
+
+
+def test_conv2d_wgrad_splitk_large(dev):
+    """Enough output pixels to force many split-K slabs (stage-0 shape at a small batch)."""
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(3)
+    layer = L.Conv2D(64, 64, 3, padding=1, use_bias=False).to(dev)
+    x = rs.randn(8, 56, 56, 64).astype(np.float32)
+    dy = rs.randn(8, 56, 56, 64).astype(np.float32)
+    xt = g(x, dev)
+    layer(xt).backward(g(dy, dev))
+    xr = torch.tensor(x).permute(0, 3, 1, 2).double()
+    dyr = torch.tensor(dy).permute(0, 3, 1, 2).double()
+    wr = torch.nn.grad.conv2d_weight(xr, (64, 64, 3, 3), dyr, padding=1).permute(2, 3, 1, 0)
+    close(layer.kernel.grad, wr, 2e-5, "wgrad split-K")
+
+
+@pytest.mark.parametrize("c,relu,scale", [(64, True, True), (3, False, False), (32, False, True), (100, True, True)])
+def test_batchnorm_train(dev, c, relu, scale):
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(c)
+    x = (rs.randn(4, 9, 11, c) * 2 + 0.5).astype(np.float32)
+    bn = L.BatchNormalization(c, epsilon=2e-5, scale=scale, relu=relu).to(dev).train()
+    gam = rs.rand(c).astype(np.float32) + 0.5
+    bet = rs.randn(c).astype(np.float32) * 0.3
+    with torch.no_grad():
+        if scale:
+            bn.gamma.copy_(g(gam, dev))
+        bn.beta.copy_(g(bet, dev))
+    xt = g(x, dev).requires_grad_(True)
+    y = bn(xt)
+    P = {"b/beta": torch.tensor(bet, dtype=torch.float64, requires_grad=True)}
+    if scale:
+        P["b/gamma"] = torch.tensor(gam, dtype=torch.float64, requires_grad=True)
+    P["b/moving_mean"] = torch.zeros(c, dtype=torch.float64)
+    P["b/moving_variance"] = torch.ones(c, dtype=torch.float64)
+    ctx = OB.Ctx(P, training=True)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = OB.batchnorm(ctx, "b", xr, eps=2e-5, scale=scale)
+    if relu:
+        yr = torch.relu(yr)
+    close(y, yr, 1e-5, "bn fwd")
+    close(bn.moving_mean, ctx.new_stats["b/moving_mean"], 1e-5, "moving mean")
+    close(bn.moving_variance, ctx.new_stats["b/moving_variance"], 1e-5, "moving var")
+    dy = rs.randn(*x.shape).astype(np.float32)
+    y.backward(g(dy, dev))
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    close(xt.grad, xr.grad, 2e-5, "bn dx")
+    close(bn.beta.grad, P["b/beta"].grad, 2e-5, "dbeta")
+    if scale:
+        close(bn.gamma.grad, P["b/gamma"].grad, 2e-5, "dgamma")
+    # inference mode uses the moving statistics
+    bn.eval()
+    yi = bn(g(x, dev))
+    ctx2 = OB.Ctx({k: (ctx.new_stats[k] if k in ctx.new_stats else v.detach()) for k, v in P.items()}, training=False)
+    yri = OB.batchnorm(ctx2, "b", torch.tensor(x, dtype=torch.float64), eps=2e-5, scale=scale)
+    close(yi, torch.relu(yri) if relu else yri, 1e-5, "bn infer")
+
+
+@pytest.mark.parametrize("k,s,pad,h,w", [(2, 2, 0, 12, 12), (2, 2, 0, 13, 11), (3, 2, 1, 16, 16), (3, 2, 1, 15, 17)])
+def test_maxpool(dev, k, s, pad, h, w):
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(k * 100 + h)
+    x = np.maximum(rs.randn(3, h, w, 20), 0).astype(np.float32)       # post-ReLU: many exact-zero ties
+    xt = g(x, dev).requires_grad_(True)
+    y = L.MaxPool2D(k, s, zero_pad=pad)(xt)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = OB.maxpool(xr, k, s, zero_pad=pad)
+    assert torch.equal(y.detach().cpu().double(), yr.detach())
+    dy = rs.randn(*yr.shape).astype(np.float32)
+    y.backward(g(dy, dev))
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    close(xt.grad, xr.grad, 1e-6, "maxpool dx")
+
+
+def test_dense_gap_add_l2(dev):
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(4)
+    for m, i, o, relu in [(32, 9216, 256, True), (8, 512, 128, True), (5, 70, 33, False), (128, 12800, 512, True)]:
+        d = L.Dense(i, o, activation="relu" if relu else None).to(dev)
+        x = rs.randn(m, i).astype(np.float32)
+        xt = g(x, dev).requires_grad_(True)
+        y = d(xt)
+        wr = d.kernel.detach().cpu().double().requires_grad_(True)
+        br = d.bias.detach().cpu().double().requires_grad_(True)
+        xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        yr = xr @ wr + br
+        if relu:
+            yr = torch.relu(yr)
+        close(y, yr, 2e-5, "dense fwd")
+        dy = rs.randn(m, o).astype(np.float32)
+        y.backward(g(dy, dev))
+        yr.backward(torch.tensor(dy, dtype=torch.float64))
+        close(xt.grad, xr.grad, 2e-5, "dense dx")
+        close(d.kernel.grad, wr.grad, 2e-5, "dense dw")
+        close(d.bias.grad, br.grad, 2e-5, "dense db")
+    x = rs.randn(4, 7, 7, 96).astype(np.float32)
+    xt = g(x, dev).requires_grad_(True)
+    y = L.GlobalAveragePooling2D()(xt)
+    close(y, torch.tensor(x).double().mean(dim=(1, 2)), 1e-6, "gap")
+    y.sum().backward()
+    close(xt.grad, torch.full(x.shape, 1 / 49.0, dtype=torch.float64), 1e-6, "gap dx")
+    a, b = rs.randn(1000).astype(np.float32), rs.randn(1000).astype(np.float32)
+    assert np.array_equal(L.add(g(a, dev), g(b, dev)).cpu().numpy(), a + b)
+    w = g(rs.randn(3, 3, 16, 8), dev).requires_grad_(True)
+    pen = L.l2_penalty(w, 2e-4)
+    close(pen, 2e-4 * (w.detach().cpu().double() ** 2).sum(), 1e-6, "l2 penalty")
+    (pen * 2).backward()
+    close(w.grad, 2 * 2 * 2e-4 * w.detach().cpu().double(), 1e-6, "l2 grad")
+
+
+def _oracle_from(model, training, dtype=torch.float64):
+    from embeddingnet_amd.backbones import keras_weights
+    params = {k: v.detach().cpu().to(dtype).requires_grad_(v.requires_grad) for k, v in keras_weights(model).items()}
+    return OB.Ctx(params, training=training)
+
+
+@pytest.mark.parametrize("name,shape,enc,batch", [("simple", (73, 73, 3), 64, 6), ("simple2", (64, 64, 3), 64, 8),
+                                                   ("resnet18", (64, 64, 3), 64, 8), ("resnet50", (64, 64, 3), 32, 4)])
+def test_backbone_forward_backward_vs_oracle(dev, name, shape, enc, batch):
+    from embeddingnet_amd import backbones as B
+    base, backbone = B.get_backbone(shape, encodings_len=enc, backbone_name=name, backbone_weights=None, seed=1,
+                                    device=dev)
+    for m in base.modules():
+        if hasattr(m, "enabled"):
+            m.enabled = False                         # dropout off for parity
+    rs = np.random.RandomState(0)
+    x = rs.rand(batch, *shape).astype(np.float32)
+    base.train()
+    emb = base(g(x, dev))
+    ctx = _oracle_from(base, training=True)
+    embr = OB.base_model(ctx, torch.tensor(x, dtype=torch.float64), backbone_name=name, encodings_len=enc)
+    close(emb, embr, 2e-4, f"{name} embeddings (train mode)")
+    wgt = rs.randn(batch, enc).astype(np.float32)
+    (emb * g(wgt, dev)).sum().backward()
+    (embr * torch.tensor(wgt, dtype=torch.float64)).sum().backward()
+    got = B.keras_weights(base)
+    # fp32 noise floor of this very network: the same oracle run in float32 vs float64.  Max-pool
+    # arg-max and ReLU decisions that flip between precisions move a few gradients by ~1e-2 in ANY
+    # fp32 implementation (tools/diag_backbone.py prints both columns), so the bound is relative to it.
+    ctx32 = _oracle_from(base, training=True, dtype=torch.float32)
+    emb32 = OB.base_model(ctx32, torch.tensor(x), backbone_name=name, encodings_len=enc)
+    (emb32 * torch.tensor(wgt)).sum().backward()
+    for k, p in ctx.params.items():
+        if p.grad is None:
+            continue
+        scale = max(p.grad.abs().max().item(), 1e-12)
+        err = (got[k].grad.detach().cpu().double() - p.grad).abs().max().item() / scale
+        floor = (ctx32.params[k].grad.double() - p.grad).abs().max().item() / scale
+        assert err < 3 * floor + 1e-4, f"{name}: grad {k} rel err {err:.2e} (fp32 oracle floor {floor:.2e})"
+    # inference path (moving stats) through Model.predict
+    pred = base.predict(x)
+    ctx_i = _oracle_from(base, training=False)
+    embi = OB.base_model(ctx_i, torch.tensor(x, dtype=torch.float64), backbone_name=name, encodings_len=enc)
+    close(pred, embi, 2e-4, f"{name} predict()")
+
+
+def test_fused_step_loss_and_grads_vs_oracle(dev):
+    """simple2 @64x64, P=8,K=4, hardest mining: total loss (triplet mean + regularisers) and all
+    parameter gradients vs the oracle composition embeddings -> sklearn-style matrix -> mining -> hinge."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.train_step import TripletTrainer
+    p, k, enc, m = 8, 4, 64, 0.5
+    base, _ = B.get_backbone((64, 64, 3), encodings_len=enc, backbone_name="simple2", backbone_weights=None,
+                             seed=2, device=dev)
+    for mod in base.modules():
+        if hasattr(mod, "enabled"):
+            mod.enabled = False
+    rs = np.random.RandomState(1)
+    cls = rs.rand(p, 64, 64, 3)
+    x = np.clip(np.repeat(cls, k, axis=0) + 0.15 * rs.randn(p * k, 64, 64, 3), 0, 1).astype(np.float32)
+    tr = TripletTrainer(base, None, p, k, margin=m, negatives_selection_mode="hardest")
+    base.train()
+    total, mean, count = tr.loss(g(x, dev))
+    total.backward()
+    ctx = _oracle_from(base, training=True)
+    embr = OB.base_model(ctx, torch.tensor(x, dtype=torch.float64), backbone_name="simple2", encodings_len=enc)
+    mined = omining.mine_from_embeddings(embr.detach().numpy().astype(np.float32), p, k, m, "hardest")
+    t = mined["triplets"]
+    assert int(count.item()) == len(t)
+    yr = torch.cat([embr[t[:, 0]], embr[t[:, 1]], embr[t[:, 2]]], dim=1)
+    e = enc
+    pos = ((yr[:, :e] - yr[:, e:2 * e]) ** 2).sum(1)
+    neg = ((yr[:, :e] - yr[:, 2 * e:]) ** 2).sum(1)
+    rows = torch.clamp(pos - neg + m, min=0)
+    np.testing.assert_allclose(rows.detach().numpy(), olosses.triplet_loss(m)(None, yr.detach().numpy()), rtol=1e-12)
+    total_r = rows.mean() + OB.regularisation(ctx)
+    # north_star: loss values within 1e-4 relative
+    assert abs(total.item() - total_r.item()) <= 1e-4 * abs(total_r.item()), (total.item(), total_r.item())
+    assert abs(mean.item() - rows.mean().item()) <= 1e-4 * abs(rows.mean().item())
+    total_r.backward()
+    got = B.keras_weights(base)
+    for kname, pr in ctx.params.items():
+        if pr.grad is None:
+            continue
+        gr = got[kname].grad.detach().cpu().double()
+        err = (gr - pr.grad).abs().max().item() / max(pr.grad.abs().max().item(), 1e-12)
+        assert err < 2e-3, f"grad {kname} rel err {err:.2e}"

@@ -1,0 +1,263 @@
+"""GPU parity: HIP loss path (through the C ABI) vs the oracle and the golden
+vectors captured from the reference.  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+from oracle import losses as olosses
+from oracle import mining as omining
+from oracle import pairwise as opair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+
+
+# ---------------------------------------------------------------- triplet loss
+@pytest.mark.parametrize("case", R.TRIPLET_CASES, ids=lambda c: c[0])
+def test_triplet_loss_golden(golden, dev, case):
+    from embeddingnet_amd.losses_and_accuracies import triplet_loss
+    name, t, e, m, kind, seed = case
+    y = R.triplet_rows(seed, t, e, kind)
+    yt = _t(y, dev).requires_grad_(True)
+    loss = triplet_loss(m)(None, yt)
+    ref = golden("triplet_loss")[f"{name}/loss"]
+    # fp32 wave-tree sums of <=512 squares of O(1) values vs the f64 reference
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    up = np.linspace(0.5, 1.5, t).astype(np.float32)
+    loss.backward(_t(up, dev))
+    gref = olosses.triplet_loss_grad(m, y, up)
+    # rows within fp32 noise of the hinge corner may flip; exclude |basic| < 1e-5
+    a, p, n = y[:, :e].astype(np.float64), y[:, e:2 * e].astype(np.float64), y[:, 2 * e:].astype(np.float64)
+    basic = ((a - p) ** 2).sum(1) - ((a - n) ** 2).sum(1) + m
+    keep = np.abs(basic) > 1e-5
+    np.testing.assert_allclose(yt.grad.cpu().numpy()[keep], gref[keep], rtol=1e-5, atol=1e-6)
+
+
+def test_triplet_loss_edges(golden, dev):
+    from embeddingnet_amd.losses_and_accuracies import triplet_loss
+    g = golden("triplet_loss")
+    y = _t(g["edge/y_pred"], dev).requires_grad_(True)
+    loss = triplet_loss(0.5)(None, y)
+    assert np.array_equal(loss.detach().cpu().numpy(), g["edge/loss"].astype(np.float32))  # exact values
+    loss.sum().backward()
+    gref = olosses.triplet_loss_grad(0.5, g["edge/y_pred"], np.ones(6))
+    assert np.array_equal(y.grad.cpu().numpy(), gref.astype(np.float32))   # incl. the exact-zero hinge row
+
+
+# ---------------------------------------------------------------- contrastive / accuracy
+@pytest.mark.parametrize("name", [c[0] for c in R.SIAMESE_CASES] + ["edge"])
+def test_contrastive_accuracy_golden(golden, dev, name):
+    from embeddingnet_amd.losses_and_accuracies import accuracy, contrastive_loss
+    g = golden("siamese_losses")
+    y, d = g[f"{name}/y_true"], g[f"{name}/y_pred"]
+    dt = _t(d, dev).requires_grad_(True)
+    loss = contrastive_loss(_t(y, dev), dt)
+    np.testing.assert_allclose(loss.item(), g[f"{name}/contrastive"], rtol=1e-5)
+    assert accuracy(_t(y, dev), dt).item() == pytest.approx(float(g[f"{name}/accuracy"]), abs=1e-7)
+    loss.backward()
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), olosses.contrastive_loss_grad(y, d), rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------- pairwise distances
+@pytest.mark.parametrize("case", R.PAIRWISE_CASES, ids=lambda c: c[0])
+def test_pairwise_golden(golden, dev, case):
+    from embeddingnet_amd import ops
+    name, n, e, seed, dup = case
+    x = R.pairwise_input(n, e, seed, dup)
+    ref = golden("pairwise_distances")[f"{name}/D"]
+    d2 = ops.pairwise_distances(_t(x, dev), squared=True).cpu().numpy()
+    d = ops.pairwise_distances(_t(x, dev)).cpu().numpy()
+    assert np.all(np.diag(d) == 0) and np.all(d >= 0)
+    np.testing.assert_array_equal(d, d.T)
+    # unit non-negative rows: the MFMA result is a k-ordered f32 fmaf chain of length E whose partial
+    # sums grow monotonically, so the error random-walks as ~sqrt(E)*2^-24 (sklearn accumulates in f64):
+    # 2e-6 up to E=512, scaled by sqrt(E/512) (x2 margin) beyond.
+    atol = 2e-6 if e <= 512 else 4e-6 * (e / 512) ** 0.5
+    np.testing.assert_allclose(d2, ref.astype(np.float64) ** 2, rtol=0, atol=atol)
+    np.testing.assert_allclose(d, ref, rtol=1e-4, atol=2e-3)
+
+
+def test_pairwise_ragged_and_asymmetric(dev):
+    """Non-multiple-of-tile N, E not a multiple of 4 (scalar loader), raw randn rows."""
+    from embeddingnet_amd import ops
+    rs = np.random.RandomState(5)
+    for n, e in [(1, 3), (7, 5), (65, 33), (130, 70), (257, 258)]:
+        x = rs.randn(n, e).astype(np.float32)
+        ref = opair.pairwise_sqdist(x)
+        d2 = ops.pairwise_distances(_t(x, dev), squared=True).cpu().numpy()
+        np.testing.assert_allclose(d2, ref, rtol=1e-5, atol=1e-4 * e / 32)
+
+
+def test_pairwise_large_properties(dev):
+    """Sweep-size matrix (N=4096, E=512): symmetry, zero diagonal, triangle spot checks vs f64 rows."""
+    from embeddingnet_amd import ops
+    rs = np.random.RandomState(7)
+    x = R.unit_nonneg_rows(rs, 4096, 512)
+    d = ops.pairwise_distances(_t(x, dev))
+    assert torch.equal(d, d.t()) and torch.all(torch.diagonal(d) == 0)
+    idx = rs.randint(0, 4096, size=(64, 2))
+    got = d.cpu().numpy()[idx[:, 0], idx[:, 1]]
+    want = np.linalg.norm(x[idx[:, 0]].astype(np.float64) - x[idx[:, 1]].astype(np.float64), axis=1)
+    want[idx[:, 0] == idx[:, 1]] = 0
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
+
+
+# ---------------------------------------------------------------- mining
+def _unpack_mask(mask, nneg):
+    m = mask.cpu().numpy().astype(np.uint32)
+    bits = ((m[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)
+    return bits.reshape(m.shape[0], -1)[:, :nneg]
+
+
+@pytest.mark.parametrize("case", R.MINING_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", R.MINING_MODES)
+def test_mining_on_reference_matrix(golden, dev, case, mode):
+    """Same f32 distance matrix the reference saw -> index work must be bit-exact."""
+    from embeddingnet_amd import ops
+    name, p, k, e, m, sigma, seed = case
+    g = golden("mining")
+    key = f"{name}/{mode}"
+    dist = _t(g[f"{name}/D"], dev)
+    trip, count, sel, mask = ops.mine_triplets(dist, p, k, m, mode, seed=1234, with_candidates=True)
+    t = int(count.item())
+    trip = trip.cpu().numpy()[:t]
+    sel = sel.cpu().numpy()
+    cand = _unpack_mask(mask, p * k - k)
+    ref_trip = g[f"{key}/triplets"]
+    assert t == len(ref_trip)
+    if bool(g[f"{key}/fallback"]):
+        assert np.array_equal(trip, ref_trip) and np.all(sel < 0)
+        return
+    if mode == "hardest":
+        assert np.array_equal(trip, ref_trip)
+    else:
+        assert np.array_equal(cand, g[f"{key}/candidates"])           # candidate sets exact
+        assert np.array_equal(trip[:, :2], ref_trip[:, :2])           # same active pairs, same order
+        o = omining.mine_triplets(g[f"{name}/D"], p, k, m, mode, rng=np.random.RandomState(0))
+        act = np.where(o["selected"] >= 0)[0]
+        for row, pair in zip(trip, act):                              # pick lies in the candidate set
+            lo = (pair // (k * (k - 1) // 2)) * k
+            q = row[2] if row[2] < lo else row[2] - k
+            assert cand[pair, q]
+
+
+def test_mining_random_pick_is_uniform(golden, dev):
+    """chi-square over seeds on a pair with several semihard candidates."""
+    from embeddingnet_amd import ops
+    g = golden("mining")
+    p, k, m = 8, 4, 0.5
+    dist = _t(g["c1_8x4_saturated/D"], dev)
+    cand = g["c1_8x4_saturated/semihard/candidates"]
+    pair = int(np.argmax(cand.sum(1)))
+    ncand = int(cand[pair].sum())
+    assert ncand >= 4
+    counts = {}
+    trials = 400
+    for seed in range(trials):
+        _, _, sel = ops.mine_triplets(dist, p, k, m, "semihard", seed=seed)
+        s = int(sel[pair].item())
+        counts[s] = counts.get(s, 0) + 1
+    lo = (pair // 6) * k
+    for s in counts:
+        assert cand[pair, s if s < lo else s - k]
+    exp = trials / ncand
+    chi2 = sum((counts.get(c, 0) - exp) ** 2 / exp for c in
+               [q if q < lo else q + k for q in np.where(cand[pair])[0]])
+    from scipy.stats import chi2 as chi2dist
+    assert chi2 < chi2dist.ppf(0.999, ncand - 1), (chi2, counts)
+
+
+def test_mining_end_to_end_from_embeddings(golden, dev):
+    """GPU distance matrix + GPU mining vs the reference's triplets on tie-free inputs."""
+    from embeddingnet_amd import ops
+    for name, p, k, e, m, sigma, seed in R.MINING_CASES[:5]:
+        g = golden("mining")
+        x = R.clustered_embeddings(seed, p, k, e, sigma)
+        d = ops.pairwise_distances(_t(x, dev))
+        trip, count, _ = ops.mine_triplets(d, p, k, m, "hardest")
+        got = trip.cpu().numpy()[: int(count.item())]
+        ref = g[f"{name}/hardest/triplets"]
+        if got.shape == ref.shape and np.array_equal(got, ref):
+            continue
+        # any difference must sit on an fp32-borderline decision of the reference's loss values
+        lv = g[f"{name}/hardest/loss_values"]
+        srt = np.sort(lv, axis=1)
+        border = (np.abs(srt[:, -1]) < 1e-4) | (srt[:, -1] - srt[:, -2] < 1e-4)
+        assert border.any(), f"{name}: triplets differ without a borderline pair"
+
+
+def test_batch_hard_vs_oracle(dev):
+    from embeddingnet_amd import ops
+    x = R.clustered_embeddings(3, 32, 4, 256, 0.3)
+    d = opair.pairwise_distances(x)
+    trip, count = ops.batch_hard(_t(d, dev), 32, 4)
+    assert int(count.item()) == 128
+    assert np.array_equal(trip.cpu().numpy(), omining.batch_hard(d, 32, 4))
+
+
+# ---------------------------------------------------------------- gather-form loss
+@pytest.mark.parametrize("p,k,e", [(8, 4, 256), (32, 4, 256), (64, 4, 512)])
+def test_triplet_gather_loss_matches_concat_form(dev, p, k, e):
+    from embeddingnet_amd import ops
+    x = R.clustered_embeddings(1, p, k, e, 0.25)
+    d = opair.pairwise_distances(x)
+    o = omining.mine_triplets(d, p, k, 0.5, "hardest")
+    tr = o["triplets"]
+    y = np.concatenate([x[tr[:, 0]], x[tr[:, 1]], x[tr[:, 2]]], axis=1)
+    ref_rows = olosses.triplet_loss(0.5)(None, y)
+    ref_grad_y = olosses.triplet_loss_grad(0.5, y, np.full(len(tr), 1.0 / len(tr)))
+    ref_demb = np.zeros((p * k, e))
+    for i, (a, pp, n) in enumerate(tr):
+        ref_demb[a] += ref_grad_y[i, :e]
+        ref_demb[pp] += ref_grad_y[i, e:2 * e]
+        ref_demb[n] += ref_grad_y[i, 2 * e:]
+    emb = _t(x, dev).requires_grad_(True)
+    trip, count, _ = ops.mine_triplets(_t(d, dev), p, k, 0.5, "hardest")
+    mean, rows = ops.triplet_gather_loss(emb, trip, count, 0.5)
+    t = int(count.item())
+    assert t == len(tr)
+    np.testing.assert_allclose(rows.cpu().numpy()[:t], ref_rows, rtol=2e-5, atol=2e-6)
+    assert np.all(rows.cpu().numpy()[t:] == 0)
+    np.testing.assert_allclose(mean.item(), ref_rows.mean(), rtol=2e-5)
+    (mean * 3.0).backward()
+    np.testing.assert_allclose(emb.grad.cpu().numpy(), 3.0 * ref_demb, rtol=2e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------- heads
+def test_l2_normalize_and_pair_distance(dev):
+    from embeddingnet_amd import ops
+    rs = np.random.RandomState(9)
+    x = rs.randn(37, 300).astype(np.float32)
+    x[5] = 0                                   # clamped branch: sum x^2 < 1e-12
+    xt = _t(x, dev).requires_grad_(True)
+    y = ops.l2_normalize(xt)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = xr * torch.rsqrt(torch.clamp((xr * xr).sum(1, keepdim=True), min=1e-12))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-7)
+    w = rs.randn(37, 300)
+    (y * _t(w, dev)).sum().backward()
+    (yr * torch.tensor(w)).sum().backward()
+    np.testing.assert_allclose(xt.grad.cpu().numpy()[np.arange(37) != 5], xr.grad.numpy()[np.arange(37) != 5],
+                               rtol=2e-4, atol=2e-5)
+    e1 = rs.rand(16, 256).astype(np.float32)
+    e2 = rs.rand(16, 256).astype(np.float32)
+    e2[3] = e1[3]                              # epsilon branch
+    t1, t2 = _t(e1, dev).requires_grad_(True), _t(e2, dev).requires_grad_(True)
+    d = ops.pair_distance(t1, t2)
+    r1, r2 = torch.tensor(e1, dtype=torch.float64, requires_grad=True), torch.tensor(e2, dtype=torch.float64, requires_grad=True)
+    dr = torch.sqrt(torch.clamp(((r1 - r2) ** 2).sum(1, keepdim=True), min=1e-7))
+    np.testing.assert_allclose(d.detach().cpu().numpy(), dr.detach().numpy(), rtol=1e-5)
+    d.sum().backward()
+    dr.sum().backward()
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), r1.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), r2.grad.numpy(), rtol=1e-4, atol=1e-6)
