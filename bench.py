@@ -30,12 +30,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole machine and oversubscribes the thread pool)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args):
     """The oracle's reference-structured step (oracle/step.py) timed on this box's host cores, on a
     bounded sample: same backbone / resolution / K, P reduced so that a step takes seconds."""
     import numpy as np
     from oracle.step import ReferenceStep
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     p, k = args.cpu_classes, args.k_samples
     ref = ReferenceStep(args.backbone, (args.image, args.image, 3), args.encodings_len, p, k, args.margin,
@@ -45,7 +58,7 @@ def cpu_baseline(args):
     x = rs.rand(p * k, args.image, args.image, 3).astype(np.float32)
     ref.step(x, rng=np.random.RandomState(0))                    # warm-up (allocator, thread pool)
     t0, n, trip = time.perf_counter(), 0, 0
-    while n < 2 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
+    while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
         _, t = ref.step(x, rng=np.random.RandomState(n))
         n += 1
         trip += t
@@ -134,6 +147,10 @@ def main():
         for name, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms_total"]):
             log(f"  {name:42s} launches {d['launches']:5d}  avg {1e3 * d['ms_total'] / d['launches']:9.1f} us  "
                 f"{d['flops_total'] / d['ms_total'] / 1e9:7.1f} TFLOP/s  share {d['ms_total'] / (1e3 * elapsed):5.1%}")
+        if os.environ.get("EMBNET_BENCH_DETAIL"):
+            for name, d in sorted(timer.detail().items(), key=lambda kv: -kv[1]["ms_total"]):
+                log(f"    {name:86s} x{d['launches'] // args.steps:2d}  avg {1e3 * d['ms_total'] / d['launches']:8.1f} us  "
+                    f"{d['flops_total'] / d['ms_total'] / 1e9:6.1f} TF/s")
         conv_ms = sum(d["ms_total"] for d in summ.values())
         log(f"  conv kernels total {conv_ms / args.steps:.2f} ms of {ms_per_step:.2f} ms per step")
         name, d = max(summ.items(), key=lambda kv: kv[1]["ms_total"])

@@ -10,6 +10,8 @@
 //   wgrad dW[(r,s,c)][k]   = sum_{(n,oh,ow)} X[n, oh*st+r-pt, ow*st+s-pl, c] * dY[(n,oh,ow)][k]
 //         A = gather of X (KM: c contiguous), B = dY as stored (KM); split-K over workgroups into
 //         fp32 slabs + a fixed-order reduce (bitwise reproducible, no float atomics)
+// All gathers are branch-free buffer loads: padding taps, rows past the edge and k past the end get
+// an out-of-range offset and read as 0 (gemm_engine.h).  VEC = 16-byte gathers (channel count % 4 == 0).
 // Roofline: MFMA f32 (157.3 TFLOP/s); algorithmic FLOP = 2 * N*OH*OW * K * R*S*C per pass.
 #include "gemm_engine.h"
 #include "../../include/embnet.h"
@@ -36,7 +38,7 @@ struct ConvGeom {
 
 constexpr int ROW_INVALID = -(1 << 28);
 
-// Decode gemm-k index kk -> (rs, inner) where inner size is `inner` (C for fwd, K for dgrad).
+// gemm-k index kk -> (r, s, inner) with `dinner` the divider of the inner size (C for fwd, K for dgrad)
 __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const FastDiv& dS, int& r, int& s, int& c) {
   uint32_t rs, cc; dinner.divmod((uint32_t)kk, rs, cc);
   uint32_t rr, ss; dS.divmod(rs, rr, ss);
@@ -44,185 +46,163 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
 }
 
 // ---- forward A: rows = output pixels, k = (r,s,c) -------------------------------------------
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadConvFwdA {
   using Tile = TileKC<ROWS>;
-  const float* x; int H, W, C, Kg; bool vec; FastDiv dC, dS; int tid;
-  int base[Tile::PASSES], ih0[Tile::PASSES], iw0[Tile::PASSES];
-  __device__ void init(const float* x_, const ConvGeom& g, int m0, int tid_) {
-    x = x_; H = g.H; W = g.W; C = g.C; Kg = g.R * g.S * g.C; dC = g.dC; dS = g.dS; tid = tid_;
-    vec = ((g.C & 3) == 0) && ((reinterpret_cast<uintptr_t>(x_) & 15) == 0);
+  Buf buf; int H, W, C, Kg; FastDiv dC, dS; int tid;
+  unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
+  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_) {
+    buf.init(x, (size_t)g.N * g.H * g.W * g.C * 4);
+    H = g.H; W = g.W; C = g.C; Kg = g.R * g.S * g.C; dC = g.dC; dS = g.dS; tid = tid_;
     const int M = g.N * g.OH * g.OW;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int m = m0 + Tile::row_of(tid, p);
-      if (m < M) {
-        uint32_t n, rem, oh, ow;
-        g.dOHW.divmod((uint32_t)m, n, rem); g.dOW.divmod(rem, oh, ow);
-        base[p] = (int)n * g.H * g.W * g.C;
-        ih0[p] = (int)oh * g.stride - g.pad_t; iw0[p] = (int)ow * g.stride - g.pad_l;
-      } else { base[p] = 0; ih0[p] = ROW_INVALID; iw0[p] = 0; }
+      uint32_t n, rem, oh, ow;
+      g.dOHW.divmod((uint32_t)min(m, M - 1), n, rem); g.dOW.divmod(rem, oh, ow);
+      base[p] = 4u * n * (unsigned)(g.H * g.W * g.C);
+      ih0[p] = m < M ? (int)oh * g.stride - g.pad_t : ROW_INVALID;
+      iw0[p] = (int)ow * g.stride - g.pad_l;
     }
   }
-  __device__ __forceinline__ float at(int p, int kk) const {
-    if (kk >= Kg) return 0.f;
+  __device__ __forceinline__ unsigned off(int p, int kk) const {
     int r, s, c; split_k(kk, dC, dS, r, s, c);
     const int ih = ih0[p] + r, iw = iw0[p] + s;
-    if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return 0.f;
-    return x[base[p] + (ih * W + iw) * C + c];
+    const bool ok = kk < Kg && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    return ok ? base[p] + 4u * (unsigned)((ih * W + iw) * C + c) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
-    if (vec) {
+    if (VEC) {
       int r, s, c; split_k(kk, dC, dS, r, s, c);
       const bool kin = kk < Kg;
 #pragma unroll
       for (int p = 0; p < Tile::PASSES; ++p) {
         const int ih = ih0[p] + r, iw = iw0[p] + s;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kin && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-          v = *reinterpret_cast<const float4*>(x + base[p] + (ih * W + iw) * C + c);
-        rg[p] = v;
+        const bool ok = kin && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        rg[p] = buf.ld4(ok ? base[p] + 4u * (unsigned)((ih * W + iw) * C + c) : OOB);
       }
     } else {
 #pragma unroll
       for (int p = 0; p < Tile::PASSES; ++p)
-        rg[p] = make_float4(at(p, kk), at(p, kk + 1), at(p, kk + 2), at(p, kk + 3));
+        rg[p] = make_float4(buf.ld1(off(p, kk)), buf.ld1(off(p, kk + 1)), buf.ld1(off(p, kk + 2)),
+                            buf.ld1(off(p, kk + 3)));
     }
   }
 };
 
 // ---- dgrad A: rows = input pixels, k = (r,s,kout) ---------------------------------------------
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadConvDgradA {
   using Tile = TileKC<ROWS>;
-  const float* dy; int OH, OW, K, Kg, stride; bool vec; FastDiv dK, dS; int tid;
-  int base[Tile::PASSES], ih0[Tile::PASSES], iw0[Tile::PASSES];
-  __device__ void init(const float* dy_, const ConvGeom& g, int m0, int tid_) {
-    dy = dy_; OH = g.OH; OW = g.OW; K = g.K; Kg = g.R * g.S * g.K; stride = g.stride; dK = g.dK; dS = g.dS; tid = tid_;
-    vec = ((g.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(dy_) & 15) == 0);
+  Buf buf; int OH, OW, K, Kg, stride; FastDiv dK, dS; int tid;
+  unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
+  __device__ void init(const float* dy, const ConvGeom& g, int m0, int tid_) {
+    buf.init(dy, (size_t)g.N * g.OH * g.OW * g.K * 4);
+    OH = g.OH; OW = g.OW; K = g.K; Kg = g.R * g.S * g.K; stride = g.stride; dK = g.dK; dS = g.dS; tid = tid_;
     const int M = g.N * g.H * g.W;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int m = m0 + Tile::row_of(tid, p);
-      if (m < M) {
-        uint32_t n, rem, h, w;
-        g.dHW.divmod((uint32_t)m, n, rem); g.dW.divmod(rem, h, w);
-        base[p] = (int)n * g.OH * g.OW * g.K;
-        ih0[p] = (int)h + g.pad_t; iw0[p] = (int)w + g.pad_l;
-      } else { base[p] = 0; ih0[p] = ROW_INVALID; iw0[p] = 0; }
+      uint32_t n, rem, h, w;
+      g.dHW.divmod((uint32_t)min(m, M - 1), n, rem); g.dW.divmod(rem, h, w);
+      base[p] = 4u * n * (unsigned)(g.OH * g.OW * g.K);
+      ih0[p] = m < M ? (int)h + g.pad_t : ROW_INVALID;
+      iw0[p] = (int)w + g.pad_l;
     }
   }
-  // output-pixel coordinate feeding input (h,w) through tap (r,s); false when none does
-  __device__ __forceinline__ bool src(int p, int r, int s, int& off) const {
+  // byte offset of dY feeding input row p through tap (r,s), channel c; OOB when no output pixel does
+  __device__ __forceinline__ unsigned src(int p, int r, int s, int c, bool kin) const {
     int th = ih0[p] - r, tw = iw0[p] - s;
-    if (th < 0 || tw < 0) return false;
-    if (stride != 1) {
-      if (stride == 2) { if ((th | tw) & 1) return false; th >>= 1; tw >>= 1; }
-      else { if (th % stride || tw % stride) return false; th /= stride; tw /= stride; }
-    }
-    if (th >= OH || tw >= OW) return false;
-    off = base[p] + (th * OW + tw) * K;
-    return true;
+    bool ok = kin && th >= 0 && tw >= 0;
+    if (stride == 2) { ok = ok && (((th | tw) & 1) == 0); th >>= 1; tw >>= 1; }
+    else if (stride != 1) { ok = ok && (th % stride == 0) && (tw % stride == 0); th /= stride; tw /= stride; }
+    ok = ok && th < OH && tw < OW;
+    return ok ? base[p] + 4u * (unsigned)((th * OW + tw) * K + c) : OOB;
   }
-  __device__ __forceinline__ float at(int p, int kk) const {
-    if (kk >= Kg) return 0.f;
-    int r, s, c, off; split_k(kk, dK, dS, r, s, c);
-    return src(p, r, s, off) ? dy[off + c] : 0.f;
+  __device__ __forceinline__ unsigned off(int p, int kk) const {
+    int r, s, c; split_k(kk, dK, dS, r, s, c);
+    return src(p, r, s, c, kk < Kg);
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
-    if (vec) {
+    if (VEC) {
       int r, s, c; split_k(kk, dK, dS, r, s, c);
       const bool kin = kk < Kg;
 #pragma unroll
-      for (int p = 0; p < Tile::PASSES; ++p) {
-        int off; float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kin && src(p, r, s, off)) v = *reinterpret_cast<const float4*>(dy + off + c);
-        rg[p] = v;
-      }
+      for (int p = 0; p < Tile::PASSES; ++p) rg[p] = buf.ld4(src(p, r, s, c, kin));
     } else {
 #pragma unroll
       for (int p = 0; p < Tile::PASSES; ++p)
-        rg[p] = make_float4(at(p, kk), at(p, kk + 1), at(p, kk + 2), at(p, kk + 3));
+        rg[p] = make_float4(buf.ld1(off(p, kk)), buf.ld1(off(p, kk + 1)), buf.ld1(off(p, kk + 2)),
+                            buf.ld1(off(p, kk + 3)));
     }
   }
 };
 
 // ---- dgrad B: rows = input channel c, k = (r,s,kout): W[((r*S+s)*C + c)*K + kout] ------------
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadConvDgradB {
   using Tile = TileKC<ROWS>;
-  const float* w; int C, K, Kg; bool vec; FastDiv dK; int row0, tid;
-  __device__ void init(const float* w_, const ConvGeom& g, int n0, int tid_) {
-    w = w_; C = g.C; K = g.K; Kg = g.R * g.S * g.K; dK = g.dK; row0 = n0; tid = tid_;
-    vec = ((g.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(w_) & 15) == 0);
+  Buf buf; int C, K, Kg; FastDiv dK; int row0, tid;
+  __device__ void init(const float* w, const ConvGeom& g, int n0, int tid_) {
+    buf.init(w, (size_t)g.R * g.S * g.C * g.K * 4);
+    C = g.C; K = g.K; Kg = g.R * g.S * g.K; dK = g.dK; row0 = n0; tid = tid_;
   }
-  __device__ __forceinline__ float at(int c, int kk) const {
-    if (kk >= Kg || c >= C) return 0.f;
+  __device__ __forceinline__ unsigned off(int c, int kk) const {
     uint32_t rs, ko; dK.divmod((uint32_t)kk, rs, ko);
-    return w[((long)rs * C + c) * K + ko];
+    return (kk < Kg && c < C) ? 4u * ((rs * (unsigned)C + (unsigned)c) * (unsigned)K + ko) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
-    uint32_t rs, ko; dK.divmod((uint32_t)kk, rs, ko);
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int c = row0 + Tile::row_of(tid, p);
-      if (vec) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < Kg && c < C) v = *reinterpret_cast<const float4*>(w + ((long)rs * C + c) * K + ko);
-        rg[p] = v;
-      } else {
-        rg[p] = make_float4(at(c, kk), at(c, kk + 1), at(c, kk + 2), at(c, kk + 3));
-      }
+      if (VEC) rg[p] = buf.ld4(off(c, kk));
+      else rg[p] = make_float4(buf.ld1(off(c, kk)), buf.ld1(off(c, kk + 1)), buf.ld1(off(c, kk + 2)),
+                               buf.ld1(off(c, kk + 3)));
     }
   }
 };
 
 // ---- wgrad A: k = output pixel (n,oh,ow), rows = (r,s,c) ------------------------------------------
-template <int ROWS>
+template <int ROWS, bool VEC>
 struct LoadConvWgradA {
   using Tile = TileKM<ROWS>;
-  const float* x; int H, W, C, Mrows, Kg, stride, pad_t, pad_l; bool vec; FastDiv dOHW, dOW, dC, dS; int HWC; int tid;
-  int r_[Tile::PASSES], s_[Tile::PASSES], c_[Tile::PASSES];    // decoded first row of each pass
-  int m_[Tile::PASSES];
-  __device__ void init(const float* x_, const ConvGeom& g, int m0, int tid_) {
-    x = x_; H = g.H; W = g.W; C = g.C; Mrows = g.R * g.S * g.C; Kg = g.N * g.OH * g.OW;
+  Buf buf; int H, W, C, Mrows, Kg, stride, pad_t, pad_l; FastDiv dOHW, dOW, dC, dS; unsigned HWC4; int tid;
+  int r_[Tile::PASSES], s_[Tile::PASSES], c_[Tile::PASSES], m_[Tile::PASSES];    // first row of each pass
+  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_) {
+    buf.init(x, (size_t)g.N * g.H * g.W * g.C * 4);
+    H = g.H; W = g.W; C = g.C; Mrows = g.R * g.S * g.C; Kg = g.N * g.OH * g.OW;
     stride = g.stride; pad_t = g.pad_t; pad_l = g.pad_l; dOHW = g.dOHW; dOW = g.dOW; dC = g.dC; dS = g.dS;
-    HWC = g.H * g.W * g.C; tid = tid_;
-    vec = ((g.C & 3) == 0) && ((reinterpret_cast<uintptr_t>(x_) & 15) == 0);
+    HWC4 = 4u * (unsigned)(g.H * g.W * g.C); tid = tid_;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       m_[p] = m0 + Tile::row_of(tid, p);
       split_k(min(m_[p], Mrows - 1), dC, dS, r_[p], s_[p], c_[p]);
     }
   }
-  __device__ __forceinline__ float at(int m, int n, int oh, int ow) const {
-    if (m >= Mrows) return 0.f;
-    int r, s, c; split_k(m, dC, dS, r, s, c);
+  __device__ __forceinline__ unsigned off(int m, unsigned n, int oh, int ow, bool kin) const {
+    int r, s, c; split_k(min(m, Mrows - 1), dC, dS, r, s, c);
     const int ih = oh * stride + r - pad_t, iw = ow * stride + s - pad_l;
-    if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return 0.f;
-    return x[n * HWC + (ih * W + iw) * C + c];
+    const bool ok = kin && m < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    return ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int kg = kt * BK + Tile::k_of(tid, p);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kg < Kg) {
-        uint32_t n, rem, oh, ow;
-        dOHW.divmod((uint32_t)kg, n, rem); dOW.divmod(rem, oh, ow);
-        if (vec) {
-          const int ih = (int)oh * stride + r_[p] - pad_t, iw = (int)ow * stride + s_[p] - pad_l;
-          if (m_[p] < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-            v = *reinterpret_cast<const float4*>(x + (int)n * HWC + (ih * W + iw) * C + c_[p]);
-        } else {
-          v = make_float4(at(m_[p], n, oh, ow), at(m_[p] + 1, n, oh, ow), at(m_[p] + 2, n, oh, ow),
-                          at(m_[p] + 3, n, oh, ow));
-        }
+      const bool kin = kg < Kg;
+      uint32_t n, rem, oh, ow;
+      dOHW.divmod((uint32_t)(kin ? kg : 0), n, rem); dOW.divmod(rem, oh, ow);
+      if (VEC) {
+        const int ih = (int)oh * stride + r_[p] - pad_t, iw = (int)ow * stride + s_[p] - pad_l;
+        const bool ok = kin && m_[p] < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        rg[p] = buf.ld4(ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c_[p]) : OOB);
+      } else {
+        rg[p] = make_float4(buf.ld1(off(m_[p], n, oh, ow, kin)), buf.ld1(off(m_[p] + 1, n, oh, ow, kin)),
+                            buf.ld1(off(m_[p] + 2, n, oh, ow, kin)), buf.ld1(off(m_[p] + 3, n, oh, ow, kin)));
       }
-      rg[p] = v;
     }
   }
 };
@@ -230,7 +210,7 @@ struct LoadConvWgradA {
 // ---------------------------------------------------------------------------------------------
 struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; };
 
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
@@ -239,8 +219,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN, tiles_m = (M + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
-  LoadConvFwdA<G::BM> la; la.init(p.x, p.g, m0, threadIdx.x);
-  LoadRowsKM<G::BN> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
+  LoadConvFwdA<G::BM, VEC> la; la.init(p.x, p.g, m0, threadIdx.x);
+  LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -255,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
 
 struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; };
 
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
@@ -264,8 +244,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   const int tiles_n = (p.g.C + G::BN - 1) / G::BN, tiles_m = (M + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
-  LoadConvDgradA<G::BM> la; la.init(p.dy, p.g, m0, threadIdx.x);
-  LoadConvDgradB<G::BN> lb; lb.init(p.w, p.g, n0, threadIdx.x);
+  LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, m0, threadIdx.x);
+  LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -276,7 +256,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
 
 struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits; };
 
-template <class G>
+// VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
+template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
@@ -286,8 +267,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   const int kt_total = (Kg + BK - 1) / BK;
   const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
-  LoadConvWgradA<G::BM> la; la.init(p.x, p.g, m0, threadIdx.x);
-  LoadRowsKM<G::BN> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
+  LoadConvWgradA<G::BM, VA> la; la.init(p.x, p.g, m0, threadIdx.x);
+  LoadRowsKM<G::BN, VB> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
   float* out = p.out + (long)blockIdx.y * M * p.g.K;
@@ -318,8 +299,9 @@ static int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int 
   EMBNET_CHECK_ARG(pad_t >= 0 && pad_l >= 0, "%s: negative padding", who);
   EMBNET_CHECK_ARG((oh - 1) * stride + 1 - pad_t <= h && (ow - 1) * stride + 1 - pad_l <= w,
                    "%s: output %dx%d reaches outside the %dx%d input", who, oh, ow, h, w);
-  EMBNET_CHECK_ARG((long)n * h * w * c < (1l << 31) && (long)n * oh * ow * k < (1l << 31) &&
-                   (long)r * s * c * k < (1l << 31), "%s: tensor exceeds 2^31 elements", who);
+  EMBNET_CHECK_ARG((size_t)n * h * w * c * 4 <= MAX_OPERAND_BYTES && (size_t)n * oh * ow * k * 4 <= MAX_OPERAND_BYTES &&
+                   (size_t)r * s * c * k * 4 <= MAX_OPERAND_BYTES,
+                   "%s: a tensor exceeds 2 GiB (buffer-addressed operands): split the batch", who);
   g.N = n; g.H = h; g.W = w; g.C = c; g.R = r; g.S = s; g.K = k; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
   g.OH = oh; g.OW = ow;
   g.dOHW = FastDiv::make(oh * ow); g.dOW = FastDiv::make(ow); g.dHW = FastDiv::make(h * w); g.dW = FastDiv::make(w);
@@ -332,6 +314,8 @@ using G128x64 = Geom<128, 64, 2, 2>;
 using G128x32 = Geom<128, 32, 4, 1>;
 using G64x64 = Geom<64, 64, 2, 2>;
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
 static int pick_tile(long m, int ncols) {
   if (ncols <= 32) return 2;
@@ -339,6 +323,15 @@ static int pick_tile(long m, int ncols) {
   if (cdiv(m, 128) * cdiv(ncols, 128) >= 512) return 0;
   return (cdiv(m, 128) * cdiv(ncols, 64) >= 256) ? 1 : 3;
 }
+static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64};
+
+#define LAUNCH_TILED(KERNEL, VECARGS, tile, grid, st, p)                              \
+  switch (tile) {                                                                     \
+    case 0: KERNEL<G128x128, VECARGS><<<grid, 256, 0, st>>>(p); break;                \
+    case 1: KERNEL<G128x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
+    case 2: KERNEL<G128x32, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
+    default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
+  }
 
 extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
@@ -348,12 +341,10 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_fwd")) return rc;
   const long M = (long)n * oh * ow;
   hipStream_t st = (hipStream_t)stream;
-  switch (pick_tile(M, k)) {
-    case 0: conv_fwd_kernel<G128x128><<<cdiv(M, 128) * cdiv(k, 128), 256, 0, st>>>(p); break;
-    case 1: conv_fwd_kernel<G128x64><<<cdiv(M, 128) * cdiv(k, 64), 256, 0, st>>>(p); break;
-    case 2: conv_fwd_kernel<G128x32><<<cdiv(M, 128) * cdiv(k, 32), 256, 0, st>>>(p); break;
-    default: conv_fwd_kernel<G64x64><<<cdiv(M, 64) * cdiv(k, 64), 256, 0, st>>>(p); break;
-  }
+  const int tile = pick_tile(M, k);
+  const int grid = cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
+  if ((c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w)) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
+  else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
   return check_launch("conv2d_fwd");
 }
 
@@ -365,20 +356,17 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
   const long M = (long)n * h * wd;
   hipStream_t st = (hipStream_t)stream;
-  switch (pick_tile(M, c)) {
-    case 0: conv_dgrad_kernel<G128x128><<<cdiv(M, 128) * cdiv(c, 128), 256, 0, st>>>(p); break;
-    case 1: conv_dgrad_kernel<G128x64><<<cdiv(M, 128) * cdiv(c, 64), 256, 0, st>>>(p); break;
-    case 2: conv_dgrad_kernel<G128x32><<<cdiv(M, 128) * cdiv(c, 32), 256, 0, st>>>(p); break;
-    default: conv_dgrad_kernel<G64x64><<<cdiv(M, 64) * cdiv(c, 64), 256, 0, st>>>(p); break;
-  }
+  const int tile = pick_tile(M, c);
+  const int grid = cdiv(M, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]);
+  if ((k & 3) == 0 && aligned16(dy) && aligned16(w)) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
+  else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
   return check_launch("conv2d_dgrad");
 }
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
 static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
   tile = k <= 32 ? 2 : (k <= 64 ? 1 : 0);
-  const int bn = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
-  const long tiles = (long)cdiv(rows, 128) * cdiv(k, bn);
+  const long tiles = (long)cdiv(rows, 128) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
   long want = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split
@@ -394,6 +382,13 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
   return splits > 1 ? (size_t)splits * r * s * c * k * sizeof(float) : 0;
 }
 
+#define LAUNCH_WGRAD(VA, VB)                                                                   \
+  switch (tile) {                                                                              \
+    case 0: conv_wgrad_kernel<G128x128, VA, VB><<<grid, 256, 0, st>>>(p); break;               \
+    case 1: conv_wgrad_kernel<G128x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
+    default: conv_wgrad_kernel<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;               \
+  }
+
 extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
                                        size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
                                        int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
@@ -408,12 +403,11 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
     return fail(EMBNET_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   if (p.splits > 1) p.out = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(cdiv(rows, 128) * cdiv(k, tile == 0 ? 128 : (tile == 1 ? 64 : 32)), p.splits);
-  switch (tile) {
-    case 0: conv_wgrad_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
-    case 1: conv_wgrad_kernel<G128x64><<<grid, 256, 0, st>>>(p); break;
-    default: conv_wgrad_kernel<G128x32><<<grid, 256, 0, st>>>(p); break;
-  }
+  const dim3 grid(cdiv(rows, 128) * cdiv(k, TILE_BN[tile]), p.splits);
+  const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
+  if (va && vb) { LAUNCH_WGRAD(true, true) }
+  else if (vb) { LAUNCH_WGRAD(false, true) }
+  else { LAUNCH_WGRAD(false, false) }
   if (p.splits > 1) {
     const long cnt = (long)rows * k;
     slab_reduce_kernel<<<cdiv(cnt, 256), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
@@ -421,8 +415,8 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
   return check_launch("conv2d_wgrad");
 }
 
-// Name (as rocprofv3 prints it) of the kernel the three entry points above launch for a geometry,
-// so a caller can attribute its own HIP-event timings to the same symbol the profiler reports.
+// Name (as rocprofv3 prints the template) of the kernel the entry points above launch for a geometry,
+// so a caller can attribute its own HIP-event timings to the symbol the profiler reports.
 extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k,
                                                  int oh, int ow) {
   static const char* names[3][4] = {

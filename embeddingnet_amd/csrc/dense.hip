@@ -9,15 +9,15 @@ namespace embnet {
 struct DenseParams { const float* a; const float* b; const float* bias; float* out; int m, n, k; int relu; };
 
 // Y[m,n] = A[m,k] (k contiguous) x B[k,n] (n contiguous)
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
-  LoadRowsKC<G::BM> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
-  LoadRowsKM<G::BN> lb; lb.init(p.b, p.n, p.n, p.k, n0, threadIdx.x);
+  LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
+  LoadRowsKM<G::BN, VEC> lb; lb.init(p.b, p.n, p.n, p.k, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.k + BK - 1) / BK, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -31,15 +31,15 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
 }
 
 // dX[m,n=in] = dY[m,k=out] (k contiguous) x W[n=in][k=out] (k contiguous)
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
-  LoadRowsKC<G::BM> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
-  LoadRowsKC<G::BN> lb; lb.init(p.b, p.k, p.n, p.k, n0, threadIdx.x);
+  LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
+  LoadRowsKC<G::BN, VEC> lb; lb.init(p.b, p.k, p.n, p.k, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.k + BK - 1) / BK, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -49,15 +49,15 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseParams p) {
 }
 
 // dW[m=in,n=out] = X[k=batch][m=in] (m contiguous) x dY[k=batch][n=out] (n contiguous)
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseParams p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
-  LoadRowsKM<G::BM> la; la.init(p.a, p.m, p.m, p.k, m0, threadIdx.x);
-  LoadRowsKM<G::BN> lb; lb.init(p.b, p.n, p.n, p.k, n0, threadIdx.x);
+  LoadRowsKM<G::BM, VEC> la; la.init(p.a, p.m, p.m, p.k, m0, threadIdx.x);
+  LoadRowsKM<G::BN, VEC> lb; lb.init(p.b, p.n, p.n, p.k, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.k + BK - 1) / BK, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -72,20 +72,27 @@ using namespace embnet;
 using G64 = Geom<64, 64, 2, 2>;
 using G128 = Geom<128, 128, 2, 2>;
 
-#define LAUNCH_DENSE(KERNEL, p, st)                                                                  \
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define LAUNCH_DENSE(KERNEL, p, vec, st)                                                             \
   do {                                                                                               \
-    if ((long)cdiv((p).m, 128) * cdiv((p).n, 128) >= 256)                                            \
-      KERNEL<G128><<<cdiv((p).m, 128) * cdiv((p).n, 128), 256, 0, st>>>(p);                          \
-    else                                                                                             \
-      KERNEL<G64><<<cdiv((p).m, 64) * cdiv((p).n, 64), 256, 0, st>>>(p);                             \
+    if ((long)cdiv((p).m, 128) * cdiv((p).n, 128) >= 256) {                                          \
+      const int grid = cdiv((p).m, 128) * cdiv((p).n, 128);                                          \
+      if (vec) KERNEL<G128, true><<<grid, 256, 0, st>>>(p); else KERNEL<G128, false><<<grid, 256, 0, st>>>(p); \
+    } else {                                                                                         \
+      const int grid = cdiv((p).m, 64) * cdiv((p).n, 64);                                            \
+      if (vec) KERNEL<G64, true><<<grid, 256, 0, st>>>(p); else KERNEL<G64, false><<<grid, 256, 0, st>>>(p);   \
+    }                                                                                                \
   } while (0)
 
 extern "C" int embnet_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y, int m, int in,
                                     int out, int relu, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "dense_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_fwd: m=%d in=%d out=%d", m, in, out);
+  EMBNET_CHECK_ARG((size_t)m * in * 4 <= MAX_OPERAND_BYTES && (size_t)in * out * 4 <= MAX_OPERAND_BYTES, "dense: operand exceeds 2 GiB");
   DenseParams p{x, w, bias, y, m, out, in, relu};
-  LAUNCH_DENSE(dense_fwd_kernel, p, (hipStream_t)stream);
+  const bool vec = (in & 3) == 0 && (out & 3) == 0 && al16(x) && al16(w);
+  LAUNCH_DENSE(dense_fwd_kernel, p, vec, (hipStream_t)stream);
   return check_launch("dense_fwd");
 }
 
@@ -94,7 +101,8 @@ extern "C" int embnet_dense_dgrad_f32(const float* dy, const float* w, float* dx
   EMBNET_CHECK_ARG(dy && w && dx, "dense_dgrad: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_dgrad: m=%d in=%d out=%d", m, in, out);
   DenseParams p{dy, w, nullptr, dx, m, in, out, 0};
-  LAUNCH_DENSE(dense_dgrad_kernel, p, (hipStream_t)stream);
+  const bool vec = (out & 3) == 0 && al16(dy) && al16(w);
+  LAUNCH_DENSE(dense_dgrad_kernel, p, vec, (hipStream_t)stream);
   return check_launch("dense_dgrad");
 }
 
@@ -103,6 +111,7 @@ extern "C" int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw
   EMBNET_CHECK_ARG(x && dy && dw, "dense_wgrad: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_wgrad: m=%d in=%d out=%d", m, in, out);
   DenseParams p{x, dy, nullptr, dw, in, out, m, 0};
-  LAUNCH_DENSE(dense_wgrad_kernel, p, (hipStream_t)stream);
+  const bool vec = (in & 3) == 0 && (out & 3) == 0 && al16(x) && al16(dy);
+  LAUNCH_DENSE(dense_wgrad_kernel, p, vec, (hipStream_t)stream);
   return check_launch("dense_wgrad");
 }

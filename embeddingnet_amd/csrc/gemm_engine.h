@@ -9,6 +9,14 @@
 // other's barrier gaps — f32 MFMA issues once per 64 cycles per SIMD, so operand
 // delivery is cheap next to the matrix pipe).
 //
+// Global loads are BRANCH-FREE buffer loads: every operand is addressed through a
+// buffer descriptor (base in SGPRs, 32-bit byte offset per lane) and anything that
+// must read as zero — rows past the matrix edge, k past K, convolution taps in the
+// padding — is given an out-of-range offset, for which the hardware returns 0.
+// (A `cond ? load : 0` in the source makes hipcc branch around each load and wait
+// vmcnt(0) per element, serialising the whole prefetch; measured 2x slower.)
+// Consequence: one operand tensor must be smaller than 2 GiB.
+//
 // Operands come in two LDS layouts, chosen per operand by the op:
 //   TileKC<ROWS>: [ROWS][BK+4]  k contiguous  (activations gathered NHWC, rows of X)
 //   TileKM<ROWS>: [BK][ROWS]    row contiguous (weights [k][cout], dY for wgrad)
@@ -24,9 +32,30 @@
 namespace embnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
+constexpr unsigned OOB = 0x80000000u;          // byte offset no operand (< 2 GiB) reaches
+constexpr size_t MAX_OPERAND_BYTES = 0x7FFFFFF0ull;
+
+// Raw buffer view of one operand tensor.
+struct Buf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ void init(const void* p, size_t bytes) {
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+  }
+  __device__ __forceinline__ float4 ld4(unsigned off) const {
+    // NB: cast the WHOLE vector.  Per-component __builtin_bit_cast(float, v.x) makes hipcc (ROCm 7.2)
+    // narrow the load to buffer_load_dword while still consuming v[0:3] — three garbage lanes.
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+  }
+  __device__ __forceinline__ float ld1(unsigned off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  }
+};
 
 template <int ROWS>
 struct TileKC {
@@ -70,65 +99,60 @@ struct TileKM {
 
 // ---- generic dense-matrix loaders ----------------------------------------
 // Matrix whose k index is contiguous: elem(row,k) = base[row*ld + k].
-template <int ROWS>
+// VEC needs ld % 4 == 0, K % 4 == 0 and a 16-byte aligned base (whole float4 chunks in or out).
+template <int ROWS, bool VEC>
 struct LoadRowsKC {
   using Tile = TileKC<ROWS>;
-  const float* base; long ld; int rows, K; bool vec;
-  int row0, tid;
-  __device__ void init(const float* b, long ld_, int rows_, int K_, int row0_, int tid_) {
-    base = b; ld = ld_; rows = rows_; K = K_; row0 = row0_; tid = tid_;
-    vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  Buf buf; int K, tid;
+  unsigned row_off[Tile::PASSES];
+  __device__ void init(const float* b, long ld, int rows, int K_, int row0, int tid_) {
+    buf.init(b, (size_t)rows * ld * 4); K = K_; tid = tid_;
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) {
+      const int row = row0 + Tile::row_of(tid, p);
+      row_off[p] = row < rows ? (unsigned)((long)row * ld * 4) : OOB;
+    }
   }
   __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
     const int k = kt * BK + Tile::k_of(tid);
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
-      const int row = row0 + Tile::row_of(tid, p);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < rows) {
-        const float* src = base + (long)row * ld + k;
-        if (vec && k + 3 < K) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (k < K) v.x = src[0];
-          if (k + 1 < K) v.y = src[1];
-          if (k + 2 < K) v.z = src[2];
-          if (k + 3 < K) v.w = src[3];
-        }
+      const unsigned off = row_off[p] + 4u * k;            // stays out of range when the row is
+      if (VEC) {
+        r[p] = buf.ld4(k < K ? off : OOB);
+      } else {
+        r[p] = make_float4(buf.ld1(k < K ? off : OOB), buf.ld1(k + 1 < K ? off + 4 : OOB),
+                           buf.ld1(k + 2 < K ? off + 8 : OOB), buf.ld1(k + 3 < K ? off + 12 : OOB));
       }
-      r[p] = v;
     }
   }
 };
 
 // Matrix whose row index is contiguous: elem(k,row) = base[k*ld + row].
-template <int ROWS>
+// VEC needs ld % 4 == 0, rows % 4 == 0 and a 16-byte aligned base.
+template <int ROWS, bool VEC>
 struct LoadRowsKM {
   using Tile = TileKM<ROWS>;
-  const float* base; long ld; int rows, K; bool vec;
-  int row0, tid;
-  __device__ void init(const float* b, long ld_, int rows_, int K_, int row0_, int tid_) {
-    base = b; ld = ld_; rows = rows_; K = K_; row0 = row0_; tid = tid_;
-    vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  Buf buf; int K, rows, tid; unsigned ldb;
+  unsigned col_off[Tile::PASSES];
+  __device__ void init(const float* b, long ld, int rows_, int K_, int row0, int tid_) {
+    buf.init(b, (size_t)K_ * ld * 4); K = K_; rows = rows_; tid = tid_; ldb = (unsigned)(ld * 4);
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) col_off[p] = 4u * (unsigned)(row0 + Tile::row_of(tid, p));
   }
   __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int k = kt * BK + Tile::k_of(tid, p);
-      const int row = row0 + Tile::row_of(tid, p);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K) {
-        const float* src = base + (long)k * ld + row;
-        if (vec && row + 3 < rows) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (row < rows) v.x = src[0];
-          if (row + 1 < rows) v.y = src[1];
-          if (row + 2 < rows) v.z = src[2];
-          if (row + 3 < rows) v.w = src[3];
-        }
+      const unsigned off = (unsigned)k * ldb + col_off[p];
+      const int row = (int)(col_off[p] >> 2);
+      if (VEC) {
+        r[p] = buf.ld4((k < K && row < rows) ? off : OOB);
+      } else {
+        const bool kin = k < K;
+        r[p] = make_float4(buf.ld1(kin && row < rows ? off : OOB), buf.ld1(kin && row + 1 < rows ? off + 4 : OOB),
+                           buf.ld1(kin && row + 2 < rows ? off + 8 : OOB), buf.ld1(kin && row + 3 < rows ? off + 12 : OOB));
       }
-      r[p] = v;
     }
   }
 };
@@ -167,7 +191,10 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
     TA::store(sA, ra, tid);
     TB::store(sB, rb, tid);
     __syncthreads();
-    if (kt + 1 < kt_end) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }   // in flight under the MFMAs
+    // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
+    // offset out of range, so the loads return zeros and need no branch
+    la.load(kt + 1 < kt_end ? kt + 1 : (1 << 24), ra);
+    lb.load(kt + 1 < kt_end ? kt + 1 : (1 << 24), rb);
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float a[G::TM][4], b[G::TN][4];

@@ -49,6 +49,23 @@ __device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __r
   }
 }
 
+// Finalize helper: one 256-thread workgroup per channel adds that channel's per-block partials in
+// double (fixed order: thread-strided, then a shuffle tree) — thread 0 gets the totals.
+__device__ __forceinline__ void block_partial_sums(const float* __restrict__ partial, int blocks, int c, int col,
+                                                   double& s_out, double& ss_out) {
+  __shared__ double red[2][4];
+  double s = 0.0, ss = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256) {
+    s += (double)partial[((long)b * 2) * c + col];
+    ss += (double)partial[((long)b * 2 + 1) * c + col];
+  }
+  s = wave_sum(s); ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  s_out = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  ss_out = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
 // ---------------------------------------------------------------- BatchNorm
 // stats pass: reads x once (4 B/elem)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long m, int c, ColGeom g,
@@ -65,10 +82,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ moving_mean,
                                                           float* __restrict__ moving_var) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += partial[((long)b * 2) * c + col]; ss += partial[((long)b * 2 + 1) * c + col]; }
+  const int col = blockIdx.x;
+  double s, ss;
+  block_partial_sums(partial, blocks, c, col, s, ss);
+  if (threadIdx.x) return;
   const double mean = s / (double)m;
   double var = ss / (double)m - mean * mean;            // biased, as Keras uses in training
   if (var < 0.0) var = 0.0;
@@ -133,11 +150,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += partial[((long)b * 2) * c + col]; ss += partial[((long)b * 2 + 1) * c + col]; }
-  dbeta[col] = (float)s; dgamma[col] = (float)ss;
+  const int col = blockIdx.x;
+  double s, ss;
+  block_partial_sums(partial, blocks, c, col, s, ss);
+  if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
 }
 
 // dx = scale * (dz - dbeta/M - xhat*dgamma/M)     (12 B/elem)
@@ -281,6 +297,23 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// out[c] = sum_{t,k} w[t][c][k] * s[t][k]   (t = filter tap): gradient of a per-channel input offset
+// through a convolution, from the per-tap sums s of the output gradient.  One workgroup per channel.
+__global__ __launch_bounds__(256) void tap_contract_kernel(const float* __restrict__ w, const float* __restrict__ s,
+                                                           int taps, int c, int k, float* __restrict__ out) {
+  __shared__ float part[4];
+  const int ch = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < taps * k; i += 256) {
+    const int t = i / k, kk = i - t * k;
+    acc = fmaf(w[((long)t * c + ch) * k + kk], s[i], acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[ch] = part[0] + part[1] + part[2] + part[3];
+}
+
 __global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out) {
   if (threadIdx.x || blockIdx.x) return;
   double s = 0.0;
@@ -290,11 +323,10 @@ __global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, fl
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                               float* __restrict__ out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
-  double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[((long)b * 2) * c + col];
-  out[col] = (float)s;
+  const int col = blockIdx.x;
+  double s, unused;
+  block_partial_sums(partial, blocks, c, col, s, unused);
+  if (threadIdx.x == 0) out[col] = (float)s;
 }
 
 }  // namespace embnet
@@ -319,7 +351,7 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   const ColGeom g = col_geom(m, c);
   float* partial = (float*)workspace;
   bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, partial);
-  bn_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(partial, g.blocks, m, c, gamma, beta, eps, momentum, save_mean,
+  bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, m, c, gamma, beta, eps, momentum, save_mean,
                                                           save_rstd, scale, shift, moving_mean, moving_var);
   affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_train_fwd");
@@ -351,7 +383,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   // save_mean/save_rstd when given, else zeros.
   if (save_mean && save_rstd) {
     bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial);
-    bn_bwd_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
+    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
@@ -409,7 +441,7 @@ extern "C" int embnet_colsum(const float* x, long m, int c, float* out, void* wo
     return fail(EMBNET_EWORKSPACE, "colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
   colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace);
-  colsum_finalize_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, out);
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, out);
   return check_launch("colsum");
 }
 
@@ -430,6 +462,13 @@ extern "C" int embnet_dropout(const float* x, long total, float rate, uint64_t s
   EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "dropout: rate %f outside [0,1)", rate);
   dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, y);
   return check_launch("dropout");
+}
+
+extern "C" int embnet_tap_contract(const float* w, const float* tap_sums, int taps, int c, int k, float* out,
+                                   void* stream) {
+  EMBNET_CHECK_ARG(w && tap_sums && out && taps > 0 && c > 0 && k > 0, "tap_contract: bad argument");
+  tap_contract_kernel<<<c, 256, 0, S(stream)>>>(w, tap_sums, taps, c, k, out);
+  return check_launch("tap_contract");
 }
 
 extern "C" size_t embnet_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }

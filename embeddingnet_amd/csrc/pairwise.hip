@@ -26,7 +26,7 @@ struct PairwiseParams {
   const float* x; const float* nn; float* d; int n, e, squared;
 };
 
-template <class G>
+template <class G, bool VEC>
 __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
 
-  LoadRowsKC<G::BM> la; la.init(p.x, p.e, p.n, p.e, m0, threadIdx.x);
-  LoadRowsKC<G::BN> lb; lb.init(p.x, p.e, p.n, p.e, n0, threadIdx.x);
+  LoadRowsKC<G::BM, VEC> la; la.init(p.x, p.e, p.n, p.e, m0, threadIdx.x);
+  LoadRowsKC<G::BN, VEC> lb; lb.init(p.x, p.e, p.n, p.e, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.e + BK - 1) / BK, smem, acc);
 
@@ -68,12 +68,16 @@ extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dis
   float* nn = (float*)workspace;
   row_sqnorm_kernel<<<cdiv(n, 4), 256, 0, s>>>(x, n, e, nn);
   PairwiseParams p{x, nn, dist, n, e, squared};
+  EMBNET_CHECK_ARG((size_t)n * e * 4 <= MAX_OPERAND_BYTES, "pairwise: embedding block exceeds 2 GiB");
+  const bool vec = (e & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  using GL = Geom<128, 128, 2, 2>;
+  using GS = Geom<64, 64, 2, 2>;
   if (n >= 1024) {
-    using G = Geom<128, 128, 2, 2>;
-    pairwise_kernel<G><<<cdiv(n, 128) * cdiv(n, 128), 256, 0, s>>>(p);
+    const int grid = cdiv(n, 128) * cdiv(n, 128);
+    if (vec) pairwise_kernel<GL, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GL, false><<<grid, 256, 0, s>>>(p);
   } else {
-    using G = Geom<64, 64, 2, 2>;
-    pairwise_kernel<G><<<cdiv(n, 64) * cdiv(n, 64), 256, 0, s>>>(p);
+    const int grid = cdiv(n, 64) * cdiv(n, 64);
+    if (vec) pairwise_kernel<GS, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GS, false><<<grid, 256, 0, s>>>(p);
   }
   return check_launch("pairwise_dist");
 }

@@ -32,9 +32,17 @@ class KernelTimer:
 
     def summary(self):
         """{kernel: dict(launches, ms_total, flops_total)} — call after a device synchronize."""
+        return self._group(lambda name, dims: name)
+
+    def detail(self):
+        """Same, keyed by (kernel, geometry) — one row per layer shape."""
+        return self._group(lambda name, dims: f"{name} n{dims[0]} {dims[1]}x{dims[2]}x{dims[3]} "
+                                              f"k{dims[4]}x{dims[5]}->{dims[6]} out{dims[7]}x{dims[8]}")
+
+    def _group(self, key):
         out = {}
-        for name, flops, s, e in self.records:
-            d = out.setdefault(name, dict(launches=0, ms_total=0.0, flops_total=0.0))
+        for name, flops, s, e, dims in self.records:
+            d = out.setdefault(key(name, dims), dict(launches=0, ms_total=0.0, flops_total=0.0))
             d["launches"] += 1
             d["ms_total"] += s.elapsed_time(e)
             d["flops_total"] += flops
@@ -53,7 +61,7 @@ def _conv_timed(kind, dims, call):
     s0.record()
     out = call()
     s1.record()
-    TIMER.records.append((name, 2.0 * n * oh * ow * k * r * s * c, s0, s1))
+    TIMER.records.append((name, 2.0 * n * oh * ow * k * r * s * c, s0, s1, dims))
     return out
 
 
@@ -291,6 +299,73 @@ class BatchNormalization(nn.Module):
     def forward(self, x):
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                   self.momentum, self.relu, self.training)
+
+
+class _InputBNConvFn(torch.autograd.Function):
+    """BN(scale=False) on the raw image followed by a conv (the zoo ResNet stem: bn_data -> conv0).
+    The image needs no gradient and the only trainable BN weight is beta, whose gradient is
+    sum(d conv-input) = contract(kernel, per-tap sums of dy); the per-tap sums are a weight-gradient
+    of an all-ones one-channel image.  This replaces a 3-channel data-gradient conv over the full
+    224x224 map (N=3 of a 32-wide MFMA tile, 3/4 of the taps structurally zero at stride 2)."""
+
+    _ones = {}
+
+    @staticmethod
+    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom):
+        x, w = _c(x), _c(w)
+        lib = _lib.lib()
+        n, h, wd, c = x.shape
+        r, s, _, k = w.shape
+        stride, pt, pl, oh, ow = geom
+        m = n * h * wd
+        a = torch.empty_like(x)
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+        check(lib.embnet_bn_train_fwd(ptr(x), m, c, None, ptr(beta), eps, momentum, 0, ptr(a), stats[0].data_ptr(),
+                                      stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                      ptr(moving_mean), ptr(moving_var), ptr(ws), ws.numel() * 4, stream()))
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+            ptr(a), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, stream())))
+        ctx.geom = geom
+        ctx.save_for_backward(a, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        lib = _lib.lib()
+        n, h, wd, c = a.shape
+        r, s, _, k = w.shape
+        stride, pt, pl, oh, ow = ctx.geom
+        dy = _c(dy)
+        dw = torch.empty_like(w)
+        ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), a.device)
+        _conv_timed(2, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+            ptr(a), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
+            stream())))
+        key = (a.device, n, h, wd)
+        ones = _InputBNConvFn._ones.get(key)
+        if ones is None:
+            ones = _InputBNConvFn._ones[key] = torch.ones((n, h, wd, 1), device=a.device, dtype=torch.float32)
+        taps = torch.empty((r, s, 1, k), device=a.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, 1, r, s, k, oh, ow), a.device)
+        _conv_timed(2, (n, h, wd, 1, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+            ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
+            stream())))
+        dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
+        check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
+        return None, dbeta, None, None, dw, None, None, None
+
+
+def input_bn_conv(x, bn, conv):
+    """bn (scale=False, no relu) then conv (no bias / activation) on an image batch."""
+    fusable = (bn.training and not x.requires_grad and bn.gamma is None and not bn.relu and conv.bias is None
+               and not conv.relu and torch.is_grad_enabled())
+    if not fusable:
+        return conv(bn(x))
+    return _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum,
+                                conv.geometry(x.shape[1], x.shape[2]))
 
 
 # ----------------------------------------------------------------------------- pooling

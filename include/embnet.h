@@ -165,6 +165,9 @@ int embnet_colsum(const float* x, long m, int c, float* out, void* workspace, si
                   void* stream);                                                                /* bias grads */
 int embnet_add(const float* a, const float* b, long total, float* y, void* stream);           /* Add() */
 int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev, float* y, void* stream);
+/* out[c] = sum_{tap,k} w[tap,c,k] * tap_sums[tap,k]: gradient of a per-channel offset added to a conv
+ * input (the zoo ResNet's bn_data beta) from per-tap sums of dy — avoids a full 3-channel dgrad. */
+int embnet_tap_contract(const float* w, const float* tap_sums, int taps, int c, int k, float* out, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
 int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream);
 /* kernel_regularizer=l2(lambda) (backbones.py:22-36): *out = alpha * sum x^2. */

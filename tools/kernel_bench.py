@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single HIP kernels through the C ABI (GPU box only).
+
+  python tools/kernel_bench.py gemm          distance-GEMM sweep: N x E grid, TFLOP/s vs 157.3
+  python tools/kernel_bench.py conv          ResNet18 layer shapes at batch 128: fwd / dgrad / wgrad TFLOP/s
+  python tools/kernel_bench.py conv --only fwd --shape 128,56,56,64,3,64,1,1
+
+Timing: HIP events on the launch stream around `iters` back-to-back launches after a warm-up.
+Algorithmic FLOP: 2*N*N*E (full matrix, no symmetry credit) / 2*N*OH*OW*K*R*S*C.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from embeddingnet_amd import _lib, ops  # noqa: E402
+from embeddingnet_amd._lib import check, ptr, stream  # noqa: E402
+
+PEAK = 157.3
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def gemm_sweep(args):
+    dev = torch.device("cuda:0")
+    rows = []
+    for n in args.n:
+        for e in args.e:
+            g = torch.Generator(device=dev).manual_seed(7)
+            x = torch.rand((n, e), device=dev, generator=g)
+            x = x / x.norm(dim=1, keepdim=True)
+            lib = _lib.lib()
+            ws = torch.empty(max(n, 256), device=dev)
+            d = torch.empty((n, n), device=dev)
+            fn = lambda: check(lib.embnet_pairwise_dist_f32(ptr(x), n, e, ptr(d), 0, ptr(ws), ws.numel() * 4, stream()))
+            t = timeit(fn, iters=args.iters)
+            tf = 2.0 * n * n * e / t / 1e12
+            rows.append(dict(N=n, E=e, us=round(t * 1e6, 1), tflops=round(tf, 2), frac=round(tf / PEAK, 4)))
+            print(f"pairwise N={n:6d} E={e:5d}  {t * 1e6:10.1f} us  {tf:7.2f} TFLOP/s  {tf / PEAK:6.1%} of fp32 MFMA peak",
+                  flush=True)
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
+RN18 = [  # n, h, w, c, k(size), cout, stride, pad
+    (128, 224, 224, 3, 7, 64, 2, 3),
+    (128, 56, 56, 64, 3, 64, 1, 1),
+    (128, 56, 56, 64, 1, 64, 1, 0),
+    (128, 56, 56, 64, 3, 128, 2, 1),
+    (128, 56, 56, 64, 1, 128, 2, 0),
+    (128, 28, 28, 128, 3, 128, 1, 1),
+    (128, 28, 28, 128, 3, 256, 2, 1),
+    (128, 14, 14, 256, 3, 256, 1, 1),
+    (128, 14, 14, 256, 3, 512, 2, 1),
+    (128, 7, 7, 512, 3, 512, 1, 1),
+]
+
+
+def conv_bench(args):
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    shapes = [tuple(int(v) for v in args.shape.split(","))] if args.shape else RN18
+    for (n, h, w, c, ks, k, st, pad) in shapes:
+        oh, ow = (h + 2 * pad - ks) // st + 1, (w + 2 * pad - ks) // st + 1
+        x = torch.randn((n, h, w, c), device=dev)
+        wt = torch.randn((ks, ks, c, k), device=dev) * 0.05
+        y = torch.empty((n, oh, ow, k), device=dev)
+        dy = torch.randn((n, oh, ow, k), device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(wt)
+        ws = torch.empty(max(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, ks, ks, k, oh, ow) // 4, 256), device=dev)
+        flop = 2.0 * n * oh * ow * k * ks * ks * c
+        calls = {
+            "fwd": lambda: check(lib.embnet_conv2d_fwd_f32(ptr(x), ptr(wt), None, ptr(y), n, h, w, c, ks, ks, k, st, pad, pad,
+                                                           oh, ow, 0, stream())),
+            "dgrad": lambda: check(lib.embnet_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(dx), n, h, w, c, ks, ks, k, st, pad, pad,
+                                                               oh, ow, stream())),
+            "wgrad": lambda: check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, w, c,
+                                                               ks, ks, k, st, pad, pad, oh, ow, stream())),
+        }
+        line = f"n{n} {h}x{w}x{c} k{ks} s{st} -> {k}: "
+        for kind, fn in calls.items():
+            if args.only and kind != args.only:
+                continue
+            t = timeit(fn, iters=args.iters)
+            line += f" {kind} {t * 1e6:8.1f} us {flop / t / 1e12:6.1f} TF/s |"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["gemm", "conv"])
+    ap.add_argument("--n", type=int, nargs="+", default=[128, 256, 1024, 4096, 16384])
+    ap.add_argument("--e", type=int, nargs="+", default=[256, 512, 4096])
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--shape", default=None)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    (gemm_sweep if a.what == "gemm" else conv_bench)(a)
