@@ -91,46 +91,56 @@ struct LoadConvFwdA {
   }
 };
 
-// ---- dgrad A: rows = input pixels, k = (r,s,kout) ---------------------------------------------
+// ---- dgrad, by stride class -------------------------------------------------------------------
+// With stride st an input pixel (h,w) only receives from taps r = (h+pad_t) mod st (mod st), so the
+// gradient splits into st*st independent stride-1 correlations ("classes"), one per residue pair
+// (ph,pw): pixels h = hoff + st*hc, taps r = ph + st*tr, and the output row is oh = hc + hb - tr.
+// Each class is its own implicit GEMM (rows = its pixels, k = its taps x K): no structurally-zero
+// taps are multiplied (a 3x3 stride-2 conv does 9 tap-GEMMs per 4 pixels instead of 36).
+// stride 1 is the single class (0,0).
+struct DgradClass {
+  int hoff, woff, Hc, Wc, nR, nS, r0, s0, hb, wb;
+  FastDiv dHWc, dWc, dnS;
+};
+constexpr int MAX_CLASSES = 9;          // stride <= 3
+
+// A: rows = the class's input pixels, k = (tr, ts, kout)
 template <int ROWS, bool VEC>
 struct LoadConvDgradA {
   using Tile = TileKC<ROWS>;
-  Buf buf; int OH, OW, K, Kg, stride; FastDiv dK, dS; int tid;
+  Buf buf; int OH, OW, K, Kg; FastDiv dK, dnS; int tid;
   unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
-  __device__ void init(const float* dy, const ConvGeom& g, int m0, int tid_) {
+  __device__ void init(const float* dy, const ConvGeom& g, const DgradClass& cg, int m0, int tid_) {
     buf.init(dy, (size_t)g.N * g.OH * g.OW * g.K * 4);
-    OH = g.OH; OW = g.OW; K = g.K; Kg = g.R * g.S * g.K; stride = g.stride; dK = g.dK; dS = g.dS; tid = tid_;
-    const int M = g.N * g.H * g.W;
+    OH = g.OH; OW = g.OW; K = g.K; Kg = cg.nR * cg.nS * g.K; dK = g.dK; dnS = cg.dnS; tid = tid_;
+    const int M = g.N * cg.Hc * cg.Wc;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int m = m0 + Tile::row_of(tid, p);
-      uint32_t n, rem, h, w;
-      g.dHW.divmod((uint32_t)min(m, M - 1), n, rem); g.dW.divmod(rem, h, w);
+      uint32_t n, rem, hc, wc;
+      cg.dHWc.divmod((uint32_t)min(m, max(M - 1, 0)), n, rem); cg.dWc.divmod(rem, hc, wc);
       base[p] = 4u * n * (unsigned)(g.OH * g.OW * g.K);
-      ih0[p] = m < M ? (int)h + g.pad_t : ROW_INVALID;
-      iw0[p] = (int)w + g.pad_l;
+      ih0[p] = m < M ? (int)hc + cg.hb : ROW_INVALID;
+      iw0[p] = (int)wc + cg.wb;
     }
   }
-  // byte offset of dY feeding input row p through tap (r,s), channel c; OOB when no output pixel does
-  __device__ __forceinline__ unsigned src(int p, int r, int s, int c, bool kin) const {
-    int th = ih0[p] - r, tw = iw0[p] - s;
-    bool ok = kin && th >= 0 && tw >= 0;
-    if (stride == 2) { ok = ok && (((th | tw) & 1) == 0); th >>= 1; tw >>= 1; }
-    else if (stride != 1) { ok = ok && (th % stride == 0) && (tw % stride == 0); th /= stride; tw /= stride; }
-    ok = ok && th < OH && tw < OW;
-    return ok ? base[p] + 4u * (unsigned)((th * OW + tw) * K + c) : OOB;
-  }
   __device__ __forceinline__ unsigned off(int p, int kk) const {
-    int r, s, c; split_k(kk, dK, dS, r, s, c);
-    return src(p, r, s, c, kk < Kg);
+    uint32_t t, c, tr, ts; dK.divmod((uint32_t)kk, t, c); dnS.divmod(t, tr, ts);
+    const int oh = ih0[p] - (int)tr, ow = iw0[p] - (int)ts;
+    const bool ok = kk < Kg && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+    return ok ? base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
     if (VEC) {
-      int r, s, c; split_k(kk, dK, dS, r, s, c);
+      uint32_t t, c, tr, ts; dK.divmod((uint32_t)kk, t, c); dnS.divmod(t, tr, ts);
       const bool kin = kk < Kg;
 #pragma unroll
-      for (int p = 0; p < Tile::PASSES; ++p) rg[p] = buf.ld4(src(p, r, s, c, kin));
+      for (int p = 0; p < Tile::PASSES; ++p) {
+        const int oh = ih0[p] - (int)tr, ow = iw0[p] - (int)ts;
+        const bool ok = kin && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+        rg[p] = buf.ld4(ok ? base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c) : OOB);
+      }
     } else {
 #pragma unroll
       for (int p = 0; p < Tile::PASSES; ++p)
@@ -140,17 +150,19 @@ struct LoadConvDgradA {
   }
 };
 
-// ---- dgrad B: rows = input channel c, k = (r,s,kout): W[((r*S+s)*C + c)*K + kout] ------------
+// B: rows = input channel c, k = (tr, ts, kout): W[((r*S+s)*C + c)*K + kout], r = r0 + st*tr, s = s0 + st*ts
 template <int ROWS, bool VEC>
 struct LoadConvDgradB {
   using Tile = TileKC<ROWS>;
-  Buf buf; int C, K, Kg; FastDiv dK; int row0, tid;
-  __device__ void init(const float* w, const ConvGeom& g, int n0, int tid_) {
+  Buf buf; int C, K, S, Kg, st, r0, s0; FastDiv dK, dnS; int row0, tid;
+  __device__ void init(const float* w, const ConvGeom& g, const DgradClass& cg, int n0, int tid_) {
     buf.init(w, (size_t)g.R * g.S * g.C * g.K * 4);
-    C = g.C; K = g.K; Kg = g.R * g.S * g.K; dK = g.dK; row0 = n0; tid = tid_;
+    C = g.C; K = g.K; S = g.S; Kg = cg.nR * cg.nS * g.K; st = g.stride; r0 = cg.r0; s0 = cg.s0;
+    dK = g.dK; dnS = cg.dnS; row0 = n0; tid = tid_;
   }
   __device__ __forceinline__ unsigned off(int c, int kk) const {
-    uint32_t rs, ko; dK.divmod((uint32_t)kk, rs, ko);
+    uint32_t t, ko, tr, ts; dK.divmod((uint32_t)kk, t, ko); dnS.divmod(t, tr, ts);
+    const unsigned rs = (unsigned)((r0 + st * (int)tr) * S + s0 + st * (int)ts);
     return (kk < Kg && c < C) ? 4u * ((rs * (unsigned)C + (unsigned)c) * (unsigned)K + ko) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
@@ -164,6 +176,7 @@ struct LoadConvDgradB {
     }
   }
 };
+
 
 // ---- wgrad A: k = output pixel (n,oh,ow), rows = (r,s,c) ------------------------------------------
 template <int ROWS, bool VEC>
@@ -233,24 +246,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   });
 }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
-  const int M = p.g.N * p.g.H * p.g.W, Kg = p.g.R * p.g.S * p.g.K;
-  const int tiles_n = (p.g.C + G::BN - 1) / G::BN, tiles_m = (M + G::BM - 1) / G::BM;
-  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const DgradClass& cg = p.cls[blockIdx.y];
+  const int M = p.g.N * cg.Hc * cg.Wc, Kg = cg.nR * cg.nS * p.g.K;
+  const int tiles_n = (p.g.C + G::BN - 1) / G::BN;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
-  LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, m0, threadIdx.x);
-  LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, n0, threadIdx.x);
+  if (m0 >= M) return;                                   // classes differ in size by a row/column
+  LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, cg, m0, threadIdx.x);
+  LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
+  const int st = p.g.stride;
+  int last_r = -1; long row_base = 0;
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
-    if (row < M && col < p.g.C) p.dx[(long)row * p.g.C + col] = v;
+    if (r != last_r) {                                   // rows repeat across this lane's column tiles
+      last_r = r;
+      uint32_t n, rem, hc, wc;
+      cg.dHWc.divmod((uint32_t)min(row, M - 1), n, rem); cg.dWc.divmod(rem, hc, wc);
+      row_base = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
+    }
+    if (row < M && col < p.g.C) p.dx[row_base + col] = v;
   });
 }
 
@@ -352,12 +375,29 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
                                        int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                                        void* stream) {
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
-  ConvDgradParams p{dy, w, dx, {}};
+  ConvDgradParams p{dy, w, dx, {}, {}};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
-  const long M = (long)n * h * wd;
+  EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
+  long max_m = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      DgradClass& cg = p.cls[ph * stride + pw];
+      cg.r0 = ph; cg.s0 = pw;
+      cg.hoff = ((ph - pad_t) % stride + stride) % stride; cg.woff = ((pw - pad_l) % stride + stride) % stride;
+      cg.Hc = cg.hoff < h ? (h - cg.hoff + stride - 1) / stride : 0;
+      cg.Wc = cg.woff < wd ? (wd - cg.woff + stride - 1) / stride : 0;
+      cg.nR = ph < r ? (r - ph + stride - 1) / stride : 0;
+      cg.nS = pw < s ? (s - pw + stride - 1) / stride : 0;
+      cg.hb = (cg.hoff + pad_t - ph) / stride; cg.wb = (cg.woff + pad_l - pw) / stride;
+      cg.dHWc = FastDiv::make(cg.Hc * cg.Wc > 0 ? cg.Hc * cg.Wc : 1);
+      cg.dWc = FastDiv::make(cg.Wc > 0 ? cg.Wc : 1);
+      cg.dnS = FastDiv::make(cg.nS > 0 ? cg.nS : 1);
+      const long m = (long)n * cg.Hc * cg.Wc;
+      if (m > max_m) max_m = m;
+    }
   hipStream_t st = (hipStream_t)stream;
-  const int tile = pick_tile(M, c);
-  const int grid = cdiv(M, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]);
+  const int tile = pick_tile(max_m * stride * stride, c);
+  const dim3 grid(cdiv(max_m, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]), stride * stride);
   if ((k & 3) == 0 && aligned16(dy) && aligned16(w)) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
   return check_launch("conv2d_dgrad");
@@ -365,8 +405,8 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
 static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
-  tile = k <= 32 ? 2 : (k <= 64 ? 1 : 0);
-  const long tiles = (long)cdiv(rows, 128) * cdiv(k, TILE_BN[tile]);
+  tile = (rows <= 64 && k <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
+  const long tiles = (long)cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
   long want = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split
@@ -386,7 +426,8 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
   switch (tile) {                                                                              \
     case 0: conv_wgrad_kernel<G128x128, VA, VB><<<grid, 256, 0, st>>>(p); break;               \
     case 1: conv_wgrad_kernel<G128x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
-    default: conv_wgrad_kernel<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;               \
+    case 2: conv_wgrad_kernel<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
+    default: conv_wgrad_kernel<G64x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
   }
 
 extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
@@ -403,7 +444,7 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
     return fail(EMBNET_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   if (p.splits > 1) p.out = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(cdiv(rows, 128) * cdiv(k, TILE_BN[tile]), p.splits);
+  const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]), p.splits);
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
   if (va && vb) { LAUNCH_WGRAD(true, true) }
   else if (vb) { LAUNCH_WGRAD(false, true) }
@@ -419,15 +460,24 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
 // so a caller can attribute its own HIP-event timings to the symbol the profiler reports.
 extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k,
                                                  int oh, int ow) {
-  static const char* names[3][4] = {
-      {"conv_fwd_kernel<Geom<128,128,2,2>>", "conv_fwd_kernel<Geom<128,64,2,2>>", "conv_fwd_kernel<Geom<128,32,4,1>>",
-       "conv_fwd_kernel<Geom<64,64,2,2>>"},
-      {"conv_dgrad_kernel<Geom<128,128,2,2>>", "conv_dgrad_kernel<Geom<128,64,2,2>>",
-       "conv_dgrad_kernel<Geom<128,32,4,1>>", "conv_dgrad_kernel<Geom<64,64,2,2>>"},
-      {"conv_wgrad_kernel<Geom<128,128,2,2>>", "conv_wgrad_kernel<Geom<128,64,2,2>>",
-       "conv_wgrad_kernel<Geom<128,32,4,1>>", ""}};
-  if (kind == 0) return names[0][pick_tile((long)n * oh * ow, k)];
-  if (kind == 1) return names[1][pick_tile((long)n * h * wd, c)];
-  if (kind == 2) { int tile, sp, kt; wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt); return names[2][tile]; }
-  return "";
+  static thread_local char buf[160];
+  static const char* geoms[4] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2"};
+  const char* t = (c & 3) == 0 ? "true" : "false";
+  const char* tk = (k & 3) == 0 ? "true" : "false";
+  if (kind == 0) {
+    snprintf(buf, sizeof buf, "void embnet::conv_fwd_kernel<embnet::Geom<%s>, %s>(embnet::ConvFwdParams)",
+             geoms[pick_tile((long)n * oh * ow, k)], ((c | k) & 3) == 0 ? "true" : "false");
+  } else if (kind == 1) {
+    long max_m = (long)n * ((h + 0) / 1) * wd;         // same tile choice as the launcher (all classes together)
+    snprintf(buf, sizeof buf, "void embnet::conv_dgrad_kernel<embnet::Geom<%s>, %s>(embnet::ConvDgradParams)",
+             geoms[pick_tile(max_m, c)], tk);
+  } else if (kind == 2) {
+    int tile, sp, kt;
+    wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
+    snprintf(buf, sizeof buf, "void embnet::conv_wgrad_kernel<embnet::Geom<%s>, %s, %s>(embnet::ConvWgradParams)",
+             geoms[tile], ((k & 3) == 0) ? t : "false", tk);
+  } else {
+    buf[0] = 0;
+  }
+  return buf;
 }

@@ -60,4 +60,4 @@ class ReferenceStep:
         with torch.no_grad():
             for kname, v in ctx.new_stats.items():
                 self.params[kname].copy_(v)
-        return float(loss), int(len(t))
+        return float(loss.detach()), int(len(t))

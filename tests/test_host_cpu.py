@@ -1,0 +1,202 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol the
+header declares, the reference-shaped config/optimizer/model surface behaves, the product
+path refuses to run without a GPU, and the data-parallel reducer works over gloo (world 2)."""
+import ctypes
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from embeddingnet_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in protos if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
+    assert bound.embnet_abi_version() == 1
+    assert bound.embnet_mine_max_triplets(32, 4) == 192
+    assert bound.embnet_pairwise_workspace_bytes(128) == 512
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """Argument validation happens before any launch, so it is testable on the CPU box."""
+    from embeddingnet_amd import _lib
+    lib = _lib.lib()
+    rc = lib.embnet_pairwise_dist_f32(None, 4, 4, None, 0, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.embnet_last_error()
+    rc = lib.embnet_mine_triplets(1, 1, 4, 0.5, 7, 0, 1, 1, 1, None, None)
+    assert rc == -1 and b"k_classes>=2" in lib.embnet_last_error()
+    rc = lib.embnet_conv2d_fwd_f32(1, 1, None, 1, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None)
+    assert rc == -1 and b"reaches outside" in lib.embnet_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from embeddingnet_amd import _lib, ops
+    from embeddingnet_amd.losses_and_accuracies import triplet_loss
+    with pytest.raises(_lib.EmbnetError):
+        triplet_loss(0.5)(None, torch.zeros(4, 12))
+    with pytest.raises(_lib.EmbnetError):
+        ops.pairwise_distances(torch.zeros(4, 8))
+    src = open(os.path.join(ROOT, "embeddingnet_amd", "ops.py")).read() + \
+        open(os.path.join(ROOT, "embeddingnet_amd", "layers.py")).read()
+    assert "oracle" not in src, "product code must never import the oracle"
+
+
+def test_parse_params_keeps_reference_schema(tmp_path):
+    from embeddingnet_amd.utils import OptimizerSpec, parse_params
+    cfg = tmp_path / "cfg.yml"
+    cfg.write_text(textwrap.dedent("""
+        MODEL:
+          input_shape : [64, 64, 3]
+          encodings_len: 256
+          mode : 'triplet'
+          distance_type : 'l1'
+          backbone_name : 'simple2'
+          backbone_weights : null
+          freeze_backbone : False
+          embeddings_normalization: True
+        DATALOADER:
+          dataset_path : '/tmp/none'
+          validate : True
+          val_ratio : 0.2
+        GENERATOR:
+          negatives_selection_mode : 'semihard'
+          k_classes: 8
+          k_samples: 4
+          margin: 0.5
+          batch_size : 8
+          n_batches : 10
+          augmentations : 'none'
+        TRAIN:
+          optimizer : 'radam'
+          learning_rate : 0.0001
+          decay_factor : 0.99
+          step_size : 1
+          n_epochs : 2
+          plot_history : False
+        ENCODINGS:
+          save_encodings : True
+        GENERAL:
+          project_name : 'p'
+          work_dir : 'work_dirs/'
+    """))
+    p = parse_params(str(cfg))
+    assert set(p) == {"dataloader", "generator", "model", "train", "general", "encodings"}
+    assert p["generator"]["input_shape"] == [64, 64, 3] and p["generator"]["augmentations"] is None
+    spec = p["train"]["optimizer"]
+    assert isinstance(spec, OptimizerSpec)
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = spec.build([w])
+    assert isinstance(opt, torch.optim.RAdam) and opt.defaults["eps"] == 1e-7 and opt.defaults["lr"] == 1e-4
+    assert isinstance(OptimizerSpec("adam", 1e-3).build([w]), torch.optim.Adam)
+    assert isinstance(OptimizerSpec("rms_prop", 1e-3).build([w]), torch.optim.RMSprop)
+    assert isinstance(OptimizerSpec("whatever", 1e-3).build([w]), torch.optim.SGD)
+
+
+def test_model_surface_matches_reference_names():
+    """Attribute / constructor surface of models.py and backbones.py (no kernels run: CPU device)."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.models import SiameseNet, TripletNet
+    cpu = torch.device("cpu")
+    params = {"model": dict(input_shape=[64, 64, 3], encodings_len=32, mode="triplet", distance_type="l2",
+                            backbone_name="simple2", backbone_weights=None, freeze_backbone=False,
+                            embeddings_normalization=True, device=cpu),
+              "dataloader": {}, "generator": {}, "train": {},
+              "general": {"work_dir": "work_dirs/", "project_name": "x"}}
+    net = TripletNet(params, training=True)
+    for attr in ("params_model", "params_dataloader", "params_generator", "params_general", "params_train",
+                 "base_model", "backbone_model", "model", "classification_model", "workdir_path",
+                 "encoded_training_data"):
+        assert hasattr(net, attr), attr
+    assert net.workdir_path == os.path.join("work_dirs/", "x")
+    names = set(B.keras_weights(net.base_model))
+    assert {"conv1/kernel", "conv1/bias", "bn7/gamma", "bn7/moving_variance", "dense1/kernel", "dense2/bias"} <= names
+    assert net.base_model.net.backbone.conv3.geometry(60, 60) == (2, 1, 1, 30, 30)     # 'same', stride 2
+    assert net.base_model.net.backbone.conv3.geometry(59, 59) == (2, 2, 2, 30, 30)
+    assert SiameseNet(params, training=True).model is not None
+    assert TripletNet(params, training=False).model is None
+    # ResNet18 parameter count (11.17 M conv + BN + 0.099 M head = 11.28 M)
+    base, backbone = B.get_backbone((224, 224, 3), encodings_len=256, backbone_name="resnet18", backbone_weights=None,
+                                    device=cpu)
+    n = sum(p.numel() for p in base.parameters())
+    assert abs(n - 11.28e6) < 0.03e6, n
+    with pytest.raises(KeyError):
+        B.get_backbone((64, 64, 3), backbone_name="vgg99", backbone_weights=None, device=cpu)
+
+
+def test_oracle_step_runs_and_learns_on_cpu():
+    """The timed CPU baseline (oracle/step.py) is a real training step: loss goes down on a fixed batch."""
+    from oracle.step import ReferenceStep
+    rs = np.random.RandomState(0)
+    p, k = 3, 3
+    cls = rs.rand(p, 64, 64, 3)
+    x = np.clip(np.repeat(cls, k, axis=0) + 0.2 * rs.randn(p * k, 64, 64, 3), 0, 1).astype(np.float32)
+    ref = ReferenceStep("simple2", (64, 64, 3), 32, p, k, 0.5, "hardest", lr=1e-3, optimizer="adam")
+    losses = [ref.step(x)[0] for _ in range(6)]
+    assert losses[-1] < losses[0]
+
+
+def test_shard_classes():
+    from embeddingnet_amd.parallel import shard_classes
+    assert [shard_classes(256, 8, r) for r in (0, 3, 7)] == [(0, 32), (96, 32), (224, 32)]
+    with pytest.raises(ValueError):
+        shard_classes(30, 8, 0)
+    with pytest.raises(ValueError):
+        shard_classes(8, 8, 0)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from embeddingnet_amd.parallel import GradReducer, init_distributed
+rank, world, _ = init_distributed("gloo")
+torch.manual_seed(0)                                   # identical initial weights on every rank
+model = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+red = GradReducer(model.parameters(), bucket_bytes=2048)        # several buckets
+assert len(red.buckets) > 1
+g = torch.Generator().manual_seed(100 + rank)                   # different local batch per rank
+x = torch.randn(16, 20, generator=g)
+for step in range(3):
+    red.zero()
+    model(x).pow(2).mean().backward()
+    red.finish()
+flat = red.flat.clone()
+# reference: mean over ranks of the local gradients, computed without the reducer
+ref = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+ref.load_state_dict(model.state_dict())
+ref(x).pow(2).mean().backward()
+want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+dist.all_reduce(want); want /= world
+assert torch.allclose(flat, want, rtol=1e-5, atol=1e-7), (flat - want).abs().max()
+for p in model.parameters():
+    assert p.grad.data_ptr() >= red.flat.data_ptr()             # grads are views of the flat buffer
+others = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(others, flat)
+assert all(torch.equal(o, flat) for o in others)               # every rank holds the same averaged gradient
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_grad_reducer_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = 29400 + os.getpid() % 500
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("ok" in o for o in outs)

@@ -7,7 +7,10 @@ from oracle import backbones as OB
 from embeddingnet_amd import backbones as B
 
 dev = torch.device("cuda:0")
-for name, shape, enc, batch in [("simple", (73, 73, 3), 64, 6), ("resnet18", (64, 64, 3), 64, 8)]:
+CASES = {"simple": ((73, 73, 3), 64, 6), "simple2": ((64, 64, 3), 64, 8), "resnet18": ((64, 64, 3), 64, 8),
+         "resnet50": ((128, 128, 3), 32, 6)}
+for name in (sys.argv[1:] or ["simple", "resnet18"]):
+    shape, enc, batch = CASES[name]
     base, _ = B.get_backbone(shape, encodings_len=enc, backbone_name=name, backbone_weights=None, seed=1, device=dev)
     rs = np.random.RandomState(0)
     x = rs.rand(batch, *shape).astype(np.float32)
