@@ -15,6 +15,7 @@
 // Roofline: MFMA f32 (157.3 TFLOP/s); algorithmic FLOP = 2 * N*OH*OW * K * R*S*C per pass.
 #include "gemm_engine.h"
 #include "../../include/embnet.h"
+#include <stdlib.h>
 
 namespace embnet {
 
@@ -301,14 +302,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   });
 }
 
-// out[i] = sum_s slabs[s][i], fixed order
+// out[i] = sum_s slabs[s][i], fixed order.  One float4 column per thread, splits walked with four
+// independent accumulators (s = 0,4,8.. / 1,5,9.. / ...) so several 16-byte loads are in flight;
+// bytes = splits * n * 4 read once (HBM/L2-bound).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long n,
                                                           float* __restrict__ out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slabs[(long)k * n + i];
-  out[i] = s;
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n4 = n >> 2;
+  if (n & 3) {                       // slabs not 16-byte aligned to each other: scalar path
+    for (long i = i4; i < n; i += (long)gridDim.x * 256) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += slabs[(long)k * n + i];
+      out[i] = s;
+    }
+    return;
+  }
+  if (i4 < n4) {
+    const float4* src = reinterpret_cast<const float4*>(slabs) + i4;
+    float4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = src[(long)(k + j) * n4];
+        a[j].x += v.x; a[j].y += v.y; a[j].z += v.z; a[j].w += v.w;
+      }
+    }
+    for (; k < splits; ++k) {
+      const float4 v = src[(long)k * n4];
+      a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i4] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                                                     (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+  }
 }
 
 }  // namespace embnet
@@ -341,10 +369,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
 static int pick_tile(long m, int ncols) {
+  if (const char* e = getenv("EMBNET_CONV_TILE")) return atoi(e);      // tuning aid (tools/kernel_bench.py)
+  // Measured on ResNet18 shapes (tools/kernel_bench.py, EMBNET_CONV_TILE sweep): workgroups all take the
+  // same time, so what matters is how evenly the grid fills the 256 CUs x (3..6 resident workgroups);
+  // 128x64 wins once it gives >= 4 workgroups per CU, 64x64 below that, 128x128 only for many rounds.
   if (ncols <= 32) return 2;
-  if (ncols <= 64) return (cdiv(m, 128) * cdiv(ncols, 64) >= 256) ? 1 : 3;
-  if (cdiv(m, 128) * cdiv(ncols, 128) >= 512) return 0;
-  return (cdiv(m, 128) * cdiv(ncols, 64) >= 256) ? 1 : 3;
+  if (cdiv(m, 128) * cdiv(ncols, 128) >= 4 * 768 && ncols >= 128) return 0;
+  return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
 }
 static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64};
 
@@ -451,7 +482,7 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
   else { LAUNCH_WGRAD(false, false) }
   if (p.splits > 1) {
     const long cnt = (long)rows * k;
-    slab_reduce_kernel<<<cdiv(cnt, 256), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
+    slab_reduce_kernel<<<cdiv(cdiv(cnt, 4) > 0 ? cdiv(cnt, 4) : 1, 256), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
   }
   return check_launch("conv2d_wgrad");
 }

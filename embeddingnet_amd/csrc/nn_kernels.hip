@@ -226,6 +226,65 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   dx[i] = g;
 }
 
+// Four channels per thread (C % 4 == 0): 16-byte loads/stores, 4-byte arg-max words.
+__global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, int n, int h, int w, int c4,
+                                                           int k, int stride, int pad, int oh, int ow,
+                                                           float* __restrict__ y, uint8_t* __restrict__ argmax) {
+  const long total = (long)n * oh * ow * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c4);
+  long t = i / c4;
+  const int x_o = (int)(t % ow); t /= ow;
+  const int y_o = (int)(t % oh);
+  const int b = (int)(t / oh);
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {255, 255, 255, 255};
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
+      const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) v = reinterpret_cast<const float4*>(x)[(((long)b * h + ih) * w + iw) * c4 + col];
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      const int tap = in ? dy * k + dx : 255;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; }
+    }
+  reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+  reinterpret_cast<uint32_t*>(argmax)[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) |
+                                           ((uint32_t)bi[3] << 24);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                           int n, int h, int w, int c4, int k, int stride, int pad,
+                                                           int oh, int ow, float* __restrict__ dx) {
+  const long total = (long)n * h * w * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c4);
+  long t = i / c4;
+  const int iw = (int)(t % w); t /= w;
+  const int ih = (int)(t % h);
+  const int b = (int)(t / h);
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const int y_hi = min((ih + pad) / stride, oh - 1), x_hi = min((iw + pad) / stride, ow - 1);
+  for (int y_o = y_hi; y_o >= 0 && y_o * stride - pad + k > ih; --y_o)
+    for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
+      const uint32_t tap = (uint32_t)((ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad)));
+      const long o = (((long)b * oh + y_o) * ow + x_o) * c4 + col;
+      const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[o];
+      if (((am & 0xff) == tap) | (((am >> 8) & 0xff) == tap) | (((am >> 16) & 0xff) == tap) | ((am >> 24) == tap)) {
+        const float4 d = reinterpret_cast<const float4*>(dy)[o];
+        if ((am & 0xff) == tap) g[0] += d.x;
+        if (((am >> 8) & 0xff) == tap) g[1] += d.y;
+        if (((am >> 16) & 0xff) == tap) g[2] += d.z;
+        if ((am >> 24) == tap) g[3] += d.w;
+      }
+    }
+  reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
+}
+
 // y[n,c] = mean over hw
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int n, int hw, int c,
                                                       float* __restrict__ y) {
@@ -401,7 +460,10 @@ extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, in
   EMBNET_CHECK_ARG((oh - 1) * stride - pad + k <= h + pad && (ow - 1) * stride - pad + k <= w + pad,
                    "maxpool_fwd: window leaves the padded image");
   const long total = (long)n * oh * ow * c;
-  maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax);
+  if ((c & 3) == 0)
+    maxpool_fwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, k, stride, pad, oh, ow, y, argmax);
+  else
+    maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax);
   return check_launch("maxpool_fwd");
 }
 
@@ -410,7 +472,10 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
   EMBNET_CHECK_ARG(dy && argmax && dx, "maxpool_bwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "maxpool_bwd: bad geometry");
   const long total = (long)n * h * w * c;
-  maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx);
+  if ((c & 3) == 0)
+    maxpool_bwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c / 4, k, stride, pad, oh, ow, dx);
+  else
+    maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx);
   return check_launch("maxpool_bwd");
 }
 
