@@ -232,7 +232,8 @@ def get_backbone(input_shape,
                               "(no network); the backbone is randomly initialised")
         if freeze_backbone:
             # reference freezes backbone_model.layers[:-2]; the last two layers (final BN + ReLU) stay trainable
-            tail = {id(p) for p in backbone.bn1.parameters()} if hasattr(backbone, "bn1") else set()
+            last_bn = getattr(backbone, "bn1", None) or getattr(backbone, "top_bn", None)
+            tail = {id(p) for p in last_bn.parameters()} if last_bn is not None else set()
             for p in backbone.parameters():
                 if id(p) not in tail:
                     p.requires_grad_(False)
@@ -254,7 +255,7 @@ def keras_weights(module):
     (net/backbone/head) dropped — the naming oracle/backbones.py uses."""
     out = {}
     for k, v in list(module.named_parameters()) + list(module.named_buffers()):
-        parts = [p for p in k.split(".") if p not in ("net", "backbone", "head")]
+        parts = [p for p in k.split(".") if p not in ("net", "backbone", "head", "base_model", "classification_model")]
         out["_".join(parts[:-1]) + "/" + parts[-1]] = v
     return out
 

@@ -169,7 +169,7 @@ class Conv2D(nn.Module):
             raise ValueError("Conv2D supports activation None or 'relu'")
         self.k, self.stride, self.padding, self.relu, self.l2 = kernel_size, strides, padding, activation == "relu", l2
         w = torch.empty(kernel_size, kernel_size, in_channels, filters)
-        (he_uniform_ if kernel_initializer == "he_uniform" else glorot_uniform_)(w, gen)
+        {"he_uniform": he_uniform_, "conv_normal": conv_normal_}.get(kernel_initializer, glorot_uniform_)(w, gen)
         self.kernel = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(filters)) if use_bias else None
 
@@ -485,6 +485,175 @@ class Dropout(nn.Module):
             return x
         self._step += 1
         return _DropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)
+
+
+# ----------------------------------------------------------------------------- MBConv pieces
+class _DepthwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, geom):
+        x, w = _c(x), _c(w)
+        n, h, wd, c = x.shape
+        r, s = w.shape[0], w.shape[1]
+        stride, pt, pl, oh, ow = geom
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        check(_lib.lib().embnet_dwconv2d_fwd_f32(ptr(x), ptr(w), ptr(y), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                 stream()))
+        ctx.geom = geom
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        lib = _lib.lib()
+        n, h, wd, c = x.shape
+        r, s = w.shape[0], w.shape[1]
+        stride, pt, pl, oh, ow = ctx.geom
+        dy = _c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.embnet_dwconv2d_dgrad_f32(ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                stream()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = workspace(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, r, s, oh, ow), x.device)
+            check(lib.embnet_dwconv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s,
+                                                stride, pt, pl, oh, ow, stream()))
+        return dx, dw, None
+
+
+def conv_normal_(t, gen):
+    """efficientnet's CONV_KERNEL_INITIALIZER: VarianceScaling(scale=2, mode='fan_out', normal)."""
+    shape = t.shape
+    fan_out = shape[-1] * int(math.prod(shape[:-2]))
+    return t.normal_(0.0, math.sqrt(2.0 / fan_out), generator=gen)
+
+
+class DepthwiseConv2D(nn.Module):
+    """Keras DepthwiseConv2D(padding='same', use_bias=False); depthwise_kernel [k,k,C,1]."""
+
+    def __init__(self, channels, kernel_size, strides=1, gen=None):
+        super().__init__()
+        self.k, self.stride = kernel_size, strides
+        w = torch.empty(kernel_size, kernel_size, channels, 1)
+        # fan_out of a depthwise kernel in Keras' VarianceScaling: k*k*depth_multiplier(=1)... uses shape[-1]*rf
+        self.depthwise_kernel = nn.Parameter(conv_normal_(w, gen))
+
+    def forward(self, x):
+        h, w = x.shape[1], x.shape[2]
+        oh, pt = same_pad(h, self.k, self.stride)
+        ow, pl = same_pad(w, self.k, self.stride)
+        return _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow))
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().embnet_activation_fwd(ptr(x), x.numel(), kind, ptr(y), stream()))
+        ctx.kind = kind
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(_lib.lib().embnet_activation_bwd(ptr(x), ptr(_c(dy)), x.numel(), ctx.kind, ptr(dx), stream()))
+        return dx, None
+
+
+def sigmoid(x):
+    return _ActFn.apply(x, 0)
+
+
+def swish(x):
+    return _ActFn.apply(x, 1)
+
+
+class Swish(nn.Module):
+    def forward(self, x):
+        return swish(x)
+
+
+class _ChannelScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _c(x), _c(s)
+        n, h, w, c = x.shape
+        y = torch.empty_like(x)
+        check(_lib.lib().embnet_channel_scale_fwd(ptr(x), ptr(s), n, h * w, c, ptr(y), stream()))
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        n, h, w, c = x.shape
+        dx, ds = torch.empty_like(x), torch.empty_like(s)
+        check(_lib.lib().embnet_channel_scale_bwd(ptr(x), ptr(s), ptr(_c(dy)), n, h * w, c, ptr(dx), ptr(ds), stream()))
+        return dx, ds
+
+
+def channel_scale(x, s):
+    """x[n,h,w,c] * s[n,c] (the squeeze-excite multiply)."""
+    return _ChannelScaleFn.apply(x, s.reshape(x.shape[0], x.shape[-1]))
+
+
+class _SampleDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        per = x.numel() // x.shape[0]
+        check(_lib.lib().embnet_sample_dropout(ptr(x), x.numel(), per, rate, seed, ptr(y), stream()))
+        ctx.cfg = (rate, seed, per)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rate, seed, per = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(_lib.lib().embnet_sample_dropout(ptr(dy), dy.numel(), per, rate, seed, ptr(dx), stream()))
+        return dx, None, None
+
+
+class DropConnect(nn.Module):
+    """efficientnet's FixedDropout(noise_shape=(None,1,1,1)): drops whole samples of the residual branch."""
+
+    def __init__(self, rate, seed=0):
+        super().__init__()
+        self.rate, self.seed, self.enabled, self._step = rate, seed, True, 0
+
+    def forward(self, x):
+        if not (self.training and self.enabled and self.rate > 0):
+            return x
+        self._step += 1
+        return _SampleDropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)
+
+
+class _AbsDiffFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        check(_lib.lib().embnet_absdiff_fwd(ptr(a), ptr(b), a.numel(), ptr(y), stream()))
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        check(_lib.lib().embnet_absdiff_bwd(ptr(a), ptr(b), ptr(_c(dy)), a.numel(), ptr(da), ptr(db), stream()))
+        return da, db
+
+
+def abs_diff(a, b):
+    return _AbsDiffFn.apply(a, b)
 
 
 class _L2PenaltyFn(torch.autograd.Function):

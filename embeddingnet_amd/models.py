@@ -102,17 +102,25 @@ class TripletNet(EmbeddingNet):
 class _SiameseGraph(nn.Module):
     """[x1, x2] -> [distance, cls1, cls2] (reference models.py:203-230); 'l2' distance head."""
 
-    def __init__(self, base_model, classification_model, distance_type):
+    def __init__(self, base_model, classification_model, distance_type, encodings_len):
         super().__init__()
-        if distance_type != 'l2':
-            raise NotImplementedError("SiameseNet: only distance_type 'l2' is implemented on the HIP path "
-                                      "(the 'l1' sigmoid head is a next-row item, DESIGN.md)")
+        if distance_type not in ('l1', 'l2'):
+            raise KeyError(f"distance_type '{distance_type}' (reference supports 'l1' and 'l2')")
         self.base_model, self.classification_model = base_model, classification_model
+        self.distance_type = distance_type
+        if distance_type == 'l1':
+            self.output_siamese = L.Dense(encodings_len, 1)          # reference models.py:221
 
     def forward(self, inputs):
         x1, x2 = inputs
         e1, e2 = self.base_model(x1), self.base_model(x2)
-        return [ops.pair_distance(e1, e2), None, None]
+        if self.distance_type == 'l1':                               # models.py:217-221
+            out = L.sigmoid(self.output_siamese(L.abs_diff(e1, e2)))
+        else:                                                        # models.py:223-228
+            out = ops.pair_distance(e1, e2)
+        # The two 'output_im*' classification outputs (models.py:211-215) carry no loss in train.py:118;
+        # they are not evaluated here (each would be one more backbone forward).
+        return [out, None, None]
 
 
 class SiameseNet(EmbeddingNet):
@@ -127,5 +135,7 @@ class SiameseNet(EmbeddingNet):
             self._create_model_siamese()
 
     def _create_model_siamese(self):
+        dev = next(self.base_model.parameters()).device
         self.model = Model(_SiameseGraph(self.base_model, self.classification_model,
-                                         self.params_model['distance_type']), name="siamese_model")
+                                         self.params_model['distance_type'],
+                                         self.params_model.get('encodings_len', 4096)), name="siamese_model").to(dev)

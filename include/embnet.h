@@ -170,6 +170,31 @@ int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev
 int embnet_tap_contract(const float* w, const float* tap_sums, int taps, int c, int k, float* out, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
 int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream);
+/* ---- EfficientNet MBConv pieces (backbones.py:84-98, `efficientnet` zoo package) and the siamese 'l1' head ---- */
+/* DepthwiseConv2D: x[n,h,w,c], w[r,s,c] (Keras depthwise_kernel [r,s,c,1]), y[n,oh,ow,c]; padding as conv2d. */
+int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s,
+                            int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
+int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
+                              int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
+size_t embnet_dwconv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int oh, int ow);
+int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              int n, int h, int wd, int c, int r, int s, int stride, int pad_t, int pad_l, int oh,
+                              int ow, void* stream);
+/* kind 0 = sigmoid, 1 = swish (x*sigmoid(x)); backward recomputes from x. */
+int embnet_activation_fwd(const float* x, long total, int kind, float* y, void* stream);
+int embnet_activation_bwd(const float* x, const float* dy, long total, int kind, float* dx, void* stream);
+/* squeeze-excite multiply: y[n,p,c] = x[n,p,c]*s[n,c]; bwd gives dx and ds[n,c]. */
+int embnet_channel_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, void* stream);
+int embnet_channel_scale_bwd(const float* x, const float* s, const float* dy, int n, int hw, int c, float* dx,
+                             float* ds, void* stream);
+/* drop-connect: Dropout with noise_shape (None,1,1,1): one keep/drop decision per sample, inverted scaling. */
+int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed, float* y,
+                          void* stream);
+/* models.py:218 L1 layer: y = |a - b|. */
+int embnet_absdiff_fwd(const float* a, const float* b, long total, float* y, void* stream);
+int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long total, float* da, float* db,
+                       void* stream);
+
 /* kernel_regularizer=l2(lambda) (backbones.py:22-36): *out = alpha * sum x^2. */
 size_t embnet_sumsq_workspace_bytes(void);
 int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace, size_t workspace_bytes,

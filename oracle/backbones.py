@@ -238,6 +238,56 @@ def resnet(ctx, x, name):
     return torch.relu(batchnorm(ctx, "bn1", x, eps=RN_EPS))
 
 
+# efficientnet (qubvel) — backbones.py:84-98
+EFN_BLOCKS = [(3, 1, 32, 16, 1, 1), (3, 2, 16, 24, 6, 2), (5, 2, 24, 40, 6, 2), (3, 3, 40, 80, 6, 2),
+              (5, 3, 80, 112, 6, 1), (5, 4, 112, 192, 6, 2), (3, 1, 192, 320, 6, 1)]
+EFN_SCALING = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b1": (1.0, 1.1), "efficientnet-b2": (1.1, 1.2),
+               "efficientnet-b3": (1.2, 1.4), "efficientnet-b4": (1.4, 1.8), "efficientnet-b5": (1.6, 2.2),
+               "efficientnet-b6": (1.8, 2.6), "efficientnet-b7": (2.0, 3.1)}
+
+
+def conv_normal(rs, shape):
+    """VarianceScaling(scale=2, mode='fan_out', distribution='normal')"""
+    _, fo = _fans(shape)
+    return rs.randn(*shape) * math.sqrt(2.0 / fo)
+
+
+def _efn_round_filters(f, width, divisor=8):
+    f *= width
+    new = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if new < 0.9 * f:
+        new += divisor
+    return int(new)
+
+
+def efficientnet(ctx, x, name):
+    width, depth = EFN_SCALING[name]
+    sw = lambda t: t * torch.sigmoid(t)
+    cv = lambda nm, t, c, k, s: conv2d(ctx, nm, t, c, k, stride=s, padding="same", bias=False, init=conv_normal)
+    x = sw(batchnorm(ctx, "stem_bn", cv("stem_conv", x, _efn_round_filters(32, width), 3, 2)))
+    idx = 0
+    for k, rep, cin, cout, e, s in EFN_BLOCKS:
+        cin, cout = _efn_round_filters(cin, width), _efn_round_filters(cout, width)
+        for i in range(int(math.ceil(depth * rep))):
+            idx += 1
+            pre = f"block{idx}_"
+            bin_, stride = (cin, s) if i == 0 else (cout, 1)
+            inp = x
+            mid = bin_ * e
+            if e != 1:
+                x = sw(batchnorm(ctx, pre + "expand_bn", cv(pre + "expand_conv", x, mid, 1, 1)))
+            x = sw(batchnorm(ctx, pre + "bn", depthwise_conv2d(ctx, pre + "dwconv", x, k, stride, conv_normal)))
+            se = max(1, int(bin_ * 0.25))
+            sq = x.mean(dim=(1, 2))
+            sq = sw(dense(ctx, pre + "se_reduce", sq, se, init=conv_normal))
+            sq = torch.sigmoid(dense(ctx, pre + "se_expand", sq, mid, init=conv_normal))
+            x = x * sq[:, None, None, :]
+            x = batchnorm(ctx, pre + "project_bn", cv(pre + "project_conv", x, cout, 1, 1))
+            if stride == 1 and bin_ == cout:
+                x = x + inp                      # drop-connect is off in parity runs (ctx.dropout False)
+    return sw(batchnorm(ctx, "top_bn", cv("top_conv", x, _efn_round_filters(1280, width), 1, 1)))
+
+
 # backbones.py:110-121
 def zoo_head(ctx, feat, enc, norm):
     x = feat.mean(dim=(1, 2))
@@ -254,6 +304,8 @@ def base_model(ctx, x, backbone_name="simple", encodings_len=4096, embeddings_no
         return simple2_head(ctx, simple2(ctx, x), encodings_len, embeddings_normalization)
     if backbone_name in RESNET:
         return zoo_head(ctx, resnet(ctx, x, backbone_name), encodings_len, embeddings_normalization)
+    if backbone_name in EFN_SCALING:
+        return zoo_head(ctx, efficientnet(ctx, x, backbone_name), encodings_len, embeddings_normalization)
     raise KeyError(backbone_name)
 
 
