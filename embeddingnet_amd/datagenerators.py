@@ -1,0 +1,236 @@
+"""Drop-in for the generator side of embedding_net/datagenerators.py (reference :16-378).
+
+The hot-path piece is TripletsDataGenerator: the reference samples P classes x K images, embeds them
+with P predict() calls, builds the distance matrix with scikit-learn and mines triplets in a Python
+double loop (:201-258).  Here the same contract (`__getitem__ -> ([A,P,N], targets)`) is served by one
+batched inference forward + the HIP distance/mining kernels; `sample_batch()` additionally hands the
+class-contiguous batch to the fused trainer (train_step.TripletTrainer), which is the fast path.
+
+Image sources: `class_files_paths[class]` may be a list of file paths (decoded with PIL — cv2 is not
+installed here — resized to input_shape, BGR order, /255 as reference :13-21,:156) or an in-memory
+float array [n,H,W,3] already in [0,1] (synthetic data).  File IO is outside the hot path.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def get_image(img_path, input_shape=None):
+    """reference utils.py:13-21 (cv2.imread + resize) on PIL: uint8 HxWx3, BGR channel order."""
+    from PIL import Image
+    if not os.path.exists(img_path):
+        print('image is not exist ' + img_path)
+        return None
+    img = Image.open(img_path).convert("RGB")
+    if input_shape:
+        img = img.resize((input_shape[0], input_shape[1]), Image.BILINEAR)
+    return np.asarray(img)[:, :, ::-1]
+
+
+class ENDataLoader():
+    """class -> file list from a directory tree (reference :89-111) or a CSV (:60-87), with the
+    per-class train/val split (:51-58)."""
+
+    def __init__(self, dataset_path, train_csv_file=None, val_csv_file=None, image_id_column='image_id',
+                 label_column='label', validate=True, val_ratio=0.1, is_google=False):
+        self.dataset_path = dataset_path
+        self.class_names = []
+        if train_csv_file is not None:
+            self.class_files_paths = self._load_from_dataframe(train_csv_file, image_id_column, label_column)
+        else:
+            self.class_files_paths = self._load_from_directory()
+        self.n_classes = len(self.class_names)
+        self.n_samples = {k: len(v) for k, v in self.class_files_paths.items()}
+        self.validate, self.val_ratio = validate, val_ratio
+        if self.validate:
+            if val_csv_file is not None:
+                self.train_data = self.class_files_paths
+                self.val_data = self._load_from_dataframe(val_csv_file, image_id_column, label_column)
+            else:
+                self.train_data, self.val_data = self.split_train_val(self.val_ratio)
+        else:
+            self.train_data, self.val_data = self.class_files_paths, {}
+
+    def split_train_val(self, val_ratio):
+        from sklearn.model_selection import train_test_split
+        train_data, val_data = {}, {}
+        for k, v in self.class_files_paths.items():
+            train_data[k], val_data[k] = train_test_split(v, test_size=val_ratio, random_state=42)
+        return train_data, val_data
+
+    def _load_from_dataframe(self, csv_file, image_id_column, label_column):
+        import pandas as pd
+        df = pd.read_csv(csv_file)
+        out = {}
+        for cl, grp in df.groupby(label_column):
+            cl = str(cl)
+            if cl not in self.class_names:
+                self.class_names.append(cl)
+            out[cl] = [os.path.join(self.dataset_path, str(p)) for p in grp[image_id_column]]
+        return out
+
+    def _load_from_directory(self):
+        out = {}
+        for cl in sorted(os.listdir(self.dataset_path)):
+            d = os.path.join(self.dataset_path, cl)
+            if os.path.isdir(d):
+                self.class_names.append(cl)
+                out[cl] = [os.path.join(d, f) for f in sorted(os.listdir(d))]
+        return out
+
+
+class SyntheticDataLoader:
+    """In-memory stand-in with the same attributes: n_classes class prototypes + noise, images in [0,1]."""
+
+    def __init__(self, n_classes, n_per_class, input_shape, noise=0.15, validate=True, val_ratio=0.2, seed=0):
+        rs = np.random.RandomState(seed)
+        h, w = input_shape[0], input_shape[1]
+        self.class_names = [f"class_{i:03d}" for i in range(n_classes)]
+        proto = rs.rand(n_classes, h, w, 3)
+        self.class_files_paths = {
+            c: np.clip(proto[i] + noise * rs.randn(n_per_class, h, w, 3), 0, 1).astype(np.float32)
+            for i, c in enumerate(self.class_names)}
+        self.n_classes = n_classes
+        self.n_samples = {k: len(v) for k, v in self.class_files_paths.items()}
+        self.validate, self.val_ratio = validate, val_ratio
+        n_val = max(1, int(round(n_per_class * val_ratio))) if validate else 0
+        self.train_data = {k: v[: len(v) - n_val] for k, v in self.class_files_paths.items()}
+        self.val_data = {k: v[len(v) - n_val:] for k, v in self.class_files_paths.items()} if validate else {}
+
+
+class ENDataGenerator:
+    def __init__(self, class_files_paths, class_names, val_gen=False, input_shape=None, batch_size=32,
+                 n_batches=10, n_batches_val=10, augmentations=None):
+        self.input_shape, self.augmentations = input_shape, augmentations
+        self.batch_size, self.n_batches, self.n_batches_val, self.val_gen = batch_size, n_batches, n_batches_val, val_gen
+        self.class_files_paths, self.class_names = class_files_paths, class_names
+        self.n_classes = len(self.class_names)
+        self.n_samples = {k: len(v) for k, v in self.class_files_paths.items()}
+
+    def __len__(self):
+        return self.n_batches_val if self.val_gen else self.n_batches
+
+    def _get_images_set(self, clsss, idxs, with_aug=True):
+        """reference :145-156 -> float array [n,H,W,3] in [0,1]."""
+        if type(clsss) is not list:
+            clsss = [clsss] * len(idxs)
+        imgs = []
+        for cl, idx in zip(clsss, idxs):
+            src = self.class_files_paths[cl]
+            if isinstance(src, np.ndarray):
+                imgs.append(src[idx])
+            else:
+                img = get_image(src[idx], self.input_shape)
+                if with_aug and self.augmentations is not None:
+                    img = self.augmentations(image=img)['image']
+                imgs.append(np.asarray(img, np.float32) / 255.)
+        return np.asarray(imgs, np.float32)
+
+
+class TripletsDataGenerator(ENDataGenerator):
+
+    def __init__(self, embedding_model, class_files_paths, class_names, n_batches=10, input_shape=None,
+                 batch_size=32, augmentations=None, k_classes=5, k_samples=5, margin=0.5,
+                 negatives_selection_mode='semihard'):
+        super().__init__(class_files_paths=class_files_paths, class_names=class_names, input_shape=input_shape,
+                         batch_size=batch_size, n_batches=n_batches, augmentations=augmentations)
+        if negatives_selection_mode not in ops.MINING_MODES:
+            raise KeyError(negatives_selection_mode)
+        self.embedding_model = embedding_model
+        self.k_classes, self.k_samples, self.margin = k_classes, k_samples, margin
+        self.mode = negatives_selection_mode
+        self._calls = 0
+
+    def sample_batch(self):
+        """reference :202-205,211-218: P classes without replacement, K images per class WITH replacement,
+        stacked class-contiguous.  Returns float32 [P*K,H,W,3]."""
+        selected = np.random.choice(self.n_classes, size=self.k_classes, replace=False)
+        classes = [self.class_names[c] for c in selected]
+        idxs = [np.random.choice(self.n_samples[cl], size=self.k_samples, replace=True) for cl in classes]
+        return np.vstack([self._get_images_set(cl, ix, with_aug=self.augmentations) for cl, ix in zip(classes, idxs)])
+
+    def get_batch_triplets_mining(self):
+        """reference :201-258 with the embedding / distance / mining work on the GPU."""
+        images = self.sample_batch()
+        dev = next(self.embedding_model.parameters()).device
+        x = torch.from_numpy(images).to(dev)
+        was = self.embedding_model.training
+        self.embedding_model.eval()                         # predict(): inference-mode BN, no dropout
+        with torch.no_grad():
+            emb = self.embedding_model(x)
+            dist = ops.pairwise_distances(emb)
+            self._calls += 1
+            trip, count, _ = ops.mine_triplets(dist, self.k_classes, self.k_samples, self.margin, self.mode,
+                                               seed=np.random.randint(0, 2 ** 31 - 1))
+        self.embedding_model.train(was)
+        t = trip[: int(count.item())].long()
+        triplets = [x[t[:, 0]], x[t[:, 1]], x[t[:, 2]]]
+        targets = torch.ones(len(t), device=dev)
+        return triplets, targets
+
+    def __getitem__(self, index):
+        return self.get_batch_triplets_mining()
+
+
+class SimpleTripletsDataGenerator(ENDataGenerator):
+    """Random (anchor, positive, negative) triplets without mining (reference :264-314); validation generator."""
+
+    def __init__(self, class_files_paths, class_names, input_shape=None, batch_size=32, n_batches=10,
+                 augmentations=None, **kwargs):
+        super().__init__(class_files_paths=class_files_paths, class_names=class_names, input_shape=input_shape,
+                         batch_size=batch_size, n_batches=n_batches, augmentations=augmentations)
+
+    def get_batch_triplets(self):
+        a, p, n = [], [], []
+        for _ in range(self.batch_size):
+            ci = random.randrange(0, self.n_classes)
+            cl = self.class_names[ci]
+            other = self.class_names[(ci + random.randrange(1, self.n_classes)) % self.n_classes]
+            n_cl = self.n_samples[cl]
+            i1 = random.randrange(0, n_cl)
+            i2 = (i1 + random.randrange(1, n_cl)) % n_cl if n_cl > 1 else i1
+            i3 = random.randrange(0, self.n_samples[other])
+            imgs = self._get_images_set([cl, cl, other], [i1, i2, i3], with_aug=self.augmentations)
+            a.append(imgs[0]); p.append(imgs[1]); n.append(imgs[2])
+        return [np.asarray(a), np.asarray(p), np.asarray(n)], np.ones((self.batch_size,), np.float32)
+
+    def __getitem__(self, index):
+        return self.get_batch_triplets()
+
+
+class SiameseDataGenerator(ENDataGenerator):
+    """Half same-class pairs (target 1), half different-class pairs (target 0) (reference :317-378)."""
+
+    def __init__(self, class_files_paths, class_names, val_gen=False, input_shape=None, batch_size=32, n_batches=10,
+                 n_batches_val=10, augmentations=None, **kwargs):
+        super().__init__(class_files_paths=class_files_paths, class_names=class_names, val_gen=val_gen,
+                         input_shape=input_shape, batch_size=batch_size, n_batches=n_batches,
+                         n_batches_val=n_batches_val, augmentations=augmentations)
+
+    def get_batch_pairs(self):
+        x1, x2 = [], []
+        targets = np.zeros((self.batch_size,), np.float32)
+        n_same = self.batch_size // 2
+        ci = random.randrange(0, self.n_classes)
+        cl = self.class_names[ci]
+        n_cl = self.n_samples[cl]
+        indxs = np.random.randint(n_cl, size=self.batch_size)
+        for i in range(self.batch_size):
+            i1 = int(indxs[i])
+            if i < n_same:
+                i2 = (i1 + random.randrange(1, n_cl)) % n_cl if n_cl > 1 else i1
+                imgs = self._get_images_set([cl, cl], [i1, i2], with_aug=self.augmentations)
+                targets[i] = 1
+            else:
+                other = self.class_names[(ci + random.randrange(1, self.n_classes)) % self.n_classes]
+                imgs = self._get_images_set([cl, other], [i1, random.randrange(0, self.n_samples[other])],
+                                            with_aug=self.augmentations)
+            x1.append(imgs[0]); x2.append(imgs[1])
+        return [np.asarray(x1), np.asarray(x2)], targets
+
+    def __getitem__(self, index):
+        return self.get_batch_pairs()

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's tools/train.py (same CLI, YAML schema and work-dir layout) on the
+MI355X hot path.
+
+    python tools/train.py <config.yml> [--resume_from weights.npz] [--synthetic N_CLASSES]
+
+Triplet mode runs the fused step (one forward, on-GPU distance matrix + mining + hinge, backward,
+optimizer); siamese mode trains SiameseNet with contrastive_loss.  Per-epoch schedule as the reference:
+lr0 * decay^floor(epoch/step) (train.py:80-81), ReduceLROnPlateau(0.1, patience 4) (:82-83),
+EarlyStopping(patience 10) (:84-86), best-only checkpoints weights/epoch_XXX.npz (:87-90).
+Multi-GPU: launch with torchrun; classes are sharded per rank and gradients all-reduced over RCCL.
+`--synthetic` swaps the file loader for an in-memory synthetic dataset (no dataset ships with the repo).
+"""
+import argparse
+import os
+import sys
+
+BASE_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT_DIR = os.path.dirname(BASE_DIR)
+sys.path.insert(0, ROOT_DIR)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from embedding_net.models import TripletNet, SiameseNet  # noqa: E402
+from embedding_net.utils import parse_params  # noqa: E402
+from embedding_net.losses_and_accuracies import contrastive_loss, triplet_loss, accuracy  # noqa: E402
+from embeddingnet_amd.datagenerators import (ENDataLoader, SyntheticDataLoader, TripletsDataGenerator,  # noqa: E402
+                                             SimpleTripletsDataGenerator, SiameseDataGenerator)
+from embeddingnet_amd.parallel import GradReducer, init_distributed, shard_classes  # noqa: E402
+from embeddingnet_amd.train_step import TripletTrainer  # noqa: E402
+
+
+def parse_args():
+    parser = argparse.ArgumentParser(description='Train an embedding network')
+    parser.add_argument('config', help='model config file path')
+    parser.add_argument('--resume_from', help='the checkpoint file to resume from')
+    parser.add_argument('--synthetic', type=int, default=0, help='use N synthetic classes instead of DATALOADER')
+    parser.add_argument('--max_epochs', type=int, default=None, help='cap TRAIN.n_epochs (smoke runs)')
+    return parser.parse_args()
+
+
+def create_save_folders(params):
+    work_dir_path = os.path.join(params['work_dir'], params['project_name'])
+    paths = {k: os.path.join(work_dir_path, v) for k, v in
+             dict(weights='weights/', pretrained='pretraining_model/weights/', encodings='encodings/', plots='plots/',
+                  tf_log='tf_log/', pretrained_log='pretraining_model/tf_log/').items()}
+    for p in [work_dir_path] + list(paths.values()):
+        os.makedirs(p, exist_ok=True)
+    return paths
+
+
+class Plateau:
+    """ReduceLROnPlateau(factor .1, patience 4) + EarlyStopping(patience 10) + best-only checkpoint."""
+
+    def __init__(self):
+        self.best, self.since_best, self.since_reduce, self.scale = float('inf'), 0, 0, 1.0
+
+    def update(self, value):
+        improved = value < self.best
+        if improved:
+            self.best, self.since_best, self.since_reduce = value, 0, 0
+        else:
+            self.since_best += 1
+            self.since_reduce += 1
+            if self.since_reduce >= 4:
+                self.scale *= 0.1
+                self.since_reduce = 0
+                print(f'ReduceLROnPlateau: lr scale -> {self.scale:g}')
+        return improved, self.since_best >= 10
+
+
+def main():
+    args = parse_args()
+    cfg = parse_params(args.config)
+    p_train, p_model, p_loader, p_gen = cfg['train'], cfg['model'], cfg['dataloader'], cfg['generator']
+    paths = create_save_folders(cfg['general'])
+    rank, world, local = init_distributed()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    p_model['device'] = dev
+
+    if args.synthetic:
+        data_loader = SyntheticDataLoader(args.synthetic, 24, p_model['input_shape'],
+                                          validate=p_loader.get('validate', True), seed=rank)
+    else:
+        data_loader = ENDataLoader(**{k: v for k, v in p_loader.items() if k != 'csv_file'})
+    monitor = 'val_loss' if data_loader.validate else 'loss'
+    gen_kw = {k: v for k, v in p_gen.items()}
+
+    siamese = p_model['mode'] == 'siamese'
+    if siamese:
+        model = SiameseNet(cfg, training=True)
+        train_gen = SiameseDataGenerator(class_files_paths=data_loader.train_data, class_names=data_loader.class_names,
+                                         **gen_kw)
+        val_gen = SiameseDataGenerator(class_files_paths=data_loader.val_data, class_names=data_loader.class_names,
+                                       val_gen=True, **gen_kw) if data_loader.validate else None
+        trainable = model.model
+    else:
+        model = TripletNet(cfg, training=True)
+        if world > 1:                                 # whole classes per rank, mining stays local
+            _, gen_kw['k_classes'] = shard_classes(p_gen['k_classes'], world, rank)
+        train_gen = TripletsDataGenerator(embedding_model=model.base_model, class_files_paths=data_loader.train_data,
+                                          class_names=data_loader.class_names, **gen_kw)
+        val_gen = SimpleTripletsDataGenerator(data_loader.val_data, data_loader.class_names,
+                                              **gen_kw) if data_loader.validate else None
+        trainable = model.base_model
+    if args.resume_from is not None:
+        model.load_model(args.resume_from)            # the mining model IS base_model, so it resumes too
+
+    params = [p for p in trainable.parameters() if p.requires_grad]
+    opt = p_train['optimizer'].build(params)
+    lr0 = p_train['learning_rate']
+    reducer = GradReducer(params) if world > 1 else None
+    trainer = None if siamese else TripletTrainer(
+        model.base_model, opt, gen_kw['k_classes'], p_gen['k_samples'], margin=p_gen['margin'],
+        negatives_selection_mode=p_gen['negatives_selection_mode'], seed=rank, reducer=reducer)
+    plateau, history = Plateau(), {'loss': [], 'val_loss': []}
+    n_epochs = min(p_train['n_epochs'], args.max_epochs or p_train['n_epochs'])
+
+    for epoch in range(n_epochs):
+        lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size']) * plateau.scale
+        for g in opt.param_groups:
+            g['lr'] = lr
+        trainable.train()
+        losses = []
+        for _ in range(len(train_gen)):
+            if siamese:
+                (x1, x2), y = train_gen[0]
+                opt.zero_grad(set_to_none=True) if reducer is None else reducer.zero()
+                out = model.model([torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)])[0]
+                loss = contrastive_loss(torch.from_numpy(y).to(dev), out)
+                loss.backward()
+                if reducer is not None:
+                    reducer.finish()
+                opt.step()
+                losses.append(loss.detach())
+            else:
+                losses.append(trainer.step(torch.from_numpy(train_gen.sample_batch()).to(dev)))
+        epoch_loss = float(torch.stack(losses).mean().item())
+        history['loss'].append(epoch_loss)
+        msg = f'Epoch {epoch + 1}/{n_epochs} - lr {lr:.3g} - loss {epoch_loss:.4f}'
+        value = epoch_loss
+        if val_gen is not None:
+            trainable.eval()
+            vals = []
+            with torch.no_grad():
+                for _ in range(len(val_gen)):
+                    xs, y = val_gen[0]
+                    xs = [torch.from_numpy(a).to(dev) for a in xs]
+                    if siamese:
+                        out = model.model(xs)[0]
+                        vals.append(contrastive_loss(torch.from_numpy(y).to(dev), out))
+                    else:
+                        vals.append(triplet_loss(p_gen['margin'])(None, model.model(xs)).mean())
+            value = float(torch.stack(vals).mean().item())
+            history['val_loss'].append(value)
+            msg += f' - val_loss {value:.4f}'
+        if rank == 0:
+            print(msg, flush=True)
+        improved, stop = plateau.update(value)
+        if improved and rank == 0:
+            path = os.path.join(paths['weights'], f'epoch_{epoch + 1:03d}.npz')
+            model.save_weights(path)
+            print(f'{monitor} improved to {value:.5f}, saving model to {path}')
+        if stop:
+            print('EarlyStopping')
+            break
+    if rank == 0:
+        np.savez(os.path.join(paths['plots'], 'history.npz'), **{k: np.asarray(v) for k, v in history.items()})
+    return history
+
+
+if __name__ == '__main__':
+    main()
