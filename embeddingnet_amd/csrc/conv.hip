@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   });
 }
 
-struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits; };
+struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; };
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
 template <class G, bool VA, bool VB>
@@ -288,14 +288,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
   const int M = p.g.R * p.g.S * p.g.C, Kg = p.g.N * p.g.OH * p.g.OW;
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
-  const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
+  // Two workgroup orders (speed only; results identical).  Default: tiles of one K-split on consecutive
+  // ids, i.e. spread over the 8 XCDs.  xcd_order=1 (EMBNET_WGRAD_XCD=1) puts all tiles of a split on ONE
+  // XCD so its L2 serves the shared X/dY pixels — HBM traffic drops ~4x on the 3x3 layers, but measured
+  // 20-25 % SLOWER (A/B in one process, tools/kernel_bench.py): the tiles hit the same L2 lines at the
+  // same instant; spreading them over eight L2s + the 256 MB Infinity Cache is faster.  Kept as a knob.
+  const int tiles = ((M + G::BM - 1) / G::BM) * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = p.xcd_order ? (slot / tiles) * 8 + xcd : blockIdx.x / tiles;
+  const int tile = p.xcd_order ? slot % tiles : blockIdx.x % tiles;
+  if (split >= p.splits) return;
+  const int m0 = (tile / tiles_n) * G::BM, n0 = (tile % tiles_n) * G::BN;
   const int kt_total = (Kg + BK - 1) / BK;
-  const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
+  const int kt0 = split * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
   LoadConvWgradA<G::BM, VA> la; la.init(p.x, p.g, m0, threadIdx.x);
   LoadRowsKM<G::BN, VB> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
-  float* out = p.out + (long)blockIdx.y * M * p.g.K;
+  float* out = p.out + (long)split * M * p.g.K;
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < M && col < p.g.K) out[(long)row * p.g.K + col] = v;
@@ -465,7 +475,8 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
                                        size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
                                        int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
-  ConvWgradParams p{x, dy, dw, {}, 0, 1};
+  ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
+  if (const char* e = getenv("EMBNET_WGRAD_XCD")) p.xcd_order = atoi(e);
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_wgrad")) return rc;
   int tile;
   const int rows = r * s * c;
@@ -475,7 +486,7 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
     return fail(EMBNET_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   if (p.splits > 1) p.out = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]), p.splits);
+  const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
   if (va && vb) { LAUNCH_WGRAD(true, true) }
   else if (vb) { LAUNCH_WGRAD(false, true) }

@@ -90,54 +90,69 @@ __global__ __launch_bounds__(256) void mean_first_kernel(const float* __restrict
   if (threadIdx.x == 0) *out = (part[0] + part[1] + part[2] + part[3]) / (float)max(cnt, 1);
 }
 
-// demb[r] = (upstream / T) * sum over triplets containing r of the hinge gradient — one workgroup
-// per embedding row scanning the (LDS-staged) triplet list: no atomics, reproducible.
+// demb[r] = (upstream / T) * sum over triplets containing r of the hinge gradient.  One workgroup
+// per embedding row: the 256 threads scan the triplet list 256 at a time, the (few) triplets that
+// touch row r are compacted IN ORDER into LDS by ballot/popcount, then every thread accumulates its
+// columns over those matches.  No atomics; the summation order is the triplet order -> reproducible.
+// Work per workgroup: T/256 index checks per thread + matches * E/256 FMAs (was T per thread).
 __global__ __launch_bounds__(256) void triplet_gather_bwd_kernel(const float* __restrict__ emb, int n_rows, int e,
                                                                  const int* __restrict__ trip,
                                                                  const int* __restrict__ count, int max_t,
                                                                  const float* __restrict__ act,
                                                                  const float* __restrict__ upstream,
                                                                  float* __restrict__ demb) {
-  constexpr int CH = 512;
-  __shared__ int s_trip[CH * 3];
-  __shared__ float s_act[CH];
+  __shared__ int s_match[256 * 3];
+  __shared__ int s_wave[4];
   const int r = blockIdx.x;
   const int cnt = min(*count, max_t);
   const float g = 2.f * (upstream ? *upstream : 1.f) / (float)max(cnt, 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // each thread owns columns c = tid, tid+256, ... (E <= 4096 -> at most 16 live accumulators)
   float accv[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) accv[i] = 0.f;
-  const float* me = emb + (long)r * e;
-  for (int t0 = 0; t0 < cnt; t0 += CH) {
-    const int m = min(CH, cnt - t0);
+  for (int t0 = 0; t0 < cnt; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    int a = -1, p = -1, n = -1;
+    bool hit = false;
+    if (t < cnt) {
+      a = trip[3 * t]; p = trip[3 * t + 1]; n = trip[3 * t + 2];
+      hit = (a == r || p == r || n == r) && act[t] != 0.f;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wave[wave] = __popcll(m);
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * m; i += 256) s_trip[i] = trip[3 * t0 + i];
-    for (int i = threadIdx.x; i < m; i += 256) s_act[i] = act[t0 + i];
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (hit) {
+      const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+      s_match[3 * slot] = a; s_match[3 * slot + 1] = p; s_match[3 * slot + 2] = n;
+    }
     __syncthreads();
-    for (int t = 0; t < m; ++t) {
-      const int a = s_trip[3 * t], p = s_trip[3 * t + 1], n = s_trip[3 * t + 2];
-      if ((a != r && p != r && n != r) || s_act[t] == 0.f) continue;   // workgroup-uniform
-      const float* ea = emb + (long)a * e; const float* ep = emb + (long)p * e; const float* en = emb + (long)n * e;
+    for (int k = 0; k < total; ++k) {
+      const int ma = s_match[3 * k], mp = s_match[3 * k + 1], mn = s_match[3 * k + 2];
+      const float* ea = emb + (long)ma * e; const float* ep = emb + (long)mp * e; const float* en = emb + (long)mn * e;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int c = threadIdx.x + 256 * i;
         if (c < e) {
           float d = 0.f;
-          if (a == r) d += en[c] - ep[c];
-          if (p == r) d += ep[c] - ea[c];
-          if (n == r) d += ea[c] - en[c];
+          if (ma == r) d += en[c] - ep[c];
+          if (mp == r) d += ep[c] - ea[c];
+          if (mn == r) d += ea[c] - en[c];
           accv[i] += d;
         }
       }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = threadIdx.x + 256 * i;
     if (c < e) demb[(long)r * e + c] = g * accv[i];
   }
-  (void)me; (void)n_rows;
+  (void)n_rows;
 }
 
 // ---- contrastive / accuracy ----------------------------------------------------------

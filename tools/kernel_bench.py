@@ -56,6 +56,42 @@ def gemm_sweep(args):
         json.dump(rows, open(args.json, "w"), indent=1)
 
 
+def losspath_bench(args):
+    """Distance matrix + mining + hinge fwd/bwd at the SURVEY §8d sizes (K=4 samples per class)."""
+    dev = torch.device("cuda:0")
+    rows = []
+    for n in args.n:
+        for e in args.e:
+            p, k = n // 4, 4
+            g = torch.Generator(device=dev).manual_seed(7)
+            c = torch.rand((p, e), device=dev, generator=g)
+            x = (c.repeat_interleave(k, 0) + 0.25 * torch.randn((n, e), device=dev, generator=g)).abs()
+            x = (x / x.norm(dim=1, keepdim=True)).requires_grad_(True)
+            d = ops.pairwise_distances(x)
+            t_pair = timeit(lambda: ops.pairwise_distances(x), iters=args.iters)
+            res = {}
+            for mode in ("hardest", "semihard"):
+                res[mode] = timeit(lambda: ops.mine_triplets(d, p, k, 0.5, mode, seed=1), iters=args.iters)
+            t_bh = timeit(lambda: ops.batch_hard(d, p, k), iters=args.iters)
+            trip, count, _ = ops.mine_triplets(d, p, k, 0.5, "hardest")
+            t_fwd = timeit(lambda: ops.triplet_gather_loss(x, trip, count, 0.5), iters=args.iters)
+
+            def fb():
+                x.grad = None
+                ops.triplet_gather_loss(x, trip, count, 0.5)[0].backward()
+            t_fb = timeit(fb, iters=args.iters)
+            row = dict(N=n, E=e, T=int(count.item()), pairwise_us=round(t_pair * 1e6, 1),
+                       mine_hardest_us=round(res["hardest"] * 1e6, 1), mine_semihard_us=round(res["semihard"] * 1e6, 1),
+                       batch_hard_us=round(t_bh * 1e6, 1), hinge_fwd_us=round(t_fwd * 1e6, 1),
+                       hinge_fwd_bwd_us=round(t_fb * 1e6, 1),
+                       mine_GBps=round(4.0 * n * n / res["hardest"] / 1e9, 1),
+                       hinge_GBps=round(8.0 * n * e / max(t_fb - t_fwd, 1e-9) / 1e9, 1))
+            rows.append(row)
+            print(row, flush=True)
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+
+
 RN18 = [  # n, h, w, c, k(size), cout, stride, pad
     (128, 224, 224, 3, 7, 64, 2, 3),
     (128, 56, 56, 64, 3, 64, 1, 1),
@@ -103,7 +139,7 @@ def conv_bench(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "conv"])
+    ap.add_argument("what", choices=["gemm", "conv", "losspath"])
     ap.add_argument("--n", type=int, nargs="+", default=[128, 256, 1024, 4096, 16384])
     ap.add_argument("--e", type=int, nargs="+", default=[256, 512, 4096])
     ap.add_argument("--iters", type=int, default=20)
@@ -111,4 +147,4 @@ if __name__ == "__main__":
     ap.add_argument("--shape", default=None)
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
-    (gemm_sweep if a.what == "gemm" else conv_bench)(a)
+    {"gemm": gemm_sweep, "conv": conv_bench, "losspath": losspath_bench}[a.what](a)
