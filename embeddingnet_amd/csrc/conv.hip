@@ -222,13 +222,16 @@ struct LoadConvWgradA {
 };
 
 // ---------------------------------------------------------------------------------------------
+template <class G, class TA, class TB>
+constexpr int SMEM_FLOATS = (TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>;
+
 struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
   const int M = p.g.N * p.g.OH * p.g.OW, Kg = p.g.R * p.g.S * p.g.C;
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN, tiles_m = (M + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -237,6 +240,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
+  if (VEC) {                                             // K % 4 == 0: 16-byte row stores
+    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < M && col < p.g.K) {
+        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.y + (long)row * p.g.K + col) = v;
+      }
+    });
+    return;
+  }
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < M && col < p.g.K) {
@@ -253,7 +267,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
   const DgradClass& cg = p.cls[blockIdx.y];
   const int M = p.g.N * cg.Hc * cg.Wc, Kg = cg.nR * cg.nS * p.g.K;
   const int tiles_n = (p.g.C + G::BN - 1) / G::BN;
@@ -265,6 +279,18 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
   const int st = p.g.stride;
+  if ((p.g.C & 3) == 0) {                                // 16-byte row stores
+    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < M && col < p.g.C) {
+        uint32_t n, rem, hc, wc;
+        cg.dHWc.divmod((uint32_t)row, n, rem); cg.dWc.divmod(rem, hc, wc);
+        const long base = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
+        *reinterpret_cast<float4*>(p.dx + base + col) = v;
+      }
+    });
+    return;
+  }
   int last_r = -1; long row_base = 0;
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
@@ -285,7 +311,7 @@ template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
   const int M = p.g.R * p.g.S * p.g.C, Kg = p.g.N * p.g.OH * p.g.OW;
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
   // Two workgroup orders (speed only; results identical).  Default: tiles of one K-split on consecutive
@@ -306,6 +332,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
   float* out = p.out + (long)split * M * p.g.K;
+  if (VB) {                                              // K % 4 == 0
+    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < M && col < p.g.K) *reinterpret_cast<float4*>(out + (long)row * p.g.K + col) = v;
+    });
+    return;
+  }
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < M && col < p.g.K) out[(long)row * p.g.K + col] = v;
@@ -353,6 +386,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 using namespace embnet;
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 static int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int k, int stride, int pad_t,
                      int pad_l, int oh, int ow, const char* who) {
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && r > 0 && s > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0,
@@ -375,7 +410,6 @@ using G128x64 = Geom<128, 64, 2, 2>;
 using G128x32 = Geom<128, 32, 4, 1>;
 using G64x64 = Geom<64, 64, 2, 2>;
 
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
 static int pick_tile(long m, int ncols) {
@@ -401,6 +435,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
                                      int ow, int relu, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  EMBNET_CHECK_ARG(aligned16(y), "conv2d_fwd: output must be 16-byte aligned");
   ConvFwdParams p{x, w, bias, y, {}, relu};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_fwd")) return rc;
   const long M = (long)n * oh * ow;
@@ -416,6 +451,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
                                        int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                                        void* stream) {
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
+  EMBNET_CHECK_ARG(aligned16(dx), "conv2d_dgrad: output must be 16-byte aligned");
   ConvDgradParams p{dy, w, dx, {}, {}};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
   EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
@@ -475,6 +511,7 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
                                        size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
                                        int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
+  EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
   if (const char* e = getenv("EMBNET_WGRAD_XCD")) p.xcd_order = atoi(e);
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_wgrad")) return rc;

@@ -228,6 +228,40 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[G::TM][G::TN], 
         f(wm + 32 * im + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wn + 32 * in + (lane & 31), acc[im][in][r]);
 }
 
+// Same walk, but as 16-byte row pieces: each wave stages one 32-row band of its sub-tile through a
+// private LDS region ([32][WTN+4]) and reads it back row-major, so the caller can issue
+// global_store_dwordx4 (256 contiguous bytes per 16 lanes) instead of one dword per lane — 4x fewer
+// store instructions; a dword-per-lane epilogue is store-ISSUE-bound (~7 B/clk/CU), and because all
+// workgroups of a round reach their epilogue together the matrix pipe idles meanwhile.
+// f(row_in_tile, col_in_tile (multiple of 4), float4).  smem must hold EPI_FLOATS<G> floats and may be
+// the operand tile buffer (a barrier is taken first).  LDS ops of one wave execute in order, so the
+// band's ds_writes are visible to the same wave's ds_reads without a barrier.
+template <class G>
+constexpr int EPI_FLOATS = 4 * 32 * (G::WTN + 4);
+
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc_row4(const f32x16 (&acc)[G::TM][G::TN], float* smem, F&& f) {
+  constexpr int LDW = G::WTN + 4, LPR = G::WTN / 4, RPI = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  float* s = smem + wave * 32 * LDW;
+  __syncthreads();
+#pragma unroll
+  for (int im = 0; im < G::TM; ++im) {
+#pragma unroll
+    for (int in = 0; in < G::TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDW + in * 32 + (lane & 31)] = acc[im][in][r];
+#pragma unroll
+    for (int rr = 0; rr < 32; rr += RPI) {
+      const int row = rr + lane / LPR, c4 = (lane % LPR) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(&s[row * LDW + c4]);
+      f(wm + 32 * im + row, wn + c4, v);
+    }
+  }
+}
+
 // blockIdx.x -> (tile_m, tile_n) keeping the workgroups that share an XCD (ids equal mod 8)
 // on neighbouring tiles so they reuse operand panels in that XCD's L2.  Bijective for any count.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -30,7 +30,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[(TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int tiles_m = (p.n + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -41,6 +41,21 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.e + BK - 1) / BK, smem, acc);
 
+  if ((p.n & 3) == 0) {                                  // 16-byte row stores of the matrix
+    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 g) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < p.n && col < p.n) {
+        const float nr = p.nn[row];
+        const float4 nc = *reinterpret_cast<const float4*>(p.nn + col);
+        float o[4] = {fmaxf(nr + nc.x - 2.f * g.x, 0.f), fmaxf(nr + nc.y - 2.f * g.y, 0.f),
+                      fmaxf(nr + nc.z - 2.f * g.z, 0.f), fmaxf(nr + nc.w - 2.f * g.w, 0.f)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (row == col + j) o[j] = 0.f; if (!p.squared) o[j] = sqrtf(o[j]); }
+        *reinterpret_cast<float4*>(p.d + (long)row * p.n + col) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    });
+    return;
+  }
   for_each_acc<G>(acc, [&](int r, int c, float g) {
     const int row = m0 + r, col = n0 + c;
     if (row < p.n && col < p.n) {
@@ -60,6 +75,8 @@ extern "C" size_t embnet_pairwise_workspace_bytes(int n) { return n > 0 ? (size_
 extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dist, int squared,
                                         void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(x && dist && workspace, "pairwise: null pointer");
+  EMBNET_CHECK_ARG(((reinterpret_cast<uintptr_t>(dist) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+                   "pairwise: dist and workspace must be 16-byte aligned");
   EMBNET_CHECK_ARG(n > 0 && e > 0, "pairwise: n=%d e=%d must be positive", n, e);
   if (workspace_bytes < embnet_pairwise_workspace_bytes(n))
     return fail(EMBNET_EWORKSPACE, "pairwise: workspace %zu < %zu bytes", workspace_bytes,

@@ -51,6 +51,17 @@ class KernelTimer:
 
 TIMER = None       # set to a KernelTimer to time conv kernels
 
+import os as _os
+OVERLAP_WGRAD = _os.environ.get("EMBNET_OVERLAP_WGRAD", "0") == "1"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
 
 def _conv_timed(kind, dims, call):
     if TIMER is None:
@@ -119,17 +130,34 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _conv_timed(1, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_dgrad_f32(
-                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, stream())))
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            need = lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow)
-            ws = workspace(need, x.device)
-            _conv_timed(2, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+        dims = (n, h, wd, c, r, s, k, oh, ow)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+
+        def run_wgrad():
+            ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+            _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_f32(
                 ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
                 stream())))
+
+        if need_dw:
+            dw = torch.empty_like(w)
+        overlap = OVERLAP_WGRAD and need_dx and need_dw
+        if overlap:
+            # dgrad and wgrad only share their inputs: run wgrad on a side stream so each kernel's tail
+            # (the last partly-filled round of workgroups) is filled by the other's workgroups.
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                run_wgrad()
+        if need_dx:
+            dx = torch.empty_like(x)
+            _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
+                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, stream())))
+        if overlap:
+            torch.cuda.current_stream().wait_stream(side)
+        elif need_dw:
+            run_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
         return dx, dw, db, None, None
