@@ -43,12 +43,13 @@ def shard_classes(k_classes_global, world, rank):
 class GradReducer:
     """Flat gradient buffer + bucketed asynchronous all-reduce (mean over ranks)."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, always_reduce=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradReducer: no trainable parameters")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())   # always_reduce: test hook
         dev, dtype = self.params[0].device, self.params[0].dtype
         order = list(reversed(self.params))                 # roughly the order backward produces them
         total = sum(p.numel() for p in order)
@@ -69,16 +70,16 @@ class GradReducer:
             self.buckets.append([start, off, pending])
         self._left = [b[2] for b in self.buckets]
         self._works = []
+        # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
+        # NCCL-only and could not be exercised on the single-GPU development box)
         self._avg = dist.ReduceOp.SUM
-        if dist.is_initialized() and dist.get_backend(process_group) == "nccl":
-            self._avg = dist.ReduceOp.AVG
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p):
         b = self._bucket_of[p]
         self._left[b] -= 1
-        if self._left[b] == 0 and self.world > 1:
+        if self._left[b] == 0 and self._reduce:
             s, e, _ = self.buckets[b]
             self._works.append(dist.all_reduce(self.flat[s:e], op=self._avg, group=self.group, async_op=True))
 
@@ -88,7 +89,7 @@ class GradReducer:
 
     def finish(self):
         """Wait for the outstanding bucket reductions (call after backward, before optimizer.step)."""
-        if self.world > 1:
+        if self._reduce:
             # parameters whose hook never fired (unused in this step) keep their bucket open; reduce those too
             for b, left in enumerate(self._left):
                 if left:

@@ -48,3 +48,50 @@ def test_train_cli_synthetic(tmp_path):
     assert any(f.startswith("epoch_") for f in os.listdir(wdir / "weights"))
     hist = np.load(wdir / "plots" / "history.npz")
     assert len(hist["loss"]) == 3 and hist["loss"][-1] < hist["loss"][0]
+
+
+def test_grad_reducer_over_rccl_single_rank():
+    """The DP reducer on the real backend (nccl = RCCL), world size 1: hooks fire, buckets are
+    all-reduced asynchronously on RCCL's stream, finish() orders them before the optimizer, and the
+    step equals the reducer-less step bit for bit."""
+    script = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from embeddingnet_amd import backbones as B
+from embeddingnet_amd.parallel import GradReducer, init_distributed
+from embeddingnet_amd.train_step import TripletTrainer
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda:0")
+x = torch.rand((16, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+res = []
+for use in (False, True):
+    base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None, seed=3, device=dev)
+    params = [p for p in base.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.1)
+    red = GradReducer(params, bucket_bytes=1 << 20, always_reduce=True) if use else None
+    if use:
+        assert len(red.buckets) > 4
+    tr = TripletTrainer(base, opt, 4, 4, margin=0.5, negatives_selection_mode="hardest", reducer=red)
+    losses = [tr.step(x).item() for _ in range(3)]
+    res.append((losses, torch.cat([p.detach().reshape(-1) for p in params]).clone()))
+assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+assert torch.equal(res[0][1], res[1][1])
+dist.destroy_process_group()
+print("reducer ok", res[0][0])
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "reducer ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_bench_under_torchrun_single_rank():
+    """bench.py through the driver's launch line (torch.distributed.run, 1 rank) prints one JSON line."""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29544", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--backbone", "simple2",
+                          "--image", "64", "--k-classes", "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "mfma"
