@@ -92,47 +92,103 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 }
 
 // dw[r,s,c] = sum_{n,oh,ow} x[n, oh*st+r-pt, ow*st+s-pl, c] * dy[n,oh,ow,c]
-// Workgroup = 256 channel lanes x a slab of output pixels; each thread keeps one accumulator per tap
-// (R*S <= 49) and writes partial[block][tap][c]; a second pass sums the slabs in fixed order.
+// Workgroup = (channel-quad lanes) x (pixel lanes) over a slab of output pixels.  Each thread keeps a
+// float4 accumulator per tap for its 4 channels, walks its pixels (one 16-byte dy load + one 16-byte x
+// load per tap, neighbours served by L1/L2), then the pixel lanes are combined through LDS and the
+// workgroup writes partial[block][tap][c]; a second kernel adds the slabs in fixed order (double).
 constexpr int DW_MAX_TAPS = 49;
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           DwGeom g, int pixels_per_block, float* __restrict__ partial) {
-  const int taps = g.R * g.S;
+template <int MAXT>
+__global__ __launch_bounds__(256) void dwconv_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            DwGeom g, int cq_lanes, int pixels_per_block,
+                                                            float* __restrict__ partial) {
+  __shared__ float4 sh[256];
+  const int taps = g.R * g.S, c4 = g.C >> 2, pix_lanes = 256 / cq_lanes;
+  const int cl = threadIdx.x % cq_lanes, pl = threadIdx.x / cq_lanes;
   const long npix = (long)g.N * g.OH * g.OW;
   const long p0 = (long)blockIdx.x * pixels_per_block, p1 = min(p0 + pixels_per_block, npix);
-  for (int c = threadIdx.x; c < g.C; c += 256) {
-    float acc[DW_MAX_TAPS];
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* d4 = reinterpret_cast<const float4*>(dy);
+  for (int cq0 = 0; cq0 < c4; cq0 += cq_lanes) {
+    const int cq = cq0 + cl;
+    float4 acc[MAXT];
 #pragma unroll
-    for (int j = 0; j < DW_MAX_TAPS; ++j) acc[j] = 0.f;
-    for (long p = p0; p < p1; ++p) {
-      long t = p;
-      const int ow = (int)(t % g.OW); t /= g.OW;
-      const int oh = (int)(t % g.OH);
-      const int n = (int)(t / g.OH);
-      const float d = dy[p * g.C + c];
+    for (int j = 0; j < MAXT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < c4) {
+      for (long p = p0 + pl; p < p1; p += pix_lanes) {
+        long t = p;
+        const int ow = (int)(t % g.OW); t /= g.OW;
+        const int oh = (int)(t % g.OH);
+        const int n = (int)(t / g.OH);
+        const float4 d = d4[p * c4 + cq];
+        int r = 0, s = 0;
 #pragma unroll
-      for (int j = 0; j < DW_MAX_TAPS; ++j) {
-        if (j < taps) {
-          const int r = j / g.S, s = j - r * g.S;
-          const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
-          if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-            acc[j] = fmaf(x[(((long)n * g.H + ih) * g.W + iw) * g.C + c], d, acc[j]);
+        for (int j = 0; j < MAXT; ++j) {
+          if (j < taps) {
+            const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
+            if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+              const float4 v = x4[(((long)n * g.H + ih) * g.W + iw) * c4 + cq];
+              acc[j].x = fmaf(v.x, d.x, acc[j].x); acc[j].y = fmaf(v.y, d.y, acc[j].y);
+              acc[j].z = fmaf(v.z, d.z, acc[j].z); acc[j].w = fmaf(v.w, d.w, acc[j].w);
+            }
+            if (++s == g.S) { s = 0; ++r; }
+          }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < DW_MAX_TAPS; ++j)
-      if (j < taps) partial[((long)blockIdx.x * taps + j) * g.C + c] = acc[j];
+    for (int j = 0; j < MAXT; ++j) {
+      if (j < taps) {                                   // workgroup-uniform
+        sh[threadIdx.x] = acc[j];
+        __syncthreads();
+        if (pl == 0 && cq < c4) {
+          float4 a = acc[j];
+          for (int k = 1; k < pix_lanes; ++k) {
+            const float4 o = sh[k * cq_lanes + cl];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+          }
+          reinterpret_cast<float4*>(partial)[((long)blockIdx.x * taps + j) * c4 + cq] = a;
+        }
+        __syncthreads();
+      }
+    }
   }
 }
 
+// scalar-channel fallback (C % 4 != 0): one thread per channel, serial over the slab
+__global__ __launch_bounds__(256) void dwconv_wgrad1_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            DwGeom g, int pixels_per_block, float* __restrict__ partial) {
+  const int taps = g.R * g.S;
+  const long npix = (long)g.N * g.OH * g.OW;
+  const long p0 = (long)blockIdx.x * pixels_per_block, p1 = min(p0 + pixels_per_block, npix);
+  for (int c = threadIdx.x; c < g.C; c += 256)
+    for (int j = 0; j < taps; ++j) {
+      const int r = j / g.S, s = j - r * g.S;
+      float acc = 0.f;
+      for (long p = p0; p < p1; ++p) {
+        long t = p;
+        const int ow = (int)(t % g.OW); t /= g.OW;
+        const int oh = (int)(t % g.OH);
+        const int n = (int)(t / g.OH);
+        const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+          acc = fmaf(x[(((long)n * g.H + ih) * g.W + iw) * g.C + c], dy[p * g.C + c], acc);
+      }
+      partial[((long)blockIdx.x * taps + j) * g.C + c] = acc;
+    }
+}
+
+// out[i] = sum_b partial[b][i]: 64 outputs x 4 slab lanes per workgroup, double accumulation, fixed order
 __global__ __launch_bounds__(256) void dw_slab_sum_kernel(const float* __restrict__ partial, int blocks, long n,
                                                           float* __restrict__ out) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ double sh[256];
+  const int ol = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + ol;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)partial[(long)b * n + i];
-  out[i] = (float)s;
+  if (i < n)
+    for (int b = bl; b < blocks; b += 4) s += (double)partial[(long)b * n + i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (bl == 0 && i < n) out[i] = (float)(sh[ol] + sh[64 + ol] + sh[128 + ol] + sh[192 + ol]);
 }
 
 // ---- activations ------------------------------------------------------------------------------
@@ -167,7 +223,33 @@ __global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restric
     y[i] = x[i] * s[n * c + col];
   }
 }
-// dx = dy * s ; ds[n,c] = sum_p dy*x  (one workgroup-row of threads per (n, c-chunk))
+// dx = dy * s ; ds[n,c] = sum_p dy*x.  Workgroup = one sample x 64 channels: 16 channel-quad lanes x 16
+// pixel lanes, float4 accesses, pixel lanes combined through LDS.
+__global__ __launch_bounds__(256) void chscale_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                           const float* __restrict__ dy, int hw, int c4,
+                                                           float* __restrict__ dx, float* __restrict__ ds) {
+  __shared__ float4 sh[256];
+  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cq = blockIdx.x * 16 + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq < c4) {
+    const float4 sv = reinterpret_cast<const float4*>(s)[(long)n * c4 + cq];
+    for (int p = pl; p < hw; p += 16) {
+      const long i = ((long)n * hw + p) * c4 + cq;
+      const float4 d = reinterpret_cast<const float4*>(dy)[i], xv = reinterpret_cast<const float4*>(x)[i];
+      reinterpret_cast<float4*>(dx)[i] = make_float4(d.x * sv.x, d.y * sv.y, d.z * sv.z, d.w * sv.w);
+      acc.x = fmaf(d.x, xv.x, acc.x); acc.y = fmaf(d.y, xv.y, acc.y);
+      acc.z = fmaf(d.z, xv.z, acc.z); acc.w = fmaf(d.w, xv.w, acc.w);
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && cq < c4) {
+    for (int k = 1; k < 16; ++k) { const float4 o = sh[k * 16 + cl]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    reinterpret_cast<float4*>(ds)[(long)n * c4 + cq] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                           const float* __restrict__ dy, int hw, int c,
                                                           float* __restrict__ dx, float* __restrict__ ds) {
@@ -252,8 +334,8 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
 }
 
 static int dw_wgrad_blocks(long npix, int& ppb) {
-  long blocks = (npix + 63) / 64;
-  if (blocks > 1024) blocks = 1024;
+  long blocks = (npix + 127) / 128;
+  if (blocks > 2048) blocks = 2048;
   ppb = (int)((npix + blocks - 1) / blocks);
   return (int)((npix + ppb - 1) / ppb);
 }
@@ -274,9 +356,16 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
     return fail(EMBNET_EWORKSPACE, "dwconv2d_wgrad: workspace too small");
   int ppb;
   const int blocks = dw_wgrad_blocks((long)n * oh * ow, ppb);
-  dwconv_wgrad_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace);
+  if ((c & 3) == 0) {
+    int cql = 1; while (cql < c / 4 && cql < 256) cql <<= 1;
+    if (r * s <= 9) dwconv_wgrad4_kernel<9><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else if (r * s <= 25) dwconv_wgrad4_kernel<25><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else dwconv_wgrad4_kernel<49><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+  } else {
+    dwconv_wgrad1_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace);
+  }
   const long cnt = (long)r * s * c;
-  dw_slab_sum_kernel<<<cdiv(cnt, 256), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw);
+  dw_slab_sum_kernel<<<cdiv(cnt, 64), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw);
   return check_launch("dwconv2d_wgrad");
 }
 
@@ -302,7 +391,8 @@ extern "C" int embnet_channel_scale_fwd(const float* x, const float* s, int n, i
 extern "C" int embnet_channel_scale_bwd(const float* x, const float* s, const float* dy, int n, int hw, int c, float* dx,
                                         float* ds, void* stream) {
   EMBNET_CHECK_ARG(x && s && dy && dx && ds && n > 0 && hw > 0 && c > 0, "channel_scale_bwd: bad argument");
-  chscale_bwd_kernel<<<dim3(cdiv(c, 256), n), 256, 0, S(stream)>>>(x, s, dy, hw, c, dx, ds);
+  if ((c & 3) == 0) chscale_bwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, s, dy, hw, c / 4, dx, ds);
+  else chscale_bwd_kernel<<<dim3(cdiv(c, 256), n), 256, 0, S(stream)>>>(x, s, dy, hw, c, dx, ds);
   return check_launch("channel_scale_bwd");
 }
 

@@ -285,7 +285,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
   reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
 }
 
-// y[n,c] = mean over hw
+// y[n,c] = mean over hw.  Workgroup = one sample x 64 channels (16 channel-quad lanes x 16 pixel lanes).
+__global__ __launch_bounds__(256) void gap_fwd4_kernel(const float* __restrict__ x, int hw, int c4, float* __restrict__ y) {
+  __shared__ float4 sh[256];
+  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cq = blockIdx.x * 16 + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq < c4)
+    for (int p = pl; p < hw; p += 16) {
+      const float4 v = reinterpret_cast<const float4*>(x)[((long)n * hw + p) * c4 + cq];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && cq < c4) {
+    for (int k = 1; k < 16; ++k) { const float4 o = sh[k * 16 + cl]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    const float inv = 1.f / (float)hw;
+    reinterpret_cast<float4*>(y)[(long)n * c4 + cq] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int n, int hw, int c,
                                                       float* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -481,7 +500,8 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
 
 extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && n > 0 && hw > 0 && c > 0, "gap_fwd: bad argument");
-  gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y);
+  if ((c & 3) == 0) gap_fwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, y);
+  else gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y);
   return check_launch("gap_fwd");
 }
 
