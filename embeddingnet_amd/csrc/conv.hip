@@ -507,9 +507,9 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
     default: conv_wgrad_kernel<G64x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
   }
 
-extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
-                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                       int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n, int h,
+                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, void* stream,
+                      bool do_main, bool do_reduce) {
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
@@ -525,14 +525,39 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
-  if (va && vb) { LAUNCH_WGRAD(true, true) }
-  else if (vb) { LAUNCH_WGRAD(false, true) }
-  else { LAUNCH_WGRAD(false, false) }
-  if (p.splits > 1) {
+  if (do_main) {
+    if (va && vb) { LAUNCH_WGRAD(true, true) }
+    else if (vb) { LAUNCH_WGRAD(false, true) }
+    else { LAUNCH_WGRAD(false, false) }
+  }
+  if (p.splits > 1 && do_reduce) {
     const long cnt = (long)rows * k;
     slab_reduce_kernel<<<cdiv(cdiv(cnt, 4) > 0 ? cdiv(cnt, 4) : 1, 256), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
   }
   return check_launch("conv2d_wgrad");
+}
+
+extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
+                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                    true, true);
+}
+
+// The same in two calls — split-K GEMM into the slabs, then the fixed-order slab sum — so a caller can
+// time the MFMA kernel alone (bench.py's roofline leg).  When the plan has a single split the first call
+// writes dw directly and the second is a no-op.
+extern "C" int embnet_conv2d_wgrad_slabs_f32(const float* x, const float* dy, float* dw, void* workspace,
+                                             size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                             int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                    true, false);
+}
+extern "C" int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, void* workspace,
+                                              size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                              int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                    false, true);
 }
 
 // Name (as rocprofv3 prints the template) of the kernel the entry points above launch for a geometry,

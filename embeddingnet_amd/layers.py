@@ -135,9 +135,12 @@ class _Conv2dFn(torch.autograd.Function):
 
         def run_wgrad():
             ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_f32(
-                ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
-                stream())))
+            args = (ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow)
+            if TIMER is None:
+                check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
+            else:                       # bracket the MFMA kernel alone; the slab sum is its own launch
+                _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_slabs_f32(*args, stream())))
+                check(lib.embnet_conv2d_wgrad_reduce_f32(*args, stream()))
 
         if need_dw:
             dw = torch.empty_like(w)

@@ -121,6 +121,14 @@ int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* wo
                             int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
                             int oh, int ow, void* stream);
 
+/* conv2d_wgrad in two calls (split-K MFMA kernel into the slabs; then the fixed-order slab sum), same
+ * arguments: lets a caller time the MFMA kernel alone.  conv2d_wgrad_f32 == slabs + reduce. */
+int embnet_conv2d_wgrad_slabs_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                  int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                                  int oh, int ow, void* stream);
+int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                   int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                                   int oh, int ow, void* stream);
 /* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
