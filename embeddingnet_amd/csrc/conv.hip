@@ -485,7 +485,11 @@ static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt
   tile = (rows <= 64 && k <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
   const long tiles = (long)cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
-  long want = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU
+  // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
+  // workgroups per CU is best; with many tiles shorter K ranges in 2-3 rounds balance better
+  long target = tiles >= 100 ? 2048 : (tiles >= 30 ? 1536 : 768);
+  if (const char* e = getenv("EMBNET_WGRAD_BLOCKS")) target = atol(e);
+  long want = (target + tiles - 1) / tiles;
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split
   if (want < 1) want = 1;
   kt_per_split = cdiv(kt_total, want);
