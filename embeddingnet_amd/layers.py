@@ -349,16 +349,29 @@ class _InputBNConvFn(torch.autograd.Function):
         r, s, _, k = w.shape
         stride, pt, pl, oh, ow = geom
         m = n * h * wd
-        a = torch.empty_like(x)
-        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)
-        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-        check(lib.embnet_bn_train_fwd(ptr(x), m, c, None, ptr(beta), eps, momentum, 0, ptr(a), stats[0].data_ptr(),
+        cp = (c + 3) // 4 * 4                      # widen 3 -> 4 channels: 16-byte gathers in the stem conv
+        if cp != c:
+            xp = torch.empty((n, h, wd, cp), device=x.device, dtype=torch.float32)
+            check(lib.embnet_pad_channels(ptr(x), m, c, cp, ptr(xp), stream()))
+            zeros = torch.zeros(cp - c, device=x.device)
+            beta_p = torch.cat([beta.detach(), zeros])
+            mm_p, mv_p = torch.cat([moving_mean, zeros]), torch.cat([moving_var, zeros + 1])
+            w_p = torch.nn.functional.pad(w.detach(), (0, 0, 0, cp - c))     # [r,s,cp,k], zero taps for the pad channel
+        else:
+            xp, beta_p, mm_p, mv_p, w_p = x, beta, moving_mean, moving_var, w
+        a = torch.empty_like(xp)
+        stats = torch.empty((4, cp), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, cp), x.device)
+        check(lib.embnet_bn_train_fwd(ptr(xp), m, cp, None, ptr(beta_p), eps, momentum, 0, ptr(a), stats[0].data_ptr(),
                                       stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                                      ptr(moving_mean), ptr(moving_var), ptr(ws), ws.numel() * 4, stream()))
+                                      ptr(mm_p), ptr(mv_p), ptr(ws), ws.numel() * 4, stream()))
+        if cp != c:                                # the pad channel is identically 0 after BN (x=0, beta=0)
+            moving_mean.copy_(mm_p[:c])
+            moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
-            ptr(a), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, stream())))
-        ctx.geom = geom
+        _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, stream())))
+        ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y
 
@@ -366,15 +379,16 @@ class _InputBNConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         a, w = ctx.saved_tensors
         lib = _lib.lib()
-        n, h, wd, c = a.shape
-        r, s, _, k = w.shape
+        n, h, wd, cp = a.shape
+        r, s, c, k = w.shape
         stride, pt, pl, oh, ow = ctx.geom
         dy = _c(dy)
-        dw = torch.empty_like(w)
-        ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), a.device)
-        _conv_timed(2, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
-            ptr(a), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
+        dw_p = torch.empty((r, s, cp, k), device=a.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, cp, r, s, k, oh, ow), a.device)
+        _conv_timed(2, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+            ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
             stream())))
+        dw = dw_p if cp == c else dw_p[:, :, :c, :].contiguous()
         key = (a.device, n, h, wd)
         ones = _InputBNConvFn._ones.get(key)
         if ones is None:

@@ -176,6 +176,8 @@ int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev
 /* out[c] = sum_{tap,k} w[tap,c,k] * tap_sums[tap,k]: gradient of a per-channel offset added to a conv
  * input (the zoo ResNet's bn_data beta) from per-tap sums of dy — avoids a full 3-channel dgrad. */
 int embnet_tap_contract(const float* w, const float* tap_sums, int taps, int c, int k, float* out, void* stream);
+/* y[pixels,cout] = [x[pixels,cin] | 0]: widens 3-channel images to 4 channels for 16-byte stem gathers. */
+int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
 int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream);
 /* ---- EfficientNet MBConv pieces (backbones.py:84-98, `efficientnet` zoo package) and the siamese 'l1' head ---- */
