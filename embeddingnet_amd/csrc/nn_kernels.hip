@@ -5,6 +5,7 @@
 // :44-75 (BatchNormalization, Dropout), :110-116 (GlobalAveragePooling2D) and the zoo ResNet blocks.
 // Roofline: HBM.  Algorithmic bytes per element are noted at each kernel.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/embnet.h"
 
 namespace embnet {
@@ -73,6 +74,98 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
     const float v = x[r * c + col]; a += v; b = fmaf(v, v, b);
   });
+}
+
+// Four channels per thread (C % 4 == 0): same two-stage reduction with 16-byte loads; lanes run over
+// channel QUADS.  partial keeps the [block][2][C] layout, so the finalize kernels are shared.
+template <class F>   // F(row, quad, float4& a, float4& b)
+__device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float* __restrict__ partial, F f) {
+  __shared__ float4 sh4[2][256];
+  const int ci = threadIdx.x % g.cl, ri = threadIdx.x / g.cl;
+  const long r0 = (long)blockIdx.x * g.rows_per_block;
+  const long r1 = min(r0 + g.rows_per_block, m);
+  for (int q0 = 0; q0 < c4; q0 += g.cl) {
+    const int q = q0 + ci;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (q < c4)
+      for (long r = r0 + ri; r < r1; r += g.rl) f(r, q, a, b);
+    sh4[0][threadIdx.x] = a; sh4[1][threadIdx.x] = b;
+    __syncthreads();
+    if (ri == 0 && q < c4) {
+      for (int k = 1; k < g.rl; ++k) {
+        const float4 oa = sh4[0][k * g.cl + ci], ob = sh4[1][k * g.cl + ci];
+        a.x += oa.x; a.y += oa.y; a.z += oa.z; a.w += oa.w;
+        b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
+      }
+      reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 0) * c4 * 4)[q] = a;
+      reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 1) * c4 * 4)[q] = b;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict__ x, long m, int c4, ColGeom g,
+                                                        float* __restrict__ partial) {
+  col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
+    const float4 v = reinterpret_cast<const float4*>(x)[r * c4 + q];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             long m, int c4, ColGeom g, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu,
+                                                             float* __restrict__ partial) {
+  col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
+    float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+    if (relu) {
+      if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
+      if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
+      if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
+      if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+    }
+    a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
+    b.x = fmaf(dz.x, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(dz.y, (xv.y - mu.y) * rs.y, b.y);
+    b.z = fmaf(dz.z, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(dz.w, (xv.w - mu.w) * rs.w, b.w);
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            long total4, int c4, float inv_m, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ dbeta,
+                                                            const float* __restrict__ dgamma, int relu, int training,
+                                                            float* __restrict__ dx) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int q = (int)(i % c4);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 dz = reinterpret_cast<const float4*>(dy)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    if (relu) {
+      if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
+      if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
+      if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
+      if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+    }
+    float4 o;
+    if (training) {
+      const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+      const float4 db = reinterpret_cast<const float4*>(dbeta)[q], dg = reinterpret_cast<const float4*>(dgamma)[q];
+      o.x = sc.x * (dz.x - db.x * inv_m - (xv.x - mu.x) * rs.x * dg.x * inv_m);
+      o.y = sc.y * (dz.y - db.y * inv_m - (xv.y - mu.y) * rs.y * dg.y * inv_m);
+      o.z = sc.z * (dz.z - db.z * inv_m - (xv.z - mu.z) * rs.z * dg.z * inv_m);
+      o.w = sc.w * (dz.w - db.w * inv_m - (xv.w - mu.w) * rs.w * dg.w * inv_m);
+    } else {
+      o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+    }
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
 }
 
 // mean/var -> scale = gamma*rstd, shift = beta - mean*scale; moving stats updated in place.
@@ -441,8 +534,15 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
     return fail(EMBNET_EWORKSPACE, "bn_train_fwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
   float* partial = (float*)workspace;
-  bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, partial);
-  bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, m, c, gamma, beta, eps, momentum, save_mean,
+  int nblocks = g.blocks;
+  if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
+    const ColGeom g4 = col_geom(m, c / 4);
+    nblocks = g4.blocks;
+    bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, partial);
+  } else {
+    bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, partial);
+  }
+  bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
                                                           save_rstd, scale, shift, moving_mean, moving_var);
   affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_train_fwd");
@@ -473,14 +573,24 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   // We only support parameter gradients in training mode; frozen BN returns dgamma = dbeta sums with xhat from
   // save_mean/save_rstd when given, else zeros.
   if (save_mean && save_rstd) {
-    bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial);
-    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
+    if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
+      const ColGeom g4 = col_geom(m, c / 4);
+      bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial);
+      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
+    } else {
+      bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial);
+      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
+    }
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
-  bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
-                                                               scale, shift, dbeta, dgamma, relu, training, dx);
+  if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR"))
+    bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
+                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx);
+  else
+    bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
+                                                                 scale, shift, dbeta, dgamma, relu, training, dx);
   return check_launch("bn_bwd");
 }
 

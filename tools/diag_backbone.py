@@ -12,6 +12,9 @@ CASES = {"simple": ((73, 73, 3), 64, 6), "simple2": ((64, 64, 3), 64, 8), "resne
 for name in (sys.argv[1:] or ["simple", "resnet18"]):
     shape, enc, batch = CASES[name]
     base, _ = B.get_backbone(shape, encodings_len=enc, backbone_name=name, backbone_weights=None, seed=1, device=dev)
+    for mod in base.modules():
+        if hasattr(mod, "enabled"):
+            mod.enabled = False          # dropout / drop-connect off for parity
     rs = np.random.RandomState(0)
     x = rs.rand(batch, *shape).astype(np.float32)
     wgt = rs.randn(batch, enc).astype(np.float32)
