@@ -50,6 +50,17 @@ __device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __r
   }
 }
 
+// Activation fused behind the BN affine: 0 none, 1 ReLU, 2 swish (z * sigmoid(z)).  Backward recomputes
+// z = x*scale + shift from the saved input, so no activation tensor or mask is stored.
+__device__ __forceinline__ float act_apply(int act, float z) {
+  return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? z / (1.f + __expf(-z)) : z);
+}
+__device__ __forceinline__ float act_grad(int act, float z, float dy) {
+  if (act == 1) return z <= 0.f ? 0.f : dy;
+  if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); return dy * (sg + z * sg * (1.f - sg)); }
+  return dy;
+}
+
 // Finalize helper: one 256-thread workgroup per channel adds that channel's per-block partials in
 // double (fixed order: thread-strided, then a shuffle tree) — thread 0 gets the totals.
 __device__ __forceinline__ void block_partial_sums(const float* __restrict__ partial, int blocks, int c, int col,
@@ -124,10 +135,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
     if (relu) {
-      if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
-      if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
-      if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
-      if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
+      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
     }
     a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
     b.x = fmaf(dz.x, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(dz.y, (xv.y - mu.y) * rs.y, b.y);
@@ -148,10 +157,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     float4 dz = reinterpret_cast<const float4*>(dy)[i];
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     if (relu) {
-      if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
-      if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
-      if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
-      if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
+      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
     }
     float4 o;
     if (training) {
@@ -215,14 +222,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       const float4 sc = *reinterpret_cast<const float4*>(scale + col);
       const float4 sh = *reinterpret_cast<const float4*>(shift + col);
       float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (relu) { o.x = act_apply(relu, o.x); o.y = act_apply(relu, o.y); o.z = act_apply(relu, o.z); o.w = act_apply(relu, o.w); }
       reinterpret_cast<float4*>(y)[i] = o;
     }
   } else {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
       const int col = (int)(i % c);
       float o = fmaf(x[i], scale[col], shift[col]);
-      y[i] = relu ? fmaxf(o, 0.f) : o;
+      y[i] = act_apply(relu, o);
     }
   }
 }
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
     const float xv = x[r * c + col];
     float dz = dy[r * c + col];
-    if (relu && fmaf(xv, scale[col], shift[col]) <= 0.f) dz = 0.f;
+    if (relu) dz = act_grad(relu, fmaf(xv, scale[col], shift[col]), dz);
     a += dz; b = fmaf(dz, (xv - mean[col]) * rstd[col], b);
   });
 }
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int col = (int)(i % c);
     const float xv = x[i];
     float dz = dy[i];
-    if (relu && fmaf(xv, scale[col], shift[col]) <= 0.f) dz = 0.f;
+    if (relu) dz = act_grad(relu, fmaf(xv, scale[col], shift[col]), dz);
     if (training) {
       const float xh = (xv - mean[col]) * rstd[col];
       dx[i] = scale[col] * (dz - dbeta[col] * inv_m - xh * dgamma[col] * inv_m);

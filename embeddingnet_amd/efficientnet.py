@@ -55,9 +55,9 @@ class MBConv(nn.Module):
         self.has_expand = expand != 1
         if self.has_expand:
             self.expand_conv = _conv(cin, mid, 1, 1, gen)
-            self.expand_bn = L.BatchNormalization(mid, epsilon=BN_EPS)
+            self.expand_bn = L.BatchNormalization(mid, epsilon=BN_EPS, activation="swish")
         self.dwconv = L.DepthwiseConv2D(mid, k, stride, gen=gen)
-        self.bn = L.BatchNormalization(mid, epsilon=BN_EPS)
+        self.bn = L.BatchNormalization(mid, epsilon=BN_EPS, activation="swish")
         se = max(1, int(cin * 0.25))
         self.gap = L.GlobalAveragePooling2D()
         self.se_reduce = L.Dense(mid, se, gen=gen)           # 1x1 convs with bias on a [n,1,1,c] tensor
@@ -73,8 +73,8 @@ class MBConv(nn.Module):
     def forward(self, inp):
         x = inp
         if self.has_expand:
-            x = L.swish(self.expand_bn(self.expand_conv(x)))
-        x = L.swish(self.bn(self.dwconv(x)))
+            x = self.expand_bn(self.expand_conv(x))
+        x = self.bn(self.dwconv(x))
         s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(self.gap(x)))))
         x = L.channel_scale(x, s)
         x = self.project_bn(self.project_conv(x))
@@ -90,7 +90,7 @@ class EfficientNet(nn.Module):
         super().__init__()
         blocks, stem, top = block_list(name)
         self.stem_conv = _conv(3, stem, 3, 2, gen)
-        self.stem_bn = L.BatchNormalization(stem, epsilon=BN_EPS)
+        self.stem_bn = L.BatchNormalization(stem, epsilon=BN_EPS, activation="swish")
         self._blocks = []
         for i, (k, cin, cout, e, s) in enumerate(blocks):
             blk = MBConv(k, cin, cout, e, s, drop_connect_rate * i / len(blocks), 100 + i, gen)
@@ -98,11 +98,11 @@ class EfficientNet(nn.Module):
             setattr(self, nm, blk)
             self._blocks.append(nm)
         self.top_conv = _conv(blocks[-1][2], top, 1, 1, gen)
-        self.top_bn = L.BatchNormalization(top, epsilon=BN_EPS)
+        self.top_bn = L.BatchNormalization(top, epsilon=BN_EPS, activation="swish")
         self.out_channels = top
 
     def forward(self, x):
-        x = L.swish(self.stem_bn(self.stem_conv(x)))
+        x = self.stem_bn(self.stem_conv(x))
         for nm in self._blocks:
             x = getattr(self, nm)(x)
-        return L.swish(self.top_bn(self.top_conv(x)))
+        return self.top_bn(self.top_conv(x))

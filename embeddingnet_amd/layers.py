@@ -319,9 +319,11 @@ class _BatchNormFn(torch.autograd.Function):
 class BatchNormalization(nn.Module):
     """Keras BatchNormalization on the last axis; `relu=True` fuses a following Activation('relu')."""
 
-    def __init__(self, channels, epsilon=1e-3, momentum=0.99, scale=True, relu=False):
+    def __init__(self, channels, epsilon=1e-3, momentum=0.99, scale=True, relu=False, activation=None):
         super().__init__()
-        self.eps, self.momentum, self.relu = epsilon, momentum, relu
+        # fused activation code of the kernels: 0 none, 1 relu, 2 swish
+        self.eps, self.momentum = epsilon, momentum
+        self.relu = {None: int(bool(relu)), "relu": 1, "swish": 2}[activation]
         self.gamma = nn.Parameter(torch.ones(channels)) if scale else None
         self.beta = nn.Parameter(torch.zeros(channels))
         self.register_buffer("moving_mean", torch.zeros(channels))

@@ -141,7 +141,8 @@ int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw, int m, in
 
 /* BatchNormalization over the last axis of x[m,c] (backbones.py:46-69; zoo ResNet BN with eps 2e-5).
  * train: biased batch variance; moving <- momentum*moving + (1-momentum)*batch (updated in place, may
- * be NULL); gamma NULL = scale=False; relu!=0 fuses the following ReLU.  save_mean/save_rstd/scale/shift
+ * be NULL); gamma NULL = scale=False; relu = fused activation after the affine: 0 none, 1 ReLU, 2 swish
+ * (backward recomputes it from x, nothing extra is stored).  save_mean/save_rstd/scale/shift
  * ([c] each) are kept by the caller for backward. */
 size_t embnet_bn_workspace_bytes(long m, int c);
 int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
