@@ -219,7 +219,7 @@ def test_backbone_forward_backward_vs_oracle(dev, name, shape, enc, batch):
     got = B.keras_weights(base)
     # fp32 noise floor of this very network: the same oracle run in float32 vs float64.  Max-pool
     # arg-max and ReLU decisions that flip between precisions move a few gradients by ~1e-2 in ANY
-    # fp32 implementation (tools/diag_backbone.py prints both columns), so the bound is relative to it.
+    # fp32 implementation (tests/diag_backbone.py prints both columns), so the bound is relative to it.
     ctx32 = _oracle_from(base, training=True, dtype=torch.float32)
     emb32 = OB.base_model(ctx32, torch.tensor(x), backbone_name=name, encodings_len=enc)
     (emb32 * torch.tensor(wgt)).sum().backward()
