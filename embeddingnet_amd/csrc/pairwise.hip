@@ -98,3 +98,110 @@ extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dis
   }
   return check_launch("pairwise_dist");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Query-vs-gallery distances and k-nearest-neighbour selection: the evaluation step right after
+// training (/root/reference/embedding_net/models.py:128-161 predict_knn / calculate_prediction_accuracy
+// through sklearn's KNeighborsClassifier, brute-force Euclidean).  Same GEMM engine, same epilogue
+// minus the diagonal rule.
+namespace embnet {
+
+struct CrossParams { const float* q; const float* x; const float* qn; const float* xn; float* d; int nq, n, e, squared; };
+
+template <class G, bool VEC>
+__global__ __launch_bounds__(256) void cross_dist_kernel(CrossParams p) {
+  using TA = TileKC<G::BM>;
+  using TB = TileKC<G::BN>;
+  __shared__ __attribute__((aligned(16))) float smem[(TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>];
+  const int tiles_n = (p.n + G::BN - 1) / G::BN;
+  const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
+  LoadRowsKC<G::BM, VEC> la; la.init(p.q, p.e, p.nq, p.e, m0, threadIdx.x);
+  LoadRowsKC<G::BN, VEC> lb; lb.init(p.x, p.e, p.n, p.e, n0, threadIdx.x);
+  f32x16 acc[G::TM][G::TN];
+  gemm_mainloop<G, TA, TB>(la, lb, 0, (p.e + BK - 1) / BK, smem, acc);
+  for_each_acc<G>(acc, [&](int r, int c, float g) {
+    const int row = m0 + r, col = n0 + c;
+    if (row < p.nq && col < p.n) {
+      const float v = fmaxf(p.qn[row] + p.xn[col] - 2.f * g, 0.f);
+      p.d[(long)row * p.n + col] = p.squared ? v : sqrtf(v);
+    }
+  });
+}
+
+// k smallest entries of each row, ascending, ties to the smaller column: one wave per row, k rounds of a
+// shuffle arg-min over the columns not yet taken (k <= 64: taken columns live one per lane).
+__global__ __launch_bounds__(256) void topk_smallest_kernel(const float* __restrict__ d, int rows, int n, int k,
+                                                            int* __restrict__ idx, float* __restrict__ val) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* r = d + (long)row * n;
+  int taken = -1;                                         // lane j remembers the column chosen in round j
+  for (int round = 0; round < k; ++round) {
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+      bool used = false;
+      for (int j = 0; j < round; ++j) used |= (__shfl(taken, j, 64) == c);
+      const float v = r[c];
+      if (!used && (v < best || (v == best && c < bi))) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == round) taken = bi;
+    if (lane == 0) { idx[(long)row * k + round] = bi; val[(long)row * k + round] = best; }
+  }
+}
+
+// majority vote over the k neighbour labels, ties to the smallest label (scipy.stats.mode, as sklearn predict)
+__global__ __launch_bounds__(256) void knn_vote_kernel(const int* __restrict__ idx, const int* __restrict__ labels,
+                                                       int rows, int k, int* __restrict__ pred) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  int best_label = 0x7fffffff, best_count = 0;
+  for (int i = 0; i < k; ++i) {
+    const int li = labels[idx[(long)row * k + i]];
+    int cnt = 0;
+    for (int j = 0; j < k; ++j) cnt += labels[idx[(long)row * k + j]] == li;
+    if (cnt > best_count || (cnt == best_count && li < best_label)) { best_count = cnt; best_label = li; }
+  }
+  pred[row] = best_label;
+}
+
+}  // namespace embnet
+
+extern "C" size_t embnet_cross_dist_workspace_bytes(int nq, int n) { return nq > 0 && n > 0 ? ((size_t)nq + n) * sizeof(float) : 0; }
+
+extern "C" int embnet_cross_dist_f32(const float* q, int nq, const float* x, int n, int e, float* dist, int squared,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(q && x && dist && workspace, "cross_dist: null pointer");
+  EMBNET_CHECK_ARG(nq > 0 && n > 0 && e > 0, "cross_dist: nq=%d n=%d e=%d must be positive", nq, n, e);
+  EMBNET_CHECK_ARG((size_t)nq * e * 4 <= MAX_OPERAND_BYTES && (size_t)n * e * 4 <= MAX_OPERAND_BYTES,
+                   "cross_dist: an embedding block exceeds 2 GiB");
+  if (workspace_bytes < embnet_cross_dist_workspace_bytes(nq, n))
+    return fail(EMBNET_EWORKSPACE, "cross_dist: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* qn = (float*)workspace; float* xn = qn + nq;
+  row_sqnorm_kernel<<<cdiv(nq, 4), 256, 0, s>>>(q, nq, e, qn);
+  row_sqnorm_kernel<<<cdiv(n, 4), 256, 0, s>>>(x, n, e, xn);
+  CrossParams p{q, x, qn, xn, dist, nq, n, e, squared};
+  const bool vec = (e & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  using GS = Geom<64, 64, 2, 2>;
+  const int grid = cdiv(nq, 64) * cdiv(n, 64);
+  if (vec) cross_dist_kernel<GS, true><<<grid, 256, 0, s>>>(p); else cross_dist_kernel<GS, false><<<grid, 256, 0, s>>>(p);
+  return check_launch("cross_dist");
+}
+
+extern "C" int embnet_topk_smallest(const float* dist, int rows, int n, int k, int32_t* idx, float* val, void* stream) {
+  EMBNET_CHECK_ARG(dist && idx && val, "topk_smallest: null pointer");
+  EMBNET_CHECK_ARG(rows > 0 && n > 0 && k > 0 && k <= 64 && k <= n, "topk_smallest: need 0 < k <= min(64, n) (k=%d n=%d)", k, n);
+  topk_smallest_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(dist, rows, n, k, idx, val);
+  return check_launch("topk_smallest");
+}
+
+extern "C" int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, int32_t* pred, void* stream) {
+  EMBNET_CHECK_ARG(idx && labels && pred && rows > 0 && k > 0, "knn_vote: bad argument");
+  knn_vote_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(idx, labels, rows, k, pred);
+  return check_launch("knn_vote");
+}

@@ -61,6 +61,93 @@ class EmbeddingNet:
         os.makedirs(save_folder, exist_ok=True)
         self.save_weights(os.path.join(save_folder, "final_model.npz"))
 
+    # -- encodings + kNN evaluation (reference models.py:61-90,128-161) ------
+    def generate_encodings(self, data_loader, max_n_samples=10, shuffle=True):
+        """{'paths', 'labels', 'encodings'} over up to max_n_samples training items per class
+        (reference :61-83).  In-memory datasets (arrays instead of file lists) record row ids as paths."""
+        import random
+        from .datagenerators import get_image
+        data_paths, data_labels, data_encodings = [], [], []
+        for class_name in data_loader.class_names:
+            data_list = data_loader.train_data[class_name]
+            idx = list(range(len(data_list)))
+            if len(idx) > max_n_samples:
+                if shuffle:
+                    random.shuffle(idx)
+                idx = idx[:max_n_samples]
+            if isinstance(data_list, np.ndarray):
+                imgs = data_list[idx]
+                data_paths += [f"{class_name}:{i}" for i in idx]
+            else:
+                paths = [data_list[i] for i in idx]
+                imgs = np.asarray([get_image(p, self.params_model['input_shape']) for p in paths], np.float32) / 255.
+                data_paths += paths
+            encods = self._generate_encodings(imgs)
+            data_encodings.extend(list(encods))
+            data_labels += [class_name] * len(encods)
+        return {'paths': data_paths, 'labels': data_labels, 'encodings': np.squeeze(np.array(data_encodings))}
+
+    def save_encodings(self, encoded_training_data, save_folder='./', save_file_name='encodings.pkl'):
+        import pickle
+        data = {k: v for k, v in encoded_training_data.items() if k != 'knn_classifier'}
+        with open(os.path.join(save_folder, save_file_name), "wb") as f:
+            pickle.dump(data, f)
+
+    def load_encodings(self, path_to_encodings, knn_k=1):
+        import pickle
+        with open(path_to_encodings, 'rb') as f:
+            self.encoded_training_data = pickle.load(f)
+        return self.fit_knn(knn_k)
+
+    def fit_knn(self, knn_k=1, encoded_training_data=None):
+        """Build encoded_training_data['knn_classifier'] — the entry predict_knn reads (reference :134-137);
+        the reference leaves its construction to external code."""
+        from .knn import KNNClassifier
+        if encoded_training_data is not None:
+            self.encoded_training_data = encoded_training_data
+        d = self.encoded_training_data
+        dev = next(self.base_model.parameters()).device if self.base_model is not None else None
+        d['knn_classifier'] = KNNClassifier(n_neighbors=knn_k, device=dev).fit(d['encodings'], d['labels'])
+        return d['knn_classifier']
+
+    def predict_knn(self, image, with_top5=False):
+        """image: path, HxWx3 uint8 array, or a float [H,W,3] array already in [0,1]."""
+        from .datagenerators import get_image
+        if type(image) is str:
+            img = np.asarray(get_image(image, self.params_model['input_shape']), np.float32) / 255.
+        else:
+            img = np.asarray(image, np.float32)
+            if img.max() > 1.5:
+                img = img / 255.
+        encoding = self.base_model.predict(np.expand_dims(img, axis=0))
+        knn = self.encoded_training_data['knn_classifier']
+        predicted_label = knn.predict(encoding)
+        if with_top5:
+            idx = knn.kneighbors(encoding, n_neighbors=5)[1]
+            return predicted_label, [self.encoded_training_data['labels'][idx[0][i]] for i in range(5)]
+        return predicted_label
+
+    def calculate_prediction_accuracy(self, data_loader):
+        """top-1 / top-5 kNN accuracy over data_loader.val_data (batched: one distance GEMM per class)."""
+        from .datagenerators import get_image
+        knn = self.encoded_training_data['knn_classifier']
+        labels = self.encoded_training_data['labels']
+        top1 = top5 = total = 0
+        for class_name, items in data_loader.val_data.items():
+            if len(items) == 0:
+                continue
+            if isinstance(items, np.ndarray):
+                imgs = items
+            else:
+                imgs = np.asarray([get_image(p, self.params_model['input_shape']) for p in items], np.float32) / 255.
+            enc = self.base_model.predict(imgs)
+            pred = knn.predict(enc)
+            idx = knn.kneighbors(enc, n_neighbors=min(5, len(labels)))[1]
+            top1 += int(np.sum(pred == class_name))
+            top5 += sum(class_name in [labels[j] for j in row] for row in idx)
+            total += len(imgs)
+        return {'top1': top1 / max(total, 1), 'top5': top5 / max(total, 1)}
+
 
 class _ClsHead(nn.Module):
     def __init__(self, base_model, e):

@@ -216,3 +216,38 @@ class _PairDistance(torch.autograd.Function):
 def pair_distance(e1, e2):
     """models.py:225: sqrt(max(sum (e1-e2)^2, 1e-7)), keepdims -> [b,1]."""
     return _PairDistance.apply(e1, e2)
+
+
+# --------------------------------------------------------------------------- evaluation: kNN on embeddings
+def cross_distances(q, x, squared=False):
+    """[nq,e] x [n,e] -> [nq,n] Euclidean distances (sklearn euclidean_distances(Q, X))."""
+    q, x = _prep(q.detach()), _prep(x.detach())
+    nq, e = q.shape
+    n = x.shape[0]
+    if x.shape[1] != e:
+        raise _lib.EmbnetError(f"cross_distances: widths differ ({e} vs {x.shape[1]})")
+    lib = _lib.lib()
+    ws = _new((max(lib.embnet_cross_dist_workspace_bytes(nq, n) // 4, 1),), q)
+    d = _new((nq, n), q)
+    check(lib.embnet_cross_dist_f32(ptr(q), nq, ptr(x), n, e, ptr(d), int(bool(squared)), ptr(ws), ws.numel() * 4,
+                                    stream()))
+    return d
+
+
+def topk_smallest(dist, k):
+    """-> (values [rows,k], indices [rows,k] int32), ascending, ties to the smaller column."""
+    dist = _prep(dist)
+    rows, n = dist.shape
+    idx = _new((rows, k), dist, torch.int32)
+    val = _new((rows, k), dist)
+    check(_lib.lib().embnet_topk_smallest(ptr(dist), rows, n, int(k), ptr(idx), ptr(val), stream()))
+    return val, idx
+
+
+def knn_vote(idx, labels):
+    """Majority label of each row's neighbours (labels int32 [n]); ties to the smallest label."""
+    idx = idx.contiguous()
+    labels = labels.to(torch.int32).contiguous()
+    pred = _new((idx.shape[0],), idx, torch.int32)
+    check(_lib.lib().embnet_knn_vote(ptr(idx), ptr(labels), idx.shape[0], idx.shape[1], ptr(pred), stream()))
+    return pred

@@ -101,6 +101,18 @@ int embnet_pair_distance_fwd(const float* e1, const float* e2, int b, int e, flo
 int embnet_pair_distance_bwd(const float* e1, const float* e2, const float* dist, const float* ddist,
                              int b, int e, float* de1, float* de2, void* stream);
 
+/* ---- evaluation right after training (models.py:128-161 predict_knn / calculate_prediction_accuracy, which
+ * go through sklearn KNeighborsClassifier, brute-force Euclidean) ---- */
+/* dist[nq,n] = Euclidean distance of every query row q[nq,e] to every gallery row x[n,e] (sklearn
+ * euclidean_distances(Q, X) semantics; squared!=0 skips the sqrt). */
+size_t embnet_cross_dist_workspace_bytes(int nq, int n);
+int embnet_cross_dist_f32(const float* q, int nq, const float* x, int n, int e, float* dist, int squared,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* idx/val[rows,k] = the k smallest entries of each row of dist[rows,n], ascending, ties to the smaller column. */
+int embnet_topk_smallest(const float* dist, int rows, int n, int k, int32_t* idx, float* val, void* stream);
+/* pred[rows] = majority label among labels[idx[row,:]], ties to the smallest label (KNeighborsClassifier.predict). */
+int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, int32_t* pred, void* stream);
+
 /* ------------------------------------------------------------------ backbone layers
  * Stand-ins for the Keras layers that backbones.py:19-121 instantiates (TensorFlow kernels in the
  * reference).  All NHWC fp32. */

@@ -251,6 +251,21 @@ def gen_mining(dg):
     _save("mining", **out)
 
 
+def gen_knn(models_src_check=True):
+    """The reference only names sklearn's KNeighborsClassifier (models.py:15,134-137); golden = real sklearn."""
+    from sklearn.neighbors import KNeighborsClassifier
+    out = {}
+    for name, nc, per, e, sigma, nq, seed in R.KNN_CASES:
+        x, y, q, qy = R.knn_data(nc, per, e, sigma, nq, seed)
+        for k in (1, 5):
+            clf = KNeighborsClassifier(n_neighbors=k).fit(x, y)
+            dist, idx = clf.kneighbors(q, n_neighbors=5)
+            out[f"{name}/k{k}/predict"] = clf.predict(q)
+            out[f"{name}/k{k}/dist5"], out[f"{name}/k{k}/idx5"] = dist.astype(np.float32), idx
+        out[f"{name}/query_labels"] = qy
+    _save("knn", **out)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("gen_golden.py needs /root/reference (build container only)")
@@ -261,6 +276,7 @@ def main():
     gen_losses(lac)
     gen_pairwise(dg)
     gen_mining(dg)
+    gen_knn()
 
 
 if __name__ == "__main__":

@@ -110,3 +110,20 @@ def pairwise_input(n, e, seed, dup):
     if dup:                       # sampling with replacement -> identical rows
         x[n // 2] = x[1]
     return x
+
+
+KNN_CASES = [  # (name, classes, per_class, E, sigma, n_query, seed)
+    ("c10_e64", 10, 20, 64, 0.35, 50, 41),
+    ("c107_e256", 107, 6, 256, 0.3, 120, 42),
+]
+
+
+def knn_data(n_classes, per_class, e, sigma, n_query, seed):
+    """Clustered unit embeddings: gallery [classes*per_class, e] with labels, and queries drawn the same way."""
+    x = clustered_embeddings(seed, n_classes, per_class + 2, e, sigma).reshape(n_classes, per_class + 2, e)
+    gallery = x[:, :per_class].reshape(-1, e)
+    labels = np.repeat(np.arange(n_classes), per_class)
+    rs = np.random.RandomState(seed + 1)
+    pick = rs.randint(0, n_classes * 2, size=n_query)
+    queries = x[:, per_class:].reshape(-1, e)[pick]
+    return gallery.copy(), labels, queries.copy(), pick // 2

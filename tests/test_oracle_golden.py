@@ -111,3 +111,17 @@ def test_batch_hard_properties():
         same = [j for j in range(32) if j // 4 == a // 4 and j != a]
         other = [j for j in range(32) if j // 4 != a // 4]
         assert d[a, p_] == max(d[a, same]) and d[a, n_] == min(d[a, other])
+
+
+@pytest.mark.parametrize("case", R.KNN_CASES, ids=lambda c: c[0])
+def test_knn_oracle_vs_sklearn_golden(golden, case):
+    from oracle import knn as oknn
+    name, nc, per, e, sigma, nq, seed = case
+    g = golden("knn")
+    x, y, q, qy = R.knn_data(nc, per, e, sigma, nq, seed)
+    assert np.array_equal(qy, g[f"{name}/query_labels"])
+    dist, idx = oknn.kneighbors(q, x, 5)
+    assert np.array_equal(idx, g[f"{name}/k1/idx5"])
+    np.testing.assert_allclose(dist, g[f"{name}/k1/dist5"], rtol=1e-6, atol=1e-6)
+    for k in (1, 5):
+        assert np.array_equal(oknn.predict(q, x, y, k), g[f"{name}/k{k}/predict"])
