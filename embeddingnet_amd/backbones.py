@@ -268,3 +268,75 @@ def load_keras_weights(module, weights, strict=True):
             t.copy_(torch.as_tensor(np.asarray(weights[k]), dtype=t.dtype).reshape(t.shape))
         elif strict:
             raise KeyError(f"missing weight {k}")
+
+
+def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, params_save_paths, max_epochs=None):
+    """Optional softmax pre-training of the backbone (reference backbones.py:128-204, run by
+    tools/train.py:164-170 when the config has SOFTMAX_PRETRAINING): GAP -> Dense(n_classes) trained with
+    categorical cross-entropy on SimpleDataGenerator batches; LR lr0*decay^floor(epoch/step),
+    ReduceLROnPlateau(0.1, patience 20), EarlyStopping(patience 10, restore best), best-only checkpoints
+    under <work_dir>/<project>/pretraining_model/weights/.  Returns the history dict."""
+    import os
+    from .datagenerators import SimpleDataGenerator
+    p = params_softmax
+    dev = next(backbone_model.parameters()).device
+    gen = torch.Generator().manual_seed(0)
+    head = Seq(gap=L.GlobalAveragePooling2D(), dense=L.Dense(backbone_model.net.out_channels
+                                                             if hasattr(backbone_model.net, "out_channels")
+                                                             else _spatial_out(backbone_model.net, tuple(p['input_shape']), dev)[2],
+                                                             data_loader.n_classes, gen=gen)).to(dev)
+    kw = dict(input_shape=p['input_shape'], batch_size=p['batch_size'], n_batches=p['steps_per_epoch'],
+              augmentations=p.get('augmentations'))
+    train_gen = SimpleDataGenerator(data_loader.train_data, data_loader.class_names, **kw)
+    val_gen = SimpleDataGenerator(data_loader.val_data, data_loader.class_names, **kw) if data_loader.validate else None
+    params = [q for q in list(backbone_model.parameters()) + list(head.parameters()) if q.requires_grad]
+    opt = p['optimizer'].build(params)
+    wdir = os.path.join(params_save_paths['work_dir'], params_save_paths['project_name'], 'pretraining_model/weights/')
+    os.makedirs(wdir, exist_ok=True)
+    best, best_state, since_best, since_reduce, scale = float('inf'), None, 0, 0, 1.0
+    history = {'loss': [], 'accuracy': [], 'val_loss': [], 'val_accuracy': []}
+    n_epochs = min(p['n_epochs'], max_epochs or p['n_epochs'])
+    for epoch in range(n_epochs):
+        for g in opt.param_groups:
+            g['lr'] = p['learning_rate'] * p['decay_factor'] ** (epoch // p['step_size']) * scale
+        backbone_model.train(); head.train()
+        ls, ac = [], []
+        for _ in range(len(train_gen)):
+            (x,), t = train_gen[0]
+            opt.zero_grad(set_to_none=True)
+            loss, acc, _ = ops.softmax_cross_entropy(head(backbone_model(torch.from_numpy(x).to(dev))),
+                                                     torch.from_numpy(t).to(dev))
+            loss.backward()
+            opt.step()
+            ls.append(loss.detach()); ac.append(acc)
+        history['loss'].append(float(torch.stack(ls).mean())); history['accuracy'].append(float(torch.stack(ac).mean()))
+        monitor = history['loss'][-1]
+        if val_gen is not None:
+            backbone_model.eval(); head.eval()
+            ls, ac = [], []
+            with torch.no_grad():
+                for _ in range(min(p.get('val_steps', len(val_gen)), len(val_gen))):
+                    (x,), t = val_gen[0]
+                    loss, acc, _ = ops.softmax_cross_entropy(head(backbone_model(torch.from_numpy(x).to(dev))),
+                                                             torch.from_numpy(t).to(dev))
+                    ls.append(loss); ac.append(acc)
+            history['val_loss'].append(float(torch.stack(ls).mean()))
+            history['val_accuracy'].append(float(torch.stack(ac).mean()))
+            monitor = history['val_loss'][-1]
+        print(f"softmax pre-training epoch {epoch + 1}/{n_epochs}: " +
+              " - ".join(f"{k} {v[-1]:.4f}" for k, v in history.items() if v), flush=True)
+        if monitor < best:
+            best, since_best, since_reduce = monitor, 0, 0
+            best_state = {k: v.detach().clone() for k, v in backbone_model.state_dict().items()}
+            np.savez(os.path.join(wdir, f"{params_save_paths['project_name']}_{epoch + 1:03d}.npz"),
+                     **{k: v.detach().cpu().numpy() for k, v in keras_weights(backbone_model).items()})
+        else:
+            since_best += 1; since_reduce += 1
+            if since_reduce >= 20:
+                scale *= 0.1; since_reduce = 0
+            if since_best >= 10:
+                print('EarlyStopping (restoring best weights)')
+                break
+    if best_state is not None:
+        backbone_model.load_state_dict(best_state)
+    return history

@@ -344,3 +344,75 @@ extern "C" int embnet_pair_distance_bwd(const float* e1, const float* e2, const 
   pair_distance_bwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(e1, e2, dist, ddist, b, e, de1, de2);
   return check_launch("pair_distance_bwd");
 }
+
+// ---- softmax + categorical cross-entropy (backbones.py:146-151: Dense(n_classes, softmax) compiled with
+// loss='categorical_crossentropy', metrics=['accuracy']; TF evaluates it from the logits of the softmax op).
+// One wave per row: max, sum-exp, loss_row = -sum_c t_c * log_softmax_c; probabilities are kept for backward.
+namespace embnet {
+
+__global__ __launch_bounds__(256) void softmax_xent_fwd_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                               int b, int c, float* __restrict__ prob,
+                                                               float* __restrict__ loss, float* __restrict__ correct) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= b) return;
+  const float* zr = z + (long)row * c; const float* tr = t + (long)row * c;
+  float mx = -INFINITY, tmx = -INFINITY; int zi = 0x7fffffff, ti = 0x7fffffff;
+  for (int j = lane; j < c; j += 64) {
+    if (zr[j] > mx) { mx = zr[j]; zi = j; }
+    if (tr[j] > tmx) { tmx = tr[j]; ti = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(mx, o, 64); int oi = __shfl_xor(zi, o, 64);
+    if (ov > mx || (ov == mx && oi < zi)) { mx = ov; zi = oi; }
+    ov = __shfl_xor(tmx, o, 64); oi = __shfl_xor(ti, o, 64);
+    if (ov > tmx || (ov == tmx && oi < ti)) { tmx = ov; ti = oi; }
+  }
+  float se = 0.f;
+  for (int j = lane; j < c; j += 64) se += __expf(zr[j] - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se);
+  float l = 0.f;
+  for (int j = lane; j < c; j += 64) {
+    prob[(long)row * c + j] = __expf(zr[j] - lse);
+    l += tr[j] * (lse - zr[j]);
+  }
+  l = wave_sum(l);
+  if (lane == 0) { loss[row] = l; correct[row] = zi == ti ? 1.f : 0.f; }
+}
+
+// dz = (*upstream / b) * (prob * sum_c t_c - t)
+__global__ __launch_bounds__(256) void softmax_xent_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ t,
+                                                               int b, int c, const float* __restrict__ upstream,
+                                                               float* __restrict__ dz) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= b) return;
+  float ts = 0.f;
+  for (int j = lane; j < c; j += 64) ts += t[(long)row * c + j];
+  ts = wave_sum(ts);
+  const float g = (upstream ? *upstream : 1.f) / (float)b;
+  for (int j = lane; j < c; j += 64)
+    dz[(long)row * c + j] = g * (prob[(long)row * c + j] * ts - t[(long)row * c + j]);
+}
+
+}  // namespace embnet
+
+extern "C" int embnet_softmax_xent_fwd(const float* logits, const float* targets, int b, int c, float* prob,
+                                       float* row_loss, float* row_correct, float* mean_loss, float* accuracy,
+                                       void* stream) {
+  EMBNET_CHECK_ARG(logits && targets && prob && row_loss && row_correct && mean_loss && accuracy,
+                   "softmax_xent_fwd: null pointer");
+  EMBNET_CHECK_ARG(b > 0 && c > 0, "softmax_xent_fwd: b=%d c=%d", b, c);
+  softmax_xent_fwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(logits, targets, b, c, prob, row_loss, row_correct);
+  mean_first_kernel<<<1, 256, 0, S(stream)>>>(row_loss, nullptr, b, mean_loss);
+  mean_first_kernel<<<1, 256, 0, S(stream)>>>(row_correct, nullptr, b, accuracy);
+  return check_launch("softmax_xent_fwd");
+}
+
+extern "C" int embnet_softmax_xent_bwd(const float* prob, const float* targets, int b, int c, const float* upstream,
+                                       float* dlogits, void* stream) {
+  EMBNET_CHECK_ARG(prob && targets && dlogits, "softmax_xent_bwd: null pointer");
+  EMBNET_CHECK_ARG(b > 0 && c > 0, "softmax_xent_bwd: b=%d c=%d", b, c);
+  softmax_xent_bwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(prob, targets, b, c, upstream, dlogits);
+  return check_launch("softmax_xent_bwd");
+}

@@ -234,3 +234,25 @@ class SiameseDataGenerator(ENDataGenerator):
 
     def __getitem__(self, index):
         return self.get_batch_pairs()
+
+
+class SimpleDataGenerator(ENDataGenerator):
+    """Random images with one-hot class targets (reference :381-418); feeds the softmax pre-training."""
+
+    def __init__(self, class_files_paths, class_names, input_shape=None, batch_size=32, n_batches=10,
+                 augmentations=None):
+        super().__init__(class_files_paths=class_files_paths, class_names=class_names, input_shape=input_shape,
+                         batch_size=batch_size, n_batches=n_batches, augmentations=augmentations)
+
+    def get_batch(self):
+        images, targets = [], np.zeros((self.batch_size, self.n_classes), np.float32)
+        for i in range(self.batch_size):
+            ci = random.randrange(0, self.n_classes)
+            cl = self.class_names[ci]
+            images.append(self._get_images_set([cl], [random.randrange(0, self.n_samples[cl])],
+                                               with_aug=self.augmentations)[0])
+            targets[i][ci] = 1
+        return [np.asarray(images, np.float32)], targets
+
+    def __getitem__(self, index):
+        return self.get_batch()

@@ -251,3 +251,34 @@ def knn_vote(idx, labels):
     pred = _new((idx.shape[0],), idx, torch.int32)
     check(_lib.lib().embnet_knn_vote(ptr(idx), ptr(labels), idx.shape[0], idx.shape[1], ptr(pred), stream()))
     return pred
+
+
+# --------------------------------------------------------------------------- softmax pre-training head
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        z, t = _prep(logits), _prep(targets)
+        b, c = z.shape
+        if t.shape != z.shape:
+            raise _lib.EmbnetError(f"categorical_crossentropy: targets {tuple(t.shape)} vs logits {tuple(z.shape)}")
+        prob, rows, corr = torch.empty_like(z), _new((b,), z), _new((b,), z)
+        mean, acc = _new((), z), _new((), z)
+        check(_lib.lib().embnet_softmax_xent_fwd(ptr(z), ptr(t), b, c, ptr(prob), ptr(rows), ptr(corr), ptr(mean),
+                                                 ptr(acc), stream()))
+        ctx.save_for_backward(prob, t)
+        ctx.mark_non_differentiable(acc, prob)
+        return mean, acc, prob
+
+    @staticmethod
+    def backward(ctx, dmean, _dacc, _dprob):
+        prob, t = ctx.saved_tensors
+        b, c = prob.shape
+        dz = torch.empty_like(prob)
+        check(_lib.lib().embnet_softmax_xent_bwd(ptr(prob), ptr(t), b, c, ptr(_prep(dmean)), ptr(dz), stream()))
+        return dz, None
+
+
+def softmax_cross_entropy(logits, targets):
+    """Keras Dense(softmax) + 'categorical_crossentropy' + 'accuracy' from the logits:
+    -> (mean loss [autograd], accuracy, probabilities)."""
+    return _SoftmaxXent.apply(logits, targets)

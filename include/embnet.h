@@ -101,6 +101,14 @@ int embnet_pair_distance_fwd(const float* e1, const float* e2, int b, int e, flo
 int embnet_pair_distance_bwd(const float* e1, const float* e2, const float* dist, const float* ddist,
                              int b, int e, float* de1, float* de2, void* stream);
 
+/* Softmax pre-training head (backbones.py:128-204: Dense(n_classes, softmax), loss 'categorical_crossentropy',
+ * metric 'accuracy'): logits/targets[b,c] (targets one-hot or soft); prob[b,c] kept for backward;
+ * *mean_loss = mean_b(-sum_c t log softmax), *accuracy = mean(argmax z == argmax t). */
+int embnet_softmax_xent_fwd(const float* logits, const float* targets, int b, int c, float* prob, float* row_loss,
+                            float* row_correct, float* mean_loss, float* accuracy, void* stream);
+int embnet_softmax_xent_bwd(const float* prob, const float* targets, int b, int c, const float* upstream,
+                            float* dlogits, void* stream);
+
 /* ---- evaluation right after training (models.py:128-161 predict_knn / calculate_prediction_accuracy, which
  * go through sklearn KNeighborsClassifier, brute-force Euclidean) ---- */
 /* dist[nq,n] = Euclidean distance of every query row q[nq,e] to every gallery row x[n,e] (sklearn

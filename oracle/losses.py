@@ -54,3 +54,18 @@ def accuracy(y_true, y_pred):
     """losses_and_accuracies.py:47 — fixed 0.5 threshold on distances."""
     y = np.asarray(y_true)
     return np.mean(np.equal(y, (np.asarray(y_pred) < 0.5).astype(y.dtype)))
+
+
+def softmax_cross_entropy(logits, targets):
+    """Keras Dense(softmax) + loss='categorical_crossentropy' (reference backbones.py:146-151; TF computes it
+    from the logits of the softmax op) and metric 'accuracy'.  Third-party arithmetic (TensorFlow 2.2):
+    parity unpinned, standard definition.  Returns (mean loss, accuracy, probabilities, dlogits of the mean)."""
+    z = np.asarray(logits, np.float64)
+    t = np.asarray(targets, np.float64)
+    zs = z - z.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(zs).sum(axis=1, keepdims=True))
+    logp = zs - lse
+    loss = -(t * logp).sum(axis=1)
+    acc = np.mean(z.argmax(1) == t.argmax(1))
+    prob = np.exp(logp)
+    return loss.mean(), acc, prob, (prob * t.sum(1, keepdims=True) - t) / z.shape[0]

@@ -202,3 +202,20 @@ def test_grad_reducer_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("ok" in o for o in outs)
+
+
+def test_softmax_oracle_matches_torch_reference():
+    """oracle.losses.softmax_cross_entropy (parity unpinned: TF arithmetic) vs torch's own CE on CPU."""
+    import torch
+    from oracle import losses as olosses
+    rs = np.random.RandomState(3)
+    z = rs.randn(9, 7) * 4
+    t = np.eye(7)[rs.randint(0, 7, 9)]
+    zt = torch.tensor(z, requires_grad=True)
+    ref = torch.nn.functional.cross_entropy(zt, torch.tensor(t.argmax(1)))
+    ref.backward()
+    loss, acc, prob, grad = olosses.softmax_cross_entropy(z, t)
+    np.testing.assert_allclose(loss, ref.item(), rtol=1e-12)
+    np.testing.assert_allclose(grad, zt.grad.numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(prob.sum(1), 1.0, rtol=1e-12)
+    assert acc == np.mean(z.argmax(1) == t.argmax(1))

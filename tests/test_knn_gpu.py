@@ -75,3 +75,36 @@ def test_encodings_and_knn_accuracy_end_to_end(tmp_path):
     yi = np.array([lookup[l] for l in enc["labels"]])
     ref = oknn.predict(q, enc["encodings"], yi, 1)
     assert np.array_equal(np.array([lookup[l] for l in clf.predict(q)]), ref)
+
+
+def test_softmax_cross_entropy_and_pretraining(tmp_path):
+    """the softmax head's loss/metric vs the oracle, then a short pre-training run learns."""
+    from embeddingnet_amd import backbones as B, ops
+    from embeddingnet_amd.datagenerators import SimpleDataGenerator, SyntheticDataLoader
+    from embeddingnet_amd.utils import get_optimizer
+    from oracle import losses as olosses
+    rs = np.random.RandomState(0)
+    for b, c in [(8, 10), (33, 107), (5, 3)]:
+        z = (rs.randn(b, c) * 3).astype(np.float32)
+        t = np.eye(c, dtype=np.float32)[rs.randint(0, c, b)]
+        zt = torch.tensor(z, device=DEV, requires_grad=True)
+        loss, acc, prob = ops.softmax_cross_entropy(zt, torch.tensor(t, device=DEV))
+        rl, ra, rp, rg = olosses.softmax_cross_entropy(z, t)
+        np.testing.assert_allclose(loss.item(), rl, rtol=2e-6)
+        assert acc.item() == pytest.approx(ra)
+        np.testing.assert_allclose(prob.cpu().numpy(), rp, rtol=2e-5, atol=1e-7)
+        (loss * 2).backward()
+        np.testing.assert_allclose(zt.grad.cpu().numpy(), 2 * rg, rtol=2e-5, atol=1e-8)
+    data = SyntheticDataLoader(5, 16, (64, 64, 3), noise=0.15, validate=True, val_ratio=0.25, seed=1)
+    gen = SimpleDataGenerator(data.train_data, data.class_names, input_shape=[64, 64, 3], batch_size=6, n_batches=3)
+    (x,), t = gen[0]
+    assert x.shape == (6, 64, 64, 3) and t.shape == (6, 5) and np.all(t.sum(1) == 1) and len(gen) == 3
+    base, backbone = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None,
+                                    device=torch.device(DEV))
+    params_softmax = dict(optimizer=get_optimizer("adam", 1e-3), learning_rate=1e-3, decay_factor=0.99, step_size=1,
+                          input_shape=[64, 64, 3], batch_size=20, val_steps=2, steps_per_epoch=8, n_epochs=4,
+                          augmentations=None)
+    hist = B.pretrain_backbone_softmax(backbone, data, params_softmax, {"work_dir": str(tmp_path), "project_name": "pre"})
+    assert hist["loss"][-1] < hist["loss"][0] and hist["accuracy"][-1] > 0.5
+    import os
+    assert os.listdir(tmp_path / "pre" / "pretraining_model" / "weights")

@@ -50,6 +50,19 @@ def test_train_cli_synthetic(tmp_path):
     assert len(hist["loss"]) == 3 and hist["loss"][-1] < hist["loss"][0]
 
 
+def test_train_cli_softmax_pretraining(tmp_path):
+    """SOFTMAX_PRETRAINING in the config -> backbone pre-training runs before the triplet stage (train.py:164-170)."""
+    cfg = open(os.path.join(ROOT, "configs", "simple2_softmax_synthetic.yml")).read().replace("work_dirs/",
+                                                                                              str(tmp_path) + "/")
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(cfg)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train.py"), str(cfg_path), "--synthetic", "10",
+                          "--max_epochs", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "softmax pre-training epoch 2/2" in out.stdout and "Epoch 2/2" in out.stdout
+    assert os.listdir(tmp_path / "simple2_synthetic" / "pretraining_model" / "weights")
+
+
 def test_grad_reducer_over_rccl_single_rank():
     """The DP reducer on the real backend (nccl = RCCL), world size 1: hooks fire, buckets are
     all-reduced asynchronously on RCCL's stream, finish() orders them before the optimizer, and the

@@ -107,6 +107,10 @@ def main():
         trainable = model.base_model
     if args.resume_from is not None:
         model.load_model(args.resume_from)            # the mining model IS base_model, so it resumes too
+    if 'softmax' in cfg:                              # reference train.py:164-170
+        from embedding_net.backbones import pretrain_backbone_softmax
+        pretrain_backbone_softmax(model.backbone_model, data_loader, cfg['softmax'], cfg['general'],
+                                  max_epochs=args.max_epochs)
 
     params = [p for p in trainable.parameters() if p.requires_grad]
     opt = p_train['optimizer'].build(params)
