@@ -12,7 +12,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libembnet_hip.so")
+LIB_PATH = os.environ.get("EMBNET_LIB") or os.path.join(_HERE, "libembnet_hip.so")   # EMBNET_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "embnet.h")
 
 _lib = None
@@ -54,7 +54,7 @@ def lib():
         for name, (res, argtypes) in parse_header().items():
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, argtypes
-        if l.embnet_abi_version() != 1:
+        if l.embnet_abi_version() != 2:
             raise EmbnetError("libembnet_hip.so ABI version mismatch")
         _lib = l
     return _lib

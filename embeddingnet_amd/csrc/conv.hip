@@ -223,9 +223,60 @@ struct LoadConvWgradA {
 
 // ---------------------------------------------------------------------------------------------
 template <class G, class TA, class TB>
-constexpr int SMEM_FLOATS = (TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>;
+constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>;
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; };
+// Remainder split ("tail"): workgroups finish in waves of 256 (one per CU), so `tiles mod 256` left-over
+// tiles would keep a few CUs busy for a whole extra tile time (784 tiles = 3.06 per CU ran 22 % longer
+// than 768).  The first n_full tiles are computed whole; each left-over tile is cut along K into `parts`
+// equal pieces computed by separate workgroups (dispatched last, so they fill the slots the full tiles
+// leave free) into raw fp32 partial tiles in the workspace, and tail_fixup_kernel sums the pieces in a
+// fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
+struct SplitTail { int n_full, parts, kt_part; float* ws; };
+
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; };
+
+// Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
+template <class G>
+__device__ __forceinline__ void tail_decode(const SplitTail& t, int bid, int kt_total, int& tile, int& k0, int& k1,
+                                            float*& part) {
+  if (bid < t.n_full) { tile = xcd_remap(bid, t.n_full); k0 = 0; k1 = kt_total; part = nullptr; return; }
+  const int j = bid - t.n_full;
+  tile = t.n_full + j / t.parts;
+  k0 = (j % t.parts) * t.kt_part; k1 = min(kt_total, k0 + t.kt_part);
+  part = t.ws + (long)j * (G::BM * G::BN);
+}
+
+// raw accumulator tile -> part[BM][BN] (whole tile: rows/cols past the matrix edge hold zeros)
+template <class G>
+__device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN], float* smem, float* part) {
+  for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
+    *reinterpret_cast<float4*>(part + r * G::BN + c) = v;
+  });
+}
+
+// out[(m0+r)*ld + n0+c] = act(sum_parts partial + bias) for the left-over tiles; one float4 per thread.
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int parts, int bm, int bn,
+                                                         int n_full, int tiles_n, long m, int cols,
+                                                         const float* __restrict__ bias, int relu,
+                                                         float* __restrict__ out) {
+  const int per_tile = bm * bn / 4;                       // float4s per tile
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(i / per_tile), e = (int)(i % per_tile) * 4;
+  const int r = e / bn, c = e % bn;
+  const int tile = n_full + t;
+  const long row = (long)(tile / tiles_n) * bm + r;
+  const int col = (tile % tiles_n) * bn + c;
+  if (row >= m || col >= cols) return;
+  const float* src = ws + (long)t * parts * bm * bn + e;
+  float4 a = *reinterpret_cast<const float4*>(src);
+  for (int k = 1; k < parts; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (long)k * bm * bn);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  *reinterpret_cast<float4*>(out + row * cols + col) = a;
+}
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
@@ -233,13 +284,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
   const int M = p.g.N * p.g.OH * p.g.OW, Kg = p.g.R * p.g.S * p.g.C;
-  const int tiles_n = (p.g.K + G::BN - 1) / G::BN, tiles_m = (M + G::BM - 1) / G::BM;
-  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
+  int id, k0, k1; float* part;
+  tail_decode<G>(p.tail, blockIdx.x, (Kg + BK - 1) / BK, id, k0, k1, part);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
   LoadConvFwdA<G::BM, VEC> la; la.init(p.x, p.g, m0, threadIdx.x);
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
+  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
+  if (part) { store_partial<G>(acc, smem, part); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
       const int row = m0 + r, col = n0 + c;
@@ -261,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   });
 }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
@@ -271,13 +324,15 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   const DgradClass& cg = p.cls[blockIdx.y];
   const int M = p.g.N * cg.Hc * cg.Wc, Kg = cg.nR * cg.nS * p.g.K;
   const int tiles_n = (p.g.C + G::BN - 1) / G::BN;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int id, k0, k1; float* part;                           // the tail split is only planned for stride 1 (one class)
+  tail_decode<G>(p.tail, blockIdx.x, (Kg + BK - 1) / BK, id, k0, k1, part);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
   if (m0 >= M) return;                                   // classes differ in size by a row/column
   LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, cg, m0, threadIdx.x);
   LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, 0, (Kg + BK - 1) / BK, smem, acc);
+  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
+  if (part) { store_partial<G>(acc, smem, part); return; }
   const int st = p.g.stride;
   if ((p.g.C & 3) == 0) {                                // 16-byte row stores
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
@@ -423,6 +478,33 @@ static int pick_tile(long m, int ncols) {
 }
 static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64};
 
+// Plan the remainder split for `tiles` output tiles of bm x bn with kt K-tiles each (see SplitTail).
+// Model: a CU retires one tile per t_tile; whole tiles cost ceil(tiles/256) of those, the split costs
+// floor(tiles/256) + ceil(rem*parts/256)/parts plus the fix-up pass over rem*parts partial tiles.
+static constexpr int NUM_CUS = 256;
+static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, SplitTail& t, size_t* need = nullptr) {
+  t.n_full = (int)tiles; t.parts = 1; t.kt_part = kt; t.ws = nullptr;
+  if (need) *need = 0;
+  static const int knob = getenv("EMBNET_CONV_TAIL") ? atoi(getenv("EMBNET_CONV_TAIL")) : 1;
+  const int rem = (int)(tiles % NUM_CUS);
+  if (!knob || rem == 0 || tiles < NUM_CUS) return;
+  const double t_tile = (double)kt * bm * bn * BK * 2.0 / (0.85 * 146e12 / NUM_CUS);        // seconds
+  const double tile_bytes = (double)bm * bn * 4;
+  double best = 1.0 * t_tile; int best_parts = 1;                                         // the left-over round, whole tiles
+  for (int parts = 2; parts <= 32 && parts <= kt / 2; ++parts) {
+    const int kt_part = cdiv(kt, parts), real = cdiv(kt, kt_part);
+    if (real != parts) continue;
+    const double cost = (double)cdiv((long)rem * parts, NUM_CUS) / parts * t_tile + 4e-6 +
+                        2.0 * rem * parts * tile_bytes / 3e12 + rem * tile_bytes / 3e12;
+    if (cost < best * 0.97) { best = cost; best_parts = parts; }
+  }
+  if (best_parts == 1) return;
+  const size_t bytes = (size_t)rem * best_parts * bm * bn * 4;
+  if (need) *need = bytes;
+  if (bytes > ws_bytes) return;                          // no (or too small a) workspace: whole tiles
+  t.n_full = (int)(tiles - rem); t.parts = best_parts; t.kt_part = cdiv(kt, best_parts);
+}
+
 #define LAUNCH_TILED(KERNEL, VECARGS, tile, grid, st, p)                              \
   switch (tile) {                                                                     \
     case 0: KERNEL<G128x128, VECARGS><<<grid, 256, 0, st>>>(p); break;                \
@@ -431,28 +513,57 @@ static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64
     default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
   }
 
+extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
+  if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;
+  const long M = (long)n * oh * ow;
+  const int tile = pick_tile(M, k);
+  SplitTail t; size_t need;
+  plan_tail((long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]), cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile],
+            0, t, &need);
+  return need;
+}
+
 extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
-                                     int ow, int relu, void* stream) {
+                                     int ow, int relu, void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
-  EMBNET_CHECK_ARG(aligned16(y), "conv2d_fwd: output must be 16-byte aligned");
-  ConvFwdParams p{x, w, bias, y, {}, relu};
+  EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace), "conv2d_fwd: output and workspace must be 16-byte aligned");
+  ConvFwdParams p{x, w, bias, y, {}, relu, {}};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_fwd")) return rc;
   const long M = (long)n * oh * ow;
   hipStream_t st = (hipStream_t)stream;
   const int tile = pick_tile(M, k);
-  const int grid = cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
-  if ((c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w)) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
+  const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
+  const bool vec = (c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w) && (!bias || aligned16(bias));
+  plan_tail(tiles, cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile], (vec && workspace) ? workspace_bytes : 0, p.tail);
+  p.tail.ws = (float*)workspace;
+  const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
+  if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
+  if (p.tail.parts > 1) {
+    const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
+    tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
+                                                                         cdiv(k, bn), M, k, bias, relu, y);
+  }
   return check_launch("conv2d_fwd");
+}
+
+extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride) {
+  if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || stride != 1 || ((c | k) & 3)) return 0;
+  const long M = (long)n * h * wd;
+  const int tile = pick_tile(M, c);
+  SplitTail t; size_t need;
+  plan_tail((long)cdiv(M, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]), cdiv((long)r * s * k, BK), TILE_BM[tile], TILE_BN[tile],
+            0, t, &need);
+  return need;
 }
 
 extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
                                        int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
-                                       void* stream) {
+                                       void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
-  EMBNET_CHECK_ARG(aligned16(dx), "conv2d_dgrad: output must be 16-byte aligned");
-  ConvDgradParams p{dy, w, dx, {}, {}};
+  EMBNET_CHECK_ARG(aligned16(dx) && aligned16(workspace), "conv2d_dgrad: output and workspace must be 16-byte aligned");
+  ConvDgradParams p{dy, w, dx, {}, {}, {}};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
   EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
   long max_m = 0;
@@ -474,9 +585,21 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
     }
   hipStream_t st = (hipStream_t)stream;
   const int tile = pick_tile(max_m * stride * stride, c);
-  const dim3 grid(cdiv(max_m, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]), stride * stride);
-  if ((k & 3) == 0 && aligned16(dy) && aligned16(w)) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
+  const long tiles = (long)cdiv(max_m, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]);
+  const bool vec = (k & 3) == 0 && aligned16(dy) && aligned16(w);
+  // stride 1 = one class whose rows are the input pixels in order, so the fix-up writes dx[row*C + col]
+  const bool can_split = vec && stride == 1 && (c & 3) == 0 && workspace;
+  plan_tail(tiles, cdiv((long)p.cls[0].nR * p.cls[0].nS * k, BK), TILE_BM[tile], TILE_BN[tile],
+            can_split ? workspace_bytes : 0, p.tail);
+  p.tail.ws = (float*)workspace;
+  const dim3 grid(p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts, stride * stride);
+  if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
+  if (p.tail.parts > 1) {
+    const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
+    tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
+                                                                         cdiv(c, bn), max_m, c, nullptr, 0, dx);
+  }
   return check_launch("conv2d_dgrad");
 }
 

@@ -13,7 +13,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
@@ -35,7 +35,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
@@ -53,7 +53,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseParams p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TA::FLOATS + TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKM<G::BM, VEC> la; la.init(p.a, p.m, p.m, p.k, m0, threadIdx.x);

@@ -4,10 +4,9 @@
 // owns a (BM/WAVES_M) x (BN/WAVES_N) sub-tile as TM x TN accumulators of 32x32.
 // The K loop runs in tiles of BK = 32: every thread prefetches its float4 pieces
 // of the NEXT A/B tiles from HBM/L2 into registers while the MFMAs consume the
-// current tiles from LDS (one LDS buffer + register prefetch, two barriers per
-// tile; 36.9 KB LDS at 128x128 so three workgroups share a CU and fill each
-// other's barrier gaps — f32 MFMA issues once per 64 cycles per SIMD, so operand
-// delivery is cheap next to the matrix pipe).
+// current tiles from LDS (two LDS stages, one barrier per tile, fragments read one
+// k-step ahead — see gemm_mainloop; f32 MFMA issues once per 64 cycles per SIMD,
+// so operand delivery is cheap next to the matrix pipe).
 //
 // Global loads are BRANCH-FREE buffer loads: every operand is addressed through a
 // buffer descriptor (base in SGPRs, 32-bit byte offset per lane) and anything that
@@ -167,15 +166,75 @@ struct Geom {
   static_assert(TM >= 1 && TN >= 1, "wave tile below one MFMA");
 };
 
-// Main loop.  LA/LB: loaders with .load(kt, regs); TA/TB: their LDS tile types.
+// LDS stages of the main loop: 2 = double-buffered, software-pipelined loop (one barrier per K tile),
+// 1 = single buffer + register prefetch (two barriers per K tile, half the LDS).
+#ifndef EMBNET_LDS_STAGES
+#define EMBNET_LDS_STAGES 1
+#endif
+constexpr int LDS_STAGES = EMBNET_LDS_STAGES;
+
+template <class TA, class TB>
+constexpr int MAIN_FLOATS = LDS_STAGES * (TA::FLOATS + TB::FLOATS);
+
+template <class G, class TA, class TB>
+__device__ __forceinline__ void load_frags(const float* st, int wm, int wn, int j, int lane,
+                                           float (&a)[G::TM][4], float (&b)[G::TN][4]) {
+#pragma unroll
+  for (int i = 0; i < G::TM; ++i) TA::frag(st, wm + 32 * i, j, lane, a[i]);
+#pragma unroll
+  for (int i = 0; i < G::TN; ++i) TB::frag(st + TA::FLOATS, wn + 32 * i, j, lane, b[i]);
+}
+
+#ifndef EMBNET_SETPRIO
+#define EMBNET_SETPRIO 0
+#endif
+#ifndef EMBNET_PIN
+#define EMBNET_PIN 0
+#endif
+__device__ __forceinline__ void pin() {
+#if EMBNET_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+template <class G>
+__device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const float (&b)[G::TN][4],
+                                          f32x16 (&acc)[G::TM][G::TN]) {
+#if EMBNET_SETPRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+      for (int in = 0; in < G::TN; ++in)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][t], b[in][t], acc[im][in], 0, 0, 0);
+#if EMBNET_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+// Main loop.  LA/LB: loaders with .load(kt, regs); TA/TB: their LDS tile types.  smem holds
+// MAIN_FLOATS<TA,TB> floats.
+//
+// Two-stage version: K tile kt is consumed from LDS stage (kt&1) in four k-steps of 8 while
+//   * the fragments of the next k-step are read one step ahead (two fragment register sets),
+//   * tile kt+1, fetched into registers during the previous iteration, is written to the other
+//     stage under step 1's MFMAs and the fetch of tile kt+2 is issued right behind it (a whole
+//     iteration of latency cover),
+//   * the single barrier sits between steps 2 and 3: by then every wave's stage writes are long
+//     complete and nobody reads this stage again (step 3's fragments were read before it), and the
+//     first fragments of the next stage are read under step 3's MFMAs.
+// A wave therefore has no point where it waits on LDS or memory with the matrix pipe empty, so the
+// loop does not depend on other workgroups to fill its gaps (few-tile layers run 1-2 waves per SIMD).
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end,
                                               float* smem, f32x16 (&acc)[G::TM][G::TN]) {
-  float* sA = smem;
-  float* sB = smem + TA::FLOATS;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  constexpr int PAST = 1 << 24;            // k tile index past any K: every offset out of range, loads return 0
 
 #pragma unroll
   for (int i = 0; i < G::TM; ++i)
@@ -185,30 +244,62 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[TA::PASSES], rb[TB::PASSES];
-  if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); }
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();                       // everyone finished reading the previous tile
-    TA::store(sA, ra, tid);
-    TB::store(sB, rb, tid);
+  if constexpr (LDS_STAGES == 2) {
+    constexpr int STAGE = TA::FLOATS + TB::FLOATS;
+    if (kt_begin >= kt_end) return;
+    la.load(kt_begin, ra); lb.load(kt_begin, rb);
+    TA::store(smem, ra, tid);
+    TB::store(smem + TA::FLOATS, rb, tid);
+    la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
+    lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
     __syncthreads();
-    // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
-    // offset out of range, so the loads return zeros and need no branch
-    la.load(kt + 1 < kt_end ? kt + 1 : (1 << 24), ra);
-    lb.load(kt + 1 < kt_end ? kt + 1 : (1 << 24), rb);
+    float a0[G::TM][4], b0[G::TN][4], a1[G::TM][4], b1[G::TN][4];
+    load_frags<G, TA, TB>(smem, wm, wn, 0, lane, a0, b0);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const float* sc = smem + cur * STAGE;
+      float* sn = smem + (cur ^ 1) * STAGE;
+      load_frags<G, TA, TB>(sc, wm, wn, 1, lane, a1, b1);
+      pin();
+      mfma_step<G>(a0, b0, acc);
+      pin();
+      load_frags<G, TA, TB>(sc, wm, wn, 2, lane, a0, b0);
+      TA::store(sn, ra, tid);
+      TB::store(sn + TA::FLOATS, rb, tid);
+      pin();
+      mfma_step<G>(a1, b1, acc);
+      pin();
+      la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
+      lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+      load_frags<G, TA, TB>(sc, wm, wn, 3, lane, a1, b1);
+      pin();
+      mfma_step<G>(a0, b0, acc);
+      pin();
+      __syncthreads();
+      load_frags<G, TA, TB>(sn, wm, wn, 0, lane, a0, b0);
+      pin();
+      mfma_step<G>(a1, b1, acc);
+      pin();
+      cur ^= 1;
+    }
+  } else {
+    float* sA = smem;
+    if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __syncthreads();                       // everyone finished reading the previous tile
+      TA::store(sA, ra, tid);
+      TB::store(sA + TA::FLOATS, rb, tid);
+      __syncthreads();
+      // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
+      // offset out of range, so the loads return zeros and need no branch
+      la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
 #pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      float a[G::TM][4], b[G::TN][4];
-#pragma unroll
-      for (int i = 0; i < G::TM; ++i) TA::frag(sA, wm + 32 * i, j, lane, a[i]);
-#pragma unroll
-      for (int i = 0; i < G::TN; ++i) TB::frag(sB, wn + 32 * i, j, lane, b[i]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int im = 0; im < G::TM; ++im)
-#pragma unroll
-          for (int in = 0; in < G::TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][t], b[in][t], acc[im][in], 0, 0, 0);
+      for (int j = 0; j < BK / 8; ++j) {
+        float a[G::TM][4], b[G::TN][4];
+        load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
+        mfma_step<G>(a, b, acc);
+      }
     }
   }
 }

@@ -30,7 +30,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[(TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int tiles_m = (p.n + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -112,7 +112,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256) void cross_dist_kernel(CrossParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
-  __shared__ __attribute__((aligned(16))) float smem[(TA::FLOATS + TB::FLOATS) > EPI_FLOATS<G> ? (TA::FLOATS + TB::FLOATS) : EPI_FLOATS<G>];
+  __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>];
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.q, p.e, p.nq, p.e, m0, threadIdx.x);

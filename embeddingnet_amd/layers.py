@@ -110,8 +110,11 @@ class _Conv2dFn(torch.autograd.Function):
             raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
         stride, pt, pl, oh, ow = geom
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(_lib.lib().embnet_conv2d_fwd_f32(
-            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), stream())))
+        lib = _lib.lib()
+        ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu),
+            ptr(ws), ws.numel() * 4, stream())))
         ctx.geom, ctx.relu, ctx.has_bias = geom, relu, bias is not None
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -155,8 +158,11 @@ class _Conv2dFn(torch.autograd.Function):
                 run_wgrad()
         if need_dx:
             dx = torch.empty_like(x)
+            # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
+            dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
             _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
-                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, stream())))
+                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(dws), dws.numel() * 4,
+                stream())))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
@@ -371,8 +377,10 @@ class _InputBNConvFn(torch.autograd.Function):
             moving_mean.copy_(mm_p[:c])
             moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+        cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
-            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, stream())))
+            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, ptr(cws), cws.numel() * 4,
+            stream())))
         ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y

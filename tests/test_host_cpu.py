@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
-    assert bound.embnet_abi_version() == 1
+    assert bound.embnet_abi_version() == 2
     assert bound.embnet_mine_max_triplets(32, 4) == 192
     assert bound.embnet_pairwise_workspace_bytes(128) == 512
 
@@ -35,9 +35,9 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert rc == -1 and b"null pointer" in lib.embnet_last_error()
     rc = lib.embnet_mine_triplets(1, 1, 4, 0.5, 7, 0, 1, 1, 1, None, None)
     assert rc == -1 and b"k_classes>=2" in lib.embnet_last_error()
-    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 8, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None)
+    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 8, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, 0, None)
     assert rc == -1 and b"16-byte aligned" in lib.embnet_last_error()
-    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 32, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None)
+    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 32, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, 0, None)
     assert rc == -1 and b"reaches outside" in lib.embnet_last_error()
 
 
