@@ -400,40 +400,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   });
 }
 
-// out[i] = sum_s slabs[s][i], fixed order.  One float4 column per thread, splits walked with four
-// independent accumulators (s = 0,4,8.. / 1,5,9.. / ...) so several 16-byte loads are in flight;
-// bytes = splits * n * 4 read once (HBM/L2-bound).
+// out[i] = sum_s slabs[s][i], fixed order.  A workgroup owns 32 float4 columns (512 contiguous bytes of
+// every slab) and spreads the slabs over 8 thread groups (slab s goes to group s % 8, each group keeping
+// two independent accumulators), then combines the groups through LDS in a fixed tree — so a [576x64]
+// gradient with 153 slabs still has ~300 workgroups x 8 x 2 sixteen-byte loads in flight instead of one
+// column walk per thread.  bytes = splits * n * 4 read once (L2 / Infinity-Cache resident: the slabs were
+// just written).  Bitwise reproducible.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long n,
                                                           float* __restrict__ out) {
-  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
-  const long n4 = n >> 2;
   if (n & 3) {                       // slabs not 16-byte aligned to each other: scalar path
-    for (long i = i4; i < n; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
       float s = 0.f;
       for (int k = 0; k < splits; ++k) s += slabs[(long)k * n + i];
       out[i] = s;
     }
     return;
   }
+  __shared__ float4 part[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long n4 = n >> 2, i4 = (long)blockIdx.x * 32 + col;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
   if (i4 < n4) {
     const float4* src = reinterpret_cast<const float4*>(slabs) + i4;
-    float4 a[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 4 <= splits; k += 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = src[(long)(k + j) * n4];
-        a[j].x += v.x; a[j].y += v.y; a[j].z += v.z; a[j].w += v.w;
-      }
+    int k = grp;
+    for (; k + 8 < splits; k += 16) {
+      const float4 u = src[(long)k * n4], v = src[(long)(k + 8) * n4];
+      a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
     }
-    for (; k < splits; ++k) {
-      const float4 v = src[(long)k * n4];
-      a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
-    }
-    reinterpret_cast<float4*>(out)[i4] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
-                                                     (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+    if (k < splits) { const float4 u = src[(long)k * n4]; a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w; }
+  }
+  part[grp][col] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (grp == 0 && i4 < n4) {
+    float4 r[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r[g] = part[g][col];
+#define EMBNET_ADD4(p, q) make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w)
+    const float4 s01 = EMBNET_ADD4(r[0], r[1]), s23 = EMBNET_ADD4(r[2], r[3]), s45 = EMBNET_ADD4(r[4], r[5]),
+                 s67 = EMBNET_ADD4(r[6], r[7]);
+    const float4 lo = EMBNET_ADD4(s01, s23), hi = EMBNET_ADD4(s45, s67);
+    reinterpret_cast<float4*>(out)[i4] = EMBNET_ADD4(lo, hi);
+#undef EMBNET_ADD4
   }
 }
 
@@ -659,7 +667,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   }
   if (p.splits > 1 && do_reduce) {
     const long cnt = (long)rows * k;
-    slab_reduce_kernel<<<cdiv(cdiv(cnt, 4) > 0 ? cdiv(cnt, 4) : 1, 256), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
+    slab_reduce_kernel<<<(cnt & 3) ? cdiv(cnt, 256) : cdiv(cnt / 4, 32), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
   }
   return check_launch("conv2d_wgrad");
 }

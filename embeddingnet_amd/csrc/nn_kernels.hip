@@ -373,14 +373,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
     for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
       const uint32_t tap = (uint32_t)((ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad)));
       const long o = (((long)b * oh + y_o) * ow + x_o) * c4 + col;
+      // both loads unconditional: independent of each other and of the compare, so the (at most four)
+      // windows of a pixel are all in flight together; dy lines are shared by neighbouring pixels (L1/L2)
       const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[o];
-      if (((am & 0xff) == tap) | (((am >> 8) & 0xff) == tap) | (((am >> 16) & 0xff) == tap) | ((am >> 24) == tap)) {
-        const float4 d = reinterpret_cast<const float4*>(dy)[o];
-        if ((am & 0xff) == tap) g[0] += d.x;
-        if (((am >> 8) & 0xff) == tap) g[1] += d.y;
-        if (((am >> 16) & 0xff) == tap) g[2] += d.z;
-        if ((am >> 24) == tap) g[3] += d.w;
-      }
+      const float4 d = reinterpret_cast<const float4*>(dy)[o];
+      g[0] += (am & 0xff) == tap ? d.x : 0.f;
+      g[1] += ((am >> 8) & 0xff) == tap ? d.y : 0.f;
+      g[2] += ((am >> 16) & 0xff) == tap ? d.z : 0.f;
+      g[3] += (am >> 24) == tap ? d.w : 0.f;
     }
   reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
 }

@@ -52,6 +52,11 @@ class KernelTimer:
 TIMER = None       # set to a KernelTimer to time conv kernels
 
 import os as _os
+# Knob (off): run each conv's wgrad on a side stream beside its dgrad.  Measured on ResNet18/MI355X: +-0 % when
+# joined right after the dgrad (both are MFMA-bound), +1.8 % when the join is deferred to the end of backward so
+# wgrad overlaps the HBM-bound BN-backward kernels — not worth per-kernel timings that no longer mean anything
+# (co-running doubles the wgrad kernel's own duration) and hand-made gradient hand-over (autograd clones dW on
+# the main stream as soon as backward() returns it).
 OVERLAP_WGRAD = _os.environ.get("EMBNET_OVERLAP_WGRAD", "0") == "1"
 _SIDE = {}
 
@@ -149,8 +154,6 @@ class _Conv2dFn(torch.autograd.Function):
             dw = torch.empty_like(w)
         overlap = OVERLAP_WGRAD and need_dx and need_dw
         if overlap:
-            # dgrad and wgrad only share their inputs: run wgrad on a side stream so each kernel's tail
-            # (the last partly-filled round of workgroups) is filled by the other's workgroups.
             main = torch.cuda.current_stream()
             side = _side_stream(x.device)
             side.wait_stream(main)
