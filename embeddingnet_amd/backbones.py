@@ -162,7 +162,7 @@ class ResNet(nn.Module):
         self.out_channels = cin
 
     def forward(self, x):
-        x = self.pooling0(self.bn0(L.input_bn_conv(x, self.bn_data, self.conv0)))
+        x = L.bn_act_maxpool(L.input_bn_conv(x, self.bn_data, self.conv0), self.bn0, self.pooling0)
         for nm in self._units:
             x = getattr(self, nm)(x)
         return self.bn1(x)

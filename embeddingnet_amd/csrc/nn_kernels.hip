@@ -385,6 +385,126 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
   reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// ---------------------------------------------------------------- BN-apply + activation + max-pool, fused
+// The zoo ResNet stem is bn0 -> relu -> ZeroPadding2D(1) -> MaxPool(3,2) on the largest activation of the
+// net (112x112x64 per image).  Unfused that is: BN apply (read x, write a), pool (read a, write y), and
+// backward pool (write da), BN reduce (read da, x), BN apply (read da, x, write dx) — five passes over the
+// big tensor.  Fused: the pool reads x and applies the affine + activation per tap (the padded zeros stay
+// zeros: padding follows the activation in the reference), and backward works from the pooled gradient:
+// the BN reductions run over the POOLED elements (each routes to the one input pixel its arg-max names,
+// whose x is gathered), and the apply pass rebuilds da per input pixel from the <= 4 windows that cover
+// it.  a and da never exist.  Bytes: fwd 4*in + 5*out; bwd reduce ~4*in + 9*out; bwd apply 8*in + 5*out.
+__global__ __launch_bounds__(256) void affine_act_maxpool_fwd4_kernel(
+    const float* __restrict__ x, int n, int h, int w, int c4, const float* __restrict__ scale,
+    const float* __restrict__ shift, int act, int k, int stride, int pad, int oh, int ow, float* __restrict__ y,
+    uint8_t* __restrict__ argmax) {
+  const long total = (long)n * oh * ow * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % c4);
+  long t = i / c4;
+  const int x_o = (int)(t % ow); t /= ow;
+  const int y_o = (int)(t % oh);
+  const int b = (int)(t / oh);
+  const float4 sc = reinterpret_cast<const float4*>(scale)[col], sh = reinterpret_cast<const float4*>(shift)[col];
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {255, 255, 255, 255};
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
+      const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+      float vv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (in) {
+        const float4 v = reinterpret_cast<const float4*>(x)[(((long)b * h + ih) * w + iw) * c4 + col];
+        vv[0] = act_apply(act, fmaf(v.x, sc.x, sh.x)); vv[1] = act_apply(act, fmaf(v.y, sc.y, sh.y));
+        vv[2] = act_apply(act, fmaf(v.z, sc.z, sh.z)); vv[3] = act_apply(act, fmaf(v.w, sc.w, sh.w));
+      }
+      const int tap = in ? dy * k + dx : 255;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; }
+    }
+  reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+  reinterpret_cast<uint32_t*>(argmax)[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) |
+                                           ((uint32_t)bi[3] << 24);
+}
+
+// dbeta / dgamma partial sums over the pooled elements (rows = n*oh*ow pooled pixels)
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce4_kernel(
+    const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ x, long mp, int h, int w,
+    int c4, int k, int stride, int pad, int oh, int ow, ColGeom g, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    float* __restrict__ partial) {
+  col_reduce2_v4(mp, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
+    const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[r * c4 + q];
+    const float4 d = reinterpret_cast<const float4*>(dy)[r * c4 + q];
+    const int x_o = (int)(r % ow); const long t = r / ow;
+    const int y_o = (int)(t % oh), bb = (int)(t / oh);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+    const float dd[4] = {d.x, d.y, d.z, d.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+    float av[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t tap = (am >> (8 * j)) & 0xff;
+      const bool on = tap != 255u;                       // window maximum was a padding zero: no gradient
+      const uint32_t tp = on ? tap : 0u;
+      const int ih = min(max(y_o * stride - pad + (int)(tp / (uint32_t)k), 0), h - 1);
+      const int iw = min(max(x_o * stride - pad + (int)(tp % (uint32_t)k), 0), w - 1);
+      const float xv = x[((((long)bb * h + ih) * w + iw) * c4 + q) * 4 + j];
+      const float dz = on ? act_grad(act, fmaf(xv, scv[j], shv[j]), dd[j]) : 0.f;
+      av[j] = dz; bv[j] = dz * ((xv - muv[j]) * rsv[j]);
+    }
+    a.x += av[0]; a.y += av[1]; a.z += av[2]; a.w += av[3];
+    b.x += bv[0]; b.y += bv[1]; b.z += bv[2]; b.w += bv[3];
+  });
+}
+
+// dx over the input pixels: da rebuilt from the covering windows, then the BN-backward formula
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply4_kernel(
+    const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ x, int n, int h, int w,
+    int c4, int k, int stride, int pad, int oh, int ow, float inv_m, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ dbeta, const float* __restrict__ dgamma, int act, int training, float* __restrict__ dx) {
+  const long total = (long)n * h * w * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % c4);
+  long t = i / c4;
+  const int iw = (int)(t % w); t /= w;
+  const int ih = (int)(t % h);
+  const int b = (int)(t / h);
+  const float4 xv = reinterpret_cast<const float4*>(x)[i];
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const int y_hi = min((ih + pad) / stride, oh - 1), x_hi = min((iw + pad) / stride, ow - 1);
+  for (int y_o = y_hi; y_o >= 0 && y_o * stride - pad + k > ih; --y_o)
+    for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
+      const uint32_t tap = (uint32_t)((ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad)));
+      const long o = (((long)b * oh + y_o) * ow + x_o) * c4 + q;
+      const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[o];
+      const float4 d = reinterpret_cast<const float4*>(dy)[o];
+      g[0] += (am & 0xff) == tap ? d.x : 0.f;
+      g[1] += ((am >> 8) & 0xff) == tap ? d.y : 0.f;
+      g[2] += ((am >> 16) & 0xff) == tap ? d.z : 0.f;
+      g[3] += (am >> 24) == tap ? d.w : 0.f;
+    }
+  const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+  float4 dz = make_float4(act_grad(act, fmaf(xv.x, sc.x, sh.x), g[0]), act_grad(act, fmaf(xv.y, sc.y, sh.y), g[1]),
+                          act_grad(act, fmaf(xv.z, sc.z, sh.z), g[2]), act_grad(act, fmaf(xv.w, sc.w, sh.w), g[3]));
+  float4 o;
+  if (training) {
+    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+    const float4 db = reinterpret_cast<const float4*>(dbeta)[q], dg = reinterpret_cast<const float4*>(dgamma)[q];
+    o.x = sc.x * (dz.x - db.x * inv_m - (xv.x - mu.x) * rs.x * dg.x * inv_m);
+    o.y = sc.y * (dz.y - db.y * inv_m - (xv.y - mu.y) * rs.y * dg.y * inv_m);
+    o.z = sc.z * (dz.z - db.z * inv_m - (xv.z - mu.z) * rs.z * dg.z * inv_m);
+    o.w = sc.w * (dz.w - db.w * inv_m - (xv.w - mu.w) * rs.w * dg.w * inv_m);
+  } else {
+    o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+  }
+  reinterpret_cast<float4*>(dx)[i] = o;
+}
+
 // y[n,c] = mean over hw.  Workgroup = one sample x 64 channels (16 channel-quad lanes x 16 pixel lanes).
 __global__ __launch_bounds__(256) void gap_fwd4_kernel(const float* __restrict__ x, int hw, int c4, float* __restrict__ y) {
   __shared__ float4 sh[256];
@@ -535,7 +655,7 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
                                    float momentum, int relu, float* y, float* save_mean, float* save_rstd,
                                    float* scale, float* shift, float* moving_mean, float* moving_var,
                                    void* workspace, size_t workspace_bytes, void* stream) {
-  EMBNET_CHECK_ARG(x && y && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
+  EMBNET_CHECK_ARG(x && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_train_fwd: m=%ld c=%d", m, c);
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "bn_train_fwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
@@ -551,17 +671,18 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   }
   bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
                                                           save_rstd, scale, shift, moving_mean, moving_var);
-  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+  if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
+    affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_train_fwd");
 }
 
 extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
                                    const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
                                    float* scale, float* shift, void* stream) {
-  EMBNET_CHECK_ARG(x && y && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
+  EMBNET_CHECK_ARG(x && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_infer_fwd: m=%ld c=%d", m, c);
   bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
-  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+  if (y) affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_infer_fwd");
 }
 
@@ -626,6 +747,53 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
   else
     maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx);
   return check_launch("maxpool_bwd");
+}
+
+extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,
+                                         int act, int k, int stride, int pad, int oh, int ow, float* y, uint8_t* argmax,
+                                         void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && y && argmax, "bn_act_maxpool_fwd: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k * k < 255 && stride > 0 && pad >= 0 && oh > 0 && ow > 0,
+                   "bn_act_maxpool_fwd: bad geometry");
+  EMBNET_CHECK_ARG((c & 3) == 0, "bn_act_maxpool_fwd: channel count %d not a multiple of 4 (use bn + maxpool)", c);
+  EMBNET_CHECK_ARG((oh - 1) * stride + k <= h + 2 * pad && (ow - 1) * stride + k <= w + 2 * pad,
+                   "bn_act_maxpool_fwd: window leaves the padded image");
+  const long total = (long)n * oh * ow * (c / 4);
+  affine_act_maxpool_fwd4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, scale, shift, act, k, stride,
+                                                                          pad, oh, ow, y, argmax);
+  return check_launch("bn_act_maxpool_fwd");
+}
+
+extern "C" size_t embnet_bn_act_maxpool_bwd_workspace_bytes(int n, int oh, int ow, int c) {
+  return embnet_bn_workspace_bytes((long)n * oh * ow, c);
+}
+
+extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
+                                         int k, int stride, int pad, int oh, int ow, const float* save_mean,
+                                         const float* save_rstd, const float* scale, const float* shift, int act,
+                                         int training, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(dy && argmax && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_act_maxpool_bwd: null pointer");
+  EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_act_maxpool_bwd: training needs saved statistics");
+  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "bn_act_maxpool_bwd: bad geometry");
+  EMBNET_CHECK_ARG((c & 3) == 0, "bn_act_maxpool_bwd: channel count %d not a multiple of 4", c);
+  const long mp = (long)n * oh * ow;
+  if (workspace_bytes < embnet_bn_workspace_bytes(mp, c))
+    return fail(EMBNET_EWORKSPACE, "bn_act_maxpool_bwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(mp, c));
+  if (save_mean && save_rstd) {
+    const ColGeom g4 = col_geom(mp, c / 4);
+    pool_bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, x, mp, h, w, c / 4, k, stride, pad, oh, ow, g4,
+                                                                 save_mean, save_rstd, scale, shift, act, (float*)workspace);
+    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma);
+  } else {
+    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
+    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+  }
+  const long total = (long)n * h * w * (c / 4);
+  pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
+                                                                    1.f / (float)((long)n * h * w), save_mean, save_rstd,
+                                                                    scale, shift, dbeta, dgamma, act, training, dx);
+  return check_launch("bn_act_maxpool_bwd");
 }
 
 extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream) {

@@ -463,6 +463,65 @@ class MaxPool2D(nn.Module):
         return _MaxPoolFn.apply(x, self.k, self.s, self.p)
 
 
+class _BNActMaxPoolFn(torch.autograd.Function):
+    """pool(act(bn(x))) without materialising the activation or its gradient (include/embnet.h:
+    embnet_bn_act_maxpool_fwd/bwd) — the zoo ResNet stem bn0 -> relu -> ZeroPadding2D(1) -> MaxPool(3,2)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, k, stride, pad):
+        x = _c(x)
+        lib = _lib.lib()
+        n, h, w, c = x.shape
+        m = n * h * w
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        if oh <= 0 or ow <= 0:
+            raise _lib.EmbnetError(f"MaxPool {k}x{k}/{stride} does not fit a {h}x{w} input")
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        if training:
+            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), None,
+                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
+                                          ws.numel() * 4, stream()))
+        else:
+            check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
+                                          int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        check(lib.embnet_bn_act_maxpool_fwd(ptr(x), n, h, w, c, stats[2].data_ptr(), stats[3].data_ptr(), int(act), k,
+                                            stride, pad, oh, ow, ptr(y), ptr(arg), stream()))
+        ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow, int(act), training, gamma is not None)
+        ctx.save_for_backward(x, stats, arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, arg = ctx.saved_tensors
+        n, h, w, c, k, stride, pad, oh, ow, act, training, has_gamma = ctx.cfg
+        lib = _lib.lib()
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_bn_act_maxpool_bwd_workspace_bytes(n, oh, ow, c), x.device)
+        mean = stats[0].data_ptr() if training else None
+        rstd = stats[1].data_ptr() if training else None
+        check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
+                                            stats[2].data_ptr(), stats[3].data_ptr(), act, int(training), ptr(dx),
+                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
+        dgamma = dgb[0] if (has_gamma and ctx.needs_input_grad[1]) else None
+        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+        return (dx, dgamma, dbeta) + (None,) * 9
+
+
+def bn_act_maxpool(x, bn, pool):
+    """pool(bn(x)) for a BatchNormalization (with its fused activation) followed by a MaxPool2D; one fused
+    pass when the channel count allows 16-byte lanes, the two layers otherwise."""
+    if x.shape[-1] % 4:
+        return pool(bn(x))
+    return _BNActMaxPoolFn.apply(x, bn.gamma, bn.beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum,
+                                 bn.relu, bn.training, pool.k, pool.s, pool.p)
+
+
 class _GapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

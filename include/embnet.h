@@ -189,6 +189,19 @@ int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int st
 int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
                        int pad, int oh, int ow, float* dx, void* stream);
 
+/* BatchNorm-apply + activation + ZeroPadding2D(pad) + MaxPool(k,stride) in one pass (the zoo ResNet stem
+ * bn0 -> relu -> pad -> pool, reference backbones.py:99-104 via image-classifiers).  scale/shift come from
+ * embnet_bn_train_fwd / embnet_bn_infer_fwd called with y = NULL.  Backward takes the POOLED gradient and
+ * returns dx (w.r.t. the BN input), dgamma, dbeta; the activation tensor and its gradient never exist.
+ * c % 4 == 0.  Same results as bn -> maxpool (sums in a different fp32 order). */
+int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift, int act,
+                              int k, int stride, int pad, int oh, int ow, float* y, uint8_t* argmax, void* stream);
+size_t embnet_bn_act_maxpool_bwd_workspace_bytes(int n, int oh, int ow, int c);
+int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c, int k,
+                              int stride, int pad, int oh, int ow, const float* save_mean, const float* save_rstd,
+                              const float* scale, const float* shift, int act, int training, float* dx, float* dgamma,
+                              float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);
 int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream);

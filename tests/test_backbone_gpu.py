@@ -47,6 +47,8 @@ CONV_CASES = [
     (2, 9, 9, 6, 10, 2, 1, "valid", True, True),      # non-vector channel counts
     (4, 7, 7, 512, 512, 3, 1, 1, False, False),       # deep K (4608)
     (2, 8, 8, 256, 64, 1, 1, "valid", False, False),  # bottleneck 1x1
+    (8, 40, 40, 256, 128, 3, 1, 1, True, True),       # 400 tiles: the 144 left-over tiles are split along K (fwd + dgrad)
+    (5, 61, 59, 128, 64, 3, 1, 1, False, False),      # 282 tiles of 64x64 with a ragged last row tile, tail split
 ]
 
 
@@ -80,6 +82,16 @@ def test_conv2d_fwd_bwd(dev, case):
     close(layer.kernel.grad, ctx.params["c/kernel"].grad, 2e-5, "wgrad")
     if bias:
         close(layer.bias.grad, ctx.params["c/bias"].grad, 2e-5, "bias grad")
+
+
+def test_conv_tail_split_is_planned_for_the_test_shapes():
+    """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
+    from embeddingnet_amd import _lib
+    lib = _lib.lib()
+    assert lib.embnet_conv2d_fwd_workspace_bytes(8, 256, 3, 3, 128, 40, 40) > 0
+    assert lib.embnet_conv2d_dgrad_workspace_bytes(8, 40, 40, 256, 3, 3, 128, 1) > 0
+    assert lib.embnet_conv2d_fwd_workspace_bytes(5, 128, 3, 3, 64, 61, 59) > 0
+    assert lib.embnet_conv2d_fwd_workspace_bytes(2, 64, 3, 3, 64, 16, 16) == 0
 
 
 def test_conv2d_wgrad_splitk_large(dev):
@@ -153,6 +165,63 @@ def test_maxpool(dev, k, s, pad, h, w):
     y.backward(g(dy, dev))
     yr.backward(torch.tensor(dy, dtype=torch.float64))
     close(xt.grad, xr.grad, 1e-6, "maxpool dx")
+
+
+@pytest.mark.parametrize("c,act,k,s,pad,h,w", [(64, "relu", 3, 2, 1, 16, 16), (8, "relu", 3, 2, 1, 15, 17),
+                                               (16, None, 2, 2, 0, 12, 10), (12, "swish", 3, 2, 1, 9, 9)])
+def test_bn_act_maxpool_fused(dev, c, act, k, s, pad, h, w):
+    """The fused stem (bn -> act -> ZeroPadding2D -> MaxPool in one pass, backward from the pooled gradient)
+    against the oracle's three separate layers, training and inference statistics."""
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(c + h)
+    x = (rs.randn(3, h, w, c) * 1.5 + 0.2).astype(np.float32)
+    bn = L.BatchNormalization(c, epsilon=2e-5, activation=act).to(dev).train()
+    pool = L.MaxPool2D(k, s, zero_pad=pad)
+    gam, bet = rs.rand(c).astype(np.float32) + 0.5, rs.randn(c).astype(np.float32) * 0.3
+    gam[::3] *= -1                                       # negative scales: max does not commute with the affine
+    with torch.no_grad():
+        bn.gamma.copy_(g(gam, dev)); bn.beta.copy_(g(bet, dev))
+    P = {"b/beta": torch.tensor(bet, dtype=torch.float64, requires_grad=True),
+         "b/gamma": torch.tensor(gam, dtype=torch.float64, requires_grad=True),
+         "b/moving_mean": torch.zeros(c, dtype=torch.float64), "b/moving_variance": torch.ones(c, dtype=torch.float64)}
+
+    def ref(ctx, xr):
+        z = OB.batchnorm(ctx, "b", xr, eps=2e-5)
+        z = torch.relu(z) if act == "relu" else (z * torch.sigmoid(z) if act == "swish" else z)
+        return OB.maxpool(z, k, s, zero_pad=pad)
+
+    xt = g(x, dev).requires_grad_(True)
+    y = L.bn_act_maxpool(xt, bn, pool)
+    ctx = OB.Ctx(P, training=True)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = ref(ctx, xr)
+    close(y, yr, 1e-5, "fused stem fwd")
+    close(bn.moving_mean, ctx.new_stats["b/moving_mean"], 1e-5, "moving mean")
+    dy = rs.randn(*yr.shape).astype(np.float32)
+    y.backward(g(dy, dev))
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    close(xt.grad, xr.grad, 2e-5, "fused stem dx")
+    close(bn.beta.grad, P["b/beta"].grad, 2e-5, "fused stem dbeta")
+    close(bn.gamma.grad, P["b/gamma"].grad, 2e-5, "fused stem dgamma")
+    # identical to our own unfused layers up to summation order
+    bn2 = L.BatchNormalization(c, epsilon=2e-5, activation=act).to(dev).train()
+    with torch.no_grad():
+        bn2.gamma.copy_(g(gam, dev)); bn2.beta.copy_(g(bet, dev))
+    x2 = g(x, dev).requires_grad_(True)
+    y2 = pool(bn2(x2))
+    assert torch.equal(y2, y)
+    y2.backward(g(dy, dev))
+    close(xt.grad, x2.grad.double().cpu(), 2e-6, "fused vs unfused dx")
+    # inference statistics, with a gradient through the frozen affine
+    bn.eval()
+    xe = g(x, dev).requires_grad_(True)
+    ye = L.bn_act_maxpool(xe, bn, pool)
+    ctx2 = OB.Ctx({kk: (ctx.new_stats[kk] if kk in ctx.new_stats else v.detach()) for kk, v in P.items()}, training=False)
+    xre = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yre = ref(ctx2, xre)
+    close(ye, yre, 1e-5, "fused stem infer")
+    ye.backward(g(dy, dev)); yre.backward(torch.tensor(dy, dtype=torch.float64))
+    close(xe.grad, xre.grad, 2e-5, "fused stem infer dx")
 
 
 def test_dense_gap_add_l2(dev):
