@@ -134,10 +134,10 @@ class ResidualUnit(nn.Module):
     def forward(self, x):
         a = self.bn1(x)
         sc = self.sc(a) if self.post else x
-        y = self.conv2(self.bn2(self.conv1(a)))
-        if self.kind != "basic":
-            y = self.conv3(self.bn3(y))
-        return L.add(y, sc)
+        y = self.bn2(self.conv1(a))
+        if self.kind == "basic":
+            return self.conv2(y, residual=sc)           # the unit's Add runs in the last conv's epilogue
+        return self.conv3(self.bn3(self.conv2(y)), residual=sc)
 
 
 class ResNet(nn.Module):

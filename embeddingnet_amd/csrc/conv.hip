@@ -233,7 +233,7 @@ constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA
 // fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
 struct SplitTail { int n_full, parts, kt_part; float* ws; };
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; };
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; };
 
 // Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
 template <class G>
@@ -258,7 +258,7 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN],
 __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int parts, int bm, int bn,
                                                          int n_full, int tiles_n, long m, int cols,
                                                          const float* __restrict__ bias, int relu,
-                                                         float* __restrict__ out) {
+                                                         const float* __restrict__ residual, float* __restrict__ out) {
   const int per_tile = bm * bn / 4;                       // float4s per tile
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int t = (int)(i / per_tile), e = (int)(i % per_tile) * 4;
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
   }
   if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
   if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  if (residual) { const float4 q = *reinterpret_cast<const float4*>(residual + row * cols + col); a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
   *reinterpret_cast<float4*>(out + row * cols + col) = a;
 }
 
@@ -299,6 +300,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
       if (row < M && col < p.g.K) {
         if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.residual) {                                  // the Add layer behind the conv (residual units)
+          const float4 q = *reinterpret_cast<const float4*>(p.residual + (long)row * p.g.K + col);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
         *reinterpret_cast<float4*>(p.y + (long)row * p.g.K + col) = v;
       }
     });
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
     if (row < M && col < p.g.K) {
       if (p.bias) v += p.bias[col];
       if (p.relu) v = fmaxf(v, 0.f);
+      if (p.residual) v += p.residual[(long)row * p.g.K + col];
       p.y[(long)row * p.g.K + col] = v;
     }
   });
@@ -533,10 +539,12 @@ extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, 
 
 extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
-                                     int ow, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int ow, int relu, const float* residual, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
-  EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace), "conv2d_fwd: output and workspace must be 16-byte aligned");
-  ConvFwdParams p{x, w, bias, y, {}, relu, {}};
+  EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace) && aligned16(residual),
+                   "conv2d_fwd: output, residual and workspace must be 16-byte aligned");
+  ConvFwdParams p{x, w, bias, y, {}, relu, {}, residual};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_fwd")) return rc;
   const long M = (long)n * oh * ow;
   hipStream_t st = (hipStream_t)stream;
@@ -551,7 +559,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
     tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
-                                                                         cdiv(k, bn), M, k, bias, relu, y);
+                                                                         cdiv(k, bn), M, k, bias, relu, residual, y);
   }
   return check_launch("conv2d_fwd");
 }
@@ -606,7 +614,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
     tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
-                                                                         cdiv(c, bn), max_m, c, nullptr, 0, dx);
+                                                                         cdiv(c, bn), max_m, c, nullptr, 0, nullptr, dx);
   }
   return check_launch("conv2d_dgrad");
 }

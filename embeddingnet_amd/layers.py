@@ -107,20 +107,26 @@ def same_pad(n, k, s):
 # ----------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, relu):
+    def forward(ctx, x, w, bias, geom, relu, residual=None):
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
         if c2 != c:
             raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
         stride, pt, pl, oh, ow = geom
+        if residual is not None:
+            if relu:
+                raise _lib.EmbnetError("conv2d: a fused residual add goes with a linear conv (no fused ReLU)")
+            residual = _c(residual)
+            if tuple(residual.shape) != (n, oh, ow, k):
+                raise _lib.EmbnetError(f"Add: shapes differ {(n, oh, ow, k)} vs {tuple(residual.shape)}")
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         lib = _lib.lib()
         ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
-            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu),
+            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
             ptr(ws), ws.numel() * 4, stream())))
-        ctx.geom, ctx.relu, ctx.has_bias = geom, relu, bias is not None
+        ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -172,7 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
             run_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None)
 
 
 def _colsum(x2d):
@@ -226,8 +232,9 @@ class Conv2D(nn.Module):
             raise _lib.EmbnetError(f"Conv2D {k}x{k}/{s} '{self.padding}' does not fit a {h}x{w} input")
         return (s, pt, pl, oh, ow)
 
-    def forward(self, x):
-        return _Conv2dFn.apply(x, self.kernel, self.bias, self.geometry(x.shape[1], x.shape[2]), self.relu)
+    def forward(self, x, residual=None):
+        """residual: the other input of the Add layer that follows this conv (added in the conv epilogue)."""
+        return _Conv2dFn.apply(x, self.kernel, self.bias, self.geometry(x.shape[1], x.shape[2]), self.relu, residual)
 
 
 # ----------------------------------------------------------------------------- dense
@@ -382,8 +389,8 @@ class _InputBNConvFn(torch.autograd.Function):
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
-            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, ptr(cws), cws.numel() * 4,
-            stream())))
+            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, ptr(cws),
+            cws.numel() * 4, stream())))
         ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y

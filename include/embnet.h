@@ -128,14 +128,15 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
 /* Conv2D (backbones.py:21-31, :44-68, zoo ResNet/EfficientNet convs): implicit GEMM on fp32 MFMA.
  * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
  * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its
- * bottom/right asymmetry, or an explicit ZeroPadding2D).  bias may be NULL; relu!=0 fuses the activation.
+ * bottom/right asymmetry, or an explicit ZeroPadding2D).  bias may be NULL; relu!=0 fuses the activation;
+ * residual (NULL or [n,oh,ow,k]) is added last — the Add layer that closes a residual unit.
  * workspace (optional, may be NULL/0): >= embnet_conv2d_fwd_workspace_bytes lets the launcher cut the
  * `tiles mod 256` left-over output tiles along K so the last round of workgroups fills every CU
  * (partial tiles + fixed-order fix-up; results differ from the unsplit launch only in fp32 summation order). */
 size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
                           int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          const float* residual, void* workspace, size_t workspace_bytes, void* stream);
 /* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only). */
 size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride);
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,

@@ -84,6 +84,26 @@ def test_conv2d_fwd_bwd(dev, case):
         close(layer.bias.grad, ctx.params["c/bias"].grad, 2e-5, "bias grad")
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (8, 40, 40, 256, 128), (2, 9, 9, 6, 10)])
+def test_conv2d_residual_epilogue(dev, shape):
+    """Conv2D(x, residual=r) == Conv2D(x) + r bit for bit (whole tiles, K-split left-over tiles and the scalar
+    path), and the Add's gradient reaches r unchanged."""
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout = shape
+    gen = torch.Generator().manual_seed(5)
+    conv = L.Conv2D(cin, cout, 3, padding=1, use_bias=False, gen=gen).to(dev)
+    x = torch.randn((n, h, w, cin), device=dev)
+    r = torch.randn((n, h, w, cout), device=dev, requires_grad=True)
+    y0 = conv(x)
+    y1 = conv(x, residual=r)
+    assert torch.equal(y1, y0 + r)
+    dy = torch.randn_like(y1)
+    y1.backward(dy)
+    assert torch.equal(r.grad, dy)
+    with pytest.raises(Exception):
+        conv(x, residual=r[:, 1:])
+
+
 def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib
