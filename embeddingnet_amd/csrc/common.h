@@ -53,6 +53,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Activation fused behind the BN affine: 0 none, 1 ReLU, 2 swish (z * sigmoid(z)).  Backward recomputes
+// z = x*scale + shift from the saved input, so no activation tensor or mask is stored.
+__device__ __forceinline__ float act_apply(int act, float z) {
+  return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? z / (1.f + __expf(-z)) : z);
+}
+__device__ __forceinline__ float act_grad(int act, float z, float dy) {
+  if (act == 1) return z <= 0.f ? 0.f : dy;
+  if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); return dy * (sg + z * sg * (1.f - sg)); }
+  return dy;
+}
+
 // Counter-based RNG: one 64-bit mix (splitmix64 finaliser) of (seed, a, b).
 // Used for the two random negative-selection rules and for dropout masks.
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

@@ -39,6 +39,22 @@ struct ConvGeom {
 
 constexpr int ROW_INVALID = -(1 << 28);
 
+// Optional per-channel transform of the conv INPUT, applied in registers between the gather and LDS:
+// a = act(x*scale[c] + shift[c]) — the BatchNormalization(+activation) in front of the conv — so the
+// normalised tensor is never written.  Padding taps / out-of-range rows stay exactly 0 (the reference
+// pads AFTER the activation).  16-byte-lane loaders only (channel count % 4 == 0).
+struct InputTransform { const float* scale; const float* shift; int act; };
+__device__ __forceinline__ float4 transform4(float4 v, bool ok, const float4& sc, const float4& sh, int act) {
+  float4 z = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  if (act == 1) {                                        // wave-uniform: the common case costs fma + max + select
+    z = make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f));
+  } else if (act == 2) {
+    z = make_float4(act_apply(2, z.x), act_apply(2, z.y), act_apply(2, z.z), act_apply(2, z.w));
+  }
+  return ok ? z : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+
 // gemm-k index kk -> (r, s, inner) with `dinner` the divider of the inner size (C for fwd, K for dgrad)
 __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const FastDiv& dS, int& r, int& s, int& c) {
   uint32_t rs, cc; dinner.divmod((uint32_t)kk, rs, cc);
@@ -47,14 +63,15 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
 }
 
 // ---- forward A: rows = output pixels, k = (r,s,c) -------------------------------------------
-template <int ROWS, bool VEC>
+template <int ROWS, bool VEC, bool TF = false>
 struct LoadConvFwdA {
   using Tile = TileKC<ROWS>;
   Buf buf; int H, W, C, Kg; FastDiv dC, dS; int tid;
   unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
-  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_) {
+  InputTransform tf; mutable unsigned okbits; mutable float4 tsc, tsh;
+  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_, const InputTransform& tf_) {
     buf.init(x, (size_t)g.N * g.H * g.W * g.C * 4);
-    H = g.H; W = g.W; C = g.C; Kg = g.R * g.S * g.C; dC = g.dC; dS = g.dS; tid = tid_;
+    H = g.H; W = g.W; C = g.C; Kg = g.R * g.S * g.C; dC = g.dC; dS = g.dS; tid = tid_; tf = tf_; okbits = 0;
     const int M = g.N * g.OH * g.OW;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
@@ -72,16 +89,27 @@ struct LoadConvFwdA {
     const bool ok = kk < Kg && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     return ok ? base[p] + 4u * (unsigned)((ih * W + iw) * C + c) : OOB;
   }
+  __device__ __forceinline__ void fix(float4 (&rg)[Tile::PASSES]) const {
+    if (!VEC || !TF) return;
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) rg[p] = transform4(rg[p], (okbits >> p) & 1u, tsc, tsh, tf.act);
+  }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
     if (VEC) {
       int r, s, c; split_k(kk, dC, dS, r, s, c);
       const bool kin = kk < Kg;
+      unsigned bits = 0;
 #pragma unroll
       for (int p = 0; p < Tile::PASSES; ++p) {
         const int ih = ih0[p] + r, iw = iw0[p] + s;
         const bool ok = kin && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        bits |= (unsigned)ok << p;
         rg[p] = buf.ld4(ok ? base[p] + 4u * (unsigned)((ih * W + iw) * C + c) : OOB);
+      }
+      if (TF) {                                           // c in [0,C) also past the K end (kk mod C)
+        okbits = bits;
+        tsc = *reinterpret_cast<const float4*>(tf.scale + c); tsh = *reinterpret_cast<const float4*>(tf.shift + c);
       }
     } else {
 #pragma unroll
@@ -125,6 +153,7 @@ struct LoadConvDgradA {
       iw0[p] = (int)wc + cg.wb;
     }
   }
+  __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
   __device__ __forceinline__ unsigned off(int p, int kk) const {
     uint32_t t, c, tr, ts; dK.divmod((uint32_t)kk, t, c); dnS.divmod(t, tr, ts);
     const int oh = ih0[p] - (int)tr, ow = iw0[p] - (int)ts;
@@ -161,6 +190,7 @@ struct LoadConvDgradB {
     C = g.C; K = g.K; S = g.S; Kg = cg.nR * cg.nS * g.K; st = g.stride; r0 = cg.r0; s0 = cg.s0;
     dK = g.dK; dnS = cg.dnS; row0 = n0; tid = tid_;
   }
+  __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
   __device__ __forceinline__ unsigned off(int c, int kk) const {
     uint32_t t, ko, tr, ts; dK.divmod((uint32_t)kk, t, ko); dnS.divmod(t, tr, ts);
     const unsigned rs = (unsigned)((r0 + st * (int)tr) * S + s0 + st * (int)ts);
@@ -180,12 +210,20 @@ struct LoadConvDgradB {
 
 
 // ---- wgrad A: k = output pixel (n,oh,ow), rows = (r,s,c) ------------------------------------------
-template <int ROWS, bool VEC>
+template <int ROWS, bool VEC, bool TF = false>
 struct LoadConvWgradA {
   using Tile = TileKM<ROWS>;
   Buf buf; int H, W, C, Mrows, Kg, stride, pad_t, pad_l; FastDiv dOHW, dOW, dC, dS; unsigned HWC4; int tid;
   int r_[Tile::PASSES], s_[Tile::PASSES], c_[Tile::PASSES], m_[Tile::PASSES];    // first row of each pass
-  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_) {
+  InputTransform tf; mutable unsigned okbits;
+  float4 tsc[Tile::PASSES], tsh[Tile::PASSES];            // rows (hence channels) of a pass never change
+  __device__ __forceinline__ void fix(float4 (&rg)[Tile::PASSES]) const {
+    if (!VEC || !TF) return;
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) rg[p] = transform4(rg[p], (okbits >> p) & 1u, tsc[p], tsh[p], tf.act);
+  }
+  __device__ void init(const float* x, const ConvGeom& g, int m0, int tid_, const InputTransform& tf_) {
+    tf = tf_; okbits = 0;
     buf.init(x, (size_t)g.N * g.H * g.W * g.C * 4);
     H = g.H; W = g.W; C = g.C; Mrows = g.R * g.S * g.C; Kg = g.N * g.OH * g.OW;
     stride = g.stride; pad_t = g.pad_t; pad_l = g.pad_l; dOHW = g.dOHW; dOW = g.dOW; dC = g.dC; dS = g.dS;
@@ -194,6 +232,10 @@ struct LoadConvWgradA {
     for (int p = 0; p < Tile::PASSES; ++p) {
       m_[p] = m0 + Tile::row_of(tid, p);
       split_k(min(m_[p], Mrows - 1), dC, dS, r_[p], s_[p], c_[p]);
+      if (VEC && TF) {                                    // rows past the end are clamped to Mrows-1 (c = C-1): read quad 0, they are masked
+        const int cq = m_[p] < Mrows ? c_[p] : 0;
+        tsc[p] = *reinterpret_cast<const float4*>(tf.scale + cq); tsh[p] = *reinterpret_cast<const float4*>(tf.shift + cq);
+      }
     }
   }
   __device__ __forceinline__ unsigned off(int m, unsigned n, int oh, int ow, bool kin) const {
@@ -203,6 +245,7 @@ struct LoadConvWgradA {
     return ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c) : OOB;
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
+    unsigned bits = 0;
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
       const int kg = kt * BK + Tile::k_of(tid, p);
@@ -212,12 +255,14 @@ struct LoadConvWgradA {
       if (VEC) {
         const int ih = (int)oh * stride + r_[p] - pad_t, iw = (int)ow * stride + s_[p] - pad_l;
         const bool ok = kin && m_[p] < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        bits |= (unsigned)ok << p;
         rg[p] = buf.ld4(ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c_[p]) : OOB);
       } else {
         rg[p] = make_float4(buf.ld1(off(m_[p], n, oh, ow, kin)), buf.ld1(off(m_[p] + 1, n, oh, ow, kin)),
                             buf.ld1(off(m_[p] + 2, n, oh, ow, kin)), buf.ld1(off(m_[p] + 3, n, oh, ow, kin)));
       }
     }
+    if (TF) okbits = bits;
   }
 };
 
@@ -233,7 +278,7 @@ constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA
 // fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
 struct SplitTail { int n_full, parts, kt_part; float* ws; };
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; };
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; };
 
 // Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
 template <class G>
@@ -279,8 +324,8 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
   *reinterpret_cast<float4*>(out + row * cols + col) = a;
 }
 
-template <class G, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
+template <class G, bool VEC, bool TF>
+__device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
   int id, k0, k1; float* part;
   tail_decode<G>(p.tail, blockIdx.x, (Kg + BK - 1) / BK, id, k0, k1, part);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
-  LoadConvFwdA<G::BM, VEC> la; la.init(p.x, p.g, m0, threadIdx.x);
+  LoadConvFwdA<G::BM, VEC, TF> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
@@ -319,6 +364,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) {
     }
   });
 }
+
+template <class G, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) { conv_fwd_body<G, VEC, false>(p); }
+// same, reading act(x*in_scale + in_shift) (InputTransform); its own symbol so the plain kernel keeps its code
+template <class G, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 
 struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; };
 
@@ -365,11 +416,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   });
 }
 
-struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; };
+struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; };
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
-template <class G, bool VA, bool VB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
+template <class G, bool VA, bool VB, bool TF>
+__device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
@@ -388,7 +439,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
   const int m0 = (tile / tiles_n) * G::BM, n0 = (tile % tiles_n) * G::BN;
   const int kt_total = (Kg + BK - 1) / BK;
   const int kt0 = split * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
-  LoadConvWgradA<G::BM, VA> la; la.init(p.x, p.g, m0, threadIdx.x);
+  LoadConvWgradA<G::BM, VA, TF> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
   LoadRowsKM<G::BN, VB> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
@@ -405,6 +456,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) {
     if (row < M && col < p.g.K) out[(long)row * p.g.K + col] = v;
   });
 }
+
+template <class G, bool VA, bool VB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) { conv_wgrad_body<G, VA, VB, false>(p); }
+template <class G, bool VA, bool VB>
+__global__ __launch_bounds__(256) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
 
 // out[i] = sum_s slabs[s][i], fixed order.  A workgroup owns 32 float4 columns (512 contiguous bytes of
 // every slab) and spreads the slabs over 8 thread groups (slab s goes to group s % 8, each group keeping
@@ -539,9 +595,11 @@ extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, 
 
 extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
-                                     int ow, int relu, const float* residual, void* workspace, size_t workspace_bytes,
+                                     int ow, int relu, const float* residual, const float* in_scale,
+                                     const float* in_shift, int in_act, void* workspace, size_t workspace_bytes,
                                      void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_fwd: in_scale and in_shift go together");
   EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace) && aligned16(residual),
                    "conv2d_fwd: output, residual and workspace must be 16-byte aligned");
   ConvFwdParams p{x, w, bias, y, {}, relu, {}, residual};
@@ -551,10 +609,14 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   const int tile = pick_tile(M, k);
   const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const bool vec = (c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w) && (!bias || aligned16(bias));
+  EMBNET_CHECK_ARG(!in_scale || (vec && aligned16(in_scale) && aligned16(in_shift)),
+                   "conv2d_fwd: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
+  p.tf = InputTransform{in_scale, in_shift, in_act};
   plan_tail(tiles, cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile], (vec && workspace) ? workspace_bytes : 0, p.tail);
   p.tail.ws = (float*)workspace;
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
-  if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
+  if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
+  else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
@@ -642,17 +704,18 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
   return splits > 1 ? (size_t)splits * r * s * c * k * sizeof(float) : 0;
 }
 
-#define LAUNCH_WGRAD(VA, VB)                                                                   \
-  switch (tile) {                                                                              \
-    case 0: conv_wgrad_kernel<G128x128, VA, VB><<<grid, 256, 0, st>>>(p); break;               \
-    case 1: conv_wgrad_kernel<G128x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
-    case 2: conv_wgrad_kernel<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
-    default: conv_wgrad_kernel<G64x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                \
+#define LAUNCH_WGRAD(KERNEL, VA, VB)                                                \
+  switch (tile) {                                                                       \
+    case 0: KERNEL<G128x128, VA, VB><<<grid, 256, 0, st>>>(p); break;                   \
+    case 1: KERNEL<G128x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
+    case 2: KERNEL<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
+    default: KERNEL<G64x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
   }
 
 static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n, int h,
-                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, void* stream,
-                      bool do_main, bool do_reduce) {
+                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                      const float* in_scale, const float* in_shift, int in_act, void* stream, bool do_main,
+                      bool do_reduce) {
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
@@ -668,10 +731,15 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
+  EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_wgrad: in_scale and in_shift go together");
+  EMBNET_CHECK_ARG(!in_scale || (va && vb && aligned16(in_scale) && aligned16(in_shift)),
+                   "conv2d_wgrad: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
+  p.tf = InputTransform{in_scale, in_shift, in_act};
   if (do_main) {
-    if (va && vb) { LAUNCH_WGRAD(true, true) }
-    else if (vb) { LAUNCH_WGRAD(false, true) }
-    else { LAUNCH_WGRAD(false, false) }
+    if (in_scale) { LAUNCH_WGRAD(conv_wgrad_tf_kernel, true, true) }
+    else if (va && vb) { LAUNCH_WGRAD(conv_wgrad_kernel, true, true) }
+    else if (vb) { LAUNCH_WGRAD(conv_wgrad_kernel, false, true) }
+    else { LAUNCH_WGRAD(conv_wgrad_kernel, false, false) }
   }
   if (p.splits > 1 && do_reduce) {
     const long cnt = (long)rows * k;
@@ -682,8 +750,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
 
 extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
                                        size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                       int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
-  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+        void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
+                    stream,
                     true, true);
 }
 
@@ -692,14 +762,18 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
 // writes dw directly and the second is a no-op.
 extern "C" int embnet_conv2d_wgrad_slabs_f32(const float* x, const float* dy, float* dw, void* workspace,
                                              size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                             int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
-  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                                             int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+        void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
+                    stream,
                     true, false);
 }
 extern "C" int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, void* workspace,
                                               size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                              int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
-  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, stream,
+                                              int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+        void* stream) {
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
+                    stream,
                     false, true);
 }
 

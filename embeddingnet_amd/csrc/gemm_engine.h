@@ -112,6 +112,7 @@ struct LoadRowsKC {
       row_off[p] = row < rows ? (unsigned)((long)row * ld * 4) : OOB;
     }
   }
+  __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
   __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
     const int k = kt * BK + Tile::k_of(tid);
 #pragma unroll
@@ -139,6 +140,7 @@ struct LoadRowsKM {
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) col_off[p] = 4u * (unsigned)(row0 + Tile::row_of(tid, p));
   }
+  __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
   __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) {
@@ -215,7 +217,9 @@ __device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const floa
 #endif
 }
 
-// Main loop.  LA/LB: loaders with .load(kt, regs); TA/TB: their LDS tile types.  smem holds
+// Main loop.  LA/LB: loaders with .load(kt, regs) and .fix(regs) — fix() runs on the fetched registers just
+// before they go to LDS (one load outstanding per loader, so it may use state load() left); TA/TB: their LDS
+// tile types.  smem holds
 // MAIN_FLOATS<TA,TB> floats.
 //
 // Two-stage version: K tile kt is consumed from LDS stage (kt&1) in four k-steps of 8 while
@@ -248,6 +252,7 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
     constexpr int STAGE = TA::FLOATS + TB::FLOATS;
     if (kt_begin >= kt_end) return;
     la.load(kt_begin, ra); lb.load(kt_begin, rb);
+    la.fix(ra); lb.fix(rb);
     TA::store(smem, ra, tid);
     TB::store(smem + TA::FLOATS, rb, tid);
     la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
@@ -264,6 +269,7 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
       mfma_step<G>(a0, b0, acc);
       pin();
       load_frags<G, TA, TB>(sc, wm, wn, 2, lane, a0, b0);
+      la.fix(ra); lb.fix(rb);
       TA::store(sn, ra, tid);
       TB::store(sn + TA::FLOATS, rb, tid);
       pin();
@@ -284,7 +290,7 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
     }
   } else {
     float* sA = smem;
-    if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); }
+    if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); }
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       __syncthreads();                       // everyone finished reading the previous tile
       TA::store(sA, ra, tid);
@@ -300,6 +306,9 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
         load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
         mfma_step<G>(a, b, acc);
       }
+      // loader's register-side transform of the tile just fetched (usually none): here, behind the MFMAs it
+      // overlaps with and outside the barrier pair, not between the barrier and the LDS store
+      la.fix(ra); lb.fix(rb);
     }
   }
 }

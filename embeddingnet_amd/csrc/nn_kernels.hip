@@ -50,17 +50,6 @@ __device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __r
   }
 }
 
-// Activation fused behind the BN affine: 0 none, 1 ReLU, 2 swish (z * sigmoid(z)).  Backward recomputes
-// z = x*scale + shift from the saved input, so no activation tensor or mask is stored.
-__device__ __forceinline__ float act_apply(int act, float z) {
-  return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? z / (1.f + __expf(-z)) : z);
-}
-__device__ __forceinline__ float act_grad(int act, float z, float dy) {
-  if (act == 1) return z <= 0.f ? 0.f : dy;
-  if (act == 2) { const float sg = 1.f / (1.f + __expf(-z)); return dy * (sg + z * sg * (1.f - sg)); }
-  return dy;
-}
-
 // Finalize helper: one 256-thread workgroup per channel adds that channel's per-block partials in
 // double (fixed order: thread-strided, then a shuffle tree) — thread 0 gets the totals.
 __device__ __forceinline__ void block_partial_sums(const float* __restrict__ partial, int blocks, int c, int col,
@@ -684,6 +673,14 @@ extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* g
   bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
   if (y) affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_infer_fwd");
+}
+
+extern "C" int embnet_affine_act(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                 void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && y, "affine_act: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0, "affine_act: m=%ld c=%d", m, c);
+  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y);
+  return check_launch("affine_act");
 }
 
 extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,

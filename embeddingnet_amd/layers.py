@@ -107,13 +107,17 @@ def same_pad(n, k, s):
 # ----------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, relu, residual=None):
+    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0):
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
         if c2 != c:
             raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
         stride, pt, pl, oh, ow = geom
+        # in_stats [4,C] (mean, rstd, scale, shift of the BatchNormalization in front): the kernels read
+        # act(x*scale + shift) on the fly, x being the BN's INPUT (layers.Deferred)
+        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
+        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
         if residual is not None:
             if relu:
                 raise _lib.EmbnetError("conv2d: a fused residual add goes with a linear conv (no fused ReLU)")
@@ -125,14 +129,15 @@ class _Conv2dFn(torch.autograd.Function):
         ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
             ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
-            ptr(ws), ws.numel() * 4, stream())))
+            in_scale, in_shift, int(in_act), ptr(ws), ws.numel() * 4, stream())))
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.in_act = int(in_act)
+        ctx.save_for_backward(x, w, y if relu else None, in_stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, in_stats = ctx.saved_tensors
         lib = _lib.lib()
         n, h, wd, c = x.shape
         r, s, _, k = w.shape
@@ -146,10 +151,13 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         dims = (n, h, wd, c, r, s, k, oh, ow)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
+        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
 
         def run_wgrad():
             ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            args = (ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow)
+            args = (ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
+                    in_scale, in_shift, ctx.in_act)
             if TIMER is None:
                 check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
             else:                       # bracket the MFMA kernel alone; the slab sum is its own launch
@@ -178,7 +186,7 @@ class _Conv2dFn(torch.autograd.Function):
             run_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
-        return dx, dw, db, None, None, (dy if ctx.has_res else None)
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None
 
 
 def _colsum(x2d):
@@ -233,7 +241,14 @@ class Conv2D(nn.Module):
         return (s, pt, pl, oh, ow)
 
     def forward(self, x, residual=None):
-        """residual: the other input of the Add layer that follows this conv (added in the conv epilogue)."""
+        """residual: the other input of the Add layer that follows this conv (added in the conv epilogue).
+        x may be a Deferred BatchNormalization output: the conv then applies the BN affine + activation itself."""
+        if isinstance(x, Deferred):
+            if self.kernel.shape[2] % 4 or self.kernel.shape[3] % 4:
+                x = x.materialize()
+            else:
+                return _Conv2dFn.apply(x.raw, self.kernel, self.bias, self.geometry(x.raw.shape[1], x.raw.shape[2]),
+                                       self.relu, residual, x.stats, x.act)
         return _Conv2dFn.apply(x, self.kernel, self.bias, self.geometry(x.shape[1], x.shape[2]), self.relu, residual)
 
 
@@ -332,6 +347,68 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class Deferred:
+    """A BatchNormalization(+activation) output that has not been written.  `raw` is the BN's input (as an
+    autograd alias whose gradient is the gradient of the BN OUTPUT), `stats` [4,C] = mean, rstd, scale, shift,
+    `act` the activation code.  Conv2D consumes it directly (include/embnet.h: in_scale/in_shift/in_act);
+    anything else calls materialize()."""
+
+    def __init__(self, raw, stats, act):
+        self.raw, self.stats, self.act = raw, stats, act
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def materialize(self):
+        return _AffineActFn.apply(self.raw, self.stats, self.act)
+
+
+class _AffineActFn(torch.autograd.Function):
+    """act(x*scale + shift) with the gradient handed to the alias unchanged (the BN node applies the chain)."""
+
+    @staticmethod
+    def forward(ctx, raw, stats, act):
+        y = torch.empty_like(raw)
+        c = raw.shape[-1]
+        check(_lib.lib().embnet_affine_act(ptr(raw), raw.numel() // c, c, stats[2].data_ptr(), stats[3].data_ptr(),
+                                           int(act), ptr(y), stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+class _BNDeferFn(torch.autograd.Function):
+    """Statistics + scale/shift only; returns an alias of x whose incoming gradient is d(BN output)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training):
+        x = _c(x)
+        lib = _lib.lib()
+        c = x.shape[-1]
+        m = x.numel() // c
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        if training:
+            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), None,
+                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
+                                          ws.numel() * 4, stream()))
+        else:
+            check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
+                                          int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+        ctx.relu, ctx.training, ctx.has_gamma = int(act), training, gamma is not None
+        ctx.save_for_backward(x, stats)
+        ctx.mark_non_differentiable(stats)
+        return x.view_as(x), stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        return _BatchNormFn.backward(ctx, dy)
+
+
 class BatchNormalization(nn.Module):
     """Keras BatchNormalization on the last axis; `relu=True` fuses a following Activation('relu')."""
 
@@ -345,7 +422,13 @@ class BatchNormalization(nn.Module):
         self.register_buffer("moving_mean", torch.zeros(channels))
         self.register_buffer("moving_variance", torch.ones(channels))
 
-    def forward(self, x):
+    def forward(self, x, defer=False):
+        """defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
+        affine + activation while gathering their input, and the normalised tensor is never written."""
+        if defer and x.shape[-1] % 4 == 0:
+            raw, stats = _BNDeferFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                          self.momentum, self.relu, self.training)
+            return Deferred(raw, stats, self.relu)
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                   self.momentum, self.relu, self.training)
 
@@ -389,8 +472,8 @@ class _InputBNConvFn(torch.autograd.Function):
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
-            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, ptr(cws),
-            cws.numel() * 4, stream())))
+            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
+            ptr(cws), cws.numel() * 4, stream())))
         ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y
@@ -407,7 +490,7 @@ class _InputBNConvFn(torch.autograd.Function):
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, cp, r, s, k, oh, ow), a.device)
         _conv_timed(2, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
-            stream())))
+            None, None, 0, stream())))
         dw = dw_p if cp == c else dw_p[:, :, :c, :].contiguous()
         key = (a.device, n, h, wd)
         ones = _InputBNConvFn._ones.get(key)
@@ -417,7 +500,7 @@ class _InputBNConvFn(torch.autograd.Function):
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, 1, r, s, k, oh, ow), a.device)
         _conv_timed(2, (n, h, wd, 1, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
             ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
-            stream())))
+            None, None, 0, stream())))
         dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
         return None, dbeta, None, None, dw, None, None, None

@@ -130,13 +130,18 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its
  * bottom/right asymmetry, or an explicit ZeroPadding2D).  bias may be NULL; relu!=0 fuses the activation;
  * residual (NULL or [n,oh,ow,k]) is added last — the Add layer that closes a residual unit.
+ * in_scale/in_shift [c] (NULL or both) + in_act (0 none, 1 relu, 2 swish): the conv reads
+ * act(x*in_scale + in_shift) instead of x — the BatchNormalization(+activation) in front of it, applied in
+ * registers between the gather and LDS so the normalised tensor is never written; padding stays 0.
+ * Needs c % 4 == 0 and k % 4 == 0.  conv2d_wgrad takes the same triple (it re-derives the conv input).
  * workspace (optional, may be NULL/0): >= embnet_conv2d_fwd_workspace_bytes lets the launcher cut the
  * `tiles mod 256` left-over output tiles along K so the last round of workgroups fills every CU
  * (partial tiles + fixed-order fix-up; results differ from the unsplit launch only in fp32 summation order). */
 size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
                           int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
-                          const float* residual, void* workspace, size_t workspace_bytes, void* stream);
+                          const float* residual, const float* in_scale, const float* in_shift, int in_act,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only). */
 size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride);
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
@@ -146,16 +151,18 @@ int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, i
 size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                             int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
-                            int oh, int ow, void* stream);
+                            int oh, int ow, const float* in_scale, const float* in_shift, int in_act, void* stream);
 
 /* conv2d_wgrad in two calls (split-K MFMA kernel into the slabs; then the fixed-order slab sum), same
  * arguments: lets a caller time the MFMA kernel alone.  conv2d_wgrad_f32 == slabs + reduce. */
 int embnet_conv2d_wgrad_slabs_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                                   int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
-                                  int oh, int ow, void* stream);
+                                  int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                                  void* stream);
 int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                                    int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
-                                   int oh, int ow, void* stream);
+                                   int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                                   void* stream);
 /* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
@@ -182,6 +189,11 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, float* dx, float* dgamma,
                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = act(x*scale[c] + shift[c]) on x[m,c]: the apply half of BatchNormalization on its own (scale/shift from
+ * bn_train_fwd / bn_infer_fwd with y = NULL), for a deferred BN output whose consumer cannot fuse it. */
+int embnet_affine_act(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                      void* stream);
 
 /* MaxPool2D (backbones.py:23,26,29: 2x2/2; zoo ResNet: ZeroPadding2D(1) + 3x3/2).  Taps outside the
  * image read 0 and take no gradient.  argmax[n,oh,ow,c] (uint8) is kept for backward. */

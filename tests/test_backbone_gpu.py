@@ -104,6 +104,37 @@ def test_conv2d_residual_epilogue(dev, shape):
         conv(x, residual=r[:, 1:])
 
 
+@pytest.mark.parametrize("shape,k,stride,act", [((2, 16, 16, 64, 64), 3, 1, "relu"), ((8, 40, 40, 256, 128), 3, 1, "relu"),
+                                                ((3, 15, 17, 64, 128), 3, 2, "relu"), ((2, 14, 14, 64, 128), 1, 2, None),
+                                                ((2, 12, 12, 32, 48), 3, 1, "swish")])
+def test_deferred_batchnorm_into_conv(dev, shape, k, stride, act):
+    """bn(x, defer=True) -> Conv2D applies the BN affine + activation while gathering (forward and wgrad):
+    outputs and every gradient equal the materialised BN -> conv path bit for bit (same operands, same order)."""
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout = shape
+    x = torch.randn((n, h, w, cin), device=dev) * 1.5 + 0.3
+    res = {}
+    for defer in (False, True):
+        gen = torch.Generator().manual_seed(11)
+        bn = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
+        conv = L.Conv2D(cin, cout, k, strides=stride, padding=k // 2, use_bias=False, gen=gen).to(dev)
+        with torch.no_grad():
+            bn.gamma.copy_(torch.linspace(-1.0, 1.5, cin)); bn.beta.copy_(torch.linspace(0.4, -0.4, cin))
+        xt = x.clone().requires_grad_(True)
+        a = bn(xt, defer=defer)
+        assert isinstance(a, L.Deferred) == defer
+        y = conv(a)
+        y.backward(torch.cos(y.detach() * 3))
+        res[defer] = (y.detach(), xt.grad, conv.kernel.grad, bn.gamma.grad, bn.beta.grad, bn.moving_mean.clone())
+        if defer:                                   # a consumer that cannot fuse gets the materialised tensor
+            bn2 = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
+            with torch.no_grad():
+                bn2.gamma.copy_(bn.gamma); bn2.beta.copy_(bn.beta)
+            assert torch.equal(bn(x, defer=True).materialize(), bn2(x))
+    for got, want, what in zip(res[True], res[False], ("y", "dx", "dW", "dgamma", "dbeta", "moving_mean")):
+        assert torch.equal(got, want), what
+
+
 def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib
