@@ -101,6 +101,7 @@ def _simple2(gen):
 
 RN_EPS = 2e-5
 DEFER_BN = __import__("os").environ.get("EMBNET_DEFER_BN", "0") == "1"
+EPILOGUE_STATS = __import__("os").environ.get("EMBNET_EPILOGUE_STATS", "1") == "1"
 RESNET = {"resnet18": ("basic", (2, 2, 2, 2)), "resnet34": ("basic", (3, 4, 6, 3)),
           "resnet50": ("bottleneck", (3, 4, 6, 3))}
 
@@ -136,13 +137,15 @@ class ResidualUnit(nn.Module):
         # DEFER_BN (off): each conv applies the affine + ReLU of the BN in front of it while gathering, so the
         # normalised tensors are never written.  Bit-identical, saves the BN-apply pass (0.31 ms of a 15.8 ms
         # ResNet18 step) but the extra VALU work in the conv / wgrad loaders costs 0.65 ms — measured, kept as a knob.
-        d = DEFER_BN
+        # emit_stats: every conv here feeds a BatchNormalization (bn2/bn3, the next unit's bn1, the net's last bn1):
+        # its epilogue also produces that BN's per-channel sums, so training reads each activation once less.
+        d, st = DEFER_BN, self.training and EPILOGUE_STATS
         a = self.bn1(x, defer=d)
         sc = self.sc(a) if self.post else x
-        y = self.bn2(self.conv1(a), defer=d)
+        y = self.bn2(self.conv1(a, emit_stats=st), defer=d)
         if self.kind == "basic":
-            return self.conv2(y, residual=sc)           # the unit's Add runs in the last conv's epilogue
-        return self.conv3(self.bn3(self.conv2(y), defer=d), residual=sc)
+            return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
+        return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d), residual=sc, emit_stats=st)
 
 
 class ResNet(nn.Module):
@@ -167,7 +170,8 @@ class ResNet(nn.Module):
         self.out_channels = cin
 
     def forward(self, x):
-        x = L.bn_act_maxpool(L.input_bn_conv(x, self.bn_data, self.conv0), self.bn0, self.pooling0)
+        x = L.bn_act_maxpool(L.input_bn_conv(x, self.bn_data, self.conv0, emit_stats=self.training and EPILOGUE_STATS), self.bn0,
+                             self.pooling0)
         for nm in self._units:
             x = getattr(self, nm)(x)
         return self.bn1(x)

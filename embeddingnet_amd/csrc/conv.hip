@@ -278,7 +278,7 @@ constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA
 // fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
 struct SplitTail { int n_full, parts, kt_part; float* ws; };
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; };
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; float* stats; int stats_rows; };
 
 // Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
 template <class G>
@@ -299,29 +299,61 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN],
   });
 }
 
-// out[(m0+r)*ld + n0+c] = act(sum_parts partial + bias) for the left-over tiles; one float4 per thread.
-__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int parts, int bm, int bn,
+// out[(m0+r)*ld + n0+c] = act(sum_parts partial + bias) (+ residual) for the left-over tiles; one float4 per
+// thread.  A workgroup covers one band of `wtm` rows (the row band a wave owns in the main kernel) x 1024/wtm
+// columns of a tile, so that it can also emit that band's per-channel sum / sum of squares (stats != NULL)
+// in the same [2][cols][tile_m * bm/wtm + band] layout the main kernel's epilogue writes.
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int parts, int bm, int bn, int wtm,
                                                          int n_full, int tiles_n, long m, int cols,
                                                          const float* __restrict__ bias, int relu,
-                                                         const float* __restrict__ residual, float* __restrict__ out) {
-  const int per_tile = bm * bn / 4;                       // float4s per tile
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int t = (int)(i / per_tile), e = (int)(i % per_tile) * 4;
-  const int r = e / bn, c = e % bn;
+                                                         const float* __restrict__ residual, float* __restrict__ out,
+                                                         float* __restrict__ stats, int stats_rows) {
+  __shared__ float4 red[2][256];
+  const int cpb = 1024 / wtm, qpb = cpb / 4;              // columns / column quads per workgroup
+  const int blocks_per_tile = bm * bn / 1024, col_groups = bn / cpb;
+  const int t = blockIdx.x / blocks_per_tile, bi = blockIdx.x % blocks_per_tile;
+  const int band = bi / col_groups, cg = bi % col_groups;
+  const int rr = threadIdx.x / qpb, r = band * wtm + rr, c = cg * cpb + (threadIdx.x % qpb) * 4;
   const int tile = n_full + t;
   const long row = (long)(tile / tiles_n) * bm + r;
   const int col = (tile % tiles_n) * bn + c;
-  if (row >= m || col >= cols) return;
-  const float* src = ws + (long)t * parts * bm * bn + e;
-  float4 a = *reinterpret_cast<const float4*>(src);
-  for (int k = 1; k < parts; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (long)k * bm * bn);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  const bool in = row < m && col < cols;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    const float* src = ws + (long)t * parts * bm * bn + r * bn + c;
+    a = *reinterpret_cast<const float4*>(src);
+    for (int k = 1; k < parts; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)k * bm * bn);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    if (residual) { const float4 q = *reinterpret_cast<const float4*>(residual + row * cols + col); a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+    *reinterpret_cast<float4*>(out + row * cols + col) = a;
   }
-  if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-  if (residual) { const float4 q = *reinterpret_cast<const float4*>(residual + row * cols + col); a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
-  *reinterpret_cast<float4*>(out + row * cols + col) = a;
+  if (!stats) return;
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+  __syncthreads();
+  for (int s = wtm / 2; s >= 1; s >>= 1) {                // fixed tree over the band's rows
+    if (rr < s) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const float4 o = red[w][threadIdx.x + s * qpb];
+        float4& d = red[w][threadIdx.x];
+        d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w;
+      }
+    }
+    __syncthreads();
+  }
+  if (rr == 0 && col < cols) {
+    const long prow = (long)(tile / tiles_n) * (bm / wtm) + band, P = stats_rows;
+    const float4 s1 = red[0][threadIdx.x], s2 = red[1][threadIdx.x];
+    float* d1 = stats + (long)col * P + prow;
+    float* d2 = d1 + (long)cols * P;
+    d1[0] = s1.x; d1[P] = s1.y; d1[2 * P] = s1.z; d1[3 * P] = s1.w;
+    d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
+  }
 }
 
 template <class G, bool VEC, bool TF>
@@ -340,6 +372,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
   if (part) { store_partial<G>(acc, smem, part); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;  // this lane's column quad: sum, sum of squares over its rows
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
       const int row = m0 + r, col = n0 + c;
       if (row < M && col < p.g.K) {
@@ -350,8 +383,26 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         *reinterpret_cast<float4*>(p.y + (long)row * p.g.K + col) = v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
       }
     });
+    if (p.stats) {
+      // BatchNorm statistics of the layer that follows, while the tile is in registers: every wave writes the
+      // column sums of its WTM-row band as partial (tile_m*WAVES_M + wave_m) of stats[2][K][P]; the BN
+      // finalize kernel adds the P rows per channel in double.  (lanes l, l+LPR, l+2*LPR.. hold the same columns)
+      constexpr int LPR = G::WTN / 4;
+      s1 = colquad_sum<LPR>(s1); s2 = colquad_sum<LPR>(s2);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int col = n0 + (wave % G::WAVES_N) * G::WTN + lane * 4;
+      if (lane < LPR && col < p.g.K) {
+        const long prow = (long)(m0 / G::BM) * G::WAVES_M + wave / G::WAVES_N, P = p.stats_rows;
+        float* d1 = p.stats + (long)col * P + prow;          // [2][K][P]: a channel's partials are contiguous for
+        float* d2 = d1 + (long)p.g.K * P;                    // the finalize kernel (it reads P floats per channel)
+        d1[0] = s1.x; d1[P] = s1.y; d1[2 * P] = s1.z; d1[3 * P] = s1.w;
+        d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
+      }
+    }
     return;
   }
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -546,7 +597,7 @@ static int pick_tile(long m, int ncols) {
   if (cdiv(m, 128) * cdiv(ncols, 128) >= 4 * 768 && ncols >= 128) return 0;
   return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
 }
-static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64};
+static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64}, TILE_WTM[4] = {64, 64, 32, 32};
 
 // Plan the remainder split for `tiles` output tiles of bm x bn with kt K-tiles each (see SplitTail).
 // Model: a CU retires one tile per t_tile; whole tiles cost ceil(tiles/256) of those, the split costs
@@ -593,11 +644,19 @@ extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, 
   return need;
 }
 
+// P of the stats[2][k][P] buffer conv2d_fwd fills (0: this geometry cannot emit statistics)
+extern "C" int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, int oh, int ow) {
+  if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;
+  const long M = (long)n * oh * ow;
+  const int tile = pick_tile(M, k);
+  return cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
+}
+
 extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
                                      int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
                                      int ow, int relu, const float* residual, const float* in_scale,
-                                     const float* in_shift, int in_act, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     const float* in_shift, int in_act, float* stats, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_fwd: in_scale and in_shift go together");
   EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace) && aligned16(residual),
@@ -611,7 +670,11 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   const bool vec = (c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w) && (!bias || aligned16(bias));
   EMBNET_CHECK_ARG(!in_scale || (vec && aligned16(in_scale) && aligned16(in_shift)),
                    "conv2d_fwd: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
+  EMBNET_CHECK_ARG(!stats || (vec && aligned16(stats)),
+                   "conv2d_fwd: epilogue statistics need channel counts that are multiples of 4 (see conv2d_fwd_stats_rows)");
   p.tf = InputTransform{in_scale, in_shift, in_act};
+  p.stats = stats;
+  p.stats_rows = cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
   plan_tail(tiles, cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile], (vec && workspace) ? workspace_bytes : 0, p.tail);
   p.tail.ws = (float*)workspace;
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
@@ -620,8 +683,8 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
-    tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
-                                                                         cdiv(k, bn), M, k, bias, relu, residual, y);
+    tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
+                                                             cdiv(k, bn), M, k, bias, relu, residual, y, stats, p.stats_rows);
   }
   return check_launch("conv2d_fwd");
 }
@@ -675,8 +738,8 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
   else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
-    tail_fixup_kernel<<<cdiv((long)rem * bm * bn / 4, 256), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, p.tail.n_full,
-                                                                         cdiv(c, bn), max_m, c, nullptr, 0, nullptr, dx);
+    tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
+                                                             cdiv(c, bn), max_m, c, nullptr, 0, nullptr, dx, nullptr, 0);
   }
   return check_launch("conv2d_dgrad");
 }

@@ -362,6 +362,17 @@ __device__ __forceinline__ void for_each_acc_row4(const f32x16 (&acc)[G::TM][G::
   }
 }
 
+// Sum a per-lane float4 over the lanes that share a column quad after for_each_acc_row4 (lane % LPR equal).
+template <int LPR>
+__device__ __forceinline__ float4 colquad_sum(float4 v) {
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+    v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+  }
+  return v;
+}
+
 // blockIdx.x -> (tile_m, tile_n) keeping the workgroups that share an XCD (ids equal mod 8)
 // on neighbouring tiles so they reuse operand panels in that XCD's L2.  Bijective for any count.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

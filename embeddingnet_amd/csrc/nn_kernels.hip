@@ -53,12 +53,18 @@ __device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __r
 // Finalize helper: one 256-thread workgroup per channel adds that channel's per-block partials in
 // double (fixed order: thread-strided, then a shuffle tree) — thread 0 gets the totals.
 __device__ __forceinline__ void block_partial_sums(const float* __restrict__ partial, int blocks, int c, int col,
-                                                   double& s_out, double& ss_out) {
+                                                   double& s_out, double& ss_out, bool by_channel = false) {
   __shared__ double red[2][4];
   double s = 0.0, ss = 0.0;
-  for (int b = threadIdx.x; b < blocks; b += 256) {
-    s += (double)partial[((long)b * 2) * c + col];
-    ss += (double)partial[((long)b * 2 + 1) * c + col];
+  if (by_channel) {                  // [2][c][blocks]: this channel's partials are contiguous (conv epilogue layout)
+    const float* p1 = partial + (long)col * blocks;
+    const float* p2 = p1 + (long)c * blocks;
+    for (int b = threadIdx.x; b < blocks; b += 256) { s += (double)p1[b]; ss += (double)p2[b]; }
+  } else {                           // [blocks][2][c]
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+      s += (double)partial[((long)b * 2) * c + col];
+      ss += (double)partial[((long)b * 2 + 1) * c + col];
+    }
   }
   s = wave_sum(s); ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
@@ -170,10 +176,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float momentum, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ moving_mean,
-                                                          float* __restrict__ moving_var) {
+                                                          float* __restrict__ moving_var, int by_channel) {
   const int col = blockIdx.x;
   double s, ss;
-  block_partial_sums(partial, blocks, c, col, s, ss);
+  block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
   if (threadIdx.x) return;
   const double mean = s / (double)m;
   double var = ss / (double)m - mean * mean;            // biased, as Keras uses in training
@@ -643,23 +649,27 @@ extern "C" size_t embnet_bn_workspace_bytes(long m, int c) {
 extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
                                    float momentum, int relu, float* y, float* save_mean, float* save_rstd,
                                    float* scale, float* shift, float* moving_mean, float* moving_var,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+                                   const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   EMBNET_CHECK_ARG(x && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_train_fwd: m=%ld c=%d", m, c);
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "bn_train_fwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
-  float* partial = (float*)workspace;
+  const float* partial = (const float*)workspace;
   int nblocks = g.blocks;
-  if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
+  if (partial_in) {                         // sum / sum-of-squares partials [2][c][rows] already produced (conv epilogue)
+    EMBNET_CHECK_ARG(partial_rows > 0, "bn_train_fwd: partial_rows=%d", partial_rows);
+    partial = partial_in; nblocks = partial_rows;
+  } else if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
     const ColGeom g4 = col_geom(m, c / 4);
     nblocks = g4.blocks;
-    bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, partial);
+    bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, (float*)workspace);
   } else {
-    bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, partial);
+    bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace);
   }
   bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
-                                                          save_rstd, scale, shift, moving_mean, moving_var);
+                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr);
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
     affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
   return check_launch("bn_train_fwd");

@@ -107,7 +107,7 @@ def same_pad(n, k, s):
 # ----------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0):
+    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None):
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
@@ -129,7 +129,7 @@ class _Conv2dFn(torch.autograd.Function):
         ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
             ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
-            in_scale, in_shift, int(in_act), ptr(ws), ws.numel() * 4, stream())))
+            in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream())))
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
         ctx.save_for_backward(x, w, y if relu else None, in_stats)
@@ -186,7 +186,7 @@ class _Conv2dFn(torch.autograd.Function):
             run_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None
 
 
 def _colsum(x2d):
@@ -240,16 +240,28 @@ class Conv2D(nn.Module):
             raise _lib.EmbnetError(f"Conv2D {k}x{k}/{s} '{self.padding}' does not fit a {h}x{w} input")
         return (s, pt, pl, oh, ow)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, emit_stats=False):
         """residual: the other input of the Add layer that follows this conv (added in the conv epilogue).
-        x may be a Deferred BatchNormalization output: the conv then applies the BN affine + activation itself."""
+        x may be a Deferred BatchNormalization output: the conv then applies the BN affine + activation itself.
+        emit_stats: a training-mode BatchNormalization reads this output next — the conv epilogue produces its
+        per-channel sums while the tiles are in registers (attached to the result as `_bn_partials`)."""
+        in_stats, in_act = None, 0
         if isinstance(x, Deferred):
             if self.kernel.shape[2] % 4 or self.kernel.shape[3] % 4:
                 x = x.materialize()
             else:
-                return _Conv2dFn.apply(x.raw, self.kernel, self.bias, self.geometry(x.raw.shape[1], x.raw.shape[2]),
-                                       self.relu, residual, x.stats, x.act)
-        return _Conv2dFn.apply(x, self.kernel, self.bias, self.geometry(x.shape[1], x.shape[2]), self.relu, residual)
+                x, in_stats, in_act = x.raw, x.stats, x.act
+        geom = self.geometry(x.shape[1], x.shape[2])
+        out_stats = None
+        if emit_stats:
+            r, s, c, k = self.kernel.shape
+            rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
+            if rows > 0:
+                out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+        y = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats)
+        if out_stats is not None:
+            y._bn_partials = out_stats
+        return y
 
 
 # ----------------------------------------------------------------------------- dense
@@ -305,9 +317,27 @@ class Dense(nn.Module):
 
 
 # ----------------------------------------------------------------------------- batch norm
+def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mean, moving_var, partials=None):
+    """embnet_bn_train_fwd; partials [2,C,P] = sums / sums of squares of x by row band from the producing conv's
+    epilogue (Conv2D(..., emit_stats=True)), which then replace the statistics pass over x."""
+    lib = _lib.lib()
+    ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+    if partials is not None and tuple(partials.shape[:2]) != (2, c):
+        raise _lib.EmbnetError(f"BatchNormalization: statistics partials {tuple(partials.shape)} for {c} channels")
+    check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), ptr(y),
+                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                  ptr(moving_mean), ptr(moving_var), ptr(partials),
+                                  partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, stream()))
+
+
+def _partials_of(x, training):
+    p = getattr(x, "_bn_partials", None) if training else None
+    return p if (p is not None and p.shape[1] == x.shape[-1]) else None
+
+
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None):
         x = _c(x)
         lib = _lib.lib()
         c = x.shape[-1]
@@ -315,11 +345,7 @@ class _BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
         if training:
-            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(relu), ptr(y),
-                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
-                                          ws.numel() * 4, stream()))
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, y, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(relu), ptr(y), stats[2].data_ptr(), stats[3].data_ptr(), stream()))
@@ -344,7 +370,7 @@ class _BatchNormFn(torch.autograd.Function):
                                 ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class Deferred:
@@ -384,18 +410,14 @@ class _BNDeferFn(torch.autograd.Function):
     """Statistics + scale/shift only; returns an alias of x whose incoming gradient is d(BN output)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, partials=None):
         x = _c(x)
         lib = _lib.lib()
         c = x.shape[-1]
         m = x.numel() // c
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
         if training:
-            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), None,
-                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
-                                          ws.numel() * 4, stream()))
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
@@ -427,10 +449,10 @@ class BatchNormalization(nn.Module):
         affine + activation while gathering their input, and the normalised tensor is never written."""
         if defer and x.shape[-1] % 4 == 0:
             raw, stats = _BNDeferFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                          self.momentum, self.relu, self.training)
+                                          self.momentum, self.relu, self.training, _partials_of(x, self.training))
             return Deferred(raw, stats, self.relu)
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                  self.momentum, self.relu, self.training)
+                                  self.momentum, self.relu, self.training, _partials_of(x, self.training))
 
 
 class _InputBNConvFn(torch.autograd.Function):
@@ -443,7 +465,7 @@ class _InputBNConvFn(torch.autograd.Function):
     _ones = {}
 
     @staticmethod
-    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom):
+    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None):
         x, w = _c(x), _c(w)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -462,10 +484,7 @@ class _InputBNConvFn(torch.autograd.Function):
             xp, beta_p, mm_p, mv_p, w_p = x, beta, moving_mean, moving_var, w
         a = torch.empty_like(xp)
         stats = torch.empty((4, cp), device=x.device, dtype=torch.float32)
-        ws = workspace(lib.embnet_bn_workspace_bytes(m, cp), x.device)
-        check(lib.embnet_bn_train_fwd(ptr(xp), m, cp, None, ptr(beta_p), eps, momentum, 0, ptr(a), stats[0].data_ptr(),
-                                      stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                                      ptr(mm_p), ptr(mv_p), ptr(ws), ws.numel() * 4, stream()))
+        _bn_train_fwd(xp, m, cp, None, beta_p, eps, momentum, 0, a, stats, mm_p, mv_p)
         if cp != c:                                # the pad channel is identically 0 after BN (x=0, beta=0)
             moving_mean.copy_(mm_p[:c])
             moving_var.copy_(mv_p[:c])
@@ -473,7 +492,7 @@ class _InputBNConvFn(torch.autograd.Function):
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
         _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
-            ptr(cws), cws.numel() * 4, stream())))
+            ptr(out_stats), ptr(cws), cws.numel() * 4, stream())))
         ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y
@@ -503,17 +522,29 @@ class _InputBNConvFn(torch.autograd.Function):
             None, None, 0, stream())))
         dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
-        return None, dbeta, None, None, dw, None, None, None
+        return None, dbeta, None, None, dw, None, None, None, None
 
 
-def input_bn_conv(x, bn, conv):
-    """bn (scale=False, no relu) then conv (no bias / activation) on an image batch."""
+def input_bn_conv(x, bn, conv, emit_stats=False):
+    """bn (scale=False, no relu) then conv (no bias / activation) on an image batch.
+    emit_stats: as Conv2D.forward (the BatchNormalization behind the conv gets its sums from the epilogue)."""
     fusable = (bn.training and not x.requires_grad and bn.gamma is None and not bn.relu and conv.bias is None
                and not conv.relu and torch.is_grad_enabled())
     if not fusable:
-        return conv(bn(x))
-    return _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum,
-                                conv.geometry(x.shape[1], x.shape[2]))
+        return conv(bn(x), emit_stats=emit_stats)
+    geom = conv.geometry(x.shape[1], x.shape[2])
+    out_stats = None
+    if emit_stats:
+        r, s, c, k = conv.kernel.shape
+        cp = c if c % 4 == 0 else c + 4 - c % 4                     # the fused stem pads the image channels
+        rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], cp, r, s, k, geom[3], geom[4])
+        if rows > 0:
+            out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+    y = _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum, geom,
+                             out_stats)
+    if out_stats is not None:
+        y._bn_partials = out_stats
+    return y
 
 
 # ----------------------------------------------------------------------------- pooling
@@ -558,7 +589,8 @@ class _BNActMaxPoolFn(torch.autograd.Function):
     embnet_bn_act_maxpool_fwd/bwd) — the zoo ResNet stem bn0 -> relu -> ZeroPadding2D(1) -> MaxPool(3,2)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, k, stride, pad):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, k, stride, pad,
+                partials=None):
         x = _c(x)
         lib = _lib.lib()
         n, h, w, c = x.shape
@@ -568,11 +600,7 @@ class _BNActMaxPoolFn(torch.autograd.Function):
             raise _lib.EmbnetError(f"MaxPool {k}x{k}/{stride} does not fit a {h}x{w} input")
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
         if training:
-            ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-            check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), None,
-                                          stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-                                          stats[3].data_ptr(), ptr(moving_mean), ptr(moving_var), ptr(ws),
-                                          ws.numel() * 4, stream()))
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
@@ -600,7 +628,7 @@ class _BNActMaxPoolFn(torch.autograd.Function):
                                             dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None
-        return (dx, dgamma, dbeta) + (None,) * 9
+        return (dx, dgamma, dbeta) + (None,) * 10
 
 
 def bn_act_maxpool(x, bn, pool):
@@ -609,7 +637,7 @@ def bn_act_maxpool(x, bn, pool):
     if x.shape[-1] % 4:
         return pool(bn(x))
     return _BNActMaxPoolFn.apply(x, bn.gamma, bn.beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum,
-                                 bn.relu, bn.training, pool.k, pool.s, pool.p)
+                                 bn.relu, bn.training, pool.k, pool.s, pool.p, _partials_of(x, bn.training))
 
 
 class _GapFn(torch.autograd.Function):

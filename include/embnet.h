@@ -134,14 +134,18 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * act(x*in_scale + in_shift) instead of x — the BatchNormalization(+activation) in front of it, applied in
  * registers between the gather and LDS so the normalised tensor is never written; padding stays 0.
  * Needs c % 4 == 0 and k % 4 == 0.  conv2d_wgrad takes the same triple (it re-derives the conv input).
+ * stats (NULL or [2][k][P], P = embnet_conv2d_fwd_stats_rows): per-channel sum and sum of squares of y, by row
+ * band, written by the epilogue while the tile is in registers — the statistics pass of the BatchNormalization
+ * that follows (hand them to embnet_bn_train_fwd as partial_in).
  * workspace (optional, may be NULL/0): >= embnet_conv2d_fwd_workspace_bytes lets the launcher cut the
  * `tiles mod 256` left-over output tiles along K so the last round of workgroups fills every CU
  * (partial tiles + fixed-order fix-up; results differ from the unsplit launch only in fp32 summation order). */
 size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
+int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
                           int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
                           const float* residual, const float* in_scale, const float* in_shift, int in_act,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          float* stats, void* workspace, size_t workspace_bytes, void* stream);
 /* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only). */
 size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride);
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
@@ -177,12 +181,14 @@ int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw, int m, in
  * train: biased batch variance; moving <- momentum*moving + (1-momentum)*batch (updated in place, may
  * be NULL); gamma NULL = scale=False; relu = fused activation after the affine: 0 none, 1 ReLU, 2 swish
  * (backward recomputes it from x, nothing extra is stored).  save_mean/save_rstd/scale/shift
- * ([c] each) are kept by the caller for backward. */
+ * ([c] each) are kept by the caller for backward.  y may be NULL (statistics and scale/shift only, for a
+ * fused consumer).  partial_in (NULL, or [2][c][partial_rows] sums / sums of squares of x over disjoint row
+ * sets, e.g. from conv2d_fwd's epilogue) replaces the kernel's own read of x for the statistics. */
 size_t embnet_bn_workspace_bytes(long m, int c);
 int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
                         float momentum, int relu, float* y, float* save_mean, float* save_rstd, float* scale,
-                        float* shift, float* moving_mean, float* moving_var, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        float* shift, float* moving_mean, float* moving_var, const float* partial_in,
+                        int partial_rows, void* workspace, size_t workspace_bytes, void* stream);
 int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
                         const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
                         float* scale, float* shift, void* stream);

@@ -35,9 +35,9 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert rc == -1 and b"null pointer" in lib.embnet_last_error()
     rc = lib.embnet_mine_triplets(1, 1, 4, 0.5, 7, 0, 1, 1, 1, None, None)
     assert rc == -1 and b"k_classes>=2" in lib.embnet_last_error()
-    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 8, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, None, None, 0, None, 0, None)
+    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 8, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, None, None, 0, None, None, 0, None)
     assert rc == -1 and b"16-byte aligned" in lib.embnet_last_error()
-    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 32, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, None, None, 0, None, 0, None)
+    rc = lib.embnet_conv2d_fwd_f32(16, 16, None, 32, 1, 8, 8, 3, 3, 3, 4, 1, 0, 0, 9, 9, 0, None, None, None, 0, None, None, 0, None)
     assert rc == -1 and b"reaches outside" in lib.embnet_last_error()
 
 
