@@ -73,8 +73,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--backbone", default="resnet18")
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--k-classes", type=int, default=32, help="classes per GPU (local batch = k_classes*k_samples)")

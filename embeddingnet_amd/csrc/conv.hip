@@ -585,6 +585,7 @@ using G128x128 = Geom<128, 128, 2, 2>;
 using G128x64 = Geom<128, 64, 2, 2>;
 using G128x32 = Geom<128, 32, 4, 1>;
 using G64x64 = Geom<64, 64, 2, 2>;
+using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 576 = 3*192 rows (4.5 tiles of 128)
 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
@@ -597,7 +598,7 @@ static int pick_tile(long m, int ncols) {
   if (cdiv(m, 128) * cdiv(ncols, 128) >= 4 * 768 && ncols >= 128) return 0;
   return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
 }
-static const int TILE_BM[4] = {128, 128, 128, 64}, TILE_BN[4] = {128, 64, 32, 64}, TILE_WTM[4] = {64, 64, 32, 32};
+static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
 
 // Plan the remainder split for `tiles` output tiles of bm x bn with kt K-tiles each (see SplitTail).
 // Model: a CU retires one tile per t_tile; whole tiles cost ceil(tiles/256) of those, the split costs
@@ -747,6 +748,8 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
 static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
   tile = (rows <= 64 && k <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
+  // 128-row tiles waste the last half tile of a 576-row (3x3x64) gradient; 192-row tiles fit it exactly
+  if (tile == 1 && rows % 192 == 0 && rows % 128 != 0 && !getenv("EMBNET_WGRAD_NO192")) tile = 4;
   const long tiles = (long)cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
   // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
@@ -772,6 +775,7 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
     case 0: KERNEL<G128x128, VA, VB><<<grid, 256, 0, st>>>(p); break;                   \
     case 1: KERNEL<G128x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
     case 2: KERNEL<G128x32, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
+    case 4: KERNEL<G192x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
     default: KERNEL<G64x64, VA, VB><<<grid, 256, 0, st>>>(p); break;                    \
   }
 
@@ -845,7 +849,7 @@ extern "C" int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, f
 extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k,
                                                  int oh, int ow) {
   static thread_local char buf[160];
-  static const char* geoms[4] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2"};
+  static const char* geoms[5] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2", "192, 64, 2, 2"};
   const char* t = (c & 3) == 0 ? "true" : "false";
   const char* tk = (k & 3) == 0 ? "true" : "false";
   if (kind == 0) {
