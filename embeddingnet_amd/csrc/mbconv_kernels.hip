@@ -91,13 +91,80 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
   else xp[0] = acc[0];
 }
 
+// Square KS x KS kernels, 4 channels per thread, branch-free: every tap issues its 16-byte load unconditionally
+// (taps outside the image read element 0 and are multiplied by 0), so the KS*KS loads of a pixel are all in flight
+// together.  The generic kernels above branch around each tap, which makes hipcc wait for one load before it
+// issues the next (EfficientNet-B0's 5x5 layers: 3-5x slower, measured).
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_fwd4_sq_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             DwGeom g, float* __restrict__ y) {
+  const int c4 = g.C >> 2;
+  const long total = (long)g.N * g.OH * g.OW * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4);
+  long t = i / c4;
+  const int ow = (int)(t % g.OW); t /= g.OW;
+  const int oh = (int)(t % g.OH);
+  const int n = (int)(t / g.OH);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < KS; ++r)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
+      const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const float4 xv = x4[ok ? (((long)n * g.H + ih) * g.W + iw) * c4 + cq : 0];
+      float4 wv = w4[(r * KS + s) * c4 + cq];
+      if (!ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+      acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+    }
+  reinterpret_cast<float4*>(y)[i] = acc;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_dgrad4_sq_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               DwGeom g, float* __restrict__ dx) {
+  const int c4 = g.C >> 2;
+  const long total = (long)g.N * g.H * g.W * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4);
+  long t = i / c4;
+  const int iw = (int)(t % g.W); t /= g.W;
+  const int ih = (int)(t % g.H);
+  const int n = (int)(t / g.H);
+  const float4* d4 = reinterpret_cast<const float4*>(dy);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < KS; ++r)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int th = ih + g.pad_t - r, tw = iw + g.pad_l - s;
+      const int oh = th / g.stride, ow = tw / g.stride;       // stride 1 or 2 in practice; exact when it divides
+      const bool ok = th >= 0 && tw >= 0 && oh * g.stride == th && ow * g.stride == tw && oh < g.OH && ow < g.OW;
+      const float4 dv = d4[ok ? (((long)n * g.OH + oh) * g.OW + ow) * c4 + cq : 0];
+      float4 wv = w4[(r * KS + s) * c4 + cq];
+      if (!ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc.x = fmaf(dv.x, wv.x, acc.x); acc.y = fmaf(dv.y, wv.y, acc.y);
+      acc.z = fmaf(dv.z, wv.z, acc.z); acc.w = fmaf(dv.w, wv.w, acc.w);
+    }
+  reinterpret_cast<float4*>(dx)[i] = acc;
+}
+
 // dw[r,s,c] = sum_{n,oh,ow} x[n, oh*st+r-pt, ow*st+s-pl, c] * dy[n,oh,ow,c]
 // Workgroup = (channel-quad lanes) x (pixel lanes) over a slab of output pixels.  Each thread keeps a
 // float4 accumulator per tap for its 4 channels, walks its pixels (one 16-byte dy load + one 16-byte x
 // load per tap, neighbours served by L1/L2), then the pixel lanes are combined through LDS and the
 // workgroup writes partial[block][tap][c]; a second kernel adds the slabs in fixed order (double).
 constexpr int DW_MAX_TAPS = 49;
-template <int MAXT>
+// KS > 0: square KS x KS kernel, taps known at compile time, loads unconditional (see above); KS = 0: any R x S
+// up to MAXT taps, with a branch per tap.
+template <int MAXT, int KS>
 __global__ __launch_bounds__(256) void dwconv_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             DwGeom g, int cq_lanes, int pixels_per_block,
                                                             float* __restrict__ partial) {
@@ -120,17 +187,29 @@ __global__ __launch_bounds__(256) void dwconv_wgrad4_kernel(const float* __restr
         const int oh = (int)(t % g.OH);
         const int n = (int)(t / g.OH);
         const float4 d = d4[p * c4 + cq];
-        int r = 0, s = 0;
+        if (KS > 0) {
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-          if (j < taps) {
-            const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
-            if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
-              const float4 v = x4[(((long)n * g.H + ih) * g.W + iw) * c4 + cq];
-              acc[j].x = fmaf(v.x, d.x, acc[j].x); acc[j].y = fmaf(v.y, d.y, acc[j].y);
-              acc[j].z = fmaf(v.z, d.z, acc[j].z); acc[j].w = fmaf(v.w, d.w, acc[j].w);
+          for (int j = 0; j < MAXT; ++j) {
+            const int ih = oh * g.stride + j / (KS > 0 ? KS : 1) - g.pad_t, iw = ow * g.stride + j % (KS > 0 ? KS : 1) - g.pad_l;
+            const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            const float4 v = x4[ok ? (((long)n * g.H + ih) * g.W + iw) * c4 + cq : 0];
+            const float4 dm = ok ? d : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[j].x = fmaf(v.x, dm.x, acc[j].x); acc[j].y = fmaf(v.y, dm.y, acc[j].y);
+            acc[j].z = fmaf(v.z, dm.z, acc[j].z); acc[j].w = fmaf(v.w, dm.w, acc[j].w);
+          }
+        } else {
+          int r = 0, s = 0;
+#pragma unroll
+          for (int j = 0; j < MAXT; ++j) {
+            if (j < taps) {
+              const int ih = oh * g.stride + r - g.pad_t, iw = ow * g.stride + s - g.pad_l;
+              if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+                const float4 v = x4[(((long)n * g.H + ih) * g.W + iw) * c4 + cq];
+                acc[j].x = fmaf(v.x, d.x, acc[j].x); acc[j].y = fmaf(v.y, d.y, acc[j].y);
+                acc[j].z = fmaf(v.z, d.z, acc[j].z); acc[j].w = fmaf(v.w, d.w, acc[j].w);
+              }
+              if (++s == g.S) { s = 0; ++r; }
             }
-            if (++s == g.S) { s = 0; ++r; }
           }
         }
       }
@@ -317,7 +396,10 @@ extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y,
   DwGeom g;
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_fwd")) return rc;
   const long total = (long)n * oh * ow * c;
-  if ((c & 3) == 0) dwconv_fwd_kernel<4><<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, w, g, y);
+  const int grid4 = cdiv(total / 4, 256);
+  if ((c & 3) == 0 && r == s && r == 3) dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
+  else if ((c & 3) == 0 && r == s && r == 5) dwconv_fwd4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
+  else if ((c & 3) == 0) dwconv_fwd_kernel<4><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
   else dwconv_fwd_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(x, w, g, y);
   return check_launch("dwconv2d_fwd");
 }
@@ -328,7 +410,10 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
   DwGeom g;
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_dgrad")) return rc;
   const long total = (long)n * h * wd * c;
-  if ((c & 3) == 0) dwconv_dgrad_kernel<4><<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(dy, w, g, dx);
+  const int grid4 = cdiv(total / 4, 256);
+  if ((c & 3) == 0 && r == s && r == 3) dwconv_dgrad4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  else if ((c & 3) == 0 && r == s && r == 5) dwconv_dgrad4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  else if ((c & 3) == 0) dwconv_dgrad_kernel<4><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
   else dwconv_dgrad_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, w, g, dx);
   return check_launch("dwconv2d_dgrad");
 }
@@ -358,9 +443,11 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
   const int blocks = dw_wgrad_blocks((long)n * oh * ow, ppb);
   if ((c & 3) == 0) {
     int cql = 1; while (cql < c / 4 && cql < 256) cql <<= 1;
-    if (r * s <= 9) dwconv_wgrad4_kernel<9><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else if (r * s <= 25) dwconv_wgrad4_kernel<25><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else dwconv_wgrad4_kernel<49><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    if (r == 3 && s == 3) dwconv_wgrad4_kernel<9, 3><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else if (r == 5 && s == 5) dwconv_wgrad4_kernel<25, 5><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else if (r * s <= 9) dwconv_wgrad4_kernel<9, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else if (r * s <= 25) dwconv_wgrad4_kernel<25, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    else dwconv_wgrad4_kernel<49, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
   } else {
     dwconv_wgrad1_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace);
   }

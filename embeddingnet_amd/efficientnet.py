@@ -73,11 +73,11 @@ class MBConv(nn.Module):
     def forward(self, inp):
         x = inp
         if self.has_expand:
-            x = self.expand_bn(self.expand_conv(x))
+            x = self.expand_bn(self.expand_conv(x, emit_stats=self.training))   # BN sums from the conv epilogue
         x = self.bn(self.dwconv(x))
         s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(self.gap(x)))))
         x = L.channel_scale(x, s)
-        x = self.project_bn(self.project_conv(x))
+        x = self.project_bn(self.project_conv(x, emit_stats=self.training))
         if self.skip:
             if self.drop is not None:
                 x = self.drop(x)
@@ -105,4 +105,4 @@ class EfficientNet(nn.Module):
         x = self.stem_bn(self.stem_conv(x))
         for nm in self._blocks:
             x = getattr(self, nm)(x)
-        return self.top_bn(self.top_conv(x))
+        return self.top_bn(self.top_conv(x, emit_stats=self.training))
