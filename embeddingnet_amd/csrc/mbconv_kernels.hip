@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd4_sq_kernel(const float* __rest
   reinterpret_cast<float4*>(y)[i] = acc;
 }
 
-template <int KS>
+template <int KS, int ST>   // ST: stride (1 or 2), compile-time so the tap -> output-pixel map needs no division
 __global__ __launch_bounds__(256) void dwconv_dgrad4_sq_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                DwGeom g, float* __restrict__ dx) {
   const int c4 = g.C >> 2;
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_sq_kernel(const float* __re
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int th = ih + g.pad_t - r, tw = iw + g.pad_l - s;
-      const int oh = th / g.stride, ow = tw / g.stride;       // stride 1 or 2 in practice; exact when it divides
-      const bool ok = th >= 0 && tw >= 0 && oh * g.stride == th && ow * g.stride == tw && oh < g.OH && ow < g.OW;
+      const int oh = th >> (ST - 1), ow = tw >> (ST - 1);
+      const bool ok = th >= 0 && tw >= 0 && (ST == 1 || (((th | tw) & 1) == 0)) && oh < g.OH && ow < g.OW;
       const float4 dv = d4[ok ? (((long)n * g.OH + oh) * g.OW + ow) * c4 + cq : 0];
       float4 wv = w4[(r * KS + s) * c4 + cq];
       if (!ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -411,8 +411,11 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_dgrad")) return rc;
   const long total = (long)n * h * wd * c;
   const int grid4 = cdiv(total / 4, 256);
-  if ((c & 3) == 0 && r == s && r == 3) dwconv_dgrad4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else if ((c & 3) == 0 && r == s && r == 5) dwconv_dgrad4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  const bool sq = (c & 3) == 0 && r == s && (stride == 1 || stride == 2);
+  if (sq && r == 3 && stride == 1) dwconv_dgrad4_sq_kernel<3, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  else if (sq && r == 3) dwconv_dgrad4_sq_kernel<3, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  else if (sq && r == 5 && stride == 1) dwconv_dgrad4_sq_kernel<5, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
+  else if (sq && r == 5) dwconv_dgrad4_sq_kernel<5, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
   else if ((c & 3) == 0) dwconv_dgrad_kernel<4><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
   else dwconv_dgrad_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, w, g, dx);
   return check_launch("dwconv2d_dgrad");
