@@ -140,8 +140,11 @@ class ResidualUnit(nn.Module):
         # emit_stats: every conv here feeds a BatchNormalization (bn2/bn3, the next unit's bn1, the net's last bn1):
         # its epilogue also produces that BN's per-channel sums, so training reads each activation once less.
         d, st = DEFER_BN, self.training and EPILOGUE_STATS
-        a = self.bn1(x, defer=d)
-        sc = self.sc(a) if self.post else x
+        if self.post:
+            a = self.bn1(x, defer=d)
+            sc = self.sc(a)
+        else:                                            # identity shortcut: its gradient joins dx inside bn1's backward
+            a, sc = self.bn1(x, defer=d, with_skip=True)
         y = self.bn2(self.conv1(a, emit_stats=st), defer=d)
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue

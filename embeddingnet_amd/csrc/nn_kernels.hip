@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ dbeta,
                                                             const float* __restrict__ dgamma, int relu, int training,
-                                                            float* __restrict__ dx) {
+                                                            const float* __restrict__ dx_add, float* __restrict__ dx) {
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     const int q = (int)(i % c4);
@@ -165,6 +165,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       o.w = sc.w * (dz.w - db.w * inv_m - (xv.w - mu.w) * rs.w * dg.w * inv_m);
     } else {
       o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+    }
+    if (dx_add) {                                        // gradient of the tensor's other consumer (identity shortcut)
+      const float4 a = reinterpret_cast<const float4*>(dx_add)[i];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
     reinterpret_cast<float4*>(dx)[i] = o;
   }
@@ -257,19 +261,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, int relu, int training,
-                                                           float* __restrict__ dx) {
+                                                           const float* __restrict__ dx_add, float* __restrict__ dx) {
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const int col = (int)(i % c);
     const float xv = x[i];
     float dz = dy[i];
     if (relu) dz = act_grad(relu, fmaf(xv, scale[col], shift[col]), dz);
+    float o;
     if (training) {
       const float xh = (xv - mean[col]) * rstd[col];
-      dx[i] = scale[col] * (dz - dbeta[col] * inv_m - xh * dgamma[col] * inv_m);
+      o = scale[col] * (dz - dbeta[col] * inv_m - xh * dgamma[col] * inv_m);
     } else {
-      dx[i] = scale[col] * dz;       // frozen statistics: plain affine
+      o = scale[col] * dz;           // frozen statistics: plain affine
     }
+    dx[i] = dx_add ? o + dx_add[i] : o;
   }
 }
 
@@ -695,8 +701,8 @@ extern "C" int embnet_affine_act(const float* x, long m, int c, const float* sca
 
 extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
                              const float* save_rstd, const float* scale, const float* shift, int relu, int training,
-                             float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             const float* dx_add, float* dx, float* dgamma, float* dbeta, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(dy && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_bwd: m=%ld c=%d", m, c);
@@ -722,10 +728,10 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   }
   if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR"))
     bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
-                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx);
+                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx);
   else
     bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
-                                                                 scale, shift, dbeta, dgamma, relu, training, dx);
+                                                                 scale, shift, dbeta, dgamma, relu, training, dx_add, dx);
   return check_launch("bn_bwd");
 }
 

@@ -337,7 +337,8 @@ def _partials_of(x, training):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
+                with_skip=False):
         x = _c(x)
         lib = _lib.lib()
         c = x.shape[-1]
@@ -351,26 +352,31 @@ class _BatchNormFn(torch.autograd.Function):
                                           int(relu), ptr(y), stats[2].data_ptr(), stats[3].data_ptr(), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
         ctx.save_for_backward(x, stats)
+        if with_skip:                       # second output: x itself, for the identity shortcut (see backward)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
+        """dskip: gradient of the pass-through copy of x (with_skip) — folded into the dx kernel instead of a
+        separate autograd accumulation pass over the tensor."""
         x, stats = ctx.saved_tensors
         lib = _lib.lib()
         c = x.shape[-1]
         m = x.numel() // c
         dy = _c(dy)
+        dskip = _c(dskip) if dskip is not None else None
         dx = torch.empty_like(x)
         dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats[0].data_ptr() if ctx.training else None
         rstd = stats[1].data_ptr() if ctx.training else None
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, stats[2].data_ptr(), stats[3].data_ptr(),
-                                int(ctx.relu), int(ctx.training), ptr(dx), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                                ptr(ws), ws.numel() * 4, stream()))
+                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), dgb[0].data_ptr(),
+                                dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class Deferred:
@@ -428,7 +434,7 @@ class _BNDeferFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        return _BatchNormFn.backward(ctx, dy)
+        return _BatchNormFn.backward(ctx, dy)[:10]
 
 
 class BatchNormalization(nn.Module):
@@ -444,9 +450,16 @@ class BatchNormalization(nn.Module):
         self.register_buffer("moving_mean", torch.zeros(channels))
         self.register_buffer("moving_variance", torch.ones(channels))
 
-    def forward(self, x, defer=False):
+    def forward(self, x, defer=False, with_skip=False):
         """defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
-        affine + activation while gathering their input, and the normalised tensor is never written."""
+        affine + activation while gathering their input, and the normalised tensor is never written.
+        with_skip=True: returns (bn(x), x) — use the second value for the identity shortcut that also consumes x,
+        so that its gradient is added inside the BN backward kernel instead of by an autograd accumulation pass."""
+        if with_skip and not defer:
+            return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), True)
+        if with_skip:
+            return self.forward(x, defer=True), x
         if defer and x.shape[-1] % 4 == 0:
             raw, stats = _BNDeferFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                           self.momentum, self.relu, self.training, _partials_of(x, self.training))

@@ -192,9 +192,11 @@ int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
                         const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
                         float* scale, float* shift, void* stream);
+/* dx_add (NULL or [m,c]) is added to dx: the gradient that reaches x through its other consumer (the identity
+ * shortcut of a residual unit), so autograd needs no separate accumulation pass. */
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
-                  const float* scale, const float* shift, int relu, int training, float* dx, float* dgamma,
-                  float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                  const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
+                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* y = act(x*scale[c] + shift[c]) on x[m,c]: the apply half of BatchNormalization on its own (scale/shift from
  * bn_train_fwd / bn_infer_fwd with y = NULL), for a deferred BN output whose consumer cannot fuse it. */

@@ -167,6 +167,28 @@ def test_conv_epilogue_statistics_feed_batchnorm(dev, shape, k, stride):
         close(got, want.double().cpu(), 2e-5, what)
 
 
+@pytest.mark.parametrize("c", [64, 6])
+def test_batchnorm_with_skip_folds_the_shortcut_gradient(dev, c):
+    """bn(x, with_skip=True) -> (bn(x), x): the gradient arriving through the pass-through copy is added inside the
+    BN backward kernel; same result as letting autograd accumulate the two gradients of x."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn((3, 10, 11, c), device=dev)
+    w1, w2 = torch.randn_like(x), torch.randn_like(x)
+    res = []
+    for fold in (False, True):
+        bn = L.BatchNormalization(c, epsilon=2e-5, relu=True).to(dev).train()
+        xt = x.clone().requires_grad_(True)
+        if fold:
+            a, skip = bn(xt, with_skip=True)
+        else:
+            a, skip = bn(xt), xt
+        ((a * w1).sum() + (skip * w2).sum()).backward()
+        res.append((a.detach(), xt.grad, bn.gamma.grad, bn.beta.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for got, want, what in zip(res[1][1:], res[0][1:], ("dx", "dgamma", "dbeta")):
+        close(got, want.double().cpu(), 1e-6, what)
+
+
 def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib
