@@ -140,12 +140,12 @@ class ResidualUnit(nn.Module):
         # emit_stats: every conv here feeds a BatchNormalization (bn2/bn3, the next unit's bn1, the net's last bn1):
         # its epilogue also produces that BN's per-channel sums, so training reads each activation once less.
         d, st = DEFER_BN, self.training and EPILOGUE_STATS
-        if self.post:
-            a = self.bn1(x, defer=d)
-            sc = self.sc(a)
+        if self.post:                                    # projection shortcut: conv1 and sc read the same tensor
+            y1, sc = L.conv_pair(self.bn1(x, defer=d), self.conv1, self.sc, emit_stats=st)
         else:                                            # identity shortcut: its gradient joins dx inside bn1's backward
             a, sc = self.bn1(x, defer=d, with_skip=True)
-        y = self.bn2(self.conv1(a, emit_stats=st), defer=d)
+            y1 = self.conv1(a, emit_stats=st)
+        y = self.bn2(y1, defer=d)
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
         return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d), residual=sc, emit_stats=st)

@@ -178,7 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
             # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
             dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
             _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
-                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(dws), dws.numel() * 4,
+                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dws), dws.numel() * 4,
                 stream())))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
@@ -187,6 +187,100 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
         return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None
+
+
+class _ConvPairFn(torch.autograd.Function):
+    """Two bias-free linear convs on the SAME input (a residual unit's first 3x3 and its 1x1 projection shortcut).
+    One autograd node, so backward writes the input gradient once: the second data-gradient kernel adds into the
+    first one's output in its epilogue (and skips the pixels its taps never reach) instead of leaving two tensors
+    for autograd to add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1):
+        x, w1, w2 = _c(x), _c(w1), _c(w2)
+        lib = _lib.lib()
+        n, h, wd, c = x.shape
+        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
+        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        ys = []
+        for w, geom, st in ((w1, geom1, out_stats1), (w2, geom2, None)):
+            r, s, c2, k = w.shape
+            if c2 != c:
+                raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
+            stride, pt, pl, oh, ow = geom
+            y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+            ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+            _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+                ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
+                int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream())))
+            ys.append(y)
+        ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
+        ctx.save_for_backward(x, w1, w2, in_stats)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, w1, w2, in_stats = ctx.saved_tensors
+        lib = _lib.lib()
+        n, h, wd, c = x.shape
+        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
+        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dws, first = [], True
+        for w, geom, dy, need_dw in ((w1, ctx.geoms[0], dy1, ctx.needs_input_grad[1]),
+                                     (w2, ctx.geoms[1], dy2, ctx.needs_input_grad[3])):
+            if dy is None:
+                dws.append(None)
+                continue
+            dy = _c(dy)
+            r, s, _, k = w.shape
+            stride, pt, pl, oh, ow = geom
+            dims = (n, h, wd, c, r, s, k, oh, ow)
+            if dx is not None:
+                sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
+                _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
+                    ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, ptr(sc),
+                    sc.numel() * 4, stream())))
+                first = False
+            dw = None
+            if need_dw:
+                dw = torch.empty_like(w)
+                ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+                args = (ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
+                        in_scale, in_shift, ctx.in_act)
+                if TIMER is None:
+                    check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
+                else:
+                    _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_slabs_f32(*args, stream())))
+                    check(lib.embnet_conv2d_wgrad_reduce_f32(*args, stream()))
+            dws.append(dw)
+        if dx is not None and first:
+            dx.zero_()
+        return dx, dws[0], None, dws[1], None, None, None, None
+
+
+def conv_pair(x, conv1, conv2, emit_stats=False):
+    """(conv1(x), conv2(x)) for two Conv2D layers reading the same tensor (or Deferred BN output); fused into one
+    autograd node when both are plain linear convs (no bias, no activation).  emit_stats applies to conv1."""
+    if conv1.bias is not None or conv2.bias is not None or conv1.relu or conv2.relu:
+        return conv1(x, emit_stats=emit_stats), conv2(x)
+    in_stats, in_act = None, 0
+    if isinstance(x, Deferred):
+        if any(cv.kernel.shape[2] % 4 or cv.kernel.shape[3] % 4 for cv in (conv1, conv2)):
+            x = x.materialize()
+        else:
+            x, in_stats, in_act = x.raw, x.stats, x.act
+    g1, g2 = conv1.geometry(x.shape[1], x.shape[2]), conv2.geometry(x.shape[1], x.shape[2])
+    out_stats = None
+    if emit_stats:
+        r, s, c, k = conv1.kernel.shape
+        rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, g1[3], g1[4])
+        if rows > 0:
+            out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+    y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats)
+    if out_stats is not None:
+        y1._bn_partials = out_stats
+    return y1, y2
 
 
 def _colsum(x2d):

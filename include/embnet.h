@@ -146,10 +146,12 @@ int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, flo
                           int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
                           const float* residual, const float* in_scale, const float* in_shift, int in_act,
                           float* stats, void* workspace, size_t workspace_bytes, void* stream);
-/* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only). */
+/* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only).
+ * accumulate != 0: dx += instead of dx = (the input feeds two convs, e.g. a residual unit's 3x3 and its 1x1
+ * projection shortcut: the second dgrad adds in its epilogue and skips pixels no tap reaches). */
 size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride);
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
-                            int k, int stride, int pad_t, int pad_l, int oh, int ow, void* workspace,
+                            int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, void* workspace,
                             size_t workspace_bytes, void* stream);
 /* dw[r,s,c,k]; split-K slabs live in `workspace` (>= embnet_conv2d_wgrad_workspace_bytes). */
 size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);

@@ -20,3 +20,18 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_rng():
+    """Layer constructors without an explicit generator draw from torch's global RNG: pin it, so a tolerance that
+    holds for one draw holds for every run."""
+    import random
+    import numpy as np
+    import torch
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(0)

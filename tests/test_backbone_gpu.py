@@ -189,6 +189,28 @@ def test_batchnorm_with_skip_folds_the_shortcut_gradient(dev, c):
         close(got, want.double().cpu(), 1e-6, what)
 
 
+@pytest.mark.parametrize("shape,stride", [((2, 16, 16, 64, 64), 1), ((3, 15, 17, 64, 128), 2), ((8, 40, 40, 256, 128), 1),
+                                          ((2, 9, 9, 6, 10), 2)])
+def test_conv_pair_accumulates_the_input_gradient(dev, shape, stride):
+    """conv_pair(x, 3x3, 1x1 projection): one node whose backward lets the second dgrad add into the first one's
+    output (skipping pixels a strided 1x1 never touches) — same values as two separate convs + autograd's add."""
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout = shape
+    x = torch.randn((n, h, w, cin), device=dev)
+    res = []
+    for fused in (False, True):
+        gen = torch.Generator().manual_seed(9)
+        c1 = L.Conv2D(cin, cout, 3, strides=stride, padding=1, use_bias=False, gen=gen).to(dev)
+        c2 = L.Conv2D(cin, cout, 1, strides=stride, padding="valid", use_bias=False, gen=gen).to(dev)
+        xt = x.clone().requires_grad_(True)
+        y1, y2 = L.conv_pair(xt, c1, c2) if fused else (c1(xt), c2(xt))
+        (y1 * torch.cos(y1.detach()) + 0.5 * y2 * torch.sin(y2.detach() * 2)).sum().backward()
+        res.append((y1.detach(), y2.detach(), xt.grad, c1.kernel.grad, c2.kernel.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for got, want, what in zip(res[1][2:], res[0][2:], ("dx", "dW1", "dW2")):
+        close(got, want.double().cpu(), 1e-6, what)
+
+
 def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib
@@ -333,8 +355,9 @@ def test_dense_gap_add_l2(dev):
     from embeddingnet_amd import layers as L
     rs = np.random.RandomState(4)
     for m, i, o, relu in [(32, 9216, 256, True), (8, 512, 128, True), (5, 70, 33, False), (128, 12800, 512, True)]:
-        d = L.Dense(i, o, activation="relu" if relu else None).to(dev)
+        d = L.Dense(i, o, activation="relu" if relu else None, gen=torch.Generator().manual_seed(i + o)).to(dev)
         x = rs.randn(m, i).astype(np.float32)
+        tol = 2e-5 * max(1.0, (i / 2048) ** 0.5)            # k-ordered f32 chains of length `in` vs f64
         xt = g(x, dev).requires_grad_(True)
         y = d(xt)
         wr = d.kernel.detach().cpu().double().requires_grad_(True)
@@ -343,13 +366,13 @@ def test_dense_gap_add_l2(dev):
         yr = xr @ wr + br
         if relu:
             yr = torch.relu(yr)
-        close(y, yr, 2e-5, "dense fwd")
+        close(y, yr, tol, "dense fwd")
         dy = rs.randn(m, o).astype(np.float32)
         y.backward(g(dy, dev))
         yr.backward(torch.tensor(dy, dtype=torch.float64))
-        close(xt.grad, xr.grad, 2e-5, "dense dx")
-        close(d.kernel.grad, wr.grad, 2e-5, "dense dw")
-        close(d.bias.grad, br.grad, 2e-5, "dense db")
+        close(xt.grad, xr.grad, tol, "dense dx")
+        close(d.kernel.grad, wr.grad, tol, "dense dw")
+        close(d.bias.grad, br.grad, tol, "dense db")
     x = rs.randn(4, 7, 7, 96).astype(np.float32)
     xt = g(x, dev).requires_grad_(True)
     y = L.GlobalAveragePooling2D()(xt)
