@@ -256,18 +256,27 @@ __global__ __launch_bounds__(256) void dwconv_wgrad1_kernel(const float* __restr
     }
 }
 
-// out[i] = sum_b partial[b][i]: 64 outputs x 4 slab lanes per workgroup, double accumulation, fixed order
+// out[i] = sum_b partial[b][i]: 16 outputs x 16 slab groups per workgroup (slab b goes to group b % 16, two
+// independent double accumulators per thread), groups combined through LDS in a fixed tree.  With up to 2048 slabs
+// a 4-group walk kept one thread on 512 dependent loads (62 us per layer on EfficientNet-B0); bitwise reproducible.
 __global__ __launch_bounds__(256) void dw_slab_sum_kernel(const float* __restrict__ partial, int blocks, long n,
                                                           float* __restrict__ out) {
   __shared__ double sh[256];
-  const int ol = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + ol;
-  double s = 0.0;
-  if (i < n)
-    for (int b = bl; b < blocks; b += 4) s += (double)partial[(long)b * n + i];
-  sh[threadIdx.x] = s;
+  const int ol = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + ol;
+  double s0 = 0.0, s1 = 0.0;
+  if (i < n) {
+    int b = bl;
+    for (; b + 16 < blocks; b += 32) { s0 += (double)partial[(long)b * n + i]; s1 += (double)partial[(long)(b + 16) * n + i]; }
+    if (b < blocks) s0 += (double)partial[(long)b * n + i];
+  }
+  sh[threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (bl == 0 && i < n) out[i] = (float)(sh[ol] + sh[64 + ol] + sh[128 + ol] + sh[192 + ol]);
+  for (int g = 8; g >= 1; g >>= 1) {
+    if (bl < g) sh[threadIdx.x] += sh[threadIdx.x + g * 16];
+    __syncthreads();
+  }
+  if (bl == 0 && i < n) out[i] = (float)sh[ol];
 }
 
 // ---- activations ------------------------------------------------------------------------------
@@ -455,7 +464,7 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
     dwconv_wgrad1_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace);
   }
   const long cnt = (long)r * s * c;
-  dw_slab_sum_kernel<<<cdiv(cnt, 64), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw);
+  dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw);
   return check_launch("dwconv2d_wgrad");
 }
 
