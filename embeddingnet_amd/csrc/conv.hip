@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) { conv_f
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   tail_decode<G>(p.tail, blockIdx.x, (Kg + BK - 1) / BK, id, k0, k1, part);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
   if (m0 >= M) return;                                   // classes differ in size by a row/column
-  if (Kg == 0 && p.accumulate) return;                   // a class no tap reaches adds nothing (1x1 stride-2: 3 of 4)
+  if (Kg == 0 && p.accumulate && p.add_src == p.dx) return;   // a class no tap reaches adds nothing (1x1 stride-2: 3 of 4)
   LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, cg, m0, threadIdx.x);
   LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
         uint32_t n, rem, hc, wc;
         cg.dHWc.divmod((uint32_t)row, n, rem); cg.dWc.divmod(rem, hc, wc);
         const long base = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
-        if (p.accumulate) {                                // dx already holds the gradient through another conv
-          const float4 o = *reinterpret_cast<const float4*>(p.dx + base + col);
+        if (p.accumulate) {                                // the gradient through the tensor's other consumer (in dx or apart)
+          const float4 o = *reinterpret_cast<const float4*>(p.add_src + base + col);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         *reinterpret_cast<float4*>(p.dx + base + col) = v;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
       cg.dHWc.divmod((uint32_t)min(row, M - 1), n, rem); cg.dWc.divmod(rem, hc, wc);
       row_base = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
     }
-    if (row < M && col < p.g.C) p.dx[row_base + col] = p.accumulate ? p.dx[row_base + col] + v : v;
+    if (row < M && col < p.g.C) p.dx[row_base + col] = p.accumulate ? p.add_src[row_base + col] + v : v;
   });
 }
 
@@ -707,10 +707,13 @@ extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int 
 
 extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
                                        int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
-                                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                                       int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dx) && aligned16(workspace), "conv2d_dgrad: output and workspace must be 16-byte aligned");
-  ConvDgradParams p{dy, w, dx, {}, {}, {}, accumulate != 0};
+  EMBNET_CHECK_ARG(!(accumulate && dx_add), "conv2d_dgrad: accumulate (into dx) or dx_add (another tensor), not both");
+  EMBNET_CHECK_ARG(aligned16(dx_add), "conv2d_dgrad: dx_add must be 16-byte aligned");
+  ConvDgradParams p{dy, w, dx, {}, {}, {}, (accumulate != 0 || dx_add) ? 1 : 0, dx_add ? dx_add : dx};
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
   EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
   long max_m = 0;
@@ -745,7 +748,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
     tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
-                                                             cdiv(c, bn), max_m, c, nullptr, 0, accumulate ? dx : nullptr, dx, nullptr, 0);
+                                                             cdiv(c, bn), max_m, c, nullptr, 0, p.accumulate ? p.add_src : nullptr, dx, nullptr, 0);
   }
   return check_launch("conv2d_dgrad");
 }

@@ -73,7 +73,13 @@ class MBConv(nn.Module):
     def forward(self, inp):
         x = inp
         if self.has_expand:
-            x = self.expand_bn(self.expand_conv(x, emit_stats=self.training))   # BN sums from the conv epilogue
+            # skip blocks: the block input feeds the expand conv and the final Add; with_skip folds the Add's gradient
+            # into the expand conv's data-gradient epilogue
+            if self.skip:
+                x, inp = self.expand_conv(x, emit_stats=self.training, with_skip=True)
+            else:
+                x = self.expand_conv(x, emit_stats=self.training)           # BN sums from the conv epilogue
+            x = self.expand_bn(x)
         x = self.bn(self.dwconv(x))
         s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(self.gap(x)))))
         x = L.channel_scale(x, s)

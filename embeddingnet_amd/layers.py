@@ -107,7 +107,7 @@ def same_pad(n, k, s):
 # ----------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None):
+    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False):
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
@@ -133,16 +133,20 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
         ctx.save_for_backward(x, w, y if relu else None, in_stats)
+        if with_skip:                       # second output: x itself, for a skip connection (see backward)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
+        """dskip: gradient of the pass-through copy of x (with_skip) — added in the data-gradient epilogue."""
         x, w, y, in_stats = ctx.saved_tensors
         lib = _lib.lib()
         n, h, wd, c = x.shape
         r, s, _, k = w.shape
         stride, pt, pl, oh, ow = ctx.geom
         dy = _c(dy)
+        dskip = _c(dskip) if dskip is not None else None
         if ctx.relu:
             dz = torch.empty_like(dy)
             check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
@@ -178,15 +182,17 @@ class _Conv2dFn(torch.autograd.Function):
             # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
             dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
             _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
-                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dws), dws.numel() * 4,
-                stream())))
+                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
+                dws.numel() * 4, stream())))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
             run_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dz.view(-1, k))
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None
+        if dskip is not None and dx is None and ctx.needs_input_grad[0]:
+            dx = dskip
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -239,8 +245,8 @@ class _ConvPairFn(torch.autograd.Function):
             if dx is not None:
                 sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
                 _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
-                    ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, ptr(sc),
-                    sc.numel() * 4, stream())))
+                    ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
+                    ptr(sc), sc.numel() * 4, stream())))
                 first = False
             dw = None
             if need_dw:
@@ -334,8 +340,10 @@ class Conv2D(nn.Module):
             raise _lib.EmbnetError(f"Conv2D {k}x{k}/{s} '{self.padding}' does not fit a {h}x{w} input")
         return (s, pt, pl, oh, ow)
 
-    def forward(self, x, residual=None, emit_stats=False):
+    def forward(self, x, residual=None, emit_stats=False, with_skip=False):
         """residual: the other input of the Add layer that follows this conv (added in the conv epilogue).
+        with_skip=True: returns (conv(x), x) — use the second value for the skip connection that also consumes x; its
+        gradient is then added in this conv's data-gradient epilogue instead of by an autograd accumulation pass.
         x may be a Deferred BatchNormalization output: the conv then applies the BN affine + activation itself.
         emit_stats: a training-mode BatchNormalization reads this output next — the conv epilogue produces its
         per-channel sums while the tiles are in registers (attached to the result as `_bn_partials`)."""
@@ -352,10 +360,11 @@ class Conv2D(nn.Module):
             rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
             if rows > 0:
                 out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
-        y = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats)
+        out = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip)
+        y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
-        return y
+        return (y, out[1]) if with_skip else y
 
 
 # ----------------------------------------------------------------------------- dense

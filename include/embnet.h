@@ -148,11 +148,12 @@ int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, flo
                           float* stats, void* workspace, size_t workspace_bytes, void* stream);
 /* dx[n,h,w,c] from dy[n,oh,ow,k] (gradient w.r.t. the conv input).  workspace as for fwd (stride 1 only).
  * accumulate != 0: dx += instead of dx = (the input feeds two convs, e.g. a residual unit's 3x3 and its 1x1
- * projection shortcut: the second dgrad adds in its epilogue and skips pixels no tap reaches). */
+ * projection shortcut: the second dgrad adds in its epilogue and skips pixels no tap reaches).
+ * dx_add (NULL or [n,h,w,c]): dx = result + dx_add — the gradient reaching x through a skip connection. */
 size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride);
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
-                            int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, const float* dx_add,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* dw[r,s,c,k]; split-K slabs live in `workspace` (>= embnet_conv2d_wgrad_workspace_bytes). */
 size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,

@@ -211,6 +211,28 @@ def test_conv_pair_accumulates_the_input_gradient(dev, shape, stride):
         close(got, want.double().cpu(), 1e-6, what)
 
 
+@pytest.mark.parametrize("shape,k,stride", [((2, 16, 16, 64, 64), 1, 1), ((8, 40, 40, 256, 128), 3, 1), ((2, 9, 9, 6, 10), 3, 1),
+                                            ((3, 15, 17, 64, 128), 3, 2)])
+def test_conv_with_skip_folds_the_skip_gradient(dev, shape, k, stride):
+    """conv(x, with_skip=True) -> (conv(x), x): the gradient of the pass-through copy is added in the data-gradient
+    epilogue (whole tiles, K-split tiles, scalar path, strided classes); same as autograd's own accumulation."""
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout = shape
+    x = torch.randn((n, h, w, cin), device=dev)
+    w2 = torch.randn_like(x)
+    res = []
+    for fold in (False, True):
+        gen = torch.Generator().manual_seed(13)
+        conv = L.Conv2D(cin, cout, k, strides=stride, padding=k // 2, use_bias=False, gen=gen).to(dev)
+        xt = x.clone().requires_grad_(True)
+        y, skip = conv(xt, with_skip=True) if fold else (conv(xt), xt)
+        ((y * torch.cos(y.detach())).sum() + (skip * w2).sum()).backward()
+        res.append((y.detach(), xt.grad, conv.kernel.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    close(res[1][1], res[0][1].double().cpu(), 1e-6, "dx")
+    close(res[1][2], res[0][2].double().cpu(), 1e-6, "dW")
+
+
 def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib

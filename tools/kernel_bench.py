@@ -126,7 +126,7 @@ def conv_bench(args):
             "fwd": lambda: check(lib.embnet_conv2d_fwd_f32(ptr(x), ptr(wt), None, ptr(y), n, h, w, c, ks, ks, k, st, pad, pad,
                                                            oh, ow, 0, None, None, None, 0, None, ptr(tws), tws.numel() * 4, stream())),
             "dgrad": lambda: check(lib.embnet_conv2d_dgrad_f32(ptr(dy), ptr(wt), ptr(dx), n, h, w, c, ks, ks, k, st, pad, pad,
-                                                               oh, ow, 0, ptr(tws), tws.numel() * 4, stream())),
+                                                               oh, ow, 0, None, ptr(tws), tws.numel() * 4, stream())),
             "wgrad": lambda: check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, w, c,
                                                                ks, ks, k, st, pad, pad, oh, ow, None, None, 0, stream())),
         }
