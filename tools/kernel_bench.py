@@ -139,9 +139,35 @@ def conv_bench(args):
         print(line, flush=True)
 
 
+def libcmp_bench(args):
+    """Vendor-library reference points for the same shapes (measurement only; nothing in the product path calls
+    them): rocBLAS/hipBLASLt fp32 GEMM through torch.matmul and MIOpen fp32 convolutions through torch (NHWC)."""
+    dev = torch.device("cuda:0")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    for n, e in [(16384, 256), (16384, 512), (16384, 4096), (4096, 4096)]:
+        x = torch.rand((n, e), device=dev)
+        t = timeit(lambda: torch.matmul(x, x.t()), iters=args.iters)
+        print(f"torch.matmul fp32  N={n} E={e}: {t * 1e6:9.1f} us {2.0 * n * n * e / t / 1e12:6.1f} TF/s", flush=True)
+    for (n, h, w, c, ks, k, st, pad) in RN18[1:]:
+        x = torch.randn((n, c, h, w), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        conv = torch.nn.Conv2d(c, k, ks, stride=st, padding=pad, bias=False).to(dev).to(memory_format=torch.channels_last)
+        y = conv(x)
+        dy = torch.randn_like(y)
+        flop = 2.0 * n * y.shape[2] * y.shape[3] * k * ks * ks * c
+        tf = timeit(lambda: conv(x), iters=args.iters)
+
+        def fb():
+            x.grad = None; conv.weight.grad = None
+            conv(x).backward(dy)
+        tfb = timeit(fb, iters=args.iters)
+        print(f"MIOpen fp32 n{n} {h}x{w}x{c} k{ks} s{st} -> {k}:  fwd {tf * 1e6:8.1f} us {flop / tf / 1e12:6.1f} TF/s | "
+              f"fwd+bwd {tfb * 1e6:8.1f} us {3 * flop / tfb / 1e12:6.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "conv", "losspath"])
+    ap.add_argument("what", choices=["gemm", "conv", "losspath", "libcmp"])
     ap.add_argument("--n", type=int, nargs="+", default=[128, 256, 1024, 4096, 16384])
     ap.add_argument("--e", type=int, nargs="+", default=[256, 512, 4096])
     ap.add_argument("--iters", type=int, default=20)
@@ -149,4 +175,4 @@ if __name__ == "__main__":
     ap.add_argument("--shape", default=None)
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
-    {"gemm": gemm_sweep, "conv": conv_bench, "losspath": losspath_bench}[a.what](a)
+    {"gemm": gemm_sweep, "conv": conv_bench, "losspath": losspath_bench, "libcmp": libcmp_bench}[a.what](a)
