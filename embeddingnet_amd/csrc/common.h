@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace embnet {
 
@@ -28,6 +29,9 @@ inline int check_launch(const char* what) {
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// tuning knobs: read once per process (each call site keeps its own `static const`)
+inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 
 // ---- device helpers ------------------------------------------------------
 constexpr int WAVE = 64;

@@ -595,7 +595,8 @@ using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
 static int pick_tile(long m, int ncols) {
-  if (const char* e = getenv("EMBNET_CONV_TILE")) return atoi(e);      // tuning aid (tools/kernel_bench.py)
+  static const int forced = (int)env_long("EMBNET_CONV_TILE", -1);    // tuning aid (tools/kernel_bench.py)
+  if (forced >= 0) return forced;
   // Measured on ResNet18 shapes (tools/kernel_bench.py, EMBNET_CONV_TILE sweep): workgroups all take the
   // same time, so what matters is how evenly the grid fills the 256 CUs x (3..6 resident workgroups);
   // 128x64 wins once it gives >= 4 workgroups per CU, 64x64 below that, 128x128 only for many rounds.
@@ -612,7 +613,7 @@ static constexpr int NUM_CUS = 256;
 static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, SplitTail& t, size_t* need = nullptr) {
   t.n_full = (int)tiles; t.parts = 1; t.kt_part = kt; t.ws = nullptr;
   if (need) *need = 0;
-  static const int knob = getenv("EMBNET_CONV_TAIL") ? atoi(getenv("EMBNET_CONV_TAIL")) : 1;
+  static const int knob = (int)env_long("EMBNET_CONV_TAIL", 1);
   const int rem = (int)(tiles % NUM_CUS);
   if (!knob || rem == 0 || tiles < NUM_CUS) return;
   const double t_tile = (double)kt * bm * bn * BK * 2.0 / (0.85 * 146e12 / NUM_CUS);        // seconds
@@ -757,13 +758,15 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
 static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
   tile = (rows <= 64 && k <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
   // 128-row tiles waste the last half tile of a 576-row (3x3x64) gradient; 192-row tiles fit it exactly
-  if (tile == 1 && rows % 192 == 0 && rows % 128 != 0 && !getenv("EMBNET_WGRAD_NO192")) tile = 4;
+  static const bool no192 = env_long("EMBNET_WGRAD_NO192", 0) != 0;
+  if (tile == 1 && rows % 192 == 0 && rows % 128 != 0 && !no192) tile = 4;
   const long tiles = (long)cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
   // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
   // workgroups per CU is best; with many tiles shorter K ranges in 2-3 rounds balance better
   long target = tiles >= 100 ? 2048 : (tiles >= 30 ? 1536 : 768);
-  if (const char* e = getenv("EMBNET_WGRAD_BLOCKS")) target = atol(e);
+  static const long forced_blocks = env_long("EMBNET_WGRAD_BLOCKS", 0);
+  if (forced_blocks > 0) target = forced_blocks;
   long want = (target + tiles - 1) / tiles;
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split
   if (want < 1) want = 1;
@@ -794,7 +797,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
-  if (const char* e = getenv("EMBNET_WGRAD_XCD")) p.xcd_order = atoi(e);
+  static const int xcd_order = (int)env_long("EMBNET_WGRAD_XCD", 0);
+  p.xcd_order = xcd_order;
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_wgrad")) return rc;
   int tile;
   const int rows = r * s * c;

@@ -10,6 +10,8 @@
 
 namespace embnet {
 
+static bool bn_scalar() { static const bool v = env_long("EMBNET_BN_SCALAR", 0) != 0; return v; }   // A/B knob
+
 // ---------------------------------------------------------------- column reductions over [M, C]
 // Layout of a 256-thread workgroup: cl channel lanes x rl row lanes (cl*rl = 256, cl a power of 2),
 // consecutive threads on consecutive channels -> coalesced rows.  Each workgroup reduces a slab of
@@ -667,7 +669,7 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   if (partial_in) {                         // sum / sum-of-squares partials [2][c][rows] already produced (conv epilogue)
     EMBNET_CHECK_ARG(partial_rows > 0, "bn_train_fwd: partial_rows=%d", partial_rows);
     partial = partial_in; nblocks = partial_rows;
-  } else if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
+  } else if ((c & 3) == 0 && !bn_scalar()) {
     const ColGeom g4 = col_geom(m, c / 4);
     nblocks = g4.blocks;
     bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, (float*)workspace);
@@ -714,7 +716,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   // We only support parameter gradients in training mode; frozen BN returns dgamma = dbeta sums with xhat from
   // save_mean/save_rstd when given, else zeros.
   if (save_mean && save_rstd) {
-    if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR")) {
+    if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);
       bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial);
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
@@ -726,7 +728,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
-  if ((c & 3) == 0 && !getenv("EMBNET_BN_SCALAR"))
+  if ((c & 3) == 0 && !bn_scalar())
     bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
                                                                       save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx);
   else
