@@ -76,9 +76,15 @@ struct TileKC {
   }
 };
 
+// Row pitch of the k-major tile: ROWS + 8 floats.  With a pitch of ROWS (a multiple of 64 floats) the two lane halves
+// of a fragment read (k rows 4 apart) land on the same LDS banks: a plain GEMM with a k-major B operand ran 101 TFLOP/s
+// at n = 4096 against 116 with the pad (both operands k-major: 109 -> 134); the conv kernels do not care (+-1 %).
+#ifndef EMBNET_KM_PAD
+#define EMBNET_KM_PAD 8
+#endif
 template <int ROWS>
 struct TileKM {
-  static constexpr int LD = ROWS;
+  static constexpr int LD = ROWS + EMBNET_KM_PAD;
   static constexpr int FLOATS = BK * LD;
   static constexpr int PASSES = BK * (ROWS / 4) / NTHREADS;
   static_assert(PASSES >= 1, "tile too small for 256 threads");
