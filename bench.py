@@ -59,7 +59,7 @@ def cpu_baseline(args):
     ref.step(x, rng=np.random.RandomState(0))                    # warm-up (allocator, thread pool)
     t0, n, trip = time.perf_counter(), 0, 0
     while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
-        _, t = ref.step(x, rng=np.random.RandomState(n))
+        _, t, _ = ref.step(x, rng=np.random.RandomState(n))
         n += 1
         trip += t
     dt = (time.perf_counter() - t0) / n

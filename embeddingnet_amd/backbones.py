@@ -243,9 +243,13 @@ def get_backbone(input_shape,
                 warnings.warn(f"backbone_weights='{backbone_weights}': pretrained weight sets are not bundled "
                               "(no network); the backbone is randomly initialised")
         if freeze_backbone:
-            # reference freezes backbone_model.layers[:-2]; the last two layers (final BN + ReLU) stay trainable
+            # reference :106-108 sets trainable=False on backbone_model.layers[:-2]; the last two layers (final BN +
+            # its activation) stay trainable.  A frozen Keras BatchNormalization also runs in inference mode.
             last_bn = getattr(backbone, "bn1", None) or getattr(backbone, "top_bn", None)
             tail = {id(p) for p in last_bn.parameters()} if last_bn is not None else set()
+            for m in backbone.modules():
+                if isinstance(m, L.BatchNormalization) and m is not last_bn:
+                    m.freeze()
             for p in backbone.parameters():
                 if id(p) not in tail:
                     p.requires_grad_(False)

@@ -278,7 +278,7 @@ constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA
 // fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
 struct SplitTail { int n_full, parts, kt_part; float* ws; };
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; float* stats; int stats_rows; };
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; float* stats; int stats_rows; int fair_from; };
 
 // Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
 template <class G>
@@ -361,16 +361,20 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int M = p.g.N * p.g.OH * p.g.OW, Kg = p.g.R * p.g.S * p.g.C;
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
   int id, k0, k1; float* part;
   tail_decode<G>(p.tail, blockIdx.x, (Kg + BK - 1) / BK, id, k0, k1, part);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
+  stamp(0);
   LoadConvFwdA<G::BM, VEC, TF> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
-  if (part) { store_partial<G>(acc, smem, part); return; }
+  stamp(2);
+  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  stamp(4);
+  if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;  // this lane's column quad: sum, sum of squares over its rows
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
@@ -403,6 +407,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
         d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
       }
     }
+    stamp(5);
     return;
   }
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -422,13 +427,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) { conv_f
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const DgradClass& cg = p.cls[blockIdx.y];
   const int M = p.g.N * cg.Hc * cg.Wc, Kg = cg.nR * cg.nS * p.g.K;
   const int tiles_n = (p.g.C + G::BN - 1) / G::BN;
@@ -437,11 +443,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
   if (m0 >= M) return;                                   // classes differ in size by a row/column
   if (Kg == 0 && p.accumulate && p.add_src == p.dx) return;   // a class no tap reaches adds nothing (1x1 stride-2: 3 of 4)
+  stamp(0);
   LoadConvDgradA<G::BM, VEC> la; la.init(p.dy, p.g, cg, m0, threadIdx.x);
   LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc);
-  if (part) { store_partial<G>(acc, smem, part); return; }
+  stamp(2);
+  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
+  stamp(4);
+  if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   const int st = p.g.stride;
   if ((p.g.C & 3) == 0) {                                // 16-byte row stores
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
@@ -457,6 +466,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
         *reinterpret_cast<float4*>(p.dx + base + col) = v;
       }
     });
+    stamp(5);
     return;
   }
   int last_r = -1; long row_base = 0;
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   });
 }
 
-struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; };
+struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; };
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
 template <class G, bool VA, bool VB, bool TF>
@@ -480,6 +490,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int M = p.g.R * p.g.S * p.g.C, Kg = p.g.N * p.g.OH * p.g.OW;
   const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
   // Two workgroup orders (speed only; results identical).  Default: tiles of one K-split on consecutive
@@ -495,16 +506,20 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   const int m0 = (tile / tiles_n) * G::BM, n0 = (tile % tiles_n) * G::BN;
   const int kt_total = (Kg + BK - 1) / BK;
   const int kt0 = split * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
+  stamp(0);
   LoadConvWgradA<G::BM, VA, TF> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
   LoadRowsKM<G::BN, VB> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
+  stamp(2);
+  gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  stamp(4);
   float* out = p.out + (long)split * M * p.g.K;
   if (VB) {                                              // K % 4 == 0
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
       const int row = m0 + r, col = n0 + c;
       if (row < M && col < p.g.K) *reinterpret_cast<float4*>(out + (long)row * p.g.K + col) = v;
     });
+    stamp(5);
     return;
   }
   for_each_acc<G>(acc, [&](int r, int c, float v) {
@@ -569,6 +584,14 @@ using namespace embnet;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#if EMBNET_STAMPS
+// diagnostic build only (not in include/embnet.h): point the conv kernels' stamp() at a device buffer of
+// 8 x uint64 per workgroup (NULL = off)
+extern "C" int embnet_debug_set_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(embnet::g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 static int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int k, int stride, int pad_t,
                      int pad_l, int oh, int ow, const char* who) {
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && r > 0 && s > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0,
@@ -605,6 +628,21 @@ static int pick_tile(long m, int ncols) {
   return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
 }
 static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
+// workgroups of each tile type a CU holds at once (registers / LDS; measured with in-kernel stamps)
+static const int TILE_RESIDENT[5] = {3, 4, 5, 7, 3};
+// Progress-ordered priority (gemm_engine.h: `fair`) for launches whose workgroups are all resident at once.  Measured
+// A/B, one process (tools/exp/ab_conv.py, ResNet18 layers at batch 128): 64x64-tile forward / data-gradient launches
+// that fit one round +1..+3 % (7 waves per SIMD end together instead of one after the other), split-K weight-gradient
+// launches +1 % in sum; 128x64 tiles (4 per CU) 7 % SLOWER when forced into lock-step, and any multi-round launch
+// slower (the last round's high-priority newcomers starve the round before).  Returns the first "fair" workgroup id.
+#ifndef EMBNET_FAIR_DEFAULT
+#define EMBNET_FAIR_DEFAULT 1
+#endif
+static int fair_from(long grid, int tile, bool wgrad) {
+  static const int knob = (int)env_long("EMBNET_FAIR_SINGLE_ROUND", EMBNET_FAIR_DEFAULT);
+  const bool single_round = grid <= 256L * TILE_RESIDENT[tile];
+  return (knob && single_round && (wgrad || tile == 3)) ? 0 : 0x7fffffff;
+}
 
 // Plan the remainder split for `tiles` output tiles of bm x bn with kt K-tiles each (see SplitTail).
 // Model: a CU retires one tile per t_tile; whole tiles cost ceil(tiles/256) of those, the split costs
@@ -685,6 +723,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   plan_tail(tiles, cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile], (vec && workspace) ? workspace_bytes : 0, p.tail);
   p.tail.ws = (float*)workspace;
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
+  p.fair_from = fair_from(grid, tile, false);
   if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
   else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
@@ -744,6 +783,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
             can_split ? workspace_bytes : 0, p.tail);
   p.tail.ws = (float*)workspace;
   const dim3 grid(p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts, stride * stride);
+  p.fair_from = fair_from((long)grid.x * grid.y, tile, false);
   if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
   else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
   if (p.tail.parts > 1) {
@@ -809,6 +849,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   if (p.splits > 1) p.out = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
+  p.fair_from = fair_from(grid.x, tile, true);
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
   EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_wgrad: in_scale and in_shift go together");
   EMBNET_CHECK_ARG(!in_scale || (va && vb && aligned16(in_scale) && aligned16(in_shift)),

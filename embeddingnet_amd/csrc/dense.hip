@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseParams p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKM<G::BM, VEC> la; la.init(p.a, p.m, p.m, p.k, m0, threadIdx.x);

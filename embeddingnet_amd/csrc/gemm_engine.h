@@ -36,6 +36,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
+
+// In-kernel time stamps (diagnostic build only: -DEMBNET_STAMPS=1, tools/exp/conv_timeline.py).  The product
+// build compiles every stamp() to nothing.  Slots per workgroup: 0 entry (s_memtime), 1 entry (s_memrealtime,
+// 100 MHz, chip-wide), 2 loaders initialised, 3 first K tile in LDS (first MFMA can issue), 4 main loop done,
+// 5 exit (s_memtime), 6 exit (s_memrealtime), 7 HW_ID | XCC_ID << 32, 8 first loads issued, 9 first tile written to
+// LDS (loads landed), 10..15 free.  16 x uint64 per workgroup, in a buffer of their own.
+#ifndef EMBNET_STAMPS
+#define EMBNET_STAMPS 0
+#endif
+#if EMBNET_STAMPS
+static __device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int slot) {
+  if (threadIdx.x != 0 || !g_stamps) return;
+  unsigned long long* d = g_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+  d[slot] = __builtin_amdgcn_s_memtime();
+  if (slot == 0 || slot == 5) d[slot + 1] = __builtin_amdgcn_s_memrealtime();
+  if (slot == 0) d[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+}
+#else
+__device__ __forceinline__ void stamp(int) {}
+#endif
 constexpr unsigned OOB = 0x80000000u;          // byte offset no operand (< 2 GiB) reaches
 constexpr size_t MAX_OPERAND_BYTES = 0x7FFFFFF0ull;
 
@@ -196,6 +218,24 @@ __device__ __forceinline__ void load_frags(const float* st, int wm, int wn, int 
 #ifndef EMBNET_SETPRIO
 #define EMBNET_SETPRIO 0
 #endif
+// Issue priority by phase.  A workgroup that starts on a CU whose other slots are in their main loops is the
+// youngest wave on each SIMD and gets the left-over issue slots: its prologue (tile decode, first loads) ran 3x
+// longer than on an idle CU (16-22k cycles vs 5k, in-kernel stamps: tools/exp/conv_timeline.py) and its epilogue
+// likewise, during which its slot does no matrix work.  Prologue and epilogue therefore run at priority 3, the
+// main loop at 0: the few hundred vector instructions they hold barely touch the older waves' MFMA stream.
+#ifndef EMBNET_PHASE_PRIO
+#define EMBNET_PHASE_PRIO 1
+#endif
+__device__ __forceinline__ void prio_hi() {
+#if EMBNET_PHASE_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void prio_lo() {
+#if EMBNET_PHASE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
 #ifndef EMBNET_PIN
 #define EMBNET_PIN 0
 #endif
@@ -238,9 +278,14 @@ __device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const floa
 //     first fragments of the next stage are read under step 3's MFMAs.
 // A wave therefore has no point where it waits on LDS or memory with the matrix pipe empty, so the
 // loop does not depend on other workgroups to fill its gaps (few-tile layers run 1-2 waves per SIMD).
+// `fair` (wave-uniform): lower this wave's issue priority as it progresses through its K range (3, 2, 1, 0 by
+// quarter) instead of running the loop at 0.  The SIMD arbitrates oldest-first, so workgroups that start together
+// finish one after the other (4 co-resident 128x64 tiles: 68, 78, 91, 105 us) — fine while new workgroups keep
+// arriving, but in the LAST round of a launch the CU ends up with 3, 2, 1 waves per SIMD and an under-fed matrix
+// pipe.  Progress-ordered priority lets the waves that are behind catch up, so the last round ends together.
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end,
-                                              float* smem, f32x16 (&acc)[G::TM][G::TN]) {
+                                              float* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
@@ -297,11 +342,27 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
   } else {
     float* sA = smem;
     if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); }
+    stamp(8);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       __syncthreads();                       // everyone finished reading the previous tile
       TA::store(sA, ra, tid);
       TB::store(sA + TA::FLOATS, rb, tid);
+#if EMBNET_STAMPS
+      if (kt == kt_begin) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(9); }     // lgkmcnt(0): the LDS writes (hence the loads) are done
+#endif
       __syncthreads();
+#if EMBNET_PHASE_PRIO
+      if (!fair) prio_lo();
+      else {
+        const int done = 4 * (kt - kt_begin), span = kt_end - kt_begin;
+        if (done >= 3 * span) __builtin_amdgcn_s_setprio(0);
+        else if (done >= 2 * span) __builtin_amdgcn_s_setprio(1);
+        else if (done >= span) __builtin_amdgcn_s_setprio(2);
+      }
+#endif
+#if EMBNET_STAMPS
+      if (kt == kt_begin) stamp(3);
+#endif
       // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
       // offset out of range, so the loads return zeros and need no branch
       la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
@@ -316,6 +377,7 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
       // overlaps with and outside the barrier pair, not between the barrier and the LDS store
       la.fix(ra); lb.fix(rb);
     }
+    prio_hi();                               // epilogue
   }
 }
 

@@ -31,15 +31,19 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int tiles_m = (p.n + G::BM - 1) / G::BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (id / tiles_n) * G::BM, n0 = (id % tiles_n) * G::BN;
 
+  stamp(0);
   LoadRowsKC<G::BM, VEC> la; la.init(p.x, p.e, p.n, p.e, m0, threadIdx.x);
   LoadRowsKC<G::BN, VEC> lb; lb.init(p.x, p.e, p.n, p.e, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
+  stamp(2);
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.e + BK - 1) / BK, smem, acc);
+  stamp(4);
 
   if ((p.n & 3) == 0) {                                  // 16-byte row stores of the matrix
     for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 g) {
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
         *reinterpret_cast<float4*>(p.d + (long)row * p.n + col) = make_float4(o[0], o[1], o[2], o[3]);
       }
     });
+    stamp(5);
     return;
   }
   for_each_acc<G>(acc, [&](int r, int c, float g) {
@@ -69,6 +74,12 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
 }  // namespace embnet
 
 using namespace embnet;
+
+#if EMBNET_STAMPS
+extern "C" int embnet_debug_set_stamps_pairwise(void* buf) {      // diagnostic build only (gemm_engine.h: stamp())
+  return hipMemcpyToSymbol(HIP_SYMBOL(embnet::g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t embnet_pairwise_workspace_bytes(int n) { return n > 0 ? (size_t)n * sizeof(float) : 0; }
 
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256) void cross_dist_kernel(CrossParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>];
+  prio_hi();                                             // prologue at raised issue priority (gemm_engine.h)
   const int tiles_n = (p.n + G::BN - 1) / G::BN;
   const int m0 = (blockIdx.x / tiles_n) * G::BM, n0 = (blockIdx.x % tiles_n) * G::BN;
   LoadRowsKC<G::BM, VEC> la; la.init(p.q, p.e, p.nq, p.e, m0, threadIdx.x);

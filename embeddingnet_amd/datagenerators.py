@@ -155,9 +155,14 @@ class TripletsDataGenerator(ENDataGenerator):
 
     def get_batch_triplets_mining(self):
         """reference :201-258 with the embedding / distance / mining work on the GPU."""
-        images = self.sample_batch()
+        return self.mine_batch(self.sample_batch())
+
+    def mine_batch(self, images):
+        """reference :211-258 on a given class-contiguous batch [P*K,H,W,3] (NumPy or device tensor): predict() ->
+        distance matrix -> negative selection -> ([A,P,N], ones[T]).  The mined row indices stay in
+        `self.last_triplets` (int64 [T,3], device)."""
         dev = next(self.embedding_model.parameters()).device
-        x = torch.from_numpy(images).to(dev)
+        x = images.to(dev) if torch.is_tensor(images) else torch.from_numpy(np.asarray(images, np.float32)).to(dev)
         was = self.embedding_model.training
         self.embedding_model.eval()                         # predict(): inference-mode BN, no dropout
         with torch.no_grad():
@@ -167,7 +172,7 @@ class TripletsDataGenerator(ENDataGenerator):
             trip, count, _ = ops.mine_triplets(dist, self.k_classes, self.k_samples, self.margin, self.mode,
                                                seed=np.random.randint(0, 2 ** 31 - 1))
         self.embedding_model.train(was)
-        t = trip[: int(count.item())].long()
+        t = self.last_triplets = trip[: int(count.item())].long()
         triplets = [x[t[:, 0]], x[t[:, 1]], x[t[:, 2]]]
         targets = torch.ones(len(t), device=dev)
         return triplets, targets

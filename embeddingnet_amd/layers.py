@@ -552,6 +552,19 @@ class BatchNormalization(nn.Module):
         self.beta = nn.Parameter(torch.zeros(channels))
         self.register_buffer("moving_mean", torch.zeros(channels))
         self.register_buffer("moving_variance", torch.ones(channels))
+        self.frozen = False
+
+    def freeze(self):
+        """Keras `layer.trainable = False` on a BatchNormalization (TF2): no weight updates AND inference mode —
+        the layer normalises with its moving statistics and stops updating them, whatever the model's mode."""
+        self.frozen = True
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        return super().train(mode and not self.frozen)
 
     def forward(self, x, defer=False, with_skip=False):
         """defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the

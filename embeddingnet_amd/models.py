@@ -16,31 +16,28 @@ from . import ops
 from .backbones import Model, get_backbone, keras_weights, load_keras_weights
 
 
+PARAM_SECTIONS = ('model', 'dataloader', 'generator', 'general', 'train')     # -> self.params_<section>
+
+
 class EmbeddingNet:
+    """Attribute surface of the reference class (models.py:24-40): the params sub-dicts as `params_<section>`
+    (`params_softmax` only when the config has SOFTMAX_PRETRAINING), `base_model`, `backbone_model`, `model`,
+    `workdir_path` = <work_dir>/<project_name>, `encoded_training_data`."""
 
     def __init__(self, params):
-        self.params_model = params['model']
-        self.params_dataloader = params['dataloader']
-        self.params_generator = params['generator']
-        self.params_general = params['general']
-        self.params_train = params['train']
+        for section in PARAM_SECTIONS:
+            setattr(self, 'params_' + section, params[section])
         if 'softmax' in params:
             self.params_softmax = params['softmax']
-
-        self.base_model = None
-        self.backbone_model = None
-        self.model = None
-
-        self.workdir_path = os.path.join(self.params_general['work_dir'],
-                                         self.params_general['project_name'])
-
+        self.base_model = self.backbone_model = self.model = None
+        general = self.params_general
+        self.workdir_path = os.path.join(general['work_dir'], general['project_name'])
         self.encoded_training_data = {}
 
     def _create_base_model(self):
+        """reference models.py:42-45: the backbone pair plus `classification_model` = Dense(1, sigmoid,
+        name 'output_img') on the embedding."""
         self.base_model, self.backbone_model = get_backbone(**self.params_model)
-        # reference models.py:44-45: Dense(1, sigmoid) 'output_img' on the embedding.  Only its
-        # pre-activation is on any loss path the reference can run, so the head stays linear here
-        # and SiameseNet applies the sigmoid where it is consumed.
         e = self.params_model.get('encodings_len', 4096)
         dev = next(self.base_model.parameters()).device
         self.classification_model = Model(_ClsHead(self.base_model, e), name="classification_model").to(dev)
@@ -49,12 +46,21 @@ class EmbeddingNet:
         return self.base_model.predict(imgs)
 
     # -- weights ---------------------------------------------------------------------------
+    def _whole_model(self):
+        """What a checkpoint covers: the trained graph (reference ModelCheckpoint saves `model.model`: base model plus,
+        for SiameseNet, the 'output_siamese' / 'output_img' heads); the base model alone before one is built."""
+        return self.model if self.model is not None else self.base_model
+
     def save_weights(self, path):
-        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in keras_weights(self.base_model).items()})
+        np.savez(path, **{k: v.detach().cpu().numpy() for k, v in keras_weights(self._whole_model()).items()})
 
     def load_model(self, file_path):
-        """Restore base-model weights saved by save_weights (reference: keras load_model :92-98)."""
-        load_keras_weights(self.base_model, np.load(file_path))
+        """Restore weights saved by save_weights (reference: keras load_model :92-98).  Base-model weights are
+        required; head weights are taken when the file has them (older checkpoints hold the base model only)."""
+        weights = np.load(file_path)
+        load_keras_weights(self.base_model, weights)
+        if self.model is not None:
+            load_keras_weights(self.model, weights, strict=False)
         self.input_shape = list(self.params_model['input_shape'])
 
     def save_base_model(self, save_folder):
@@ -155,8 +161,11 @@ class _ClsHead(nn.Module):
         self.base_model = base_model
         self.output_img = L.Dense(e, 1)
 
+    def head(self, emb):
+        return L.sigmoid(self.output_img(emb))               # Dense(units=1, activation='sigmoid'), models.py:44
+
     def forward(self, x):
-        return self.output_img(self.base_model(x))
+        return self.head(self.base_model(x))
 
 
 class _TripletGraph(nn.Module):
@@ -205,9 +214,11 @@ class _SiameseGraph(nn.Module):
             out = L.sigmoid(self.output_siamese(L.abs_diff(e1, e2)))
         else:                                                        # models.py:223-228
             out = ops.pair_distance(e1, e2)
-        # The two 'output_im*' classification outputs (models.py:211-215) carry no loss in train.py:118;
-        # they are not evaluated here (each would be one more backbone forward).
-        return [out, None, None]
+        # 'output_im1' / 'output_im2' (models.py:211-215): classification_model on each input.  It shares every
+        # layer with base_model, so its value is the head applied to the embedding already computed (the reference
+        # graph runs the shared layers a second time to the same result); they carry no loss in train.py:118.
+        head = self.classification_model.net.head
+        return [out, head(e1), head(e2)]
 
 
 class SiameseNet(EmbeddingNet):

@@ -1,0 +1,136 @@
+"""The optimizers the reference builds in embedding_net/utils.py:143-153 — `optimizers.Adam(lr)`,
+`optimizers.RMSprop(lr)`, `keras_radam.RAdam(lr)`, else `optimizers.SGD(lr)` — with the Keras update rules and
+defaults (Adam/RAdam b1 .9, b2 .999, eps 1e-7; RMSprop rho .9, eps 1e-7, no momentum; plain SGD).
+
+torch.optim's Adam/RAdam fold epsilon into the bias-corrected denominator differently (eps/sqrt(1-b2^t) instead of
+eps), so they are not the reference's rules; these are.  Each `step()` is ONE launch of `embnet_optimizer_step`
+(csrc/optimizer.hip) over every parameter tensor: a device table of {w, g, slot1, slot2, n} descriptors plus a
+static chunk list.  The table is re-uploaded only when a gradient pointer changed since the last step (with the
+caching allocator they normally do not).  A parameter without a gradient is skipped, as Keras does.
+The classes are torch.optim.Optimizer subclasses, so param_groups[...]['lr'] scheduling and state_dict() work
+as usual.  GPU tensors only (the library has no CPU path).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+RULE = {"sgd": 0, "rms_prop": 1, "adam": 2, "radam": 3}
+
+
+class KerasOptimizer(torch.optim.Optimizer):
+    """rule: 'sgd' | 'rms_prop' | 'adam' | 'radam' (the names utils.get_optimizer dispatches on)."""
+
+    def __init__(self, params, rule, lr, beta_1=0.9, beta_2=0.999, rho=0.9, epsilon=1e-7):
+        if rule not in RULE:
+            raise KeyError(rule)
+        super().__init__(params, dict(lr=float(lr)))
+        self.rule, self.b1, self.b2, self.rho, self.eps = rule, beta_1, beta_2, rho, epsilon
+        self.iterations = 0
+        self._tensors = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not self._tensors:
+            raise ValueError("optimizer got no trainable parameters")
+        if len(self.param_groups) != 1:
+            raise ValueError("one parameter group (the reference sets a single learning rate)")
+        self._ptrs, self._table, self._chunks, self._host, self._copied = None, None, None, None, None
+
+    # -- state ----------------------------------------------------------------------------
+    def _slots(self, p):
+        st = self.state[p]
+        n = {"sgd": 0, "rms_prop": 1, "adam": 2, "radam": 2}[self.rule]
+        for i in range(n):
+            if f"slot{i + 1}" not in st:
+                st[f"slot{i + 1}"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st.get("slot1"), st.get("slot2")
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["iterations"] = self.iterations
+        return d
+
+    def load_state_dict(self, d):
+        d = dict(d)
+        self.iterations = int(d.pop("iterations", 0))
+        super().load_state_dict(d)
+        self._ptrs = None
+
+    # -- one launch -----------------------------------------------------------------------
+    def _coefficients(self, lr, t):
+        """-> (kernel rule, b1, b2, c1, c2), scalars in double (oracle/optimizers.py states the rules)."""
+        if self.rule == "sgd":
+            return 0, 0.0, 0.0, 0.0, 0.0
+        if self.rule == "rms_prop":
+            return 1, self.rho, 0.0, 0.0, 0.0
+        b1, b2 = self.b1, self.b2
+        if self.rule == "adam":
+            return 2, b1, b2, lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), 0.0
+        sma_inf = 2.0 / (1.0 - b2) - 1.0
+        sma_t = sma_inf - 2.0 * t * b2 ** t / (1.0 - b2 ** t)
+        if sma_t >= 5.0:
+            r_t = math.sqrt((sma_t - 4.0) / (sma_inf - 4.0) * (sma_t - 2.0) / (sma_inf - 2.0) * sma_inf / sma_t)
+            return 3, b1, b2, lr * r_t / (1.0 - b1 ** t), 1.0 / (1.0 - b2 ** t)
+        return 4, b1, b2, lr / (1.0 - b1 ** t), 0.0
+
+    def _build_table(self):
+        lib = _lib.lib()
+        dev = self._tensors[0].device
+        rows, ptrs = [], []
+        for p in self._tensors:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.EmbnetError("KerasOptimizer: parameters must be contiguous fp32 GPU tensors")
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape):
+                raise _lib.EmbnetError("KerasOptimizer: gradients must be dense contiguous fp32")
+            s1, s2 = self._slots(p)
+            gp = g.data_ptr() if g is not None else 0
+            rows.append((p.data_ptr(), gp, s1.data_ptr() if s1 is not None else 0,
+                         s2.data_ptr() if s2 is not None else 0, p.numel()))
+            ptrs.append(gp)
+        if self._chunks is None:
+            ce = lib.embnet_optimizer_chunk_elems()
+            ck = [(i, c) for i, p in enumerate(self._tensors) for c in range(-(-p.numel() // ce))]
+            self._chunks = torch.tensor(ck, dtype=torch.int32, device=dev)
+            self._host = torch.empty((len(rows), 5), dtype=torch.int64).pin_memory()
+            self._table = torch.empty((len(rows), 5), dtype=torch.int64, device=dev)
+        if self._copied is not None:
+            self._copied.synchronize()                    # the previous upload still reads the pinned staging rows
+        self._host.copy_(torch.from_numpy(np.asarray(rows, dtype=np.uint64).view(np.int64)))
+        self._table.copy_(self._host, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record()
+        self._ptrs = ptrs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        cur = [p.grad.data_ptr() if p.grad is not None else 0 for p in self._tensors]
+        if cur != self._ptrs:
+            self._build_table()
+        self.iterations += 1
+        lr = float(self.param_groups[0]["lr"])
+        rule, b1, b2, c1, c2 = self._coefficients(lr, self.iterations)
+        check(_lib.lib().embnet_optimizer_step(rule, self._table.data_ptr(), len(self._tensors), self._chunks.data_ptr(),
+                                               self._chunks.shape[0], lr, b1, b2, self.eps, c1, c2, _lib.stream()))
+        return loss
+
+
+def SGD(params, lr):
+    return KerasOptimizer(params, "sgd", lr)
+
+
+def Adam(params, lr):
+    return KerasOptimizer(params, "adam", lr)
+
+
+def RMSprop(params, lr):
+    return KerasOptimizer(params, "rms_prop", lr)
+
+
+def RAdam(params, lr):
+    return KerasOptimizer(params, "radam", lr)

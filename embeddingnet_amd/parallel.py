@@ -40,8 +40,61 @@ def shard_classes(k_classes_global, world, rank):
     return rank * per, per
 
 
+def broadcast_model(module, src=0, process_group=None):
+    """Make every rank start from rank `src`'s parameters AND buffers (BatchNorm moving statistics): one flat
+    broadcast.  Call after construction, after --resume_from, and after any rank-local pre-training."""
+    if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+        return
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=src, group=process_group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+def average_buffers(module, process_group=None):
+    """Mean of the floating-point buffers (BatchNorm moving statistics) over the ranks — each rank normalises its own
+    local batches (no SyncBN, as in the reference), so a checkpoint should hold the average, not rank 0's copy."""
+    if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+        return
+    bufs = [b.data for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.all_reduce(flat, group=process_group)
+    flat /= dist.get_world_size(process_group)
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
+
+
+def all_reduce_mean(value, device=None, process_group=None):
+    """Mean over ranks of a Python float / 0-d tensor (the scalar loss all-reduce SURVEY §8e asks for: logging, and
+    the plateau / early-stopping decisions, which must be identical on every rank).  Returns a float."""
+    if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(process_group) == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=process_group)
+    return float(t.item()) / dist.get_world_size(process_group)
+
+
 class GradReducer:
-    """Flat gradient buffer + bucketed asynchronous all-reduce (mean over ranks)."""
+    """Flat gradient buffer + bucketed asynchronous all-reduce (mean over ranks).
+
+    Contract: the reducer owns the parameters' `.grad` (views of one flat buffer).  Start a step with `zero()`,
+    never `optimizer.zero_grad(set_to_none=True)`; a gradient found outside the buffer (someone dropped the view)
+    is copied back in and re-bound by the hook, so the all-reduce never silently misses it.  A parameter that took
+    no part in a step contributes zeros (its bucket is still reduced, so the ranks stay in step).
+    Bucket order: parameters are laid out in the order the FIRST backward produced their gradients (recorded by the
+    hooks, rank 0's order broadcast so every rank agrees), so from step 2 on each bucket closes as early as possible.
+    """
 
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, always_reduce=False):
         self.params = [p for p in params if p.requires_grad]
@@ -51,15 +104,30 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())   # always_reduce: test hook
         dev, dtype = self.params[0].device, self.params[0].dtype
-        order = list(reversed(self.params))                 # roughly the order backward produces them
-        total = sum(p.numel() for p in order)
+        self._bucket_bytes = bucket_bytes
+        total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dtype)
-        self.buckets, self._bucket_of = [], {}
+        self._layout(list(reversed(self.params)))           # first guess: reverse definition order
+        self._seen, self._ordered = [], False               # hook order of the first backward
+        self._works = []
+        # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
+        # NCCL-only and could not be exercised on the single-GPU development box)
+        self._avg = dist.ReduceOp.SUM
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _layout(self, order, keep=False):
+        """Assign flat-buffer slots and buckets in `order`; keep=True carries the current gradients over."""
+        old = {p: p.grad.clone() for p in order} if keep else None
+        self.buckets, self._bucket_of, self._slot = [], {}, {}
         off, start, pending = 0, 0, 0
-        per_bucket = max(bucket_bytes // self.flat.element_size(), 1)
+        per_bucket = max(self._bucket_bytes // self.flat.element_size(), 1)
         for p in order:
             n = p.numel()
+            self._slot[p] = (off, n)
             p.grad = self.flat[off:off + n].view_as(p)
+            if keep:
+                p.grad.copy_(old[p])
             self._bucket_of[p] = len(self.buckets)
             off += n
             pending += 1
@@ -68,15 +136,17 @@ class GradReducer:
                 start, pending = off, 0
         if pending:
             self.buckets.append([start, off, pending])
+        self.order = list(order)
         self._left = [b[2] for b in self.buckets]
-        self._works = []
-        # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
-        # NCCL-only and could not be exercised on the single-GPU development box)
-        self._avg = dist.ReduceOp.SUM
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p):
+        off, n = self._slot[p]
+        if p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+            view = self.flat[off:off + n].view_as(p)        # the gradient was re-allocated outside the buffer
+            view.copy_(p.grad)
+            p.grad = view
+        if not self._ordered:
+            self._seen.append(p)
         b = self._bucket_of[p]
         self._left[b] -= 1
         if self._left[b] == 0 and self._reduce:
@@ -101,3 +171,20 @@ class GradReducer:
         self._works = []
         if self.world > 1 and self._avg == dist.ReduceOp.SUM:
             self.flat.div_(self.world)
+        if not self._ordered:
+            self._adopt_first_backward_order()
+
+    def _adopt_first_backward_order(self):
+        """After the first step: re-lay the buffer in the order the hooks fired (rank 0's, so all ranks agree)."""
+        self._ordered = True
+        index = {p: i for i, p in enumerate(self.params)}
+        seen = [index[p] for p in self._seen]
+        seen += [i for i in range(len(self.params)) if i not in set(seen)]      # parameters that never fired: last
+        self._seen = []
+        order = torch.tensor(seen, dtype=torch.int64, device=self.flat.device if self._reduce and
+                             dist.get_backend(self.group) == "nccl" else "cpu")
+        if self._reduce:
+            dist.broadcast(order, src=0, group=self.group)
+        new = [self.params[i] for i in order.tolist()]
+        if new != self.order:
+            self._layout(new, keep=True)

@@ -36,9 +36,11 @@ class TripletTrainer:
         with torch.no_grad():
             dist = ops.pairwise_distances(emb)
             if self.mode == "batch_hard":
-                return ops.batch_hard(dist, self.p, self.k)
-            trip, count, _ = ops.mine_triplets(dist, self.p, self.k, self.margin, self.mode,
-                                               seed=(self.seed << 20) + self.step_no)
+                trip, count = ops.batch_hard(dist, self.p, self.k)
+            else:
+                trip, count, _ = ops.mine_triplets(dist, self.p, self.k, self.margin, self.mode,
+                                                   seed=(self.seed << 20) + self.step_no)
+            self.last_triplets = (trip, count)      # device tensors; only the first count[0] rows are live
             return trip, count
 
     def loss(self, images):
@@ -59,6 +61,7 @@ class TripletTrainer:
         else:
             self.opt.zero_grad(set_to_none=True)
         total, mean, count = self.loss(images)
+        self.last_total = total.detach()        # triplet mean + kernel regularisers (what Keras reports as `loss`)
         total.backward()
         if self.reducer is not None:
             self.reducer.finish()

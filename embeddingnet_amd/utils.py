@@ -1,27 +1,34 @@
 """Drop-in for the config / optimizer part of embedding_net/utils.py (reference :143-197).
 
-parse_params keeps the reference's YAML schema and returned dict layout.  The one structural
-difference: Keras optimizers are constructed without parameters, torch optimizers need them, so
-params['train']['optimizer'] is an OptimizerSpec whose .build(parameters) returns the torch optimizer
-with the Keras defaults (Adam/RMSprop/RAdam epsilon 1e-7, RMSprop rho .9, plain SGD).
+`parse_params` keeps the reference's YAML schema and the layout of the dict it returns (lower-case
+section keys; MODEL.input_shape mirrored into GENERATOR and SOFTMAX_PRETRAINING; the optimizer entry of a
+section replaced by an optimizer object; `augmentations` keys set).  One structural difference: Keras
+optimizers are constructed without parameters, ours need them, so the optimizer object is an
+`OptimizerSpec` whose `.build(parameters)` returns the optimizer (embeddingnet_amd/optimizers.py: the
+Keras update rules and defaults, one HIP launch per step).
 """
 import yaml
 
+# YAML section -> key of the returned dict (reference utils.py:169-195); the last one is optional
+SECTIONS = (("DATALOADER", "dataloader"), ("GENERATOR", "generator"), ("MODEL", "model"), ("TRAIN", "train"),
+            ("GENERAL", "general"), ("ENCODINGS", "encodings"))
+OPTIONAL_SECTION = ("SOFTMAX_PRETRAINING", "softmax")
+
 
 class OptimizerSpec:
+    """What `get_optimizer(name, lr)` returns: the optimizer's rule and learning rate, bound to parameters later."""
+
     def __init__(self, name, learning_rate):
         self.name, self.learning_rate = name, float(learning_rate)
 
+    @property
+    def rule(self):
+        """reference utils.py:144-152: 'adam', 'rms_prop', 'radam', anything else is plain SGD."""
+        return self.name if self.name in ("adam", "rms_prop", "radam") else "sgd"
+
     def build(self, parameters):
-        import torch
-        lr = self.learning_rate
-        if self.name == 'adam':
-            return torch.optim.Adam(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-7)
-        if self.name == 'rms_prop':
-            return torch.optim.RMSprop(parameters, lr=lr, alpha=0.9, eps=1e-7)
-        if self.name == 'radam':
-            return torch.optim.RAdam(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-7)
-        return torch.optim.SGD(parameters, lr=lr)
+        from .optimizers import KerasOptimizer
+        return KerasOptimizer(parameters, self.rule, self.learning_rate)
 
     def __repr__(self):
         return f"OptimizerSpec({self.name!r}, lr={self.learning_rate})"
@@ -31,41 +38,26 @@ def get_optimizer(name, learning_rate):
     return OptimizerSpec(name, learning_rate)
 
 
+def _finish_section(section, input_shape):
+    """A section that drives training (TRAIN-like or SOFTMAX_PRETRAINING): optimizer name -> object."""
+    section['optimizer'] = get_optimizer(section['optimizer'], section['learning_rate'])
+    if input_shape is not None:
+        section['input_shape'] = input_shape
+        # The reference builds albumentations pipelines only under the misspelt key 'augmentations_type'
+        # (utils.py:160-164), i.e. never with the shipped configs; image augmentation is outside the hot path.
+        section['augmentations'] = None
+    return section
+
+
 def parse_params(filename='configs/road_signs.yml'):
     with open(filename, 'r') as ymlfile:
         cfg = yaml.safe_load(ymlfile)
-
-    # The reference only builds augmentations when the (misspelt) key 'augmentations_type' exists
-    # (utils.py:160-164), i.e. never with the shipped configs; image augmentation is outside the hot path.
-    augmentations = None
-
-    optimizer = get_optimizer(cfg['TRAIN']['optimizer'],
-                              cfg['TRAIN']['learning_rate'])
-
-    params_dataloader = cfg['DATALOADER']
-    params_generator = cfg['GENERATOR']
-    params_model = cfg['MODEL']
-    params_train = cfg['TRAIN']
-    params_general = cfg['GENERAL']
-    params_encodings = cfg.get('ENCODINGS', {})
-
-    params_generator['input_shape'] = params_model['input_shape']
-    params_train['optimizer'] = optimizer
-    params_generator['augmentations'] = augmentations
-
-    params = {'dataloader': params_dataloader,
-              'generator': params_generator,
-              'model': params_model,
-              'train': params_train,
-              'general': params_general,
-              'encodings': params_encodings}
-
-    if 'SOFTMAX_PRETRAINING' in cfg:
-        params_softmax = cfg['SOFTMAX_PRETRAINING']
-        params_softmax['augmentations'] = augmentations
-        params_softmax['input_shape'] = params_model['input_shape']
-        params_softmax['optimizer'] = get_optimizer(cfg['SOFTMAX_PRETRAINING']['optimizer'],
-                                                    cfg['SOFTMAX_PRETRAINING']['learning_rate'])
-        params['softmax'] = params_softmax
-
+    params = {key: (cfg[section] if section != "ENCODINGS" else cfg.get(section, {})) for section, key in SECTIONS}
+    shape = params['model']['input_shape']
+    params['generator']['input_shape'] = shape
+    params['generator']['augmentations'] = None
+    _finish_section(params['train'], None)
+    section, key = OPTIONAL_SECTION
+    if section in cfg:
+        params[key] = _finish_section(cfg[section], shape)
     return params

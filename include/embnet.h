@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 2
+#define EMBNET_ABI_VERSION 3
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -273,6 +273,28 @@ int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long tot
 size_t embnet_sumsq_workspace_bytes(void);
 int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace, size_t workspace_bytes,
                  void* stream);
+
+/* ------------------------------------------------------------------ optimizer update
+ * utils.py:143-153 get_optimizer(name, lr): `Adam(lr)`, `RMSprop(lr)`, `keras_radam.RAdam(lr)`, else `SGD(lr)`
+ * with the library defaults — applied by Keras after train.py:160-177's compile/fit.  One launch updates every
+ * tensor (multi-tensor apply).
+ *   table   device array of n_tensors descriptors, 40 bytes each:
+ *             { float* w; const float* g; float* slot1; float* slot2; int64 n; }
+ *           g == NULL: the variable got no gradient this step and is skipped (Keras' behaviour);
+ *           slot1/slot2: Adam/RAdam m and v, RMSprop rms (slot2 unused), SGD none — zero-initialised by the caller;
+ *   chunks  device int32 [n_chunks][2] = (tensor index, chunk index within it), chunk = embnet_optimizer_chunk_elems()
+ *           consecutive elements; every element of every tensor must be covered exactly once;
+ *   rule and host-computed scalars (t = 1-based step count):
+ *     EMBNET_OPT_SGD         w -= lr*g
+ *     EMBNET_OPT_RMSPROP     rms = b1*rms + (1-b1)*g^2;  w -= lr*g/(sqrt(rms)+eps)                 (b1 = rho)
+ *     EMBNET_OPT_ADAM        m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2;  w -= c1*m/(sqrt(v)+eps),      c1 = lr*sqrt(1-b2^t)/(1-b1^t)
+ *     EMBNET_OPT_RADAM       m, v as Adam;  w -= c1*m/(sqrt(v*c2)+eps),    c1 = lr*r_t/(1-b1^t), c2 = 1/(1-b2^t)   (sma_t >= 5)
+ *     EMBNET_OPT_RADAM_WARM  m, v as Adam;  w -= c1*m,                     c1 = lr/(1-b1^t)                          (sma_t < 5)
+ * HBM-bound: 12 (SGD) .. 28 (Adam/RAdam) bytes per element. */
+enum { EMBNET_OPT_SGD = 0, EMBNET_OPT_RMSPROP = 1, EMBNET_OPT_ADAM = 2, EMBNET_OPT_RADAM = 3, EMBNET_OPT_RADAM_WARM = 4 };
+int embnet_optimizer_chunk_elems(void);
+int embnet_optimizer_step(int rule, const void* table, int n_tensors, const int32_t* chunks, int n_chunks,
+                          float lr, float b1, float b2, float eps, float c1, float c2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,12 @@ class Ctx:
         self.rs = np.random.RandomState(seed)
         self.new_stats = {}
         self.reg = []          # (lambda, tensor) kernel regularisers hit in this pass
+        self.taps = None       # set to a dict to record named intermediate activations (tests)
+
+    def tap(self, name, x):
+        if self.taps is not None:
+            self.taps[name] = x
+        return x
 
     def get(self, name, shape, init):
         if name not in self.params:
@@ -121,6 +127,10 @@ def batchnorm(ctx, name, x, eps=1e-3, momentum=0.99, scale=True):
         red = tuple(range(x.dim() - 1))
         mean = x.mean(dim=red)
         var = x.var(dim=red, unbiased=False)
+        # a layer called several times in one step (the three branches of models.py:181-183) updates its moving
+        # statistics once per call, each update starting from the previous one's result
+        mm = ctx.new_stats.get(name + "/moving_mean", mm)
+        mv = ctx.new_stats.get(name + "/moving_variance", mv)
         ctx.new_stats[name + "/moving_mean"] = (momentum * mm + (1 - momentum) * mean).detach()
         ctx.new_stats[name + "/moving_variance"] = (momentum * mv + (1 - momentum) * var).detach()
     else:
@@ -159,13 +169,10 @@ def l2_normalize(x):
 # ---------------------------------------------------------------------------
 # backbones.py:19-41
 def simple(ctx, x):
-    x = conv2d(ctx, "conv1", x, 64, 10, relu=True, l2=2e-4)
-    x = maxpool(x)
-    x = conv2d(ctx, "conv2", x, 128, 7, relu=True, l2=2e-4)
-    x = maxpool(x)
-    x = conv2d(ctx, "conv3", x, 128, 4, relu=True, l2=2e-4)
-    x = maxpool(x)
-    x = conv2d(ctx, "conv4", x, 256, 4, relu=True, l2=2e-4)
+    x = ctx.tap("pool1", maxpool(conv2d(ctx, "conv1", x, 64, 10, relu=True, l2=2e-4)))
+    x = ctx.tap("pool2", maxpool(conv2d(ctx, "conv2", x, 128, 7, relu=True, l2=2e-4)))
+    x = ctx.tap("pool3", maxpool(conv2d(ctx, "conv3", x, 128, 4, relu=True, l2=2e-4)))
+    x = ctx.tap("conv4", conv2d(ctx, "conv4", x, 256, 4, relu=True, l2=2e-4))
     return x.reshape(x.shape[0], -1)
 
 
@@ -178,7 +185,7 @@ def simple_head(ctx, feat, enc, norm):
 def simple2(ctx, x):
     def cbr(i, x, c, k, stride=1, padding="valid"):
         x = conv2d(ctx, f"conv{i}", x, c, k, stride=stride, padding=padding, relu=True, l2=2e-4)
-        return batchnorm(ctx, f"bn{i}", x)
+        return ctx.tap(f"bn{i}", batchnorm(ctx, f"bn{i}", x))
     x = cbr(1, x, 32, 3)
     x = cbr(2, x, 32, 3)
     x = cbr(3, x, 32, 5, 2, "same")
@@ -213,8 +220,9 @@ def resnet(ctx, x, name):
     kind, reps = RESNET[name]
     x = batchnorm(ctx, "bn_data", x, eps=RN_EPS, scale=False)
     x = _rn_conv(ctx, "conv0", x, 64, 7, 2, 3)
+    x = ctx.tap("conv0", x)
     x = torch.relu(batchnorm(ctx, "bn0", x, eps=RN_EPS))
-    x = maxpool(x, 3, 2, zero_pad=1)
+    x = ctx.tap("pooling0", maxpool(x, 3, 2, zero_pad=1))
     for stage, rep in enumerate(reps):
         f = 64 * 2 ** stage
         for blk in range(rep):
@@ -234,8 +242,8 @@ def resnet(ctx, x, name):
                 y = _rn_conv(ctx, pre + "conv2", y, f, 3, stride, 1)
                 y = torch.relu(batchnorm(ctx, pre + "bn3", y, eps=RN_EPS))
                 y = _rn_conv(ctx, pre + "conv3", y, f * 4, 1)
-            x = y + sc
-    return torch.relu(batchnorm(ctx, "bn1", x, eps=RN_EPS))
+            x = ctx.tap(pre[:-1], y + sc)
+    return ctx.tap("bn1", torch.relu(batchnorm(ctx, "bn1", x, eps=RN_EPS)))
 
 
 # efficientnet (qubvel) — backbones.py:84-98
@@ -264,7 +272,7 @@ def efficientnet(ctx, x, name):
     width, depth = EFN_SCALING[name]
     sw = lambda t: t * torch.sigmoid(t)
     cv = lambda nm, t, c, k, s: conv2d(ctx, nm, t, c, k, stride=s, padding="same", bias=False, init=conv_normal)
-    x = sw(batchnorm(ctx, "stem_bn", cv("stem_conv", x, _efn_round_filters(32, width), 3, 2)))
+    x = ctx.tap("stem", sw(batchnorm(ctx, "stem_bn", cv("stem_conv", x, _efn_round_filters(32, width), 3, 2))))
     idx = 0
     for k, rep, cin, cout, e, s in EFN_BLOCKS:
         cin, cout = _efn_round_filters(cin, width), _efn_round_filters(cout, width)
@@ -285,14 +293,15 @@ def efficientnet(ctx, x, name):
             x = batchnorm(ctx, pre + "project_bn", cv(pre + "project_conv", x, cout, 1, 1))
             if stride == 1 and bin_ == cout:
                 x = x + inp                      # drop-connect is off in parity runs (ctx.dropout False)
+            ctx.tap(pre[:-1], x)
     return sw(batchnorm(ctx, "top_bn", cv("top_conv", x, _efn_round_filters(1280, width), 1, 1)))
 
 
 # backbones.py:110-121
 def zoo_head(ctx, feat, enc, norm):
-    x = feat.mean(dim=(1, 2))
-    x = dense(ctx, "dense1", x, enc // 2, relu=True)
-    e = dense(ctx, "dense2", x, enc, relu=True)
+    x = ctx.tap("gap", feat.mean(dim=(1, 2)))
+    x = ctx.tap("dense1", dense(ctx, "dense1", x, enc // 2, relu=True))
+    e = ctx.tap("dense2", dense(ctx, "dense2", x, enc, relu=True))
     return l2_normalize(e) if norm else e
 
 
@@ -322,6 +331,16 @@ def regularisation(ctx):
 def triplet_model(ctx, a, p, n, **kw):
     """models.py:176-186 — three calls of the shared base model, concat on last axis."""
     return torch.cat([base_model(ctx, a, **kw), base_model(ctx, p, **kw), base_model(ctx, n, **kw)], dim=-1)
+
+
+def classification_head(ctx, emb):
+    """models.py:44 — Dense(units=1, activation='sigmoid', name='output_img') on the embedding."""
+    return torch.sigmoid(dense(ctx, "output_img", emb, 1))
+
+
+def siamese_l1_output(ctx, e1, e2):
+    """models.py:217-221 — sigmoid(Dense(1, name='output_siamese')(|e1 - e2|))."""
+    return torch.sigmoid(dense(ctx, "output_siamese", (e1 - e2).abs(), 1))
 
 
 def siamese_l2_distance(e1, e2):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
-    assert bound.embnet_abi_version() == 2
+    assert bound.embnet_abi_version() == 3
     assert bound.embnet_mine_max_triplets(32, 4) == 192
     assert bound.embnet_pairwise_workspace_bytes(128) == 512
 
@@ -97,11 +97,52 @@ def test_parse_params_keeps_reference_schema(tmp_path):
     spec = p["train"]["optimizer"]
     assert isinstance(spec, OptimizerSpec)
     w = torch.nn.Parameter(torch.zeros(3))
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd.optimizers import KerasOptimizer
     opt = spec.build([w])
-    assert isinstance(opt, torch.optim.RAdam) and opt.defaults["eps"] == 1e-7 and opt.defaults["lr"] == 1e-4
-    assert isinstance(OptimizerSpec("adam", 1e-3).build([w]), torch.optim.Adam)
-    assert isinstance(OptimizerSpec("rms_prop", 1e-3).build([w]), torch.optim.RMSprop)
-    assert isinstance(OptimizerSpec("whatever", 1e-3).build([w]), torch.optim.SGD)
+    assert isinstance(opt, KerasOptimizer) and isinstance(opt, torch.optim.Optimizer)
+    assert (opt.rule, opt.eps, opt.defaults["lr"], opt.b1, opt.b2) == ("radam", 1e-7, 1e-4, 0.9, 0.999)
+    assert OptimizerSpec("adam", 1e-3).build([w]).rule == "adam"
+    assert OptimizerSpec("rms_prop", 1e-3).build([w]).rule == "rms_prop"
+    assert OptimizerSpec("whatever", 1e-3).build([w]).rule == "sgd"         # reference utils.py:151-152
+    w.grad = torch.ones(3)
+    with pytest.raises(_lib.EmbnetError):                                   # the update is a HIP launch: no CPU path
+        opt.step()
+    # RAdam's host-side scalars: un-rectified for the first steps (sma_t < 5), rectified after
+    assert opt._coefficients(1e-4, 1)[0] == 4 and opt._coefficients(1e-4, 6)[0] == 3
+
+
+def test_oracle_optimizer_rules_against_torch_optim():
+    """oracle/optimizers.py (parity unpinned: TF 2.2 / keras_radam rules restated) cross-checked against torch.optim on
+    CPU where the two rules coincide: SGD and RMSprop exactly; Adam / RAdam up to where epsilon enters (Keras adds eps
+    to sqrt(v) before the bias correction, torch after), so they agree to ~eps/|g| on O(1) gradients."""
+    from oracle import optimizers as OO
+    rs = np.random.RandomState(0)
+    w0 = [rs.randn(5, 3), rs.randn(7)]
+    grads = [[rs.randn(5, 3), rs.randn(7)] for _ in range(12)]
+    for name, topt, tol in (("sgd", lambda p: torch.optim.SGD(p, lr=1e-2), 1e-13),
+                            ("rms_prop", lambda p: torch.optim.RMSprop(p, lr=1e-2, alpha=0.9, eps=1e-7), 1e-13),
+                            ("adam", lambda p: torch.optim.Adam(p, lr=1e-2, eps=1e-7), 2e-6),
+                            ("radam", lambda p: torch.optim.RAdam(p, lr=1e-2, eps=1e-7), 2e-6)):
+        wn = [a.copy() for a in w0]
+        wt = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in w0]
+        oo, to = OO.get_optimizer(name, 1e-2), topt(wt)
+        for g in grads:
+            oo.step(wn, g)
+            for t, gg in zip(wt, g):
+                t.grad = torch.tensor(gg)
+            to.step()
+        for a, t in zip(wn, wt):
+            np.testing.assert_allclose(a, t.detach().numpy(), rtol=tol, atol=tol)
+    # known answer, Adam step 1: m = .1 g, v = .001 g^2, lr_t = lr sqrt(.001)/.1 -> w - lr * g/(|g| + eps/sqrt(.001))... Keras form:
+    w, g = [np.array([1.0])], [np.array([0.5])]
+    OO.Adam(0.1).step(w, g)
+    lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(w[0], 1.0 - lr_t * 0.05 / (np.sqrt(0.001 * 0.25) + 1e-7), rtol=1e-14)
+    # RAdam: steps 1..5 are plain bias-corrected momentum (sma_t < 5), the 6th is rectified
+    w, r = [np.array([0.0])], OO.RAdam(0.1)
+    r.step(w, [np.array([2.0])])
+    np.testing.assert_allclose(w[0], -0.1 * 2.0, rtol=1e-14)                # m^ = g at t = 1
 
 
 def test_model_surface_matches_reference_names():

@@ -27,7 +27,8 @@ from embedding_net.utils import parse_params  # noqa: E402
 from embedding_net.losses_and_accuracies import contrastive_loss, triplet_loss, accuracy  # noqa: E402
 from embeddingnet_amd.datagenerators import (ENDataLoader, SyntheticDataLoader, TripletsDataGenerator,  # noqa: E402
                                              SimpleTripletsDataGenerator, SiameseDataGenerator)
-from embeddingnet_amd.parallel import GradReducer, init_distributed, shard_classes  # noqa: E402
+from embeddingnet_amd.parallel import (GradReducer, all_reduce_mean, average_buffers, broadcast_model,  # noqa: E402
+                                       init_distributed, shard_classes)
 from embeddingnet_amd.train_step import TripletTrainer  # noqa: E402
 
 
@@ -66,23 +67,49 @@ class Plateau:
             if self.since_reduce >= 4:
                 self.scale *= 0.1
                 self.since_reduce = 0
-                print(f'ReduceLROnPlateau: lr scale -> {self.scale:g}')
+                print(f'ReduceLROnPlateau: lr scale -> {self.scale:g}', flush=True)
         return improved, self.since_best >= 10
+
+
+def apply_gpu_ids(gpu_ids):
+    """GENERAL.gpu_ids (reference train.py:121-133: CUDA_VISIBLE_DEVICES + n_gpu): the listed devices become the
+    visible ones; with more than one id and no launcher around us, re-run this script as one process per listed GPU
+    under torch.distributed.run (the data-parallel world) and exit with its status.  Must run before the GPU is touched."""
+    if not gpu_ids:
+        return
+    ids = [s.strip() for s in str(gpu_ids).split(',') if s.strip()]
+    if 'WORLD_SIZE' in os.environ:                    # already under torchrun: the launcher decided the world
+        if int(os.environ['WORLD_SIZE']) != len(ids):
+            print(f"GENERAL.gpu_ids lists {len(ids)} devices but WORLD_SIZE={os.environ['WORLD_SIZE']}: using the launcher's world")
+        return
+    os.environ.setdefault('HIP_VISIBLE_DEVICES', ','.join(ids))
+    print(f'Using gpu ids: {",".join(ids)}')
+    if len(ids) > 1:
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={len(ids)}',
+               '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 1000),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
 
 def main():
     args = parse_args()
     cfg = parse_params(args.config)
     p_train, p_model, p_loader, p_gen = cfg['train'], cfg['model'], cfg['dataloader'], cfg['generator']
+    apply_gpu_ids(cfg['general'].get('gpu_ids'))
     paths = create_save_folders(cfg['general'])
     rank, world, local = init_distributed()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     p_model['device'] = dev
+    # every rank builds the same dataset and the same initial model; what differs per rank is what it samples
+    import random
+    random.seed(1234 + rank)
+    np.random.seed(1234 + rank)
 
     if args.synthetic:
         data_loader = SyntheticDataLoader(args.synthetic, 24, p_model['input_shape'],
-                                          validate=p_loader.get('validate', True), seed=rank)
+                                          validate=p_loader.get('validate', True), seed=0)
     else:
         data_loader = ENDataLoader(**{k: v for k, v in p_loader.items() if k != 'csv_file'})
     monitor = 'val_loss' if data_loader.validate else 'loss'
@@ -107,10 +134,11 @@ def main():
         trainable = model.base_model
     if args.resume_from is not None:
         model.load_model(args.resume_from)            # the mining model IS base_model, so it resumes too
-    if 'softmax' in cfg:                              # reference train.py:164-170
-        from embedding_net.backbones import pretrain_backbone_softmax
+    if 'softmax' in cfg and rank == 0:                # reference train.py:164-170; one rank trains and writes the
+        from embedding_net.backbones import pretrain_backbone_softmax        # pre-training checkpoints, all receive them
         pretrain_backbone_softmax(model.backbone_model, data_loader, cfg['softmax'], cfg['general'],
                                   max_epochs=args.max_epochs)
+    broadcast_model(trainable)                        # identical start on every rank: parameters and BN buffers
 
     params = [p for p in trainable.parameters() if p.requires_grad]
     opt = p_train['optimizer'].build(params)
@@ -141,7 +169,7 @@ def main():
                 losses.append(loss.detach())
             else:
                 losses.append(trainer.step(torch.from_numpy(train_gen.sample_batch()).to(dev)))
-        epoch_loss = float(torch.stack(losses).mean().item())
+        epoch_loss = all_reduce_mean(float(torch.stack(losses).mean().item()))     # mean over ranks (logging + monitor)
         history['loss'].append(epoch_loss)
         msg = f'Epoch {epoch + 1}/{n_epochs} - lr {lr:.3g} - loss {epoch_loss:.4f}'
         value = epoch_loss
@@ -157,12 +185,14 @@ def main():
                         vals.append(contrastive_loss(torch.from_numpy(y).to(dev), out))
                     else:
                         vals.append(triplet_loss(p_gen['margin'])(None, model.model(xs)).mean())
-            value = float(torch.stack(vals).mean().item())
+            value = all_reduce_mean(float(torch.stack(vals).mean().item()))
             history['val_loss'].append(value)
             msg += f' - val_loss {value:.4f}'
         if rank == 0:
             print(msg, flush=True)
-        improved, stop = plateau.update(value)
+        improved, stop = plateau.update(value)        # `value` is the all-reduced mean: same LR scale / stop on every rank
+        if improved:
+            average_buffers(trainable)                # BN moving statistics: mean over the ranks' local batches
         if improved and rank == 0:
             path = os.path.join(paths['weights'], f'epoch_{epoch + 1:03d}.npz')
             model.save_weights(path)
