@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training images/sec of the fused metric-learning step
-(ResNet18, 224x224, triplet loss with online hardest-negative mining, local batch 32x4=128,
-E=256, margin 0.5 — BASELINE.json configs[1]) on N MI355X GPUs of one node.
+"""Headline benchmark: training images/sec of the metric-learning hot path on N MI355X GPUs of one node.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A step = one pass of the hot path over one synthetic batch already resident in HBM: backbone
-forward -> NxN distance matrix -> mine-and-select -> hinge -> backward -> (RCCL all-reduce of the
-gradient) -> RAdam update.  fp32 throughout.  Rank 0 prints ONE JSON line; details go to stderr.
+Default workload = BASELINE.json configs[1] (C2): ResNet18, 224x224, triplet loss with online hardest-negative mining,
+local batch 32x4 = 128, E = 256, margin 0.5.  Other configs of BASELINE.json:
+  --config c1   simple2 64x64, 8x4 = 32, semihard                      (configs[0])
+  --config c3   ResNet50 224x224 Siamese ('l2' head), contrastive loss, 256 pairs (configs[2])
+  --config c5   EfficientNet-B0 224x224, semihard, E = 512, local batch 64x4 = 256 (one rank of configs[4])
+(C4 = C2 at --gpus 8).  A step = one pass of the hot path over one synthetic batch already resident in HBM: backbone
+forward -> NxN distance matrix -> mine-and-select -> hinge -> backward -> (RCCL all-reduce of the gradient) -> optimizer
+(siamese: two branch forwards -> pair distance -> contrastive loss -> backward -> optimizer).  fp32 throughout.
+Rank 0 prints ONE JSON line; details go to stderr.
+
+roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
+every 4th timed step; the kernel with the largest total time is reported against the roofline that bounds it — MFMA
+fp32 (157.3 TFLOP/s) for the GEMM-engine kernels with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
+copy rate also given) for the streaming kernels with their algorithmic bytes.
 """
 import argparse
 import json
@@ -22,8 +31,16 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBPS, HBM_COPY_GBPS = 8000.0, 6290.0     # same guide: HBM3E spec / measured float4 copy
 # forward MACs per 224x224 image; training FLOP = 3 passes x 2 FLOP/MAC
-FWD_GMAC = {"resnet18": 1.826, "resnet50": 4.1, "simple2": 0.136, "simple": 0.991}
+FWD_GMAC = {"resnet18": 1.826, "resnet50": 4.1, "efficientnet-b0": 0.39}
+CONFIGS = {   # name -> argument defaults
+    "c1": dict(mode="triplet", backbone="simple2", image=64, k_classes=8, k_samples=4, encodings_len=256, mining="semihard"),
+    "c2": dict(mode="triplet", backbone="resnet18", image=224, k_classes=32, k_samples=4, encodings_len=256, mining="hardest"),
+    "c3": dict(mode="siamese", backbone="resnet50", image=224, pairs=256, encodings_len=256),
+    "c5": dict(mode="triplet", backbone="efficientnet-b0", image=224, k_classes=64, k_samples=4, encodings_len=512,
+               mining="semihard"),
+}
 
 
 def log(*a):
@@ -44,30 +61,80 @@ def usable_cores():
 
 
 def cpu_baseline(args):
-    """The oracle's reference-structured step (oracle/step.py) timed on this box's host cores, on a
-    bounded sample: same backbone / resolution / K, P reduced so that a step takes seconds."""
+    """The oracle's reference-structured step (oracle/step.py) timed on this box's host cores, on a bounded sample:
+    same backbone / resolution / K, batch reduced so that a step takes seconds."""
     import numpy as np
-    from oracle.step import ReferenceStep
+    from oracle.step import ReferenceStep, SiameseReferenceStep
     cores = usable_cores()
     torch.set_num_threads(cores)
-    p, k = args.cpu_classes, args.k_samples
-    ref = ReferenceStep(args.backbone, (args.image, args.image, 3), args.encodings_len, p, k, args.margin,
-                        args.mining if args.mining != "batch_hard" else "hardest", lr=args.lr, seed=0,
-                        optimizer="radam")
     rs = np.random.RandomState(1234)
-    x = rs.rand(p * k, args.image, args.image, 3).astype(np.float32)
-    ref.step(x, rng=np.random.RandomState(0))                    # warm-up (allocator, thread pool)
-    t0, n, trip = time.perf_counter(), 0, 0
+    shape = (args.image, args.image, 3)
+    if args.mode == "siamese":
+        b = args.cpu_pairs
+        ref = SiameseReferenceStep(args.backbone, shape, args.encodings_len, lr=args.lr, optimizer=args.optimizer)
+        x1, x2 = rs.rand(b, *shape).astype(np.float32), rs.rand(b, *shape).astype(np.float32)
+        y = (np.arange(b) < b // 2).astype(np.float32)
+        run, unique = (lambda i: ref.step(x1, x2, y)), 2 * b
+        what = (f"oracle/step.py SiameseReferenceStep (2 branch fwd/bwd + contrastive + {args.optimizer}) on torch-CPU fp32, "
+                f"{args.backbone} {args.image}x{args.image}, {b} pairs = {unique} images/step")
+    else:
+        p, k = args.cpu_classes, args.k_samples
+        ref = ReferenceStep(args.backbone, shape, args.encodings_len, p, k, args.margin,
+                            args.mining if args.mining != "batch_hard" else "hardest", lr=args.lr, optimizer=args.optimizer)
+        x = rs.rand(p * k, *shape).astype(np.float32)
+        trip = []
+        run, unique = (lambda i: trip.append(ref.step(x, rng=np.random.RandomState(i))[1])), p * k
+        what = (f"oracle/step.py ReferenceStep (P predict() calls + f64 distance matrix + Python mining loop + 3-branch "
+                f"fwd/bwd + {args.optimizer}) on torch-CPU fp32, {args.backbone} {args.image}x{args.image}, batch {p}x{k}={unique} "
+                f"unique images/step (the timed GPU step has {args.k_classes}x{k})")
+    run(0)                                                        # warm-up (allocator, thread pool)
+    t0, n = time.perf_counter(), 0
     while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
-        _, t, _ = ref.step(x, rng=np.random.RandomState(n))
         n += 1
-        trip += t
+        run(n)
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(p * k / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/step.py ReferenceStep (P predict() calls + f64 distance matrix + Python mining loop + "
-                      f"3-branch fwd/bwd + RAdam) on torch-CPU fp32, {args.backbone} {args.image}x{args.image}, "
-                      f"batch {p}x{k}={p * k} unique images/step, {n} steps of {dt:.2f} s, "
-                      f"mean {trip / n:.1f} triplets (= {3 * trip / n / dt:.2f} branch images/sec)"}
+    return {"value": round(unique / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{what}, {n} steps of {dt:.2f} s"}
+
+
+def roofline_from_trace(records, traced_steps, ms_per_step, workload):
+    """records: [(kernel, ms, work, unit, bytes)] over `traced_steps` steps -> (roofline dict, per-kernel table)."""
+    by = {}
+    for name, ms, work, unit, nbytes in records:
+        d = by.setdefault(name, dict(launches=0, ms=0.0, work=0.0, bytes=0.0, unit=unit))
+        d["launches"] += 1; d["ms"] += ms; d["work"] += work; d["bytes"] += nbytes
+    if not by:
+        return None, by
+    table = sorted(by.items(), key=lambda kv: -kv[1]["ms"])
+    for name, d in table[:14]:
+        rate = d["work"] / d["ms"] / 1e9 if d["unit"] == 0 else d["work"] / d["ms"] / 1e6
+        log(f"  {name[:104]:104s} x{d['launches'] // traced_steps:3d}/step  avg {1e3 * d['ms'] / d['launches']:8.1f} us  "
+            f"{rate:8.1f} {'TFLOP/s' if d['unit'] == 0 else 'GB/s'}  {d['ms'] / traced_steps:6.3f} ms/step")
+    total_ms = sum(d["ms"] for d in by.values()) / traced_steps
+    log(f"  traced kernels total {total_ms:.2f} ms of {ms_per_step:.2f} ms per step ({traced_steps} traced steps)")
+    name, d = table[0]
+    avg_us = 1e3 * d["ms"] / d["launches"]
+    if d["unit"] == 0:
+        achieved = d["work"] / d["ms"] / 1e9
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                "flop_per_launch": d["work"] / d["launches"]}
+    else:
+        achieved = d["work"] / d["ms"] / 1e6
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBPS, 4)}
+    roof.update(launches=d["launches"], avg_us=round(avg_us, 1), traffic_algorithmic=round(d["bytes"] / d["launches"]),
+                share_of_step=round(d["ms"] / traced_steps / ms_per_step, 4))
+    # measured HBM bytes per launch (PMC counters, separate rocprofv3 passes): only from a profile of THIS workload
+    roof["traffic"] = None
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(tpath):
+        prof = json.load(open(tpath)).get(workload, {})
+        if name in prof.get("kernels", {}):
+            roof["traffic"] = prof["kernels"][name]
+            roof["traffic_source"] = f"profiles/r02_pmc_traffic.json [{workload}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["traffic_algorithmic"], 1), 2)
+    return roof, by
 
 
 def main():
@@ -75,24 +142,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--backbone", default="resnet18")
-    ap.add_argument("--image", type=int, default=224)
-    ap.add_argument("--k-classes", type=int, default=32, help="classes per GPU (local batch = k_classes*k_samples)")
-    ap.add_argument("--k-samples", type=int, default=4)
-    ap.add_argument("--encodings-len", type=int, default=256)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=None, choices=["triplet", "siamese"])
+    ap.add_argument("--backbone", default=None)
+    ap.add_argument("--image", type=int, default=None)
+    ap.add_argument("--k-classes", type=int, default=None, help="classes per GPU (local batch = k_classes*k_samples)")
+    ap.add_argument("--k-samples", type=int, default=None)
+    ap.add_argument("--pairs", type=int, default=None, help="siamese: pairs per GPU (first half same class)")
+    ap.add_argument("--encodings-len", type=int, default=None)
     ap.add_argument("--margin", type=float, default=0.5)
-    ap.add_argument("--mining", default="hardest", choices=["hardest", "semihard", "random_hard", "batch_hard"])
+    ap.add_argument("--mining", default=None, choices=["hardest", "semihard", "random_hard", "batch_hard"])
+    ap.add_argument("--optimizer", default="radam", choices=["radam", "adam", "rms_prop", "sgd"])
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-classes", type=int, default=4)
+    ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    for key, val in dict(k_classes=32, k_samples=4, pairs=256, mining="hardest", **CONFIGS[args.config]).items():
+        if getattr(args, key, None) is None:
+            setattr(args, key, val)
 
     from embeddingnet_amd import _lib
     from embeddingnet_amd import backbones as B
-    from embeddingnet_amd import layers as L
-    from embeddingnet_amd.parallel import GradReducer, init_distributed
+    from embeddingnet_amd.parallel import GradReducer, broadcast_model, init_distributed
     from embeddingnet_amd.train_step import TripletTrainer
     from embeddingnet_amd.utils import get_optimizer
 
@@ -104,16 +178,48 @@ def main():
     _lib.lib()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-
-    base, _ = B.get_backbone((args.image, args.image, 3), encodings_len=args.encodings_len,
-                             backbone_name=args.backbone, backbone_weights=None, seed=0, device=dev)
-    opt = get_optimizer("radam", args.lr).build([p for p in base.parameters() if p.requires_grad])
-    reducer = GradReducer(base.parameters()) if world > 1 else None
-    trainer = TripletTrainer(base, opt, args.k_classes, args.k_samples, margin=args.margin,
-                             negatives_selection_mode=args.mining, seed=rank, reducer=reducer)
-    n_local = args.k_classes * args.k_samples
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.rand((n_local, args.image, args.image, 3), generator=gen, device=dev)   # resident in HBM
+    shape = (args.image, args.image, 3)
+
+    if args.mode == "siamese":
+        from embeddingnet_amd.losses_and_accuracies import contrastive_loss
+        from embeddingnet_amd.models import SiameseNet
+        net = SiameseNet({"model": dict(input_shape=list(shape), encodings_len=args.encodings_len, mode="siamese",
+                                        distance_type="l2", backbone_name=args.backbone, backbone_weights=None,
+                                        freeze_backbone=False, embeddings_normalization=True, device=dev, seed=0),
+                          "dataloader": {}, "generator": {}, "train": {},
+                          "general": {"work_dir": "work_dirs/", "project_name": "bench"}}, training=True)
+        model = net.model
+        params = [p for p in net.base_model.parameters() if p.requires_grad]      # the 'l2' head has no weights of its own
+        n_local = 2 * args.pairs
+        x1 = torch.rand((args.pairs,) + shape, generator=gen, device=dev)       # resident in HBM
+        x2 = torch.rand((args.pairs,) + shape, generator=gen, device=dev)
+        y = (torch.arange(args.pairs, device=dev) < args.pairs // 2).float().reshape(-1, 1)   # datagenerators.py:345-374
+    else:
+        model, _ = B.get_backbone(shape, encodings_len=args.encodings_len, backbone_name=args.backbone,
+                                  backbone_weights=None, seed=0, device=dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        n_local = args.k_classes * args.k_samples
+        images = torch.rand((n_local,) + shape, generator=gen, device=dev)     # resident in HBM
+    broadcast_model(model)                                    # identical start on every rank (parameters + BN buffers)
+    opt = get_optimizer(args.optimizer, args.lr).build(params)
+    reducer = GradReducer(params) if world > 1 else None
+
+    if args.mode == "siamese":
+        model.train()
+
+        def step():
+            reducer.zero() if reducer is not None else opt.zero_grad(set_to_none=True)
+            loss = contrastive_loss(y, model([x1, x2])[0])
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            opt.step()
+            return loss.detach()
+    else:
+        trainer = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin,
+                                 negatives_selection_mode=args.mining, seed=rank, reducer=reducer)
+        step = lambda: trainer.step(images)
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,63 +228,52 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(images)
-    timer = None if args.no_kernel_timer else L.KernelTimer()
+        step()
+    trace = rank == 0 and not args.no_kernel_timer
+    if trace:
+        _lib.trace_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP-event brackets around the conv kernels on every 4th timed step: each bracket is two marker
-        # packets on the stream, and ~120 of them per step cost ~8 % of the step if applied to all steps
-        L.TIMER = timer if i % 4 == 0 else None
-        loss = trainer.step(images)
+        if trace:          # ~250 event pairs per traced step: kept to every 4th step so they cost < 2 % of the timed region
+            _lib.trace_enable(i % 4 == 0)
+        loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    L.TIMER = None
+    _lib.trace_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_local * world * args.steps / elapsed
-
     if rank != 0:
         return
+
     roofline = None
-    if timer is not None:
-        summ = timer.summary()
-        for name, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms_total"]):
-            log(f"  {name:100s} launches {d['launches']:5d}  avg {1e3 * d['ms_total'] / d['launches']:9.1f} us  "
-                f"{d['flops_total'] / d['ms_total'] / 1e9:7.1f} TFLOP/s")
-        if os.environ.get("EMBNET_BENCH_DETAIL"):
-            for name, d in sorted(timer.detail().items(), key=lambda kv: -kv[1]["ms_total"]):
-                log(f"    {name:86s} x{d['launches']:3d}  avg {1e3 * d['ms_total'] / d['launches']:8.1f} us  "
-                    f"{d['flops_total'] / d['ms_total'] / 1e9:6.1f} TF/s")
-        conv_ms = sum(d["ms_total"] for d in summ.values())
-        timed_steps = (args.steps + 3) // 4
-        log(f"  conv kernels total {conv_ms / timed_steps:.2f} ms of {ms_per_step:.2f} ms per step "
-            f"(brackets on {timed_steps} of {args.steps} steps)")
-        name, d = max(summ.items(), key=lambda kv: kv[1]["ms_total"])
-        achieved = d["flops_total"] / d["ms_total"] / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(name)
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "launches": d["launches"], "avg_us": round(1e3 * d["ms_total"] / d["launches"], 1),
-                    "flop_per_launch": d["flops_total"] / d["launches"]}
-        if args.backbone in FWD_GMAC and args.image == 224:
-            roofline["end_to_end_frac"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
-                                                (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+    if trace:
+        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + 3) // 4, ms_per_step, args.config)
+        if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
+            roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
+                                                             (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+    if args.mode == "siamese":
+        metric = f"images/sec training ({args.backbone}, {args.image}², Siamese contrastive) @ 1/2/4/8 GPU"
+        workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), SiameseNet 'l2' head + contrastive_loss, "
+                    f"{args.pairs} pairs per GPU (first half same class) = {n_local} images, E={args.encodings_len}, "
+                    f"{args.optimizer}, fp32")
+    else:
+        label = {"resnet18": "ResNet18", "resnet50": "ResNet50", "efficientnet-b0": "EfficientNet-B0"}.get(args.backbone, args.backbone)
+        mining = "batch-hard" if (args.mining in ("hardest", "batch_hard")) else args.mining
+        metric = f"images/sec training ({label}, {args.image}², triplet {mining}) @ 1/2/4/8 GPU"
+        workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), 107-class P x K sampling, local batch "
+                    f"{args.k_classes}x{args.k_samples}={n_local}, E={args.encodings_len}, margin {args.margin}, mining "
+                    f"'{args.mining}' per local batch, {args.optimizer}, fp32")
     out = {
-        "metric": "images/sec training (ResNet18, 224², triplet batch-hard) @ 1/2/4/8 GPU",
-        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), 107-class P x K sampling, "
-                               f"local batch {args.k_classes}x{args.k_samples}={n_local}, E={args.encodings_len}, "
-                               f"margin {args.margin}, mining '{args.mining}' per local batch, RAdam, fp32",
-                   "global_batch": n_local * world, "parallelism": f"dp{world}", "final_loss": float(loss.item())},
+        "metric": metric, "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "baseline_config": args.config, "global_batch": n_local * world,
+                   "parallelism": f"dp{world}", "final_loss": float(loss.item())},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -82,3 +82,26 @@ def stream():
 
 def f32(x):
     return float(x)
+
+
+# ---- per-kernel timing (embnet_trace_*: HIP events inside the library around every kernel launch) ----------------
+def trace_enable(on):
+    lib().embnet_trace_enable(int(bool(on)))
+
+
+def trace_reset():
+    lib().embnet_trace_reset()
+
+
+def trace_records():
+    """-> [(kernel name, ms, algorithmic work, unit, algorithmic bytes)] — unit 0: FLOP, 1: bytes.  Waits for the
+    recorded events."""
+    l = lib()
+    name = ctypes.create_string_buffer(160)
+    ms, work, unit, nbytes = ctypes.c_float(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+    out = []
+    for i in range(l.embnet_trace_count()):
+        check(l.embnet_trace_get(i, ctypes.addressof(name), 160, ctypes.addressof(ms), ctypes.addressof(work),
+                                 ctypes.addressof(unit), ctypes.addressof(nbytes)))
+        out.append((name.value.decode(), ms.value, work.value, unit.value, nbytes.value))
+    return out

@@ -30,6 +30,26 @@ inline int check_launch(const char* what) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- optional per-kernel timing (embnet_trace_*, include/embnet.h) --------
+// A TraceScope around ONE kernel launch records a HIP event before and after it on the launch stream together with
+// the kernel's name and its ALGORITHMIC work (FLOP for the MFMA-bound kernels, bytes for the HBM-bound ones).  Off
+// (the default) it costs one relaxed load per launch.  bench.py turns it on for a sample of the timed steps.
+enum : int { TRACE_FLOP = 0, TRACE_BYTES = 1 };
+bool trace_on();
+struct TraceScope {
+  int idx;
+  hipStream_t s;
+  TraceScope(const char* name, int unit, double work, void* stream, double bytes = -1.0);
+  ~TraceScope();
+};
+#define EMBNET_CAT2(a, b) a##b
+#define EMBNET_CAT(a, b) EMBNET_CAT2(a, b)
+#define EMBNET_TRACE(name, unit, work, stream) \
+  ::embnet::TraceScope EMBNET_CAT(trace_scope_, __LINE__)(name, unit, (double)(work), (void*)(stream))
+// MFMA-bound kernel: FLOP plus the bytes its operands and result occupy (what it must move once)
+#define EMBNET_TRACE_FLOP(name, flop, bytes, stream) \
+  ::embnet::TraceScope EMBNET_CAT(trace_scope_, __LINE__)(name, ::embnet::TRACE_FLOP, (double)(flop), (void*)(stream), (double)(bytes))
+
 // tuning knobs: read once per process (each call site keeps its own `static const`)
 inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 

@@ -66,6 +66,7 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
 template <int ROWS, bool VEC, bool TF = false>
 struct LoadConvFwdA {
   using Tile = TileKC<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC && !TF;
   Buf buf; int H, W, C, Kg; FastDiv dC, dS; int tid;
   unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
   InputTransform tf; mutable unsigned okbits; mutable float4 tsc, tsh;
@@ -94,6 +95,14 @@ struct LoadConvFwdA {
 #pragma unroll
     for (int p = 0; p < Tile::PASSES; ++p) rg[p] = transform4(rg[p], (okbits >> p) & 1u, tsc, tsh, tf.act);
   }
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& rg) const {       // VEC && !TF (CAN_INTERLEAVE)
+    const int kk = kt * BK + Tile::k_of(tid);
+    int r, s, c; split_k(kk, dC, dS, r, s, c);
+    const int ih = ih0[p] + r, iw = iw0[p] + s;
+    const bool ok = kk < Kg && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const unsigned o = opaque(base[p] + 4u * (unsigned)((ih * W + iw) * C + c));
+    rg = buf.ld4(ok ? o : OOB);
+  }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
     if (VEC) {
@@ -105,7 +114,8 @@ struct LoadConvFwdA {
         const int ih = ih0[p] + r, iw = iw0[p] + s;
         const bool ok = kin && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
         bits |= (unsigned)ok << p;
-        rg[p] = buf.ld4(ok ? base[p] + 4u * (unsigned)((ih * W + iw) * C + c) : OOB);
+        const unsigned o = opaque(base[p] + 4u * (unsigned)((ih * W + iw) * C + c));
+        rg[p] = buf.ld4(ok ? o : OOB);
       }
       if (TF) {                                           // c in [0,C) also past the K end (kk mod C)
         okbits = bits;
@@ -137,6 +147,7 @@ constexpr int MAX_CLASSES = 9;          // stride <= 3
 template <int ROWS, bool VEC>
 struct LoadConvDgradA {
   using Tile = TileKC<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC;
   Buf buf; int OH, OW, K, Kg; FastDiv dK, dnS; int tid;
   unsigned base[Tile::PASSES]; int ih0[Tile::PASSES], iw0[Tile::PASSES];
   __device__ void init(const float* dy, const ConvGeom& g, const DgradClass& cg, int m0, int tid_) {
@@ -160,6 +171,14 @@ struct LoadConvDgradA {
     const bool ok = kk < Kg && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
     return ok ? base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c) : OOB;
   }
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& rg) const {       // VEC (CAN_INTERLEAVE)
+    const int kk = kt * BK + Tile::k_of(tid);
+    uint32_t t, c, tr, ts; dK.divmod((uint32_t)kk, t, c); dnS.divmod(t, tr, ts);
+    const int oh = ih0[p] - (int)tr, ow = iw0[p] - (int)ts;
+    const bool ok = kk < Kg && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+    const unsigned o = opaque(base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c));
+    rg = buf.ld4(ok ? o : OOB);
+  }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
     if (VEC) {
@@ -169,7 +188,8 @@ struct LoadConvDgradA {
       for (int p = 0; p < Tile::PASSES; ++p) {
         const int oh = ih0[p] - (int)tr, ow = iw0[p] - (int)ts;
         const bool ok = kin && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
-        rg[p] = buf.ld4(ok ? base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c) : OOB);
+        const unsigned o = opaque(base[p] + 4u * (unsigned)((oh * OW + ow) * K + (int)c));
+        rg[p] = buf.ld4(ok ? o : OOB);
       }
     } else {
 #pragma unroll
@@ -184,6 +204,7 @@ struct LoadConvDgradA {
 template <int ROWS, bool VEC>
 struct LoadConvDgradB {
   using Tile = TileKC<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC;
   Buf buf; int C, K, S, Kg, st, r0, s0; FastDiv dK, dnS; int row0, tid;
   __device__ void init(const float* w, const ConvGeom& g, const DgradClass& cg, int n0, int tid_) {
     buf.init(w, (size_t)g.R * g.S * g.C * g.K * 4);
@@ -195,6 +216,9 @@ struct LoadConvDgradB {
     uint32_t t, ko, tr, ts; dK.divmod((uint32_t)kk, t, ko); dnS.divmod(t, tr, ts);
     const unsigned rs = (unsigned)((r0 + st * (int)tr) * S + s0 + st * (int)ts);
     return (kk < Kg && c < C) ? 4u * ((rs * (unsigned)C + (unsigned)c) * (unsigned)K + ko) : OOB;
+  }
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& rg) const {       // VEC (CAN_INTERLEAVE)
+    rg = buf.ld4(off(row0 + Tile::row_of(tid, p), kt * BK + Tile::k_of(tid)));
   }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     const int kk = kt * BK + Tile::k_of(tid);
@@ -213,6 +237,7 @@ struct LoadConvDgradB {
 template <int ROWS, bool VEC, bool TF = false>
 struct LoadConvWgradA {
   using Tile = TileKM<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC && !TF;
   Buf buf; int H, W, C, Mrows, Kg, stride, pad_t, pad_l; FastDiv dOHW, dOW, dC, dS; unsigned HWC4; int tid;
   int r_[Tile::PASSES], s_[Tile::PASSES], c_[Tile::PASSES], m_[Tile::PASSES];    // first row of each pass
   InputTransform tf; mutable unsigned okbits;
@@ -244,6 +269,16 @@ struct LoadConvWgradA {
     const bool ok = kin && m < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     return ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c) : OOB;
   }
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& rg) const {       // VEC && !TF (CAN_INTERLEAVE)
+    const int kg = kt * BK + Tile::k_of(tid, p);
+    const bool kin = kg < Kg;
+    uint32_t n, rem, oh, ow;
+    dOHW.divmod((uint32_t)(kin ? kg : 0), n, rem); dOW.divmod(rem, oh, ow);
+    const int ih = (int)oh * stride + r_[p] - pad_t, iw = (int)ow * stride + s_[p] - pad_l;
+    const bool ok = kin && m_[p] < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const unsigned o = opaque(n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c_[p]));
+    rg = buf.ld4(ok ? o : OOB);
+  }
   __device__ __forceinline__ void load(int kt, float4 (&rg)[Tile::PASSES]) const {
     unsigned bits = 0;
 #pragma unroll
@@ -256,7 +291,8 @@ struct LoadConvWgradA {
         const int ih = (int)oh * stride + r_[p] - pad_t, iw = (int)ow * stride + s_[p] - pad_l;
         const bool ok = kin && m_[p] < Mrows && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
         bits |= (unsigned)ok << p;
-        rg[p] = buf.ld4(ok ? n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c_[p]) : OOB);
+        const unsigned o = opaque(n * HWC4 + 4u * (unsigned)((ih * W + iw) * C + c_[p]));
+        rg[p] = buf.ld4(ok ? o : OOB);
       } else {
         rg[p] = make_float4(buf.ld1(off(m_[p], n, oh, ow, kin)), buf.ld1(off(m_[p] + 1, n, oh, ow, kin)),
                             buf.ld1(off(m_[p] + 2, n, oh, ow, kin)), buf.ld1(off(m_[p] + 3, n, oh, ow, kin)));
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   });
 }
 
-struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; };
+struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; int stagger; };
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
 template <class G, bool VA, bool VB, bool TF>
@@ -511,7 +547,12 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   LoadRowsKM<G::BN, VB> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
-  gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  // stagger > 0 (with xcd_order): the tiles of one split, co-resident on one XCD, start their K ranges `stagger`
+  // tiles apart (wrapping around), so they want different L2 lines at any instant but the same ones within a few
+  // tiles' time.  Two passes over the rotated range; the accumulators carry over.
+  const int rot = p.stagger > 0 ? min((tile * p.stagger) % max(kt1 - kt0, 1), kt1 - kt0) : 0;
+  gemm_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  if (rot > 0) { prio_lo(); gemm_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
   stamp(4);
   float* out = p.out + (long)split * M * p.g.K;
   if (VB) {                                              // K % 4 == 0
@@ -671,6 +712,14 @@ static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, Split
   t.n_full = (int)(tiles - rem); t.parts = best_parts; t.kt_part = cdiv(kt, best_parts);
 }
 
+// kernel name as rocprofv3 prints it, for the trace log (and embnet_conv2d_kernel_name)
+static const char* GEOM_NAME[5] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2", "192, 64, 2, 2"};
+static const char* conv_kernel_name(const char* kernel, const char* params, int tile, const char* flags) {
+  static thread_local char buf[160];
+  snprintf(buf, sizeof buf, "void embnet::%s<embnet::Geom<%s>, %s>(embnet::%s)", kernel, GEOM_NAME[tile], flags, params);
+  return buf;
+}
+
 #define LAUNCH_TILED(KERNEL, VECARGS, tile, grid, st, p)                              \
   switch (tile) {                                                                     \
     case 0: KERNEL<G128x128, VECARGS><<<grid, 256, 0, st>>>(p); break;                \
@@ -724,11 +773,18 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   p.tail.ws = (float*)workspace;
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
   p.fair_from = fair_from(grid, tile, false);
-  if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
-  else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
-  else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
+  const double flop = 2.0 * M * k * r * s * c;
+  {
+    EMBNET_TRACE_FLOP(conv_kernel_name(in_scale ? "conv_fwd_tf_kernel" : "conv_fwd_kernel", "ConvFwdParams", tile,
+                                       (vec || in_scale) ? "true" : "false"), flop,
+                      4.0 * ((double)n * h * wd * c + (double)r * s * c * k + (double)M * k * (residual ? 2 : 1)), st);
+    if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
+    else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
+    else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
+  }
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
+    EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (p.tail.parts + 1 + (residual ? 1 : 0)), st);
     tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
                                                              cdiv(k, bn), M, k, bias, relu, residual, y, stats, p.stats_rows);
   }
@@ -784,10 +840,16 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
   p.tail.ws = (float*)workspace;
   const dim3 grid(p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts, stride * stride);
   p.fair_from = fair_from((long)grid.x * grid.y, tile, false);
-  if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
-  else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
+  {
+    EMBNET_TRACE_FLOP(conv_kernel_name("conv_dgrad_kernel", "ConvDgradParams", tile, vec ? "true" : "false"),
+                      2.0 * n * oh * ow * (double)k * r * s * c,
+                      4.0 * ((double)n * oh * ow * k + (double)r * s * c * k + (double)n * h * wd * c * (p.accumulate ? 2 : 1)), st);
+    if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
+    else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
+  }
   if (p.tail.parts > 1) {
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
+    EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (p.tail.parts + 1 + (p.accumulate ? 1 : 0)), st);
     tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
                                                              cdiv(c, bn), max_m, c, nullptr, 0, p.accumulate ? p.add_src : nullptr, dx, nullptr, 0);
   }
@@ -837,8 +899,16 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
-  static const int xcd_order = (int)env_long("EMBNET_WGRAD_XCD", 0);
+#ifndef EMBNET_WGRAD_XCD_DEFAULT
+#define EMBNET_WGRAD_XCD_DEFAULT 0
+#endif
+#ifndef EMBNET_WGRAD_STAGGER_DEFAULT
+#define EMBNET_WGRAD_STAGGER_DEFAULT 0
+#endif
+  static const int xcd_order = (int)env_long("EMBNET_WGRAD_XCD", EMBNET_WGRAD_XCD_DEFAULT);
+  static const int stagger = (int)env_long("EMBNET_WGRAD_STAGGER", EMBNET_WGRAD_STAGGER_DEFAULT);
   p.xcd_order = xcd_order;
+  p.stagger = xcd_order ? stagger : 0;
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_wgrad")) return rc;
   int tile;
   const int rows = r * s * c;
@@ -856,6 +926,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
                    "conv2d_wgrad: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
   p.tf = InputTransform{in_scale, in_shift, in_act};
   if (do_main) {
+    EMBNET_TRACE_FLOP(conv_kernel_name(in_scale ? "conv_wgrad_tf_kernel" : "conv_wgrad_kernel", "ConvWgradParams", tile,
+                                       (in_scale || (va && vb)) ? "true, true" : (vb ? "false, true" : "false, false")),
+                      2.0 * n * oh * ow * (double)k * rows,
+                      4.0 * ((double)n * h * wd * c + (double)n * oh * ow * k + (double)rows * k * p.splits), st);
     if (in_scale) { LAUNCH_WGRAD(conv_wgrad_tf_kernel, true, true) }
     else if (va && vb) { LAUNCH_WGRAD(conv_wgrad_kernel, true, true) }
     else if (vb) { LAUNCH_WGRAD(conv_wgrad_kernel, false, true) }
@@ -863,6 +937,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   }
   if (p.splits > 1 && do_reduce) {
     const long cnt = (long)rows * k;
+    EMBNET_TRACE("embnet::slab_reduce_kernel", TRACE_BYTES, 4.0 * cnt * (p.splits + 1), st);
     slab_reduce_kernel<<<(cnt & 3) ? cdiv(cnt, 256) : cdiv(cnt / 4, 32), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
   }
   return check_launch("conv2d_wgrad");
@@ -902,7 +977,7 @@ extern "C" int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, f
 extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k,
                                                  int oh, int ow) {
   static thread_local char buf[160];
-  static const char* geoms[5] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2", "192, 64, 2, 2"};
+  const char* const* geoms = GEOM_NAME;
   const char* t = (c & 3) == 0 ? "true" : "false";
   const char* tk = (k & 3) == 0 ? "true" : "false";
   if (kind == 0) {

@@ -79,6 +79,7 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 #define LAUNCH_DENSE(KERNEL, p, vec, st)                                                             \
   do {                                                                                               \
+    EMBNET_TRACE("embnet::" #KERNEL, TRACE_FLOP, 2.0 * (p).m * (p).n * (p).k, st);                   \
     if ((long)cdiv((p).m, 128) * cdiv((p).n, 128) >= 256) {                                          \
       const int grid = cdiv((p).m, 128) * cdiv((p).n, 128);                                          \
       if (vec) KERNEL<G128, true><<<grid, 256, 0, st>>>(p); else KERNEL<G128, false><<<grid, 256, 0, st>>>(p); \

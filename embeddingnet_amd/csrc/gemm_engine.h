@@ -61,6 +61,19 @@ __device__ __forceinline__ void stamp(int) {}
 constexpr unsigned OOB = 0x80000000u;          // byte offset no operand (< 2 GiB) reaches
 constexpr size_t MAX_OPERAND_BYTES = 0x7FFFFFF0ull;
 
+#ifndef EMBNET_INTERLEAVE
+#define EMBNET_INTERLEAVE 0
+#endif
+// Keeps an address computation unconditional: without it hipcc turns `ok ? offset : OOB` into a branch around the
+// offset arithmetic (s_and_saveexec / s_cbranch_execz per load), which splits the K-tile body into many basic blocks
+// and pins every load in front of the MFMAs.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+#if EMBNET_INTERLEAVE
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // Raw buffer view of one operand tensor.
 struct Buf {
   __amdgpu_buffer_rsrc_t r;
@@ -68,6 +81,10 @@ struct Buf {
     r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
   }
   __device__ __forceinline__ float4 ld4(unsigned off) const {
+#if defined(EMBNET_ABLATE) && EMBNET_ABLATE == 5     // diagnostic: the address arithmetic stays, the load instruction does not
+    asm volatile("" :: "v"(off));
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     // NB: cast the WHOLE vector.  Per-component __builtin_bit_cast(float, v.x) makes hipcc (ROCm 7.2)
     // narrow the load to buffer_load_dword while still consuming v[0:3] — three garbage lanes.
     const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
@@ -130,6 +147,7 @@ struct TileKM {
 template <int ROWS, bool VEC>
 struct LoadRowsKC {
   using Tile = TileKC<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC;
   Buf buf; int K, tid;
   unsigned row_off[Tile::PASSES];
   __device__ void init(const float* b, long ld, int rows, int K_, int row0, int tid_) {
@@ -141,18 +159,20 @@ struct LoadRowsKC {
     }
   }
   __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
-  __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
+  // one pass (one 16-byte piece per thread) of K tile kt: the main loop issues the passes one at a time between its MFMAs
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& r) const {
     const int k = kt * BK + Tile::k_of(tid);
-#pragma unroll
-    for (int p = 0; p < Tile::PASSES; ++p) {
-      const unsigned off = row_off[p] + 4u * k;            // stays out of range when the row is
-      if (VEC) {
-        r[p] = buf.ld4(k < K ? off : OOB);
-      } else {
-        r[p] = make_float4(buf.ld1(k < K ? off : OOB), buf.ld1(k + 1 < K ? off + 4 : OOB),
-                           buf.ld1(k + 2 < K ? off + 8 : OOB), buf.ld1(k + 3 < K ? off + 12 : OOB));
-      }
+    const unsigned off = row_off[p] + 4u * k;              // stays out of range when the row is
+    if (VEC) {
+      r = buf.ld4(k < K ? off : OOB);
+    } else {
+      r = make_float4(buf.ld1(k < K ? off : OOB), buf.ld1(k + 1 < K ? off + 4 : OOB),
+                      buf.ld1(k + 2 < K ? off + 8 : OOB), buf.ld1(k + 3 < K ? off + 12 : OOB));
     }
+  }
+  __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
+#pragma unroll
+    for (int p = 0; p < Tile::PASSES; ++p) load_pass(kt, p, r[p]);
   }
 };
 
@@ -161,6 +181,7 @@ struct LoadRowsKC {
 template <int ROWS, bool VEC>
 struct LoadRowsKM {
   using Tile = TileKM<ROWS>;
+  static constexpr bool CAN_INTERLEAVE = VEC;
   Buf buf; int K, rows, tid; unsigned ldb;
   unsigned col_off[Tile::PASSES];
   __device__ void init(const float* b, long ld, int rows_, int K_, int row0, int tid_) {
@@ -169,20 +190,21 @@ struct LoadRowsKM {
     for (int p = 0; p < Tile::PASSES; ++p) col_off[p] = 4u * (unsigned)(row0 + Tile::row_of(tid, p));
   }
   __device__ __forceinline__ void fix(float4 (&)[Tile::PASSES]) const {}
+  __device__ __forceinline__ void load_pass(int kt, int p, float4& r) const {
+    const int k = kt * BK + Tile::k_of(tid, p);
+    const unsigned off = (unsigned)k * ldb + col_off[p];
+    const int row = (int)(col_off[p] >> 2);
+    if (VEC) {
+      r = buf.ld4((k < K && row < rows) ? off : OOB);
+    } else {
+      const bool kin = k < K;
+      r = make_float4(buf.ld1(kin && row < rows ? off : OOB), buf.ld1(kin && row + 1 < rows ? off + 4 : OOB),
+                      buf.ld1(kin && row + 2 < rows ? off + 8 : OOB), buf.ld1(kin && row + 3 < rows ? off + 12 : OOB));
+    }
+  }
   __device__ __forceinline__ void load(int kt, float4 (&r)[Tile::PASSES]) const {
 #pragma unroll
-    for (int p = 0; p < Tile::PASSES; ++p) {
-      const int k = kt * BK + Tile::k_of(tid, p);
-      const unsigned off = (unsigned)k * ldb + col_off[p];
-      const int row = (int)(col_off[p] >> 2);
-      if (VEC) {
-        r[p] = buf.ld4((k < K && row < rows) ? off : OOB);
-      } else {
-        const bool kin = k < K;
-        r[p] = make_float4(buf.ld1(kin && row < rows ? off : OOB), buf.ld1(kin && row + 1 < rows ? off + 4 : OOB),
-                           buf.ld1(kin && row + 2 < rows ? off + 8 : OOB), buf.ld1(kin && row + 3 < rows ? off + 12 : OOB));
-      }
-    }
+    for (int p = 0; p < Tile::PASSES; ++p) load_pass(kt, p, r[p]);
   }
 };
 
@@ -225,6 +247,12 @@ __device__ __forceinline__ void load_frags(const float* st, int wm, int wn, int 
 // main loop at 0: the few hundred vector instructions they hold barely touch the older waves' MFMA stream.
 #ifndef EMBNET_PHASE_PRIO
 #define EMBNET_PHASE_PRIO 1
+#endif
+#ifndef EMBNET_ABLATE
+#define EMBNET_ABLATE 0
+#endif
+#ifndef EMBNET_INTERLEAVE
+#define EMBNET_INTERLEAVE 0
 #endif
 __device__ __forceinline__ void prio_hi() {
 #if EMBNET_PHASE_PRIO
@@ -285,18 +313,21 @@ __device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const floa
 // pipe.  Progress-ordered priority lets the waves that are behind catch up, so the last round ends together.
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end,
-                                              float* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false) {
+                                              float* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false,
+                                              bool zero_acc = true) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
   constexpr int PAST = 1 << 24;            // k tile index past any K: every offset out of range, loads return 0
 
+  if (zero_acc) {                            // false: continue accumulating (a K range visited in two pieces)
 #pragma unroll
-  for (int i = 0; i < G::TM; ++i)
+    for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < G::TN; ++j)
+      for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   float4 ra[TA::PASSES], rb[TB::PASSES];
   if constexpr (LDS_STAGES == 2) {
@@ -343,7 +374,20 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
     float* sA = smem;
     if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); }
     stamp(8);
+#if EMBNET_ABLATE >= 2 && EMBNET_ABLATE != 4
+    // diagnostic builds (wrong results by construction; tools/exp only): 1 = no global loads inside the loop,
+    // 2 = also no LDS writes and no barriers (operand tiles written once), 3 = also no fragment reads (MFMA only)
+    TA::store(sA, ra, tid);
+    TB::store(sA + TA::FLOATS, rb, tid);
+    __syncthreads();
+    prio_lo();
+#endif
+#if EMBNET_ABLATE == 3
+    float a3[G::TM][4], b3[G::TN][4];
+    load_frags<G, TA, TB>(sA, wm, wn, 0, lane, a3, b3);
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
+#if EMBNET_ABLATE < 2 || EMBNET_ABLATE == 4
       __syncthreads();                       // everyone finished reading the previous tile
       TA::store(sA, ra, tid);
       TB::store(sA + TA::FLOATS, rb, tid);
@@ -363,15 +407,55 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
 #if EMBNET_STAMPS
       if (kt == kt_begin) stamp(3);
 #endif
+#endif
+#if EMBNET_ABLATE == 4                      // diagnostic: same instructions, but every prefetch re-reads the FIRST tile (cache hits)
+      la.load(kt + 1 < kt_end ? kt_begin : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt_begin : PAST, rb);
+#elif EMBNET_ABLATE < 1
       // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
       // offset out of range, so the loads return zeros and need no branch
-      la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
-      lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+      if constexpr (!(EMBNET_INTERLEAVE && LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE)) {
+        la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+        lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+      }
+#endif
+#if EMBNET_INTERLEAVE && EMBNET_ABLATE == 0
+      // The prefetch of the next tile is issued pass by pass BEHIND the first three k-steps' MFMAs instead of as a
+      // burst in front of them: a vector-memory instruction holds the SIMD's issue port for ~60+ cycles, and in a
+      // burst the co-resident waves' MFMAs (one due every 64 cycles) queue behind it.  (Ablation, tools/exp: the same
+      // kernels run 12-17 % faster without the loads in the loop, and not at all faster when the loads always hit the
+      // cache — what costs is their issue, not their latency.)  Past the end the k bound puts every offset out of range.
+      if constexpr (LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE) {
+        constexpr int NV = TA::PASSES + TB::PASSES;
+        const int ktn = kt + 1 < kt_end ? kt + 1 : PAST;
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+          float a[G::TM][4], b[G::TN][4];
+          load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
+          mfma_step<G>(a, b, acc);
+          if (j < 3) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = j * NV / 3; v < (j + 1) * NV / 3; ++v) {
+              if (v < TA::PASSES) la.load_pass(ktn, v, ra[v < TA::PASSES ? v : 0]);
+              else lb.load_pass(ktn, v - TA::PASSES, rb[v >= TA::PASSES ? v - TA::PASSES : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int j = 0; j < BK / 8; ++j) {
+#if EMBNET_ABLATE == 3
+        mfma_step<G>(a3, b3, acc);
+        asm volatile("" ::: "memory");
+#else
         float a[G::TM][4], b[G::TN][4];
         load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
         mfma_step<G>(a, b, acc);
+#endif
       }
       // loader's register-side transform of the tile just fetched (usually none): here, behind the MFMAs it
       // overlaps with and outside the barrier pair, not between the barrier and the LDS store

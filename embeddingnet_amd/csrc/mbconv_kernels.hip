@@ -406,10 +406,10 @@ extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y,
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_fwd")) return rc;
   const long total = (long)n * oh * ow * c;
   const int grid4 = cdiv(total / 4, 256);
-  if ((c & 3) == 0 && r == s && r == 3) dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
-  else if ((c & 3) == 0 && r == s && r == 5) dwconv_fwd4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
-  else if ((c & 3) == 0) dwconv_fwd_kernel<4><<<grid4, 256, 0, S(stream)>>>(x, w, g, y);
-  else dwconv_fwd_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(x, w, g, y);
+  if ((c & 3) == 0 && r == s && r == 3) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
+  else if ((c & 3) == 0 && r == s && r == 5) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
+  else if ((c & 3) == 0) { EMBNET_TRACE("embnet::dwconv_fwd_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd_kernel<4><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
+  else { EMBNET_TRACE("embnet::dwconv_fwd_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(x, w, g, y); }
   return check_launch("dwconv2d_fwd");
 }
 
@@ -421,12 +421,12 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
   const long total = (long)n * h * wd * c;
   const int grid4 = cdiv(total / 4, 256);
   const bool sq = (c & 3) == 0 && r == s && (stride == 1 || stride == 2);
-  if (sq && r == 3 && stride == 1) dwconv_dgrad4_sq_kernel<3, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else if (sq && r == 3) dwconv_dgrad4_sq_kernel<3, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else if (sq && r == 5 && stride == 1) dwconv_dgrad4_sq_kernel<5, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else if (sq && r == 5) dwconv_dgrad4_sq_kernel<5, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else if ((c & 3) == 0) dwconv_dgrad_kernel<4><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx);
-  else dwconv_dgrad_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, w, g, dx);
+  if (sq && r == 3 && stride == 1) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<3, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
+  else if (sq && r == 3) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<3, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
+  else if (sq && r == 5 && stride == 1) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<5, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
+  else if (sq && r == 5) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<5, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
+  else if ((c & 3) == 0) { EMBNET_TRACE("embnet::dwconv_dgrad_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad_kernel<4><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
+  else { EMBNET_TRACE("embnet::dwconv_dgrad_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, w, g, dx); }
   return check_launch("dwconv2d_dgrad");
 }
 
@@ -455,43 +455,43 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
   const int blocks = dw_wgrad_blocks((long)n * oh * ow, ppb);
   if ((c & 3) == 0) {
     int cql = 1; while (cql < c / 4 && cql < 256) cql <<= 1;
-    if (r == 3 && s == 3) dwconv_wgrad4_kernel<9, 3><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else if (r == 5 && s == 5) dwconv_wgrad4_kernel<25, 5><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else if (r * s <= 9) dwconv_wgrad4_kernel<9, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else if (r * s <= 25) dwconv_wgrad4_kernel<25, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
-    else dwconv_wgrad4_kernel<49, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace);
+    if (r == 3 && s == 3) { EMBNET_TRACE("embnet::dwconv_wgrad4_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad4_kernel<9, 3><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace); }
+    else if (r == 5 && s == 5) { EMBNET_TRACE("embnet::dwconv_wgrad4_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad4_kernel<25, 5><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace); }
+    else if (r * s <= 9) { EMBNET_TRACE("embnet::dwconv_wgrad4_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad4_kernel<9, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace); }
+    else if (r * s <= 25) { EMBNET_TRACE("embnet::dwconv_wgrad4_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad4_kernel<25, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace); }
+    else { EMBNET_TRACE("embnet::dwconv_wgrad4_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad4_kernel<49, 0><<<blocks, 256, 0, S(stream)>>>(x, dy, g, cql, ppb, (float*)workspace); }
   } else {
-    dwconv_wgrad1_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace);
+    { EMBNET_TRACE("embnet::dwconv_wgrad1_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwconv_wgrad1_kernel<<<blocks, 256, 0, S(stream)>>>(x, dy, g, ppb, (float*)workspace); }
   }
   const long cnt = (long)r * s * c;
-  dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw);
+  { EMBNET_TRACE("embnet::dw_slab_sum_kernel", TRACE_BYTES, 4.0 * cnt * (blocks + 1), stream); dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw); }
   return check_launch("dwconv2d_wgrad");
 }
 
 extern "C" int embnet_activation_fwd(const float* x, long total, int kind, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0 && (kind == 0 || kind == 1), "activation_fwd: bad argument");
-  act_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, kind, y);
+  { EMBNET_TRACE("embnet::act_fwd_kernel", TRACE_BYTES, 8.0 * total, stream); act_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, kind, y); }
   return check_launch("activation_fwd");
 }
 
 extern "C" int embnet_activation_bwd(const float* x, const float* dy, long total, int kind, float* dx, void* stream) {
   EMBNET_CHECK_ARG(x && dy && dx && total > 0 && (kind == 0 || kind == 1), "activation_bwd: bad argument");
-  act_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, dy, total, kind, dx);
+  { EMBNET_TRACE("embnet::act_bwd_kernel", TRACE_BYTES, 12.0 * total, stream); act_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, dy, total, kind, dx); }
   return check_launch("activation_bwd");
 }
 
 extern "C" int embnet_channel_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && s && y && n > 0 && hw > 0 && c > 0, "channel_scale_fwd: bad argument");
   const long total = (long)n * hw * c;
-  chscale_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, s, total, hw, c, y);
+  { EMBNET_TRACE("embnet::chscale_fwd_kernel", TRACE_BYTES, 8.0 * total, stream); chscale_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, s, total, hw, c, y); }
   return check_launch("channel_scale_fwd");
 }
 
 extern "C" int embnet_channel_scale_bwd(const float* x, const float* s, const float* dy, int n, int hw, int c, float* dx,
                                         float* ds, void* stream) {
   EMBNET_CHECK_ARG(x && s && dy && dx && ds && n > 0 && hw > 0 && c > 0, "channel_scale_bwd: bad argument");
-  if ((c & 3) == 0) chscale_bwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, s, dy, hw, c / 4, dx, ds);
-  else chscale_bwd_kernel<<<dim3(cdiv(c, 256), n), 256, 0, S(stream)>>>(x, s, dy, hw, c, dx, ds);
+  if ((c & 3) == 0) { EMBNET_TRACE("embnet::chscale_bwd4_kernel", TRACE_BYTES, 12.0 * n * hw * c, stream); chscale_bwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, s, dy, hw, c / 4, dx, ds); }
+  else { EMBNET_TRACE("embnet::chscale_bwd_kernel", TRACE_BYTES, 12.0 * n * hw * c, stream); chscale_bwd_kernel<<<dim3(cdiv(c, 256), n), 256, 0, S(stream)>>>(x, s, dy, hw, c, dx, ds); }
   return check_launch("channel_scale_bwd");
 }
 
@@ -499,19 +499,19 @@ extern "C" int embnet_sample_dropout(const float* x, long total, long per_sample
                                      void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0 && per_sample > 0, "sample_dropout: bad argument");
   EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "sample_dropout: rate %f outside [0,1)", rate);
-  sample_dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, per_sample, rate, seed, y);
+  { EMBNET_TRACE("embnet::sample_dropout_kernel", TRACE_BYTES, 8.0 * total, stream); sample_dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, per_sample, rate, seed, y); }
   return check_launch("sample_dropout");
 }
 
 extern "C" int embnet_absdiff_fwd(const float* a, const float* b, long total, float* y, void* stream) {
   EMBNET_CHECK_ARG(a && b && y && total > 0, "absdiff_fwd: bad argument");
-  absdiff_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y);
+  { EMBNET_TRACE("embnet::absdiff_fwd_kernel", TRACE_BYTES, 12.0 * total, stream); absdiff_fwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y); }
   return check_launch("absdiff_fwd");
 }
 
 extern "C" int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long total, float* da, float* db,
                                   void* stream) {
   EMBNET_CHECK_ARG(a && b && dy && da && db && total > 0, "absdiff_bwd: bad argument");
-  absdiff_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, dy, total, da, db);
+  { EMBNET_TRACE("embnet::absdiff_bwd_kernel", TRACE_BYTES, 20.0 * total, stream); absdiff_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, dy, total, da, db); }
   return check_launch("absdiff_bwd");
 }

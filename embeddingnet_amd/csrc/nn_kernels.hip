@@ -672,14 +672,14 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   } else if ((c & 3) == 0 && !bn_scalar()) {
     const ColGeom g4 = col_geom(m, c / 4);
     nblocks = g4.blocks;
-    bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, (float*)workspace);
+    { EMBNET_TRACE("embnet::bn_stats4_kernel", TRACE_BYTES, 4.0 * m * c, stream); bn_stats4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(x, m, c / 4, g4, (float*)workspace); }
   } else {
-    bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace);
+    { EMBNET_TRACE("embnet::bn_stats_kernel", TRACE_BYTES, 4.0 * m * c, stream); bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace); }
   }
-  bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
-                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr);
+  { EMBNET_TRACE("embnet::bn_finalize_kernel", TRACE_BYTES, 8.0 * nblocks * c, stream); bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
+                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr); }
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
-    affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
   return check_launch("bn_train_fwd");
 }
 
@@ -689,7 +689,7 @@ extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* g
   EMBNET_CHECK_ARG(x && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_infer_fwd: m=%ld c=%d", m, c);
   bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
-  if (y) affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y);
+  if (y) { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
   return check_launch("bn_infer_fwd");
 }
 
@@ -697,7 +697,7 @@ extern "C" int embnet_affine_act(const float* x, long m, int c, const float* sca
                                  void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && y, "affine_act: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "affine_act: m=%ld c=%d", m, c);
-  affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y);
+  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y); }
   return check_launch("affine_act");
 }
 
@@ -718,10 +718,10 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   if (save_mean && save_rstd) {
     if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);
-      bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial);
+      { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial); }
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
     } else {
-      bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial);
+      { EMBNET_TRACE("embnet::bn_bwd_reduce_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial); }
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
     }
   } else {
@@ -729,11 +729,11 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
-                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx);
+    { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
+                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
   else
-    bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
-                                                                 scale, shift, dbeta, dgamma, relu, training, dx_add, dx);
+    { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
+                                                                 scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
   return check_launch("bn_bwd");
 }
 
@@ -746,9 +746,9 @@ extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, in
                    "maxpool_fwd: window leaves the padded image");
   const long total = (long)n * oh * ow * c;
   if ((c & 3) == 0)
-    maxpool_fwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, k, stride, pad, oh, ow, y, argmax);
+    { EMBNET_TRACE("embnet::maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 5.0 * total, stream); maxpool_fwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, k, stride, pad, oh, ow, y, argmax); }
   else
-    maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax);
+    { EMBNET_TRACE("embnet::maxpool_fwd_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 5.0 * total, stream); maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax); }
   return check_launch("maxpool_fwd");
 }
 
@@ -758,9 +758,9 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "maxpool_bwd: bad geometry");
   const long total = (long)n * h * w * c;
   if ((c & 3) == 0)
-    maxpool_bwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c / 4, k, stride, pad, oh, ow, dx);
+    { EMBNET_TRACE("embnet::maxpool_bwd4_kernel", TRACE_BYTES, 4.0 * total + 5.0 * n * oh * ow * c, stream); maxpool_bwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c / 4, k, stride, pad, oh, ow, dx); }
   else
-    maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx);
+    { EMBNET_TRACE("embnet::maxpool_bwd_kernel", TRACE_BYTES, 4.0 * total + 5.0 * n * oh * ow * c, stream); maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx); }
   return check_launch("maxpool_bwd");
 }
 
@@ -774,8 +774,8 @@ extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, in
   EMBNET_CHECK_ARG((oh - 1) * stride + k <= h + 2 * pad && (ow - 1) * stride + k <= w + 2 * pad,
                    "bn_act_maxpool_fwd: window leaves the padded image");
   const long total = (long)n * oh * ow * (c / 4);
-  affine_act_maxpool_fwd4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, scale, shift, act, k, stride,
-                                                                          pad, oh, ow, y, argmax);
+  { EMBNET_TRACE("embnet::affine_act_maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 20.0 * total, stream); affine_act_maxpool_fwd4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, scale, shift, act, k, stride,
+                                                                          pad, oh, ow, y, argmax); }
   return check_launch("bn_act_maxpool_fwd");
 }
 
@@ -797,36 +797,36 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
     return fail(EMBNET_EWORKSPACE, "bn_act_maxpool_bwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(mp, c));
   if (save_mean && save_rstd) {
     const ColGeom g4 = col_geom(mp, c / 4);
-    pool_bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, x, mp, h, w, c / 4, k, stride, pad, oh, ow, g4,
-                                                                 save_mean, save_rstd, scale, shift, act, (float*)workspace);
+    { EMBNET_TRACE("embnet::pool_bn_bwd_reduce4_kernel", TRACE_BYTES, 9.0 * mp * c, stream); pool_bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, x, mp, h, w, c / 4, k, stride, pad, oh, ow, g4,
+                                                                 save_mean, save_rstd, scale, shift, act, (float*)workspace); }
     bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   const long total = (long)n * h * w * (c / 4);
-  pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
+  { EMBNET_TRACE("embnet::pool_bn_bwd_apply4_kernel", TRACE_BYTES, 32.0 * total + 5.0 * mp * c, stream); pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
                                                                     1.f / (float)((long)n * h * w), save_mean, save_rstd,
-                                                                    scale, shift, dbeta, dgamma, act, training, dx);
+                                                                    scale, shift, dbeta, dgamma, act, training, dx); }
   return check_launch("bn_act_maxpool_bwd");
 }
 
 extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && n > 0 && hw > 0 && c > 0, "gap_fwd: bad argument");
-  if ((c & 3) == 0) gap_fwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, y);
-  else gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y);
+  if ((c & 3) == 0) { EMBNET_TRACE("embnet::gap_fwd4_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_fwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, y); }
+  else { EMBNET_TRACE("embnet::gap_fwd_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y); }
   return check_launch("gap_fwd");
 }
 
 extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream) {
   EMBNET_CHECK_ARG(dy && dx && n > 0 && hw > 0 && c > 0, "gap_bwd: bad argument");
-  gap_bwd_kernel<<<cdiv((long)n * hw * c, 256), 256, 0, S(stream)>>>(dy, n, hw, c, dx);
+  { EMBNET_TRACE("embnet::gap_bwd_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_bwd_kernel<<<cdiv((long)n * hw * c, 256), 256, 0, S(stream)>>>(dy, n, hw, c, dx); }
   return check_launch("gap_bwd");
 }
 
 extern "C" int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void* stream) {
   EMBNET_CHECK_ARG(dy && y && dz && total > 0, "relu_bwd: bad argument");
-  relu_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(dy, y, total, dz);
+  { EMBNET_TRACE("embnet::relu_bwd_kernel", TRACE_BYTES, 12.0 * total, stream); relu_bwd_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(dy, y, total, dz); }
   return check_launch("relu_bwd");
 }
 
@@ -838,27 +838,27 @@ extern "C" int embnet_colsum(const float* x, long m, int c, float* out, void* wo
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
-  colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace);
+  { EMBNET_TRACE("embnet::colsum_kernel", TRACE_BYTES, 4.0 * m * c, stream); colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace); }
   colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, out);
   return check_launch("colsum");
 }
 
 extern "C" int embnet_add(const float* a, const float* b, long total, float* y, void* stream) {
   EMBNET_CHECK_ARG(a && b && y && total > 0, "add: bad argument");
-  add_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y);
+  { EMBNET_TRACE("embnet::add_kernel", TRACE_BYTES, 12.0 * total, stream); add_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y); }
   return check_launch("add");
 }
 
 extern "C" int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0, "scale: bad argument");
-  scale_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, alpha, alpha_dev, y);
+  { EMBNET_TRACE("embnet::scale_kernel", TRACE_BYTES, 8.0 * total, stream); scale_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, alpha, alpha_dev, y); }
   return check_launch("scale");
 }
 
 extern "C" int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0, "dropout: bad argument");
   EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "dropout: rate %f outside [0,1)", rate);
-  dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, y);
+  { EMBNET_TRACE("embnet::dropout_kernel", TRACE_BYTES, 8.0 * total, stream); dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, y); }
   return check_launch("dropout");
 }
 
@@ -871,7 +871,7 @@ extern "C" int embnet_tap_contract(const float* w, const float* tap_sums, int ta
 
 extern "C" int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && pixels > 0 && cin > 0 && cout >= cin, "pad_channels: bad argument");
-  pad_channels_kernel<<<ew_blocks(pixels * cout), 256, 0, S(stream)>>>(x, pixels, cin, cout, y);
+  { EMBNET_TRACE("embnet::pad_channels_kernel", TRACE_BYTES, 4.0 * pixels * (cin + cout), stream); pad_channels_kernel<<<ew_blocks(pixels * cout), 256, 0, S(stream)>>>(x, pixels, cin, cout, y); }
   return check_launch("pad_channels");
 }
 
@@ -882,7 +882,7 @@ extern "C" int embnet_sumsq(const float* x, long total, float alpha, float* out,
   EMBNET_CHECK_ARG(x && out && workspace && total > 0, "sumsq: bad argument");
   if (workspace_bytes < embnet_sumsq_workspace_bytes()) return fail(EMBNET_EWORKSPACE, "sumsq: workspace too small");
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-  sumsq_partial_kernel<<<blocks, 256, 0, S(stream)>>>(x, total, (float*)workspace);
+  { EMBNET_TRACE("embnet::sumsq_partial_kernel", TRACE_BYTES, 4.0 * total, stream); sumsq_partial_kernel<<<blocks, 256, 0, S(stream)>>>(x, total, (float*)workspace); }
   sum_finalize_kernel<<<1, 64, 0, S(stream)>>>((const float*)workspace, blocks, alpha, out);
   return check_launch("sumsq");
 }

@@ -83,6 +83,9 @@ extern "C" int embnet_optimizer_step(int rule, const void* table, int n_tensors,
   const OptCoef k{lr, b1, b2, eps, c1, c2};
   const OptTensor* t = (const OptTensor*)table;
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes: chunk count x chunk size x 4 B x (w read+write, g read, each slot read+write)
+  EMBNET_TRACE("embnet::opt_step_kernel", TRACE_BYTES,
+               4.0 * n_chunks * OPT_CHUNK * (rule == EMBNET_OPT_SGD ? 3 : (rule == EMBNET_OPT_RMSPROP ? 5 : 7)), s);
   switch (rule) {
     case EMBNET_OPT_SGD: opt_step_kernel<EMBNET_OPT_SGD><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
     case EMBNET_OPT_RMSPROP: opt_step_kernel<EMBNET_OPT_RMSPROP><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;

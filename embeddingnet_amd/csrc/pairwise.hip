@@ -100,6 +100,7 @@ extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dis
   const bool vec = (e & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   using GL = Geom<128, 128, 2, 2>;
   using GS = Geom<64, 64, 2, 2>;
+  EMBNET_TRACE("embnet::pairwise_kernel", TRACE_FLOP, 2.0 * n * n * e, s);
   if (n >= 1024) {
     const int grid = cdiv(n, 128) * cdiv(n, 128);
     if (vec) pairwise_kernel<GL, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GL, false><<<grid, 256, 0, s>>>(p);

@@ -40,7 +40,7 @@ class ENDataLoader():
         self.dataset_path = dataset_path
         self.class_names = []
         if train_csv_file is not None:
-            self.class_files_paths = self._load_from_dataframe(train_csv_file, image_id_column, label_column)
+            self.class_files_paths = self._load_from_dataframe(train_csv_file, image_id_column, label_column, is_google)
         else:
             self.class_files_paths = self._load_from_directory()
         self.n_classes = len(self.class_names)
@@ -49,7 +49,7 @@ class ENDataLoader():
         if self.validate:
             if val_csv_file is not None:
                 self.train_data = self.class_files_paths
-                self.val_data = self._load_from_dataframe(val_csv_file, image_id_column, label_column)
+                self.val_data = self._load_from_dataframe(val_csv_file, image_id_column, label_column, is_google)
             else:
                 self.train_data, self.val_data = self.split_train_val(self.val_ratio)
         else:
@@ -62,24 +62,45 @@ class ENDataLoader():
             train_data[k], val_data[k] = train_test_split(v, test_size=val_ratio, random_state=42)
         return train_data, val_data
 
-    def _load_from_dataframe(self, csv_file, image_id_column, label_column):
+    def _load_from_dataframe(self, csv_file, image_id_column, label_column, is_google=False):
+        """reference :60-87: classes in order of first appearance in the CSV; paths are dataset_path/<image_id>, or, for
+        the Google-Landmarks layout (is_google), dataset_path/<id[0]>/<id[1]>/<id[2]>/<id>.jpg.  (The reference also
+        caches the result in ./tmp/data.pickle and silently reuses it for ANY later csv; that cache is not kept.)"""
         import pandas as pd
         df = pd.read_csv(csv_file)
-        out = {}
-        for cl, grp in df.groupby(label_column):
-            cl = str(cl)
+        names = [str(c) for c in df[label_column].unique()]
+        for cl in names:
             if cl not in self.class_names:
                 self.class_names.append(cl)
-            out[cl] = [os.path.join(self.dataset_path, str(p)) for p in grp[image_id_column]]
+        out = {}
+        for cl, raw in zip(names, df[label_column].unique()):
+            ids = [str(f) for f in df.loc[df[label_column] == raw][image_id_column]]
+            if is_google:
+                out[cl] = [os.path.join(self.dataset_path, f'{f[0]}/{f[1]}/{f[2]}/', f + '.jpg') for f in ids]
+            else:
+                out[cl] = [os.path.join(self.dataset_path, f) for f in ids]
         return out
 
+    @staticmethod
+    def _is_image(name):
+        """reference :100-102: `.jpg`, or `.png` not starting with '._' (operator precedence as written there)."""
+        return name.endswith('.jpg') or (name.endswith('.png') and not name.startswith('._'))
+
     def _load_from_directory(self):
+        """reference :89-111: one class per sub-directory; images directly inside it, or inside its own sub-directories
+        when it has any.  Listing order is sorted here (os.scandir order in the reference is arbitrary)."""
         out = {}
         for cl in sorted(os.listdir(self.dataset_path)):
             d = os.path.join(self.dataset_path, cl)
-            if os.path.isdir(d):
-                self.class_names.append(cl)
-                out[cl] = [os.path.join(d, f) for f in sorted(os.listdir(d))]
+            if not os.path.isdir(d):
+                continue
+            self.class_names.append(cl)
+            subdirs = [os.path.join(d, s) for s in sorted(os.listdir(d)) if os.path.isdir(os.path.join(d, s))]
+            files = []
+            for folder in (subdirs if subdirs else [d]):
+                files += [os.path.join(folder, f) for f in sorted(os.listdir(folder))
+                          if os.path.isfile(os.path.join(folder, f)) and self._is_image(f)]
+            out[cl] = files
         return out
 
 

@@ -23,34 +23,6 @@ from ._lib import check, ptr, stream
 _WS = {}
 
 
-class KernelTimer:
-    """Optional HIP-event brackets around the conv launches (bench.py's roofline leg).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
-
-    def __init__(self):
-        self.records = []          # (kernel name, flops, start event, end event)
-
-    def summary(self):
-        """{kernel: dict(launches, ms_total, flops_total)} — call after a device synchronize."""
-        return self._group(lambda name, dims: name)
-
-    def detail(self):
-        """Same, keyed by (kernel, geometry) — one row per layer shape."""
-        return self._group(lambda name, dims: f"{name} n{dims[0]} {dims[1]}x{dims[2]}x{dims[3]} "
-                                              f"k{dims[4]}x{dims[5]}->{dims[6]} out{dims[7]}x{dims[8]}")
-
-    def _group(self, key):
-        out = {}
-        for name, flops, s, e, dims in self.records:
-            d = out.setdefault(key(name, dims), dict(launches=0, ms_total=0.0, flops_total=0.0))
-            d["launches"] += 1
-            d["ms_total"] += s.elapsed_time(e)
-            d["flops_total"] += flops
-        return out
-
-
-TIMER = None       # set to a KernelTimer to time conv kernels
-
 import os as _os
 # Knob (off): run each conv's wgrad on a side stream beside its dgrad.  Measured on ResNet18/MI355X: +-0 % when
 # joined right after the dgrad (both are MFMA-bound), +1.8 % when the join is deferred to the end of backward so
@@ -66,19 +38,6 @@ def _side_stream(device):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
-
-
-def _conv_timed(kind, dims, call):
-    if TIMER is None:
-        return call()
-    n, h, wd, c, r, s, k, oh, ow = dims
-    name = _lib.lib().embnet_conv2d_kernel_name(kind, n, h, wd, c, r, s, k, oh, ow).decode()
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s0.record()
-    out = call()
-    s1.record()
-    TIMER.records.append((name, 2.0 * n * oh * ow * k * r * s * c, s0, s1, dims))
-    return out
 
 
 def workspace(nbytes, device):
@@ -127,9 +86,9 @@ class _Conv2dFn(torch.autograd.Function):
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         lib = _lib.lib()
         ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-        _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+        check(lib.embnet_conv2d_fwd_f32(
             ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
-            in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream())))
+            in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
         ctx.save_for_backward(x, w, y if relu else None, in_stats)
@@ -153,7 +112,6 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = db = None
-        dims = (n, h, wd, c, r, s, k, oh, ow)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         in_scale = in_stats[2].data_ptr() if in_stats is not None else None
         in_shift = in_stats[3].data_ptr() if in_stats is not None else None
@@ -162,11 +120,7 @@ class _Conv2dFn(torch.autograd.Function):
             ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
             args = (ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
                     in_scale, in_shift, ctx.in_act)
-            if TIMER is None:
-                check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
-            else:                       # bracket the MFMA kernel alone; the slab sum is its own launch
-                _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_slabs_f32(*args, stream())))
-                check(lib.embnet_conv2d_wgrad_reduce_f32(*args, stream()))
+            check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
 
         if need_dw:
             dw = torch.empty_like(w)
@@ -181,9 +135,9 @@ class _Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
             dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-            _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
+            check(lib.embnet_conv2d_dgrad_f32(
                 ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
-                dws.numel() * 4, stream())))
+                dws.numel() * 4, stream()))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
@@ -216,9 +170,9 @@ class _ConvPairFn(torch.autograd.Function):
             stride, pt, pl, oh, ow = geom
             y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
             ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            _conv_timed(0, (n, h, wd, c, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+            check(lib.embnet_conv2d_fwd_f32(
                 ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
-                int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream())))
+                int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
             ys.append(y)
         ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
         ctx.save_for_backward(x, w1, w2, in_stats)
@@ -241,12 +195,11 @@ class _ConvPairFn(torch.autograd.Function):
             dy = _c(dy)
             r, s, _, k = w.shape
             stride, pt, pl, oh, ow = geom
-            dims = (n, h, wd, c, r, s, k, oh, ow)
             if dx is not None:
                 sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-                _conv_timed(1, dims, lambda: check(lib.embnet_conv2d_dgrad_f32(
+                check(lib.embnet_conv2d_dgrad_f32(
                     ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
-                    ptr(sc), sc.numel() * 4, stream())))
+                    ptr(sc), sc.numel() * 4, stream()))
                 first = False
             dw = None
             if need_dw:
@@ -254,11 +207,7 @@ class _ConvPairFn(torch.autograd.Function):
                 ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
                 args = (ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
                         in_scale, in_shift, ctx.in_act)
-                if TIMER is None:
-                    check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
-                else:
-                    _conv_timed(2, dims, lambda: check(lib.embnet_conv2d_wgrad_slabs_f32(*args, stream())))
-                    check(lib.embnet_conv2d_wgrad_reduce_f32(*args, stream()))
+                check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
             dws.append(dw)
         if dx is not None and first:
             dx.zero_()
@@ -619,9 +568,9 @@ class _InputBNConvFn(torch.autograd.Function):
             moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
-        _conv_timed(0, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_fwd_f32(
+        check(lib.embnet_conv2d_fwd_f32(
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
-            ptr(out_stats), ptr(cws), cws.numel() * 4, stream())))
+            ptr(out_stats), ptr(cws), cws.numel() * 4, stream()))
         ctx.geom, ctx.c = geom, c
         ctx.save_for_backward(a, w)
         return y
@@ -636,9 +585,9 @@ class _InputBNConvFn(torch.autograd.Function):
         dy = _c(dy)
         dw_p = torch.empty((r, s, cp, k), device=a.device, dtype=torch.float32)
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, cp, r, s, k, oh, ow), a.device)
-        _conv_timed(2, (n, h, wd, cp, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+        check(lib.embnet_conv2d_wgrad_f32(
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
-            None, None, 0, stream())))
+            None, None, 0, stream()))
         dw = dw_p if cp == c else dw_p[:, :, :c, :].contiguous()
         key = (a.device, n, h, wd)
         ones = _InputBNConvFn._ones.get(key)
@@ -646,9 +595,9 @@ class _InputBNConvFn(torch.autograd.Function):
             ones = _InputBNConvFn._ones[key] = torch.ones((n, h, wd, 1), device=a.device, dtype=torch.float32)
         taps = torch.empty((r, s, 1, k), device=a.device, dtype=torch.float32)
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, 1, r, s, k, oh, ow), a.device)
-        _conv_timed(2, (n, h, wd, 1, r, s, k, oh, ow), lambda: check(lib.embnet_conv2d_wgrad_f32(
+        check(lib.embnet_conv2d_wgrad_f32(
             ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
-            None, None, 0, stream())))
+            None, None, 0, stream()))
         dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
         return None, dbeta, None, None, dw, None, None, None, None

@@ -186,5 +186,5 @@ class GradReducer:
         if self._reduce:
             dist.broadcast(order, src=0, group=self.group)
         new = [self.params[i] for i in order.tolist()]
-        if new != self.order:
+        if any(a is not b for a, b in zip(new, self.order)):
             self._layout(new, keep=True)

@@ -38,6 +38,18 @@ enum {
 int embnet_abi_version(void);
 const char* embnet_last_error(void);
 
+/* Optional per-kernel timing (bench.py's roofline leg; build-defined, nothing in the reference to stand in for).
+ * While enabled, every kernel launch of the entry points below is bracketed by two HIP events on the launch stream
+ * and logged with the kernel's name and its ALGORITHMIC work: unit 0 = FLOP (MFMA-bound kernels: 2*M*N*K of the
+ * GEMM the kernel computes), unit 1 = bytes (HBM-bound kernels: the bytes the operation must read and write once,
+ * DESIGN.md §3.2); `bytes` is that byte count for every kernel (for a conv: input + kernel + output, once each).
+ * embnet_trace_get waits for record i's end event and returns its duration; name/ms/work/unit/bytes are HOST
+ * pointers.  Disabled (the default) a launch pays one flag test. */
+int embnet_trace_enable(int on);          /* returns the previous state; the log is kept until embnet_trace_reset */
+int embnet_trace_reset(void);
+int embnet_trace_count(void);
+int embnet_trace_get(int i, char* name, int name_cap, float* ms, double* work, int* unit, double* bytes);
+
 /* ------------------------------------------------------------------ loss path */
 
 /* datagenerators.py:219 `pairwise_distances(all_embeddings)` (scikit-learn euclidean):

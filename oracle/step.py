@@ -30,7 +30,7 @@ class ReferenceStep:
         if params is None:
             with torch.no_grad():                              # materialise the weights (float32 initialisers)
                 OB.base_model(ctx, torch.zeros((2,) + self.shape), **self.kw)
-        self.params = {k: v.detach().to(dtype) for k, v in ctx.params.items()}
+        self.params = {k: v.detach().clone().to(dtype) for k, v in ctx.params.items()}      # own copies
         self.names = [k for k in self.params if "moving_" not in k]
         for k in self.names:
             self.params[k].requires_grad_(True)
@@ -67,7 +67,7 @@ class ReferenceStep:
         total = loss + OB.regularisation(ctx)
         ws = [self.params[k] for k in self.names]
         grads = torch.autograd.grad(total, ws, allow_unused=True)
-        self.last_grad_max = {k: (0.0 if g is None else float(g.abs().max())) for k, g in zip(self.names, grads)}
+        self.last_grads = {k: g for k, g in zip(self.names, grads) if g is not None}      # kept for the parity tests
         with torch.no_grad():
             arrs = [w.detach().numpy() for w in ws]            # views: the update lands in the tensors
             if self.dtype == torch.float64:
@@ -80,3 +80,42 @@ class ReferenceStep:
             for kname, v in ctx.new_stats.items():
                 self.params[kname].copy_(v)
         return float(loss.detach()), int(len(t)), float(total.detach())
+
+
+class SiameseReferenceStep:
+    """The reference's siamese training step (tools/train.py:108-119, models.py:203-230, 'l2' distance head):
+    two forwards of the shared base model (two BatchNorm batches), d = sqrt(max(sum (e1-e2)^2, eps)),
+    contrastive_loss (losses_and_accuracies.py:4-11), backward, Keras-rule optimizer.  PARITY UNPINNED like the rest
+    of this file (Keras layers)."""
+
+    def __init__(self, backbone_name, input_shape, encodings_len, lr=1e-3, seed=0, params=None, optimizer="adam",
+                 dtype=torch.float32):
+        self.kw = dict(backbone_name=backbone_name, encodings_len=encodings_len)
+        self.shape, self.dtype = tuple(input_shape), dtype
+        ctx = OB.Ctx(params, training=False, seed=seed)
+        if params is None:
+            with torch.no_grad():
+                OB.base_model(ctx, torch.zeros((2,) + self.shape), **self.kw)
+        self.params = {k: v.detach().clone().to(dtype) for k, v in ctx.params.items()}      # own copies
+        self.names = [k for k in self.params if "moving_" not in k]
+        for k in self.names:
+            self.params[k].requires_grad_(True)
+        self.opt = OO.get_optimizer(optimizer, lr)
+
+    def step(self, x1, x2, y):
+        """x1, x2: [B,H,W,3]; y: [B] or [B,1], 1 = same class.  Returns the contrastive loss."""
+        x1, x2 = torch.as_tensor(x1, dtype=self.dtype), torch.as_tensor(x2, dtype=self.dtype)
+        yt = torch.as_tensor(np.asarray(y), dtype=self.dtype).reshape(-1, 1)
+        ctx = OB.Ctx(self.params, training=True)
+        d = OB.siamese_l2_distance(OB.base_model(ctx, x1, **self.kw), OB.base_model(ctx, x2, **self.kw))
+        loss = (yt * d ** 2 + (1 - yt) * torch.clamp(1 - d, min=0) ** 2).mean()
+        ws = [self.params[k] for k in self.names]
+        grads = torch.autograd.grad(loss + OB.regularisation(ctx), ws, allow_unused=True)
+        with torch.no_grad():
+            up = [w.detach().numpy().astype(np.float64) for w in ws]
+            self.opt.step(up, [None if g is None else g.numpy() for g in grads])
+            for w, u in zip(ws, up):
+                w.copy_(torch.as_tensor(u).to(self.dtype))
+            for kname, v in ctx.new_stats.items():
+                self.params[kname].copy_(v)
+        return float(loss.detach())

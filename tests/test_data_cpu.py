@@ -1,0 +1,121 @@
+"""CPU tests of the input side of the hot path: ENDataLoader (directory tree, CSV, Google-Landmarks
+layout), get_image (decode, resize, BGR), and the batch layouts the generators hand to the training step
+(reference datagenerators.py:16-111, 145-156, 264-418; utils.py:13-21).  No GPU: these are host-side."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _png(path, rgb, size=(20, 12)):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.new("RGB", size, rgb).save(path)
+
+
+@pytest.fixture()
+def tree(tmp_path):
+    """3 classes x 10 images; class 'c2' keeps its images one level deeper; plus files the reference skips."""
+    root = tmp_path / "data"
+    for ci, cl in enumerate(["c0", "c1", "c2"]):
+        for i in range(10):
+            sub = "part%d/" % (i % 2) if cl == "c2" else ""
+            _png(str(root / cl / (sub + "img%02d.%s" % (i, "png" if i % 2 else "jpg"))), (10 * i, 40 + 20 * ci, 200))
+    (root / "c0" / "notes.txt").write_text("not an image")
+    _png(str(root / "c0" / "._hidden.png"), (0, 0, 0))
+    (root / "readme.md").write_text("not a class")
+    return root
+
+
+def test_get_image_decodes_resizes_and_returns_bgr(tmp_path):
+    from embeddingnet_amd.datagenerators import get_image
+    _png(str(tmp_path / "a.png"), (10, 20, 30), size=(20, 12))
+    img = get_image(str(tmp_path / "a.png"))
+    assert img.dtype == np.uint8 and img.shape == (12, 20, 3)
+    assert tuple(img[0, 0]) == (30, 20, 10)                               # cv2.imread order: B, G, R
+    small = get_image(str(tmp_path / "a.png"), [8, 6, 3])
+    assert small.shape == (6, 8, 3)                                       # cv2.resize(img, (input_shape[0], input_shape[1])) = (w, h)
+    assert get_image(str(tmp_path / "missing.png")) is None
+
+
+def test_loader_from_directory(tree):
+    from embeddingnet_amd.datagenerators import ENDataLoader
+    dl = ENDataLoader(str(tree), validate=True, val_ratio=0.2)
+    assert dl.class_names == ["c0", "c1", "c2"] and dl.n_classes == 3
+    assert dl.n_samples == {"c0": 10, "c1": 10, "c2": 10}                  # txt and '._' files skipped, sub-dirs walked
+    assert all(len(dl.train_data[c]) == 8 and len(dl.val_data[c]) == 2 for c in dl.class_names)
+    assert not set(dl.train_data["c1"]) & set(dl.val_data["c1"])
+    again = ENDataLoader(str(tree), validate=True, val_ratio=0.2)          # train_test_split(random_state=42)
+    assert again.val_data == dl.val_data
+    flat = ENDataLoader(str(tree), validate=False)
+    assert flat.val_data == {} and flat.train_data == flat.class_files_paths
+
+
+def test_loader_from_csv_and_google_layout(tree, tmp_path):
+    import pandas as pd
+    from embeddingnet_amd.datagenerators import ENDataLoader
+    rows = [("c1/img%02d.%s" % (i, "png" if i % 2 else "jpg"), "beta") for i in range(6)] + \
+           [("c0/img%02d.%s" % (i, "png" if i % 2 else "jpg"), "alpha") for i in range(4)]
+    csv = tmp_path / "train.csv"
+    pd.DataFrame(rows, columns=["image_id", "label"]).to_csv(csv, index=False)
+    dl = ENDataLoader(str(tree), train_csv_file=str(csv), validate=False)
+    assert dl.class_names == ["beta", "alpha"]                              # order of first appearance (:74)
+    assert dl.n_samples == {"beta": 6, "alpha": 4}
+    assert all(os.path.exists(p) for p in dl.train_data["alpha"])
+    vcsv = tmp_path / "val.csv"
+    pd.DataFrame(rows[:2] + rows[-2:], columns=["image_id", "label"]).to_csv(vcsv, index=False)
+    dv = ENDataLoader(str(tree), train_csv_file=str(csv), val_csv_file=str(vcsv), validate=True)
+    assert dv.train_data == dv.class_files_paths and {k: len(v) for k, v in dv.val_data.items()} == {"beta": 2, "alpha": 2}
+    gcsv = tmp_path / "g.csv"
+    pd.DataFrame([("abcdef", 7), ("a1c9", 7)], columns=["id", "landmark_id"]).to_csv(gcsv, index=False)
+    dg = ENDataLoader("/data/gl", train_csv_file=str(gcsv), image_id_column="id", label_column="landmark_id",
+                      validate=False, is_google=True)
+    assert dg.train_data == {"7": ["/data/gl/a/b/c/abcdef.jpg", "/data/gl/a/1/c/a1c9.jpg"]}
+
+
+def test_images_set_contract(tree):
+    """_get_images_set: float32 [n,H,W,3] in [0,1], BGR, resized to input_shape (reference :145-156)."""
+    from embeddingnet_amd.datagenerators import ENDataGenerator, ENDataLoader
+    dl = ENDataLoader(str(tree), validate=False)
+    gen = ENDataGenerator(dl.train_data, dl.class_names, input_shape=[16, 16, 3])
+    x = gen._get_images_set("c1", [1, 3])
+    assert x.dtype == np.float32 and x.shape == (2, 16, 16, 3) and 0 <= x.min() and x.max() <= 1
+    np.testing.assert_allclose(x[0, 0, 0], np.array([200, 60, 10]) / 255., atol=1e-6)      # B, G, R of img01.png
+    mixed = gen._get_images_set(["c0", "c2"], [1, 1])
+    np.testing.assert_allclose(mixed[:, 0, 0, 1], np.array([40, 80]) / 255., atol=1e-6)
+
+
+def test_generator_batch_layouts(tree):
+    from embeddingnet_amd.datagenerators import (ENDataLoader, SiameseDataGenerator, SimpleDataGenerator,
+                                                 SimpleTripletsDataGenerator)
+    dl = ENDataLoader(str(tree), validate=False)
+    kw = dict(input_shape=[16, 16, 3], batch_size=8, n_batches=3)
+    (x1, x2), y = SiameseDataGenerator(dl.train_data, dl.class_names, **kw)[0]
+    assert x1.shape == x2.shape == (8, 16, 16, 3) and y.tolist() == [1, 1, 1, 1, 0, 0, 0, 0]   # :355-374
+    cls_of = lambda v: np.round((v[:, 0, 0, 1] * 255 - 40) / 20).astype(int)   # green encodes the class (40 + 20 ci; jpg is lossy)
+    assert np.array_equal(cls_of(x2[:4]), cls_of(x1[:4])) and not np.any(cls_of(x2[4:]) == cls_of(x1[4:]))
+    val = SiameseDataGenerator(dl.train_data, dl.class_names, val_gen=True, n_batches_val=5, **kw)
+    assert len(val) == 5
+    (a, p, n), t = SimpleTripletsDataGenerator(dl.train_data, dl.class_names, **kw)[0]
+    assert a.shape == p.shape == n.shape == (8, 16, 16, 3) and t.shape == (8,) and np.all(t == 1)
+    assert np.array_equal(cls_of(a), cls_of(p)) and not np.any(cls_of(a) == cls_of(n))
+    (x,), onehot = SimpleDataGenerator(dl.train_data, dl.class_names, **kw)[0]
+    assert x.shape == (8, 16, 16, 3) and onehot.shape == (8, 3) and np.all(onehot.sum(1) == 1)
+    assert np.array_equal(onehot.argmax(1), cls_of(x))
+
+
+def test_triplet_sampler_is_class_contiguous_with_replacement(tree):
+    """sample_batch(): P classes without replacement, K images per class WITH replacement, class blocks contiguous
+    (reference :202-205, 226-227) — host-side part of TripletsDataGenerator; no model needed."""
+    from embeddingnet_amd.datagenerators import ENDataLoader, TripletsDataGenerator
+    dl = ENDataLoader(str(tree), validate=False)
+    gen = TripletsDataGenerator(embedding_model=None, class_files_paths=dl.train_data, class_names=dl.class_names,
+                                input_shape=[16, 16, 3], k_classes=3, k_samples=12, margin=0.5,
+                                negatives_selection_mode="semihard")
+    np.random.seed(1)
+    batch = gen.sample_batch()
+    assert batch.shape == (36, 16, 16, 3)
+    cls = np.round((batch[:, 0, 0, 1] * 255 - 40) / 20).astype(int).reshape(3, 12)
+    assert (cls == cls[:, :1]).all() and len(set(cls[:, 0])) == 3          # contiguous blocks, distinct classes
+    with pytest.raises(KeyError):
+        TripletsDataGenerator(None, dl.train_data, dl.class_names, negatives_selection_mode="nope")

@@ -102,8 +102,9 @@ def _slice_consistency(key, dev, n_full, n_piece, seed, oracle_slice0=False):
     for s in range(0, n_full, n_piece):
         ys, dxs, dws = _run(layer, x[s:s + n_piece].contiguous(), dy[s:s + n_piece].contiguous())
         # same operands in the same K order except where a K-split tail tile sums its parts in another order
-        assert rel(yf[s:s + n_piece], ys) < 1e-6, (key, "fwd", s)
-        assert rel(dxf[s:s + n_piece], dxs) < 1e-6, (key, "dgrad", s)
+        # (fp32 chains of up to R*S*C terms regrouped: a few ulp of the largest output)
+        assert rel(yf[s:s + n_piece], ys) < 5e-6, (key, "fwd", s)
+        assert rel(dxf[s:s + n_piece], dxs) < 5e-6, (key, "dgrad", s)
         dw_sum += dws.double()
         if s == 0 and oracle_slice0:
             wkey = "c/kernel"

@@ -200,31 +200,69 @@ def test_shard_classes():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
-from embeddingnet_amd.parallel import GradReducer, init_distributed
+from embeddingnet_amd.parallel import (GradReducer, all_reduce_mean, average_buffers, broadcast_model, init_distributed,
+                                       shard_classes)
 rank, world, _ = init_distributed("gloo")
-torch.manual_seed(0)                                   # identical initial weights on every rank
-model = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
-red = GradReducer(model.parameters(), bucket_bytes=2048)        # several buckets
+assert shard_classes(8, world, rank) == (rank * 4, 4)           # whole classes per rank, as tools/train.py shards them
+torch.manual_seed(100 + rank)                                   # ranks start DIFFERENT ...
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.bn, self.b = torch.nn.Linear(20, 64), torch.nn.BatchNorm1d(64), torch.nn.Linear(64, 8)
+        self.unused = torch.nn.Linear(5, 5)                     # trainable but not on the step's graph (no hook fires)
+        self.frozen = torch.nn.Linear(64, 64)
+        for p in self.frozen.parameters():
+            p.requires_grad_(False)                             # a frozen backbone layer: not in the reducer at all
+    def forward(self, x):
+        return self.b(torch.relu(self.bn(self.a(x)) + self.frozen(torch.zeros(1, 64))))
+model = Net()
+broadcast_model(model)                                          # ... and are made identical: parameters AND buffers
+state = torch.cat([t.detach().reshape(-1).float() for t in list(model.parameters()) + list(model.buffers())])
+others = [torch.zeros_like(state) for _ in range(world)]
+dist.all_gather(others, state)
+assert all(torch.equal(o, others[0]) for o in others), "broadcast_model left the ranks different"
+params = [p for p in model.parameters() if p.requires_grad]
+red = GradReducer(params, bucket_bytes=2048)                    # several buckets
 assert len(red.buckets) > 1
+first_layout = list(red.order)
 g = torch.Generator().manual_seed(100 + rank)                   # different local batch per rank
 x = torch.randn(16, 20, generator=g)
 for step in range(3):
-    red.zero()
+    red.zero()                                                  # re-arms the bucket counters
     model(x).pow(2).mean().backward()
     red.finish()
+    if step == 0:                                               # layout now follows the first backward's hook order:
+        assert red.order[0] is model.b.bias or red.order[0] is model.b.weight, "last layer's gradients come first"
+        assert red.order[-1] is model.unused.bias or red.order[-1] is model.unused.weight, "never-fired parameters last"
 flat = red.flat.clone()
 # reference: mean over ranks of the local gradients, computed without the reducer
-ref = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+ref = Net()
 ref.load_state_dict(model.state_dict())
 ref(x).pow(2).mean().backward()
-want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+want = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1)
+                  for q in [dict(ref.named_parameters())[n] for n in
+                            [next(n for n, p in model.named_parameters() if p is o) for o in red.order]]])
 dist.all_reduce(want); want /= world
 assert torch.allclose(flat, want, rtol=1e-5, atol=1e-7), (flat - want).abs().max()
-for p in model.parameters():
-    assert p.grad.data_ptr() >= red.flat.data_ptr()             # grads are views of the flat buffer
+assert float(model.unused.weight.grad.abs().max()) == 0.0       # unused parameter: zero gradient, bucket still reduced
+for p in params:
+    off, n = red._slot[p]
+    assert p.grad.data_ptr() == red.flat.data_ptr() + 4 * off   # grads are views of the flat buffer
 others = [torch.zeros_like(flat) for _ in range(world)]
 dist.all_gather(others, flat)
 assert all(torch.equal(o, flat) for o in others)               # every rank holds the same averaged gradient
+# a caller that dropped the views (zero_grad(set_to_none=True)): the hooks copy the gradients back into the buffer
+for p in params:
+    p.grad = None
+red.zero()
+model(x).pow(2).mean().backward()
+red.finish()
+assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+# scalar all-reduce used for the logged loss / plateau decisions, and the BatchNorm buffer average before a checkpoint
+assert all_reduce_mean(float(rank)) == 0.5
+model.bn.running_mean.fill_(float(rank))
+average_buffers(model)
+assert torch.all(model.bn.running_mean == 0.5)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
