@@ -100,6 +100,12 @@ def cpu_baseline(args):
 def roofline_from_trace(records, traced_steps, ms_per_step, workload):
     """records: [(kernel, ms, work, unit, bytes)] over `traced_steps` steps -> (roofline dict, per-kernel table)."""
     by = {}
+    detail = os.environ.get("EMBNET_BENCH_DETAIL")       # substring of a kernel name: list its launches one by one
+    if detail:
+        for name, ms, work, unit, nbytes in records[: len(records) // max(traced_steps, 1)]:
+            if detail in name:
+                log(f"    {name[:70]:70s} {1e3 * ms:9.1f} us  {work / 1e6:10.1f} {'MFLOP' if unit == 0 else 'MB'}  "
+                    f"{work / ms / (1e9 if unit == 0 else 1e6):8.1f} {'TFLOP/s' if unit == 0 else 'GB/s'}")
     for name, ms, work, unit, nbytes in records:
         d = by.setdefault(name, dict(launches=0, ms=0.0, work=0.0, bytes=0.0, unit=unit))
         d["launches"] += 1; d["ms"] += ms; d["work"] += work; d["bytes"] += nbytes
@@ -160,7 +166,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
-    for key, val in dict(k_classes=32, k_samples=4, pairs=256, mining="hardest", **CONFIGS[args.config]).items():
+    for key, val in {**dict(k_classes=32, k_samples=4, pairs=256, mining="hardest"), **CONFIGS[args.config]}.items():
         if getattr(args, key, None) is None:
             setattr(args, key, val)
 

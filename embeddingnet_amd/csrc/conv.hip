@@ -858,7 +858,8 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
 static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
-  tile = (rows <= 64 && k <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
+  // few gradient rows (1x1 convs on 16..64 channels, EfficientNet): 64-row tiles, whatever the width
+  tile = (rows <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
   // 128-row tiles waste the last half tile of a 576-row (3x3x64) gradient; 192-row tiles fit it exactly
   static const bool no192 = env_long("EMBNET_WGRAD_NO192", 0) != 0;
   if (tile == 1 && rows % 192 == 0 && rows % 128 != 0 && !no192) tile = 4;

@@ -156,6 +156,199 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_sq_kernel(const float* __re
   reinterpret_cast<float4*>(dx)[i] = acc;
 }
 
+// ---- register-blocked square kernels (the EfficientNet layers: 3x3 / 5x5, stride 1 / 2, C % 4 == 0) -------------
+// One thread per (channel quad, output row, block of TW = 4 output columns).  The per-pixel kernels above issue KS*KS
+// 16-byte image loads + KS*KS weight loads per output quad and run at 1.3-2.2 TB/s of algorithmic traffic on
+// EfficientNet-B0 (bound by L1 request rate, not HBM); a column block shares its input columns between its outputs and
+// its weight loads between TW outputs: 5x5 stride 1 needs 8 image loads per kernel row for 4 outputs (40 + 25 per 4
+// outputs instead of 200).  Loads are unconditional (out-of-image taps read element 0 and are zeroed in registers).
+constexpr int DW_TW = 4;
+
+// FLIP = false: forward correlation  y[oh,ow] = sum x[oh*ST+r-pt, ow*ST+s-pl] * w[r,s]
+// FLIP = true (ST = 1 only): the same loop as the stride-1 DATA GRADIENT: dx = correlate(dy, flipped w) with pads
+// KS-1-pt / KS-1-pl — the launcher swaps the roles (g.H/W = size of the tensor read, g.OH/OW = size written).
+template <int KS, int ST, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          DwGeom g, float* __restrict__ y) {
+  constexpr int TW = DW_TW, NX = (TW - 1) * ST + KS;
+  const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW;
+  const long total = (long)g.N * g.OH * wb_n * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4);
+  long t = i / c4;
+  const int ow0 = (int)(t % wb_n) * TW; t /= wb_n;
+  const int oh = (int)(t % g.OH);
+  const int n = (int)(t / g.OH);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 acc[TW];
+#pragma unroll
+  for (int q = 0; q < TW; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int iw0 = ow0 * ST - g.pad_l;
+  // one kernel row at a time for 5x5 (unrolled, hipcc hoists all 40-55 image loads of a block: 256+ registers, one wave per SIMD)
+#pragma unroll KS == 3 ? 3 : 1
+  for (int r = 0; r < KS; ++r) {
+    const int ih = oh * ST + r - g.pad_t;
+    const bool rok = (unsigned)ih < (unsigned)g.H;
+    const long rbase = ((long)n * g.H + (rok ? ih : 0)) * g.W;
+    float4 xr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int iw = iw0 + j;
+      const bool ok = rok && (unsigned)iw < (unsigned)g.W;
+      xr[j] = x4[ok ? (rbase + iw) * c4 + cq : 0];
+      if (!ok) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const float4 wv = w4[(FLIP ? (KS - 1 - r) * KS + (KS - 1 - s_) : r * KS + s_) * c4 + cq];
+#pragma unroll
+      for (int q = 0; q < TW; ++q) {
+        const float4 v = xr[q * ST + s_];
+        acc[q].x = fmaf(v.x, wv.x, acc[q].x); acc[q].y = fmaf(v.y, wv.y, acc[q].y);
+        acc[q].z = fmaf(v.z, wv.z, acc[q].z); acc[q].w = fmaf(v.w, wv.w, acc[q].w);
+      }
+    }
+  }
+  float4* yo = reinterpret_cast<float4*>(y) + (((long)n * g.OH + oh) * g.OW + ow0) * c4 + cq;
+#pragma unroll
+  for (int q = 0; q < TW; ++q)
+    if (ow0 + q < g.OW) yo[(long)q * c4] = acc[q];
+}
+
+// Stride-2 data gradient: dx[ih,iw] = sum over (r,s) with (ih+pt-r) and (iw+pl-s) even of dy[(ih+pt-r)/2, (iw+pl-s)/2] * w[r,s].
+// Block of 4 dx columns starting at a multiple of 4, so which taps are live in each column only depends on the column's
+// offset t and the parity PLP of pad_l: s = s0(t) + 2b with s0 = (t + PLP) & 1, and the dy column is
+// base + e(t) - b, e(t) = (t + PLP - s0) / 2, base = w0/2 + (pad_l - PLP)/2.  All register indices are static.
+template <int KS, int PLP>
+__global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                   DwGeom g, float* __restrict__ dx) {
+  constexpr int TW = DW_TW, OFF = (KS - 1) / 2, MAXE = PLP ? 2 : 1, NX = MAXE + OFF + 1;
+  const int c4 = g.C >> 2, wb_n = (g.W + TW - 1) / TW;
+  const long total = (long)g.N * g.H * wb_n * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4);
+  long t = i / c4;
+  const int w0 = (int)(t % wb_n) * TW; t /= wb_n;
+  const int ih = (int)(t % g.H);
+  const int n = (int)(t / g.H);
+  const float4* d4 = reinterpret_cast<const float4*>(dy);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 acc[TW];
+#pragma unroll
+  for (int q = 0; q < TW; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r0 = (ih + g.pad_t) & 1;                     // rows r = r0, r0+2, .. reach this dx row
+  const int base = (w0 >> 1) + ((g.pad_l - PLP) >> 1) - OFF;
+#pragma unroll KS == 3 ? 2 : 1
+  for (int a = 0; a < (KS + 1) / 2; ++a) {
+    const int r = r0 + 2 * a;
+    const int th = ih + g.pad_t - r;
+    const int oh = th >> 1;
+    const bool rok = r < KS && th >= 0 && oh < g.OH;
+    const long rbase = ((long)n * g.OH + (rok ? oh : 0)) * g.OW;
+    float4 dr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int ow = base + j;
+      const bool ok = rok && (unsigned)ow < (unsigned)g.OW;
+      dr[j] = d4[ok ? (rbase + ow) * c4 + cq : 0];
+      if (!ok) dr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4* wr = w4 + (long)(rok ? r : 0) * KS * c4 + cq;
+#pragma unroll
+    for (int q = 0; q < TW; ++q) {
+      constexpr int dummy = 0; (void)dummy;
+      const int s0 = (q + PLP) & 1, e = (q + PLP - s0) / 2;
+#pragma unroll
+      for (int b = 0; b < (KS + 1) / 2; ++b) {
+        if (s0 + 2 * b < KS) {                            // compile-time after unrolling
+          const float4 wv = wr[(long)(s0 + 2 * b) * c4];
+          const float4 v = dr[e - b + OFF];
+          acc[q].x = fmaf(v.x, wv.x, acc[q].x); acc[q].y = fmaf(v.y, wv.y, acc[q].y);
+          acc[q].z = fmaf(v.z, wv.z, acc[q].z); acc[q].w = fmaf(v.w, wv.w, acc[q].w);
+        }
+      }
+    }
+  }
+  float4* xo = reinterpret_cast<float4*>(dx) + (((long)n * g.H + ih) * g.W + w0) * c4 + cq;
+#pragma unroll
+  for (int q = 0; q < TW; ++q)
+    if (w0 + q < g.W) xo[(long)q * c4] = acc[q];
+}
+
+// Weight gradient, same column blocking, one WAVE per kernel row (workgroup = KS waves): wave r accumulates dw[r, 0..KS)
+// for its lanes' channel quads over the workgroup's slab of (row, 4-column block) units, so a thread holds KS accumulator
+// quads instead of KS*KS (a 5x5 kernel's 25 plus a unit's image quads took 300+ registers whatever the loop order: one
+// wave per SIMD; walking the slab once per kernel row with one accumulator row re-streamed it from HBM five times).
+// The KS waves of a workgroup walk the same units at the same time: the 4 dy quads of a unit are fetched once and hit L1
+// for the other waves, the image rows overlap between neighbouring units.  Per unit and wave: 4 + (TW-1)*ST+KS loads for
+// 4*KS FMAs per channel.  Lanes = (channel-quad lanes) x (unit lanes); the unit lanes are summed with a fixed xor
+// butterfly, the slabs by dw_slab_sum_kernel: bitwise reproducible.
+template <int KS, int ST>
+__global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     DwGeom g, int cq_lanes, int units_per_block,
+                                                                     float* __restrict__ partial) {
+  constexpr int TW = DW_TW, NX = (TW - 1) * ST + KS, TAPS = KS * KS;
+  const int c4 = g.C >> 2, unit_lanes = 64 / cq_lanes, wb_n = (g.OW + TW - 1) / TW;
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cl = lane % cq_lanes, ul = lane / cq_lanes;
+  const int nunits = g.N * g.OH * wb_n;
+  const int u0 = blockIdx.x * units_per_block, u1 = min(u0 + units_per_block, nunits);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* d4 = reinterpret_cast<const float4*>(dy);
+  {                                                        // grid.y = channel-quad group: late layers have few pixels, many channels
+    const int cq = blockIdx.y * cq_lanes + cl;
+    float4 acc[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < c4) {
+      for (int u = u0 + ul; u < u1; u += unit_lanes) {
+        const int row = u / wb_n, ow0 = (u - row * wb_n) * TW;
+        const int n = row / g.OH, oh = row - n * g.OH;
+        float4 d[TW];
+        const long dbase = ((long)row * g.OW + ow0) * c4 + cq;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+          const bool ok = ow0 + q < g.OW;
+          d[q] = d4[ok ? dbase + (long)q * c4 : 0];
+          if (!ok) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int iw0 = ow0 * ST - g.pad_l, ih = oh * ST + r - g.pad_t;
+        const bool rok = (unsigned)ih < (unsigned)g.H;
+        const long rbase = ((long)n * g.H + (rok ? ih : 0)) * g.W;
+        float4 xr[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          const int iw = iw0 + j;
+          const bool ok = rok && (unsigned)iw < (unsigned)g.W;
+          xr[j] = x4[ok ? (rbase + iw) * c4 + cq : 0];
+          if (!ok) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+          for (int q = 0; q < TW; ++q) {
+            const float4 v = xr[q * ST + s_];
+            acc[s_].x = fmaf(v.x, d[q].x, acc[s_].x); acc[s_].y = fmaf(v.y, d[q].y, acc[s_].y);
+            acc[s_].z = fmaf(v.z, d[q].z, acc[s_].z); acc[s_].w = fmaf(v.w, d[q].w, acc[s_].w);
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      float4 a = acc[j];
+      for (int o = cq_lanes; o < 64; o <<= 1) {           // unit lanes of one channel quad: lanes cl, cl+cq_lanes, ..
+        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+        a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+      }
+      if (ul == 0 && cq < c4)
+        reinterpret_cast<float4*>(partial)[((long)blockIdx.x * TAPS + r * KS + j) * c4 + cq] = a;
+    }
+  }
+}
+
 // dw[r,s,c] = sum_{n,oh,ow} x[n, oh*st+r-pt, ow*st+s-pl, c] * dy[n,oh,ow,c]
 // Workgroup = (channel-quad lanes) x (pixel lanes) over a slab of output pixels.  Each thread keeps a
 // float4 accumulator per tap for its 4 channels, walks its pixels (one 16-byte dy load + one 16-byte x
@@ -399,6 +592,9 @@ static int make_dw(DwGeom& g, int n, int h, int w, int c, int r, int s, int stri
   return 0;
 }
 
+// EMBNET_DW_ROWS=0 falls back to the per-pixel kernels (A/B)
+static bool dw_rows() { static const bool on = env_long("EMBNET_DW_ROWS", 1) != 0; return on; }
+
 extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
                                        int s, int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "dwconv2d_fwd: null pointer");
@@ -406,6 +602,15 @@ extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y,
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_fwd")) return rc;
   const long total = (long)n * oh * ow * c;
   const int grid4 = cdiv(total / 4, 256);
+  if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
+    const int gridr = cdiv((long)n * oh * cdiv(ow, DW_TW) * (c / 4), 256);
+    EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream);
+    if (r == 3 && stride == 1) dwconv_row4_kernel<3, 1, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
+    else if (r == 3) dwconv_row4_kernel<3, 2, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
+    else if (stride == 1) dwconv_row4_kernel<5, 1, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
+    else dwconv_row4_kernel<5, 2, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
+    return check_launch("dwconv2d_fwd");
+  }
   if ((c & 3) == 0 && r == s && r == 3) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
   else if ((c & 3) == 0 && r == s && r == 5) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<5><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
   else if ((c & 3) == 0) { EMBNET_TRACE("embnet::dwconv_fwd_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd_kernel<4><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
@@ -420,6 +625,23 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_dgrad")) return rc;
   const long total = (long)n * h * wd * c;
   const int grid4 = cdiv(total / 4, 256);
+  if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
+    const int gridr = cdiv((long)n * h * cdiv(wd, DW_TW) * (c / 4), 256);
+    EMBNET_TRACE(stride == 1 ? "embnet::dwconv_row4_kernel" : "embnet::dwconv_dgrad4_s2_row_kernel", TRACE_BYTES,
+                 4.0 * total + 4.0 * n * oh * ow * c, stream);
+    if (stride == 1) {         // correlation of dy with the flipped kernel: the forward loop with the roles swapped
+      const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
+      if (r == 3) dwconv_row4_kernel<3, 1, true><<<gridr, 256, 0, S(stream)>>>(dy, w, gf, dx);
+      else dwconv_row4_kernel<5, 1, true><<<gridr, 256, 0, S(stream)>>>(dy, w, gf, dx);
+    } else if (r == 3) {
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<3, 1><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
+      else dwconv_dgrad4_s2_row_kernel<3, 0><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
+    } else {
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<5, 1><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
+      else dwconv_dgrad4_s2_row_kernel<5, 0><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
+    }
+    return check_launch("dwconv2d_dgrad");
+  }
   const bool sq = (c & 3) == 0 && r == s && (stride == 1 || stride == 2);
   if (sq && r == 3 && stride == 1) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<3, 1><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
   else if (sq && r == 3) { EMBNET_TRACE("embnet::dwconv_dgrad4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream); dwconv_dgrad4_sq_kernel<3, 2><<<grid4, 256, 0, S(stream)>>>(dy, w, g, dx); }
@@ -437,10 +659,25 @@ static int dw_wgrad_blocks(long npix, int& ppb) {
   return (int)((npix + ppb - 1) / ppb);
 }
 
+// slabs of (row, column-block) units for the wave-per-kernel-row kernel: enough workgroups (slabs x channel groups) to
+// fill the chip even when a layer has few pixels (7x7x1152: 3584 units), at most 2048 partial slabs for dw_slab_sum
+static int dw_wave_slabs(long nunits, int c, int& cq_lanes, int& cgroups, int& upb) {
+  cq_lanes = 1; while (cq_lanes < c / 4 && cq_lanes < 64) cq_lanes <<= 1;
+  cgroups = cdiv(c / 4, cq_lanes);
+  long slabs = (nunits + 15) / 16;
+  const long cap = 2048 / cgroups > 0 ? 2048 / cgroups : 1;
+  if (slabs > cap) slabs = cap;
+  if (slabs < 1) slabs = 1;
+  upb = (int)((nunits + slabs - 1) / slabs);
+  return (int)((nunits + upb - 1) / upb);
+}
+
 extern "C" size_t embnet_dwconv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || oh <= 0 || ow <= 0) return 0;
-  int ppb;
-  return (size_t)dw_wgrad_blocks((long)n * oh * ow, ppb) * r * s * c * sizeof(float);
+  int ppb, cql, cg;            // the larger of the two kernels' slab counts (the query does not know the stride)
+  const int b0 = dw_wgrad_blocks((long)n * oh * ow, ppb);
+  const int b1 = (c & 3) ? 0 : dw_wave_slabs((long)n * oh * cdiv(ow, DW_TW), c, cql, cg, ppb);
+  return (size_t)(b0 > b1 ? b0 : b1) * r * s * c * sizeof(float);
 }
 
 extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
@@ -452,6 +689,21 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
   if (workspace_bytes < embnet_dwconv2d_wgrad_workspace_bytes(n, c, r, s, oh, ow))
     return fail(EMBNET_EWORKSPACE, "dwconv2d_wgrad: workspace too small");
   int ppb;
+  if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
+    int upb, cql, cgroups;
+    const int blocks = dw_wave_slabs((long)n * oh * cdiv(ow, DW_TW), c, cql, cgroups, upb);
+    const dim3 grid(blocks, cgroups);
+    {
+      EMBNET_TRACE("embnet::dwconv_wgrad4_wave_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream);
+      if (r == 3 && stride == 1) dwconv_wgrad4_wave_kernel<3, 1><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
+      else if (r == 3) dwconv_wgrad4_wave_kernel<3, 2><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
+      else if (stride == 1) dwconv_wgrad4_wave_kernel<5, 1><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
+      else dwconv_wgrad4_wave_kernel<5, 2><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
+    }
+    const long cnt = (long)r * s * c;
+    { EMBNET_TRACE("embnet::dw_slab_sum_kernel", TRACE_BYTES, 4.0 * cnt * (blocks + 1), stream); dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw); }
+    return check_launch("dwconv2d_wgrad");
+  }
   const int blocks = dw_wgrad_blocks((long)n * oh * ow, ppb);
   if ((c & 3) == 0) {
     int cql = 1; while (cql < c / 4 && cql < 256) cql <<= 1;

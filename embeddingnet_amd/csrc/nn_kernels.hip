@@ -61,7 +61,20 @@ __device__ __forceinline__ void block_partial_sums(const float* __restrict__ par
   if (by_channel) {                  // [2][c][blocks]: this channel's partials are contiguous (conv epilogue layout)
     const float* p1 = partial + (long)col * blocks;
     const float* p2 = p1 + (long)c * blocks;
-    for (int b = threadIdx.x; b < blocks; b += 256) { s += (double)p1[b]; ss += (double)p2[b]; }
+    if ((blocks & 3) == 0 && ((reinterpret_cast<uintptr_t>(partial) & 15) == 0)) {
+      // thousands of row-band partials per channel on the early layers (56x56: 6272): 16-byte loads, four in flight
+      const float4* q1 = reinterpret_cast<const float4*>(p1);
+      const float4* q2 = reinterpret_cast<const float4*>(p2);
+      const int nb4 = blocks >> 2;
+#pragma unroll 4
+      for (int b = threadIdx.x; b < nb4; b += 256) {
+        const float4 u = q1[b], v = q2[b];
+        s += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
+        ss += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      }
+    } else {
+      for (int b = threadIdx.x; b < blocks; b += 256) { s += (double)p1[b]; ss += (double)p2[b]; }
+    }
   } else {                           // [blocks][2][c]
     for (int b = threadIdx.x; b < blocks; b += 256) {
       s += (double)partial[((long)b * 2) * c + col];

@@ -134,6 +134,54 @@ def triplet_gather_loss(emb, triplets, count, margin):
     return _TripletGatherLoss.apply(emb, triplets, count, float(margin))
 
 
+_FUSED_WS = {}
+
+
+def fused_loss_supported(k_classes, k_samples, e):
+    return bool(_lib.lib().embnet_fused_loss_supported(int(k_classes), int(k_samples), int(e)))
+
+
+class _FusedTripletLoss(torch.autograd.Function):
+    """distance matrix + mining + gathered hinge + mean in one launch (embnet_fused_triplet_loss_fwd); the backward is
+    the gather form's (embnet_triplet_gather_bwd), since the outputs are the same."""
+
+    @staticmethod
+    def forward(ctx, emb, p, k, margin, mode, seed):
+        emb = _prep(emb)
+        n, e = emb.shape
+        lib = _lib.lib()
+        code = 3 if mode == "batch_hard" else MINING_MODES[mode]
+        rows = n if code == 3 else lib.embnet_mine_max_triplets(p, k)
+        trip = _new((rows, 3), emb, torch.int32)
+        count = _new((1,), emb, torch.int32)
+        sel = _new((max(p * (k * (k - 1) // 2), 1),), emb, torch.int32)
+        loss, act, mean = _new((rows,), emb), _new((rows,), emb), _new((), emb)
+        key = (emb.device.index, torch.cuda.current_stream().cuda_stream, p, k)
+        ws = _FUSED_WS.get(key)
+        if ws is None:                                      # zero-filled once; the kernel re-arms its counter itself
+            ws = _FUSED_WS[key] = torch.zeros(max(lib.embnet_fused_loss_workspace_bytes(p, k) // 4, 8), device=emb.device)
+        check(lib.embnet_fused_triplet_loss_fwd(ptr(emb), p, k, e, f32(margin), code, int(seed) & (2 ** 64 - 1), ptr(trip),
+                                                ptr(count), ptr(sel), ptr(loss), ptr(act), ptr(mean), ptr(ws),
+                                                ws.numel() * 4, stream()))
+        ctx.save_for_backward(emb, trip, count, act)
+        ctx.mark_non_differentiable(loss, trip, count)
+        return mean, loss, trip, count
+
+    @staticmethod
+    def backward(ctx, dmean, _dloss, _dtrip, _dcount):
+        emb, trip, count, act = ctx.saved_tensors
+        n, e = emb.shape
+        demb = torch.empty_like(emb)
+        check(_lib.lib().embnet_triplet_gather_bwd(ptr(emb), n, e, ptr(trip), ptr(count), trip.shape[0], ptr(act),
+                                                   ptr(_prep(dmean)), ptr(demb), stream()))
+        return demb, None, None, None, None, None
+
+
+def fused_triplet_loss(emb, k_classes, k_samples, margin, mode, seed=0):
+    """-> (mean loss [autograd], per-triplet losses, triplets [rows,3] int32, count [1] int32); one launch."""
+    return _FusedTripletLoss.apply(emb, int(k_classes), int(k_samples), float(margin), mode, int(seed))
+
+
 # --------------------------------------------------------------------------- contrastive / accuracy
 class _Contrastive(torch.autograd.Function):
     @staticmethod

@@ -17,6 +17,8 @@ Documented semantic difference (SURVEY §7 hard part f): the reference mines wit
 embeddings and normalises the a/p/n branches as three separate BN batches; the fused step mines on
 the training-mode embeddings of the one batch.
 """
+import os
+
 import torch
 
 from . import layers as L
@@ -29,6 +31,8 @@ class TripletTrainer:
         self.model, self.opt = base_model, optimizer
         self.p, self.k, self.margin, self.mode = int(k_classes), int(k_samples), float(margin), negatives_selection_mode
         self.seed, self.step_no, self.reducer = int(seed), 0, reducer
+        # one launch for distance matrix + mining + hinge + mean when the batch fits the fused kernel (N <= 512)
+        self.fused_loss = os.environ.get("EMBNET_FUSED_LOSS", "1") == "1"
         if self.mode not in tuple(ops.MINING_MODES) + ("batch_hard",):
             raise KeyError(self.mode)
 
@@ -48,8 +52,13 @@ class TripletTrainer:
         if images.shape[0] != self.p * self.k:
             raise ValueError(f"batch of {images.shape[0]} images != k_classes*k_samples = {self.p * self.k}")
         emb = self.model(images)
-        trip, count = self.mine(emb)
-        mean, _ = ops.triplet_gather_loss(emb, trip, count, self.margin)
+        if self.fused_loss and ops.fused_loss_supported(self.p, self.k, emb.shape[1]):
+            mean, _, trip, count = ops.fused_triplet_loss(emb, self.p, self.k, self.margin, self.mode,
+                                                          seed=(self.seed << 20) + self.step_no)
+            self.last_triplets = (trip, count)
+        else:
+            trip, count = self.mine(emb)
+            mean, _ = ops.triplet_gather_loss(emb, trip, count, self.margin)
         reg = L.regularization_loss(self.model)
         return (mean if reg is None else mean + reg), mean, count
 

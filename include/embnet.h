@@ -32,7 +32,8 @@ extern "C" {
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
   EMBNET_MINE_HARDEST = 1,     /* datagenerators.py:188-190 */
-  EMBNET_MINE_RANDOM_HARD = 2  /* datagenerators.py:192-194 */
+  EMBNET_MINE_RANDOM_HARD = 2, /* datagenerators.py:192-194 */
+  EMBNET_MINE_BATCH_HARD = 3   /* Hermans et al. (README.md:112 cites it; not in the reference's code): fused entry point only */
 };
 
 int embnet_abi_version(void);
@@ -285,6 +286,22 @@ int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long tot
 size_t embnet_sumsq_workspace_bytes(void);
 int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace, size_t workspace_bytes,
                  void* stream);
+
+/* The same loss path in ONE launch for small batches (the sizes the reference trains at): distances of each class's K
+ * anchors to all N = p*k rows (sklearn arithmetic, kept in LDS), mine-and-select (mode as embnet_mine_triplets, or
+ * EMBNET_MINE_BATCH_HARD), squared-L2 hinge of each selected triplet, and — by the last workgroup to finish — compaction
+ * in pair order, the reference's fallback triplet and the mean.  Stands in for datagenerators.py:219,225-250 +
+ * losses_and_accuracies.py:26-42 (+ Keras' mean), i.e. for embnet_pairwise_dist_f32 + embnet_mine_triplets +
+ * embnet_triplet_gather_fwd, and writes the same outputs (triplets[T,3], count, selected[pairs], loss[max_t],
+ * active[max_t], mean_loss), so embnet_triplet_gather_bwd is the backward of both.  batch-hard: T = N, one triplet per
+ * anchor, `selected` unused; triplets/loss/active must hold N rows.
+ * embnet_fused_loss_supported: 1 when N <= 512, k <= 16 and k*(e+N) floats fit 64 KiB of LDS.
+ * workspace (embnet_fused_loss_workspace_bytes): zero-filled ONCE by the caller; every launch leaves its counter zeroed. */
+int embnet_fused_loss_supported(int p, int k, int e);
+size_t embnet_fused_loss_workspace_bytes(int p, int k);
+int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int e, float margin, int mode, uint64_t seed,
+                                  int32_t* triplets, int32_t* count, int32_t* selected, float* loss, float* active,
+                                  float* mean_loss, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ optimizer update
  * utils.py:143-153 get_optimizer(name, lr): `Adam(lr)`, `RMSprop(lr)`, `keras_radam.RAdam(lr)`, else `SGD(lr)`

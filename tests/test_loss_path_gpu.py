@@ -261,3 +261,108 @@ def test_l2_normalize_and_pair_distance(dev):
     dr.sum().backward()
     np.testing.assert_allclose(t1.grad.cpu().numpy(), r1.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(t2.grad.cpu().numpy(), r2.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------- fused loss path (one launch)
+def _borderline(lv, tol=1e-4):
+    """pairs of the reference's loss_values whose decision an fp32 distance error can flip"""
+    srt = np.sort(lv, axis=1)
+    return (np.abs(srt[:, -1]) < tol) | (srt[:, -1] - srt[:, -2] < tol)
+
+
+@pytest.mark.parametrize("case", R.MINING_CASES, ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", R.MINING_MODES)
+def test_fused_loss_path_golden(golden, dev, case, mode):
+    """embnet_fused_triplet_loss_fwd (distance + mining + hinge + mean, one launch) on the golden mining inputs: the
+    reference's triplets for 'hardest' (and its fallback), picks inside the reference's candidate sets for the two random
+    rules; loss rows, mean and the embedding gradient equal to the three-kernel path on the same triplets."""
+    from embeddingnet_amd import ops
+    name, p, k, e, m, sigma, seed = case
+    g = golden("mining")
+    key = f"{name}/{mode}"
+    assert ops.fused_loss_supported(p, k, e)
+    xs = R.clustered_embeddings(seed, p, k, e, sigma)       # the recipe the fixture's X / D came from (X is not stored for c5)
+    if g[f"{name}/X"].size:
+        assert np.array_equal(xs, g[f"{name}/X"])
+    x = _t(xs, dev).requires_grad_(True)
+    for rep in range(2):                                   # second launch: the arrival counter re-armed itself
+        mean, rows, trip, count = ops.fused_triplet_loss(x, p, k, m, mode, seed=77)
+    t = int(count.item())
+    got = trip.cpu().numpy()[:t]
+    ref_trip = g[f"{key}/triplets"]
+    if bool(g[f"{key}/fallback"]):
+        assert np.array_equal(got, ref_trip)
+    elif mode == "hardest":
+        if not (got.shape == ref_trip.shape and np.array_equal(got, ref_trip)):
+            assert _borderline(g[f"{key}/loss_values"]).any(), f"{name}: triplets differ without a borderline pair"
+    else:
+        cand = g[f"{key}/candidates"]
+        ppc = k * (k - 1) // 2
+        active = np.where(cand.any(1))[0]
+        pairs = {(int(a), int(b)): int(c) for a, b, c in got}
+        for pair in range(p * ppc):
+            lo = (pair // ppc) * k
+            i, j = [(a, b) for a in range(k) for b in range(a + 1, k)][pair % ppc]
+            sel = pairs.get((lo + i, lo + j))
+            if sel is None:
+                assert pair not in active or _borderline(g[f"{key}/loss_values"][pair:pair + 1]).any() or \
+                    np.abs(g[f"{key}/loss_values"][pair] - m).min() < 1e-4 or np.abs(g[f"{key}/loss_values"][pair]).min() < 1e-4
+            else:
+                q = sel if sel < lo else sel - k
+                lvq = g[f"{key}/loss_values"][pair][q]
+                assert cand[pair, q] or abs(lvq) < 1e-4 or abs(lvq - m) < 1e-4, (pair, sel)
+    # same triplets through the separate kernels: identical rows / mean / gradient
+    x2 = x.detach().clone().requires_grad_(True)
+    mean2, rows2 = ops.triplet_gather_loss(x2, trip, count, m)
+    assert torch.equal(rows[:t], rows2[:t]) and torch.all(rows[t:] == 0)
+    assert abs(mean.item() - mean2.item()) <= 1e-6 * abs(mean2.item()) + 1e-9
+    (mean * 2.0).backward()
+    (mean2 * 2.0).backward()
+    assert torch.equal(x.grad, x2.grad)
+
+
+def test_fused_loss_path_batch_hard_and_limits(dev):
+    from embeddingnet_amd import _lib, ops
+    x = R.clustered_embeddings(3, 32, 4, 256, 0.3)
+    emb = _t(x, dev).requires_grad_(True)
+    mean, rows, trip, count = ops.fused_triplet_loss(emb, 32, 4, 0.5, "batch_hard")
+    assert int(count.item()) == 128
+    want = omining.batch_hard(opair.pairwise_distances(x), 32, 4)
+    got = trip.cpu().numpy()
+    if not np.array_equal(got, want):                      # fp32 distances: a differing pick must be a near-tie
+        d = opair.pairwise_distances(x)
+        for (a, p1, n1), (_, p2, n2) in zip(got, want):
+            assert abs(d[a, p1] - d[a, p2]) < 1e-5 and abs(d[a, n1] - d[a, n2]) < 1e-5
+    y = np.concatenate([x[got[:, 0]], x[got[:, 1]], x[got[:, 2]]], axis=1)
+    ref_rows = olosses.triplet_loss(0.5)(None, y)
+    np.testing.assert_allclose(rows.cpu().numpy(), ref_rows, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(mean.item(), ref_rows.mean(), rtol=2e-5)
+    mean.backward()
+    assert torch.isfinite(emb.grad).all() and emb.grad.abs().max() > 0
+    assert ops.fused_loss_supported(64, 4, 512) and ops.fused_loss_supported(8, 4, 256)        # C5, C1
+    assert not ops.fused_loss_supported(256, 4, 256) and not ops.fused_loss_supported(8, 4, 8192)
+    with pytest.raises(_lib.EmbnetError):
+        ops.fused_triplet_loss(_t(np.zeros((1024, 256), np.float32), dev), 256, 4, 0.5, "hardest")
+
+
+def test_fused_and_unfused_trainer_steps_agree(dev):
+    """TripletTrainer with the one-launch loss path vs the separate kernels: same triplets, same loss, same update."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    x = torch.rand((32, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    res = []
+    for fused in (True, False):
+        base, _ = B.get_backbone((64, 64, 3), encodings_len=64, backbone_name="simple2", backbone_weights=None, seed=5, device=dev)
+        for mod in base.modules():
+            if hasattr(mod, "enabled"):
+                mod.enabled = False
+        tr = TripletTrainer(base, KerasOptimizer([q for q in base.parameters()], "sgd", 0.01), 8, 4, margin=0.5,
+                            negatives_selection_mode="hardest")
+        tr.fused_loss = fused
+        losses = [tr.step(x).item() for _ in range(3)]
+        trip, count = tr.last_triplets
+        res.append((losses, trip[: int(count.item())].cpu().numpy(), torch.cat([q.detach().reshape(-1) for q in base.parameters()])))
+    assert np.array_equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-6, atol=1e-8)

@@ -29,7 +29,10 @@ def close(got, want, rtol, what=""):
 
 
 @pytest.mark.parametrize("n,h,w,c,k,s", [(2, 16, 16, 32, 3, 1), (3, 15, 17, 96, 3, 2), (2, 14, 14, 240, 5, 2),
-                                         (2, 7, 7, 672, 5, 1), (2, 9, 9, 6, 3, 1)])
+                                         (2, 7, 7, 672, 5, 1), (2, 9, 9, 6, 3, 1),
+                                         # register-blocked kernels: even and odd left padding at stride 2, ragged column blocks
+                                         (2, 16, 16, 32, 3, 2), (2, 15, 15, 32, 5, 2), (1, 13, 18, 16, 5, 1), (1, 12, 22, 40, 3, 1),
+                                         (2, 21, 10, 24, 5, 2), (3, 10, 6, 8, 3, 2)])
 def test_depthwise_conv(dev, n, h, w, c, k, s):
     from embeddingnet_amd import layers as L
     rs = np.random.RandomState(n * 100 + c)
