@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+MFMA_BF16_PEAK_TFLOPS = 16 * 157.3    # same guide, § Matrix cores: bf16 dense = 16 x the f32-input rate (~2.5 PF)
 HBM_PEAK_GBPS, HBM_COPY_GBPS = 8000.0, 6290.0     # same guide: HBM3E spec / measured float4 copy
 # forward MACs per 224x224 image; training FLOP = 3 passes x 2 FLOP/MAC
 FWD_GMAC = {"resnet18": 1.826, "resnet50": 4.1, "efficientnet-b0": 0.39}
@@ -97,7 +98,7 @@ def cpu_baseline(args):
             "sample": f"{what}, {n} steps of {dt:.2f} s"}
 
 
-def roofline_from_trace(records, traced_steps, ms_per_step, workload):
+def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms=1):
     """records: [(kernel, ms, work, unit, bytes)] over `traced_steps` steps -> (roofline dict, per-kernel table)."""
     by = {}
     detail = os.environ.get("EMBNET_BENCH_DETAIL")       # substring of a kernel name: list its launches one by one
@@ -112,7 +113,7 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload):
     if not by:
         return None, by
     table = sorted(by.items(), key=lambda kv: -kv[1]["ms"])
-    for name, d in table[:14]:
+    for name, d in table[:int(os.environ.get("EMBNET_BENCH_ROWS", "14"))]:
         rate = d["work"] / d["ms"] / 1e9 if d["unit"] == 0 else d["work"] / d["ms"] / 1e6
         log(f"  {name[:104]:104s} x{d['launches'] // traced_steps:3d}/step  avg {1e3 * d['ms'] / d['launches']:8.1f} us  "
             f"{rate:8.1f} {'TFLOP/s' if d['unit'] == 0 else 'GB/s'}  {d['ms'] / traced_steps:6.3f} ms/step")
@@ -121,10 +122,22 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload):
     name, d = table[0]
     avg_us = 1e3 * d["ms"] / d["launches"]
     if d["unit"] == 0:
-        achieved = d["work"] / d["ms"] / 1e9
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                "flop_per_launch": d["work"] / d["launches"]}
+        achieved = d["work"] / d["ms"] / 1e9              # algorithmic (fp32) FLOP: 2 * M * N * K per launch
+        terms = conv_terms if "conv_" in name else 1
+        if terms > 1:
+            # the conv kernels form every fp32 product from `terms` bf16 MFMA terms (exact 3-way split, include/embnet.h):
+            # the matrix pipe executes terms x the algorithmic FLOP, on the bf16 instruction -> priced against the bf16 peak
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(terms * achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(terms * achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "arithmetic": f"fp32 operands and accumulation; each product = {terms} v_mfma_f32_32x32x16_bf16 terms of an "
+                                  "exact three-way bf16 split; `achieved` counts the executed bf16 MFMA FLOP",
+                    "fp32_equivalent_tflops": round(achieved, 2),
+                    "fp32_equivalent_over_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                    "flop_per_launch": d["work"] / d["launches"]}
+        else:
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                    "flop_per_launch": d["work"] / d["launches"]}
     else:
         achieved = d["work"] / d["ms"] / 1e6
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -258,7 +271,8 @@ def main():
 
     roofline = None
     if trace:
-        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + 3) // 4, ms_per_step, args.config)
+        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + 3) // 4, ms_per_step, args.config,
+                                          _lib.lib().embnet_conv_mfma_terms())
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
                                                              (MFMA_F32_PEAK_TFLOPS * 1e12), 4)

@@ -303,8 +303,25 @@ struct LoadConvWgradA {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Arithmetic of the convolution main loops: 1 = fp32 products as six bf16 MFMA terms of an exact three-way split
+// (gemm_engine.h, "bf16x6"; error vs fp64 no larger than the fp32 MFMA's), 0 = v_mfma_f32_32x32x2_f32.
+#ifndef EMBNET_CONV_SPLIT
+#define EMBNET_CONV_SPLIT 1
+#endif
+template <class TA, class TB>
+constexpr int CONV_MAIN_FLOATS = EMBNET_CONV_SPLIT ? (MAIN3_BYTES<TA, TB> + 3) / 4 : MAIN_FLOATS<TA, TB>;
 template <class G, class TA, class TB>
-constexpr int SMEM_FLOATS = MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>;
+constexpr int SMEM_FLOATS = CONV_MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? CONV_MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>;
+
+template <class G, class TA, class TB, class LA, class LB>
+__device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end, float* smem,
+                                              f32x16 (&acc)[G::TM][G::TN], bool fair = false, bool zero_acc = true) {
+#if EMBNET_CONV_SPLIT
+  gemm_mainloop3<G, TA, TB>(la, lb, kt_begin, kt_end, reinterpret_cast<unsigned char*>(smem), acc, fair, zero_acc);
+#else
+  gemm_mainloop<G, TA, TB>(la, lb, kt_begin, kt_end, smem, acc, fair, zero_acc);
+#endif
+}
 
 // Remainder split ("tail"): workgroups finish in waves of 256 (one per CU), so `tiles mod 256` left-over
 // tiles would keep a few CUs busy for a whole extra tile time (784 tiles = 3.06 per CU ran 22 % longer
@@ -408,7 +425,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
-  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
   stamp(4);
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
@@ -484,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
   LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
-  gemm_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
+  conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
   stamp(4);
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   const int st = p.g.stride;
@@ -551,8 +568,8 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   // tiles apart (wrapping around), so they want different L2 lines at any instant but the same ones within a few
   // tiles' time.  Two passes over the rotated range; the accumulators carry over.
   const int rot = p.stagger > 0 ? min((tile * p.stagger) % max(kt1 - kt0, 1), kt1 - kt0) : 0;
-  gemm_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
-  if (rot > 0) { prio_lo(); gemm_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
+  conv_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
   stamp(4);
   float* out = p.out + (long)split * M * p.g.K;
   if (VB) {                                              // K % 4 == 0
@@ -659,7 +676,7 @@ using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
 static int pick_tile(long m, int ncols) {
-  static const int forced = (int)env_long("EMBNET_CONV_TILE", -1);    // tuning aid (tools/kernel_bench.py)
+  const int forced = (int)env_long("EMBNET_CONV_TILE", -1);    // tuning aid (tools/exp/tile_sweep.py), read per call
   if (forced >= 0) return forced;
   // Measured on ResNet18 shapes (tools/kernel_bench.py, EMBNET_CONV_TILE sweep): workgroups all take the
   // same time, so what matters is how evenly the grid fills the 256 CUs x (3..6 resident workgroups);
@@ -670,7 +687,11 @@ static int pick_tile(long m, int ncols) {
 }
 static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
 // workgroups of each tile type a CU holds at once (registers / LDS; measured with in-kernel stamps)
+#if EMBNET_CONV_SPLIT
+static const int TILE_RESIDENT[5] = {2, 3, 4, 4, 2};
+#else
 static const int TILE_RESIDENT[5] = {3, 4, 5, 7, 3};
+#endif
 // Progress-ordered priority (gemm_engine.h: `fair`) for launches whose workgroups are all resident at once.  Measured
 // A/B, one process (tools/exp/ab_conv.py, ResNet18 layers at batch 128): 64x64-tile forward / data-gradient launches
 // that fit one round +1..+3 % (7 waves per SIMD end together instead of one after the other), split-K weight-gradient
@@ -727,6 +748,8 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
     case 2: KERNEL<G128x32, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
     default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
   }
+
+extern "C" int embnet_conv_mfma_terms(void) { return EMBNET_CONV_SPLIT ? 6 : 1; }
 
 extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;
@@ -863,12 +886,14 @@ static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt
   // 128-row tiles waste the last half tile of a 576-row (3x3x64) gradient; 192-row tiles fit it exactly
   static const bool no192 = env_long("EMBNET_WGRAD_NO192", 0) != 0;
   if (tile == 1 && rows % 192 == 0 && rows % 128 != 0 && !no192) tile = 4;
+  const int forced_tile = (int)env_long("EMBNET_WGRAD_TILE", -1);
+  if (forced_tile >= 0) tile = forced_tile;
   const long tiles = (long)cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const int kt_total = cdiv(kg, BK);
   // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
   // workgroups per CU is best; with many tiles shorter K ranges in 2-3 rounds balance better
   long target = tiles >= 100 ? 2048 : (tiles >= 30 ? 1536 : 768);
-  static const long forced_blocks = env_long("EMBNET_WGRAD_BLOCKS", 0);
+  const long forced_blocks = env_long("EMBNET_WGRAD_BLOCKS", 0);   // tuning aids, read per call
   if (forced_blocks > 0) target = forced_blocks;
   long want = (target + tiles - 1) / tiles;
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split

@@ -465,6 +465,191 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
   }
 }
 
+// ---- fp32 products from bf16 matrix instructions: exact three-way split, six terms ("bf16x6") -----------------
+// gfx950 has no xf32 and its fp32 MFMA runs at 1/16 of the bf16 rate.  Every fp32 operand x is split EXACTLY into
+// three bf16 pieces x = x1 + x2 + x3 (8 significant bits each, by truncation: x1 = top 16 bits of x, x2 = top 16 bits
+// of x - x1, x3 = x - x1 - x2, which fits), and a product x*y is accumulated as the six terms
+//   x1y3 + x3y1 + x2y2 + x1y2 + x2y1 + x1y1        (each exact in the fp32 accumulator's multiplier)
+// the dropped x2y3 + x3y2 + x3y3 are <= 2^-24 |x||y|, below the rounding of one fp32 product.  Measured against an
+// fp64 reference (tools/exp/bf16x6_gemm.hip, K = 576..4096): max error 2.8-3.7e-7 of sum|a b|, the k-ordered fp32 fma
+// chain of v_mfma_f32_32x32x2_f32 3.4-4.8e-7 — the split path is not a reduced-precision path.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight fp32 MFMAs (64 cycles each, K = 2): 192 vs 512
+// matrix-pipe cycles for the same 32x32x16 block.
+// LDS holds the three pieces as separate bf16 planes.  The thread -> (row, k) mapping of the loaders is the fp32
+// tiles' (TileKC / TileKM), so every loader works unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct Split4 { uint2 p[3]; };                 // four consecutive elements: 8 bytes per plane
+
+__device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) {      // {top half of a, top half of b}
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
+__device__ __forceinline__ Split4 split4(const float4 v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t a[4], b[4], c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = __float_as_uint(x[i]);
+    const float r1 = x[i] - __uint_as_float(a[i] & 0xffff0000u);
+    b[i] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b[i] & 0xffff0000u);
+    c[i] = __float_as_uint(r2);
+  }
+  Split4 s;
+#if defined(EMBNET_SPLIT_ABLATE)             // diagnostic build (wrong results): no residual arithmetic, the packing only
+  s.p[0] = make_uint2(hi16_pair(a[0], a[1]), hi16_pair(a[2], a[3]));
+  s.p[1] = s.p[0]; s.p[2] = s.p[0];
+  return s;
+#endif
+  s.p[0] = make_uint2(hi16_pair(a[0], a[1]), hi16_pair(a[2], a[3]));
+  s.p[1] = make_uint2(hi16_pair(b[0], b[1]), hi16_pair(b[2], b[3]));
+  s.p[2] = make_uint2(hi16_pair(c[0], c[1]), hi16_pair(c[2], c[3]));
+  return s;
+}
+
+// k-contiguous operand: three planes [ROWS][32 k] of bf16, 80-byte row pitch (64 + 16: the 16-byte fragment reads of
+// a 32-row block fall on 16 distinct 16-byte bank slots).  Lane (i = lane&31, h = lane>>5) of k16-step st reads
+// k = 16 st + 8 h .. +7 of row i with one ds_read_b128 per plane — the A/B operand map of v_mfma_f32_32x32x16_bf16.
+template <int ROWS>
+struct TileKC3 {
+  using Map = TileKC<ROWS>;
+  static constexpr int PASSES = Map::PASSES, PITCH = 80, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
+  __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      unsigned char* d = s + Map::row_of(tid, p) * PITCH + Map::k_of(tid) * 2;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
+    }
+  }
+  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
+    const unsigned char* a = s + (r0 + (lane & 31)) * PITCH + (2 * st + (lane >> 5)) * 16;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const bf16x8*>(a + q * PLANE);
+  }
+};
+
+// row-contiguous (k-major) operand: three planes [32 k][ROWS] of bf16; the fragment (8 consecutive k of one row per
+// lane) comes from two ds_read_b64_tr_b16 per plane — each 16-lane group reads a 4 k x 16 rows block and receives it
+// transposed (lane 4q+p supplies the address of k-row q, rows 4p..4p+3; lane i receives row i, k-row q in element q).
+// Pitch: 2*ROWS bytes, +64 unless that is already 64 mod 128, so the four k-rows of a block sit on different banks.
+template <int ROWS>
+struct TileKM3 {
+  using Map = TileKM<ROWS>;
+  static constexpr int PASSES = Map::PASSES;
+  static constexpr int PITCH = 2 * ROWS + ((2 * ROWS) % 128 == 64 ? 0 : 64), PLANE = BK * PITCH, BYTES = 3 * PLANE;
+  __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      unsigned char* d = s + Map::k_of(tid, p) * PITCH + Map::row_of(tid, p) * 2;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
+    }
+  }
+  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
+    const int k = 16 * st + 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int row = r0 + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    const unsigned char* a = s + k * PITCH + row * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE + 4 * PITCH));
+      const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      v[q] = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+};
+
+template <class T> struct SplitTile;
+template <int R> struct SplitTile<TileKC<R>> { using type = TileKC3<R>; };
+template <int R> struct SplitTile<TileKM<R>> { using type = TileKM3<R>; };
+
+template <class TA, class TB>
+constexpr int MAIN3_BYTES = SplitTile<TA>::type::BYTES + SplitTile<TB>::type::BYTES;
+
+// one k16-step: six terms per accumulator, smallest first; the accumulators of a wave alternate inside a term so
+// consecutive MFMAs are independent
+template <class G>
+__device__ __forceinline__ void mfma_step3(const bf16x8 (&a)[G::TM][3], const bf16x8 (&b)[G::TN][3],
+                                           f32x16 (&acc)[G::TM][G::TN]) {
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+      for (int in = 0; in < G::TN; ++in)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[im][PA[t]], b[in][PB[t]], acc[im][in], 0, 0, 0);
+}
+
+// Main loop of the split path: same structure as the single-stage fp32 loop (one LDS buffer, the next K tile
+// prefetched into registers under the MFMAs, two barriers per tile).  The split arithmetic (11 VALU ops per pair of
+// elements) runs on the prefetched registers BEHIND the MFMAs and outside the barrier pair, so between the barriers
+// there are only the 8-byte LDS stores; TA/TB are the fp32 tile types the loaders were written for.
+template <class G, class TA, class TB, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int kt_begin, int kt_end,
+                                               unsigned char* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false,
+                                               bool zero_acc = true) {
+  using SA = typename SplitTile<TA>::type;
+  using SB = typename SplitTile<TB>::type;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  constexpr int PAST = 1 << 24;
+  if (zero_acc) {
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  float4 ra[TA::PASSES], rb[TB::PASSES];
+  Split4 pa[TA::PASSES], pb[TB::PASSES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + SA::BYTES;
+  auto split_all = [&]() {
+#pragma unroll
+    for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
+#pragma unroll
+    for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
+  };
+  if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); split_all(); }
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();                         // everyone finished reading the previous tile
+    SA::store(sA, pa, tid);
+    SB::store(sB, pb, tid);
+    __syncthreads();
+#if EMBNET_PHASE_PRIO
+    if (!fair) prio_lo();
+    else {
+      const int done = 4 * (kt - kt_begin), span = kt_end - kt_begin;
+      if (done >= 3 * span) __builtin_amdgcn_s_setprio(0);
+      else if (done >= 2 * span) __builtin_amdgcn_s_setprio(1);
+      else if (done >= span) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
+    la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+    lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+#pragma unroll
+    for (int st = 0; st < BK / 16; ++st) {
+      bf16x8 a[G::TM][3], b[G::TN][3];
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, st, lane, a[i]);
+#pragma unroll
+      for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
+      mfma_step3<G>(a, b, acc);
+    }
+    la.fix(ra); lb.fix(rb);
+    if (kt + 1 < kt_end) split_all();
+  }
+  prio_hi();                                 // epilogue
+}
+
 // Walk the accumulators: f(row_in_tile, col_in_tile, value) for this lane's elements.
 // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <class G, class F>

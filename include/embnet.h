@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 3
+#define EMBNET_ABI_VERSION 4
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -138,7 +138,11 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * Stand-ins for the Keras layers that backbones.py:19-121 instantiates (TensorFlow kernels in the
  * reference).  All NHWC fp32. */
 
-/* Conv2D (backbones.py:21-31, :44-68, zoo ResNet/EfficientNet convs): implicit GEMM on fp32 MFMA.
+/* Conv2D (backbones.py:21-31, :44-68, zoo ResNet/EfficientNet convs): implicit GEMM.  fp32 in, fp32 out, fp32
+ * accumulation; each fp32 product is formed on the bf16 matrix instruction from an EXACT three-way split of both
+ * operands (x = x1 + x2 + x3, six of the nine cross terms; the three dropped are <= 2^-24 |x||y|), which measures
+ * no further from an fp64 reference than the fp32 MFMA's fma chain and runs at 16/6 of its rate.
+ * embnet_conv_mfma_terms() = bf16 MFMA terms per product in this build (6), or 1 for a build on v_mfma_f32_32x32x2_f32.
  * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
  * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its
  * bottom/right asymmetry, or an explicit ZeroPadding2D).  bias may be NULL; relu!=0 fuses the activation;
@@ -153,6 +157,7 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * workspace (optional, may be NULL/0): >= embnet_conv2d_fwd_workspace_bytes lets the launcher cut the
  * `tiles mod 256` left-over output tiles along K so the last round of workgroups fills every CU
  * (partial tiles + fixed-order fix-up; results differ from the unsplit launch only in fp32 summation order). */
+int embnet_conv_mfma_terms(void);
 size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
