@@ -675,14 +675,26 @@ using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 
 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
-static int pick_tile(long m, int ncols) {
+static int pick_tile(long m, int ncols, bool strided_dgrad = false) {
   const int forced = (int)env_long("EMBNET_CONV_TILE", -1);    // tuning aid (tools/exp/tile_sweep.py), read per call
   if (forced >= 0) return forced;
   // Measured on ResNet18 shapes (tools/kernel_bench.py, EMBNET_CONV_TILE sweep): workgroups all take the
   // same time, so what matters is how evenly the grid fills the 256 CUs x (3..6 resident workgroups);
   // 128x64 wins once it gives >= 4 workgroups per CU, 64x64 below that, 128x128 only for many rounds.
   if (ncols <= 32) return 2;
+#if EMBNET_CONV_SPLIT
+  // Split arithmetic (tools/exp/tile_sweep.py, profiles/r02_tile_sweep_split.txt): the split VALU work and the loads
+  // per MFMA fall with the tile size, two 128x128 workgroups fit a CU, and the matrix pipe is 2.7x faster, so the
+  // big tile wins as soon as it gives every CU 1.5 tiles (28x28x128 -> 256: 95 us vs 103 / 114 for 128x64 / 64x64).
+  // In the training step (bench.py, EMBNET_BENCH_DETAIL, per layer): 14x14x256 -> 256 195 us vs 221 forward and
+  // 198 vs 235 data gradient, 28x28x128 s2 -> 256 105 vs 117; 128-wide layers are neutral, and the stride classes of
+  // a strided data gradient (unequal K per class) lose with the big tile (162 vs 114 us) -> they keep the old rule.
+  static const long t128_min = env_long("EMBNET_CONV_T128_MIN", 384);
+  const long t128 = cdiv(m, 128) * cdiv(ncols, 128);
+  if ((ncols >= 256 && !strided_dgrad && t128 >= t128_min) || (ncols >= 128 && t128 >= 4 * 768)) return 0;
+#else
   if (cdiv(m, 128) * cdiv(ncols, 128) >= 4 * 768 && ncols >= 128) return 0;
+#endif
   return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
 }
 static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
@@ -853,7 +865,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
       if (m > max_m) max_m = m;
     }
   hipStream_t st = (hipStream_t)stream;
-  const int tile = pick_tile(max_m * stride * stride, c);
+  const int tile = pick_tile(max_m * stride * stride, c, stride > 1);
   const long tiles = (long)cdiv(max_m, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]);
   const bool vec = (k & 3) == 0 && aligned16(dy) && aligned16(w);
   // stride 1 = one class whose rows are the input pixels in order, so the fix-up writes dx[row*C + col]
@@ -892,7 +904,12 @@ static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt
   const int kt_total = cdiv(kg, BK);
   // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
   // workgroups per CU is best; with many tiles shorter K ranges in 2-3 rounds balance better
+#if EMBNET_CONV_SPLIT
+  // two workgroups per CU: one round (512) for few tiles, two for 25..99, short K ranges beyond (same sweep)
+  long target = tiles >= 100 ? 2048 : (tiles >= 25 ? 1024 : (tiles <= 2 ? 768 : 512));   // stem (2 tiles, 50k K tiles): 768
+#else
   long target = tiles >= 100 ? 2048 : (tiles >= 30 ? 1536 : 768);
+#endif
   const long forced_blocks = env_long("EMBNET_WGRAD_BLOCKS", 0);   // tuning aids, read per call
   if (forced_blocks > 0) target = forced_blocks;
   long want = (target + tiles - 1) / tiles;
@@ -1012,7 +1029,7 @@ extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd,
   } else if (kind == 1) {
     long max_m = (long)n * ((h + 0) / 1) * wd;         // same tile choice as the launcher (all classes together)
     snprintf(buf, sizeof buf, "void embnet::conv_dgrad_kernel<embnet::Geom<%s>, %s>(embnet::ConvDgradParams)",
-             geoms[pick_tile(max_m, c)], tk);
+             geoms[pick_tile(max_m, c, oh < h)], tk);
   } else if (kind == 2) {
     int tile, sp, kt;
     wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
