@@ -313,6 +313,12 @@ constexpr int CONV_MAIN_FLOATS = EMBNET_CONV_SPLIT ? (MAIN3_BYTES<TA, TB> + 3) /
 template <class G, class TA, class TB>
 constexpr int SMEM_FLOATS = CONV_MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? CONV_MAIN_FLOATS<TA, TB> : EPI_FLOATS<G>;
 
+// Workgroups per CU the LDS image allows (one wave of each on every SIMD) -> the register budget hipcc must keep
+// for the 16-byte-load kernels (the scalar-load variants for odd channel counts would spill)
+// (__launch_bounds__'s second argument is waves per SIMD): 128x128 and 192x64 two, 128x64 three, smaller tiles four.
+template <class G>
+constexpr int CONV_OCC = !EMBNET_CONV_SPLIT ? 1 : (G::BM * G::BN >= 192 * 64 ? 2 : (G::BM * G::BN >= 128 * 64 ? 3 : 4));
+
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end, float* smem,
                                               f32x16 (&acc)[G::TM][G::TN], bool fair = false, bool zero_acc = true) {
@@ -475,7 +481,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
 }
 
 template <class G, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdParams p) { conv_fwd_body<G, VEC, false>(p); }
+__global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_fwd_kernel(ConvFwdParams p) { conv_fwd_body<G, VEC, false>(p); }
 // same, reading act(x*in_scale + in_shift) (InputTransform); its own symbol so the plain kernel keeps its code
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { con
 struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; };
 
 template <class G, bool VEC>
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(ConvDgradParams p) {
+__global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(ConvDgradParams p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
@@ -587,7 +593,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
 }
 
 template <class G, bool VA, bool VB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradParams p) { conv_wgrad_body<G, VA, VB, false>(p); }
+__global__ __launch_bounds__(256, (VA && VB) ? CONV_OCC<G> : 1) void conv_wgrad_kernel(ConvWgradParams p) { conv_wgrad_body<G, VA, VB, false>(p); }
 template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
 

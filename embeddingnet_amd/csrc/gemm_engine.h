@@ -467,12 +467,12 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
 
 // ---- fp32 products from bf16 matrix instructions: exact three-way split, six terms ("bf16x6") -----------------
 // gfx950 has no xf32 and its fp32 MFMA runs at 1/16 of the bf16 rate.  Every fp32 operand x is split EXACTLY into
-// three bf16 pieces x = x1 + x2 + x3 (8 significant bits each, by truncation: x1 = top 16 bits of x, x2 = top 16 bits
-// of x - x1, x3 = x - x1 - x2, which fits), and a product x*y is accumulated as the six terms
+// three bf16 pieces x = x1 + x2 + x3 (8 significant bits each, see split4), and a product x*y is accumulated as the
+// six terms
 //   x1y3 + x3y1 + x2y2 + x1y2 + x2y1 + x1y1        (each exact in the fp32 accumulator's multiplier)
-// the dropped x2y3 + x3y2 + x3y3 are <= 2^-24 |x||y|, below the rounding of one fp32 product.  Measured against an
-// fp64 reference (tools/exp/bf16x6_gemm.hip, K = 576..4096): max error 2.8-3.7e-7 of sum|a b|, the k-ordered fp32 fma
-// chain of v_mfma_f32_32x32x2_f32 3.4-4.8e-7 — the split path is not a reduced-precision path.  Six
+// the dropped x2y3 + x3y2 + x3y3 are <= 2^-20 |x||y| (typically 2^-22).  Measured against an
+// fp64 reference (tools/exp/bf16x6_gemm.hip, K = 576..4096): max error 2.8-3.7e-7 of sum|a b|, the
+// k-ordered fp32 fma chain of v_mfma_f32_32x32x2_f32 3.4-4.8e-7 — the split path is not a reduced-precision path.  Six
 // v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight fp32 MFMAs (64 cycles each, K = 2): 192 vs 512
 // matrix-pipe cycles for the same 32x32x16 block.
 // LDS holds the three pieces as separate bf16 planes.  The thread -> (row, k) mapping of the loaders is the fp32
@@ -487,6 +487,11 @@ __device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) {      // 
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
 
+// x = x1 + x2 + x3 by truncation: x1 = top 16 bits of x, x2 = top 16 bits of x - x1, x3 = x - x1 - x2 (both
+// differences are exact and the last has at most 8 significant bits left, so it is a bf16).
+// Round-to-nearest pieces (v_cvt_pk_bf16_f32) halve the dropped terms and remove their bias, but measured the same
+// error against fp64 (3.4e-7 vs 3.7e-7 of sum|a b| at K = 4096: the fp32 accumulation dominates either way) and ran the
+// conv kernels 6-7 % slower (tools/exp/bf16x6_gemm.hip, profiles/r02_exp_ab_split_rne.txt) -> truncation.
 __device__ __forceinline__ Split4 split4(const float4 v) {
   const float x[4] = {v.x, v.y, v.z, v.w};
   uint32_t a[4], b[4], c[4];
@@ -499,12 +504,11 @@ __device__ __forceinline__ Split4 split4(const float4 v) {
     c[i] = __float_as_uint(r2);
   }
   Split4 s;
-#if defined(EMBNET_SPLIT_ABLATE)             // diagnostic build (wrong results): no residual arithmetic, the packing only
   s.p[0] = make_uint2(hi16_pair(a[0], a[1]), hi16_pair(a[2], a[3]));
+#if defined(EMBNET_SPLIT_ABLATE)             // diagnostic build (wrong results): no residual arithmetic, the packing only
   s.p[1] = s.p[0]; s.p[2] = s.p[0];
   return s;
 #endif
-  s.p[0] = make_uint2(hi16_pair(a[0], a[1]), hi16_pair(a[2], a[3]));
   s.p[1] = make_uint2(hi16_pair(b[0], b[1]), hi16_pair(b[2], b[3]));
   s.p[2] = make_uint2(hi16_pair(c[0], c[1]), hi16_pair(c[2], c[3]));
   return s;
@@ -586,10 +590,23 @@ __device__ __forceinline__ void mfma_step3(const bf16x8 (&a)[G::TM][3], const bf
         acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[im][PA[t]], b[in][PB[t]], acc[im][in], 0, 0, 0);
 }
 
-// Main loop of the split path: same structure as the single-stage fp32 loop (one LDS buffer, the next K tile
-// prefetched into registers under the MFMAs, two barriers per tile).  The split arithmetic (11 VALU ops per pair of
-// elements) runs on the prefetched registers BEHIND the MFMAs and outside the barrier pair, so between the barriers
-// there are only the 8-byte LDS stores; TA/TB are the fp32 tile types the loaders were written for.
+// Main loop of the split path: one LDS buffer, two barriers per K tile, the split arithmetic (11 VALU ops per pair of
+// elements) on prefetched registers BEHIND the MFMAs and outside the barrier pair, so between the barriers there are
+// only the 8-byte LDS stores.  TA/TB are the fp32 tile types the loaders were written for.
+// Prefetch distance: the MFMA phase of a K tile is 2.7x shorter than the fp32 loop's (24-48 bf16 MFMAs of 32 cycles
+// per wave: 0.3-0.6 us), shorter than an HBM or L2 round trip, so a tile fetched during tile kt's MFMAs is not there
+// when they end (PMC: matrix pipe 34-42 % busy at distance 1).  DIST = 2 keeps two register sets in flight: tile
+// kt+2 is requested before tile kt's MFMAs and first touched (split) after tile kt+1's.  Loaders whose fix() uses
+// state of their last load() (the optional input transform) stay at distance 1.
+// Measured (tools/exp/ab_conv.py, profiles/r02_exp_ab_split_dist2.txt): DIST = 2 costs 48-130 more registers (352
+// for the 128x128 forward kernel: one workgroup per CU instead of two, 128x64: two instead of three) and is 5-30 %
+// SLOWER on every layer that loses occupancy, 2-3 % faster on the 64x64-tile layers only -> off.
+#ifndef EMBNET_SPLIT_DIST
+#define EMBNET_SPLIT_DIST 1
+#endif
+#ifndef EMBNET_SPLIT_EARLY
+#define EMBNET_SPLIT_EARLY 1
+#endif
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int kt_begin, int kt_end,
                                                unsigned char* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false,
@@ -608,18 +625,16 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  float4 ra[TA::PASSES], rb[TB::PASSES];
   Split4 pa[TA::PASSES], pb[TB::PASSES];
   unsigned char* sA = smem;
   unsigned char* sB = smem + SA::BYTES;
-  auto split_all = [&]() {
+  auto split_all = [&](const float4 (&ra)[TA::PASSES], const float4 (&rb)[TB::PASSES]) {
 #pragma unroll
     for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
 #pragma unroll
     for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
   };
-  if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); split_all(); }
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto to_lds = [&](int kt) {
     __syncthreads();                         // everyone finished reading the previous tile
     SA::store(sA, pa, tid);
     SB::store(sB, pb, tid);
@@ -633,8 +648,8 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
       else if (done >= span) __builtin_amdgcn_s_setprio(2);
     }
 #endif
-    la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
-    lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+  };
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int st = 0; st < BK / 16; ++st) {
       bf16x8 a[G::TM][3], b[G::TN][3];
@@ -644,8 +659,69 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
       for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
       mfma_step3<G>(a, b, acc);
     }
-    la.fix(ra); lb.fix(rb);
-    if (kt + 1 < kt_end) split_all();
+  };
+  if (kt_begin >= kt_end) { prio_hi(); return; }
+  if constexpr (EMBNET_SPLIT_DIST == 2 && LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE) {
+    float4 ra0[TA::PASSES], rb0[TB::PASSES], ra1[TA::PASSES], rb1[TB::PASSES];
+    la.load(kt_begin, ra0); lb.load(kt_begin, rb0);
+    if (kt_begin + 1 < kt_end) { la.load(kt_begin + 1, ra1); lb.load(kt_begin + 1, rb1); }
+    split_all(ra0, rb0);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      to_lds(kt);                                                            // tile kt
+      if (kt + 2 < kt_end) { la.load(kt + 2, ra0); lb.load(kt + 2, rb0); }
+      mfma_tile();
+      if (kt + 1 >= kt_end) break;
+      split_all(ra1, rb1);                                                   // requested one iteration ago
+      to_lds(kt + 1);                                                        // tile kt + 1
+      if (kt + 3 < kt_end) { la.load(kt + 3, ra1); lb.load(kt + 3, rb1); }
+      mfma_tile();
+      if (kt + 2 < kt_end) split_all(ra0, rb0);
+    }
+  } else {
+    float4 ra[TA::PASSES], rb[TB::PASSES];
+    la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb);
+    split_all(ra, rb);
+#if EMBNET_ABLATE >= 2        // diagnostic builds (wrong results; tools/exp): 1 = no global loads in the loop, 2 = also no
+    to_lds(kt_begin);         // split / LDS stores / barriers, 3 = also no fragment reads (MFMA only)
+#endif
+#if EMBNET_ABLATE == 3
+    bf16x8 a3[G::TM][3], b3[G::TN][3];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, 0, lane, a3[i]);
+#pragma unroll
+    for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, 0, lane, b3[i]);
+#endif
+#if EMBNET_SPLIT_EARLY
+    // the registers are free as soon as they are split: request tile kt+2 right behind the split of tile kt+1 (before
+    // the barrier pair and the LDS stores of the next iteration) instead of after them
+    la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
+    lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
+#endif
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+#if EMBNET_ABLATE < 2
+      to_lds(kt);
+#endif
+#if EMBNET_ABLATE == 4        // diagnostic: same instructions, every prefetch re-reads the first tile (cache hits)
+      la.load(kt + 1 < kt_end ? kt_begin : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt_begin : PAST, rb);
+#elif EMBNET_ABLATE < 1 && !EMBNET_SPLIT_EARLY
+      la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+#endif
+#if EMBNET_ABLATE == 3
+      mfma_step3<G>(a3, b3, acc); asm volatile("" ::: "memory"); mfma_step3<G>(a3, b3, acc); asm volatile("" ::: "memory");
+#else
+      mfma_tile();
+#endif
+#if EMBNET_ABLATE < 2 || EMBNET_ABLATE == 4
+      la.fix(ra); lb.fix(rb);
+      if (kt + 1 < kt_end) split_all(ra, rb);
+#endif
+#if EMBNET_SPLIT_EARLY
+      la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
+      lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+#endif
+    }
   }
   prio_hi();                                 // epilogue
 }

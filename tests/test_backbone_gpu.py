@@ -84,6 +84,51 @@ def test_conv2d_fwd_bwd(dev, case):
         close(layer.bias.grad, ctx.params["c/bias"].grad, 2e-5, "bias grad")
 
 
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64, 64, 3), (2, 8, 8, 512, 128, 3), (4, 12, 12, 256, 256, 1)])
+def test_conv2d_products_are_fp32_accurate(dev, shape):
+    """The conv kernels form each fp32 product from bf16 matrix-instruction terms of an exact three-way operand split
+    (include/embnet.h).  This pins that the result is fp32-class, not bf16- or tf32-class: on operands spread over six
+    decades, every output / gradient element is as close to the float64 result (relative to sum|a||b|) as a float32
+    convolution on the CPU is, within a factor 2 (measured: 0.75-1.6 x; three terms instead of six would be 5-10 x off,
+    one term 1000 x), and on small integers, where every partial sum is representable, it is exact."""
+    n, h, w, cin, cout, k = shape
+    rs = np.random.RandomState(7)
+    x = (rs.randn(n, h, w, cin) * 10.0 ** rs.uniform(-3, 3, (n, h, w, cin))).astype(np.float32)
+    kern = (rs.randn(k, k, cin, cout) * 10.0 ** rs.uniform(-3, 3, (k, k, cin, cout))).astype(np.float32)
+    dy = (rs.randn(n, h, w, cout) * 10.0 ** rs.uniform(-3, 3, (n, h, w, cout))).astype(np.float32)
+
+    def run64(x_, k_, dy_, dt=torch.float64):
+        xr = torch.tensor(x_, dtype=dt, requires_grad=True)
+        kr = torch.tensor(k_, dtype=dt, requires_grad=True)
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), kr.permute(3, 2, 0, 1), padding=k // 2).permute(0, 2, 3, 1)
+        yr.backward(torch.tensor(dy_, dtype=dt))
+        return yr.detach().double().numpy(), xr.grad.double().numpy(), kr.grad.double().numpy()
+
+    from embeddingnet_amd import layers as L
+    layer = L.Conv2D(cin, cout, k, padding=k // 2, use_bias=False).to(dev)
+
+    def run_gpu(x_, k_, dy_):
+        with torch.no_grad():
+            layer.kernel.copy_(g(k_, dev))
+        layer.kernel.grad = None
+        xt = g(x_, dev).requires_grad_(True)
+        y = layer(xt)
+        y.backward(g(dy_, dev))
+        return [t.detach().cpu().double().numpy() for t in (y, xt.grad, layer.kernel.grad)]
+
+    want = run64(x, kern, dy)
+    mag = run64(np.abs(x), np.abs(kern), np.abs(dy))           # sum |a||b| of every output / gradient element
+    cpu32 = run64(x, kern, dy, torch.float32)
+    for name, got, c32, ref, m in zip(("fwd", "dgrad", "wgrad"), run_gpu(x, kern, dy), cpu32, want, mag):
+        err, err32 = (np.abs(got - ref) / m).max(), (np.abs(c32 - ref) / m).max()
+        assert err <= max(2 * err32, 5e-7), f"{name}: max |err| / sum|a||b| = {err:.2e}, float32 CPU conv {err32:.2e}"
+    xi = rs.randint(-60, 61, x.shape).astype(np.float32)
+    ki = rs.randint(-3, 4, kern.shape).astype(np.float32)
+    di = rs.randint(-2, 3, dy.shape).astype(np.float32)
+    for name, got, ref in zip(("fwd", "dgrad", "wgrad"), run_gpu(xi, ki, di), run64(xi, ki, di)):
+        assert np.array_equal(got, ref), f"{name}: integer operands must come out exact"
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (8, 40, 40, 256, 128), (2, 9, 9, 6, 10)])
 def test_conv2d_residual_epilogue(dev, shape):
     """Conv2D(x, residual=r) == Conv2D(x) + r bit for bit (whole tiles, K-split left-over tiles and the scalar

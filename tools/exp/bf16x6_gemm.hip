@@ -22,21 +22,35 @@ __device__ __forceinline__ uint32_t hi_pair(uint32_t a, uint32_t b) {      // {b
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
 
-// x = p1 + p2 + p3 exactly; four consecutive k values -> 8 bytes per plane
+// x = p1 + p2 + p3 exactly; four consecutive k values -> 8 bytes per plane.  -DTRUNC: truncated pieces (first version:
+// a systematic 2^-22 shrink); default: round-to-nearest pieces (v_cvt_pk_bf16_f32), as the library does.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rne_pair(float a, float b) {
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
   const float x[4] = {v.x, v.y, v.z, v.w};
-  uint32_t a[4], b[4], c[4];
+  uint32_t p[3][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[i] = __float_as_uint(x[i]);
-    const float r1 = x[i] - __uint_as_float(a[i] & 0xffff0000u);
-    b[i] = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(b[i] & 0xffff0000u);
-    c[i] = __float_as_uint(r2);
+  for (int h = 0; h < 2; ++h) {
+    const float a0 = x[2 * h], a1 = x[2 * h + 1];
+#ifdef TRUNC
+    p[0][h] = hi_pair(__float_as_uint(a0), __float_as_uint(a1));
+#else
+    p[0][h] = rne_pair(a0, a1);
+#endif
+    const float b0 = a0 - __uint_as_float(p[0][h] << 16), b1 = a1 - __uint_as_float(p[0][h] & 0xffff0000u);
+#ifdef TRUNC
+    p[1][h] = hi_pair(__float_as_uint(b0), __float_as_uint(b1));
+#else
+    p[1][h] = rne_pair(b0, b1);
+#endif
+    const float c0 = b0 - __uint_as_float(p[1][h] << 16), c1 = b1 - __uint_as_float(p[1][h] & 0xffff0000u);
+    p[2][h] = hi_pair(__float_as_uint(c0), __float_as_uint(c1));
   }
-  p1 = make_uint2(hi_pair(a[0], a[1]), hi_pair(a[2], a[3]));
-  p2 = make_uint2(hi_pair(b[0], b[1]), hi_pair(b[2], b[3]));
-  p3 = make_uint2(hi_pair(c[0], c[1]), hi_pair(c[2], c[3]));
+  p1 = make_uint2(p[0][0], p[0][1]); p2 = make_uint2(p[1][0], p[1][1]); p3 = make_uint2(p[2][0], p[2][1]);
 }
 
 template <int TERMS>
@@ -167,8 +181,8 @@ int main() {
     const int M = s[0], N = s[1], K = s[2];
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
     srand(1);
-    for (auto& v : hA) v = (float)rand() / RAND_MAX * 2.f - 1.f;
-    for (auto& v : hB) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * ((rand() & 7) == 0 ? 37.f : 1.f);
+    for (auto& v : hA) v = (float)rand() / (float)RAND_MAX * 2.f - 1.f;
+    for (auto& v : hB) v = ((float)rand() / (float)RAND_MAX * 2.f - 1.f) * ((rand() & 7) == 0 ? 37.f : 1.f);
     float *dA, *dB, *dC;
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
