@@ -49,15 +49,18 @@ struct FusedLossParams {
   int max_t;
 };
 
-__global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossParams q) {
+constexpr int FUSED_THREADS = 1024;                      // 16 waves: the distance phase is a chain of L2 round trips per wave
+
+__global__ __launch_bounds__(FUSED_THREADS) void fused_triplet_loss_fwd_kernel(FusedLossParams q) {
   __shared__ __attribute__((aligned(16))) float lds[FUSED_LDS_FLOATS];
   __shared__ float norm_a[16];
   __shared__ int s_last;
   const int n = q.n, k = q.k, e = q.e, c = blockIdx.x, lo = c * k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = FUSED_THREADS / 64;
   float* A = lds;                                        // [k][e] the class's rows
   float* D = lds + k * e;                                // [k][n] distances anchor -> row
-  for (int i = tid; i < k * e; i += 256) A[i] = q.emb[(long)lo * e + i];
+  for (int i = tid; i < k * e; i += FUSED_THREADS) A[i] = q.emb[(long)lo * e + i];
   __syncthreads();
   if (wave == 0)
     for (int a = 0; a < k; ++a) {
@@ -68,16 +71,26 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
     }
   __syncthreads();
   // A: distances.  Row r of the block against the K anchors; the row is read once, 16 anchors per sweep at most.
-  for (int r = wave; r < n; r += 4) {
+  // (the first version walked a row 64 columns at a time, one dependent L2 round trip each: 128 of them per wave at
+  // N = 128, E = 256 = 124 us for the launch; eight loads in flight per lane and 16 waves leave 8 round trips)
+  for (int r = wave; r < n; r += NW) {
     const float* y = q.emb + (long)r * e;
     float dot[16], ny = 0.f;
 #pragma unroll
     for (int a = 0; a < 16; ++a) dot[a] = 0.f;
-    for (int cc = lane; cc < e; cc += 64) {
-      const float yv = y[cc];
-      ny = fmaf(yv, yv, ny);
+    for (int c0 = 0; c0 < e; c0 += 512) {                // same per-lane column order as before: results unchanged
+      float yv[8];
 #pragma unroll
-      for (int a = 0; a < 16; ++a) if (a < k) dot[a] = fmaf(A[a * e + cc], yv, dot[a]);
+      for (int j = 0; j < 8; ++j) { const int cc = c0 + lane + 64 * j; yv[j] = cc < e ? y[cc] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cc = c0 + lane + 64 * j;
+        if (cc < e) {
+          ny = fmaf(yv[j], yv[j], ny);
+#pragma unroll
+          for (int a = 0; a < 16; ++a) if (a < k) dot[a] = fmaf(A[a * e + cc], yv[j], dot[a]);
+        }
+      }
     }
     ny = wave_sum(ny);
 #pragma unroll
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
   const int nneg = n - k;
   if (q.mode == EMBNET_MINE_BATCH_HARD) {
     // Hermans batch-hard (build-defined): per anchor the farthest positive and the closest negative; slot = anchor
-    for (int a = wave; a < k; a += 4) {
+    for (int a = wave; a < k; a += NW) {
       const float* row = D + a * n;
       float bp = -INFINITY, bn = INFINITY; int ip = 0x7fffffff, in_ = 0x7fffffff;
       for (int col = lane; col < n; col += 64) {
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
       }
     }
   } else {
-    for (int pr = wave; pr < ppc; pr += 4) {
+    for (int pr = wave; pr < ppc; pr += NW) {
       int ii, jj;
       pair_of(pr, k, ii, jj);
       const float* row = D + ii * n;
@@ -199,12 +212,15 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
   }
   __syncthreads();
   if (!s_last) return;
-  __shared__ float part[4];
-  __shared__ int wave_tot[4];
+  // the reductions keep the 256-thread order of the kernels they stand in for (mine_compact_kernel, mean_first_kernel):
+  // waves 4..15 only take part in the barriers
+  __shared__ float part[NW];
+  __shared__ int wave_tot[NW];
   __shared__ int base_s;
+  const bool low = tid < 256;
   if (q.mode == EMBNET_MINE_BATCH_HARD) {
     float s = 0.f;
-    for (int i = tid; i < n; i += 256) s += __hip_atomic_load(&q.loss[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (low) for (int i = tid; i < n; i += 256) s += __hip_atomic_load(&q.loss[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s = wave_sum(s);
     if (lane == 0) part[wave] = s;
     __syncthreads();
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
   __syncthreads();
   for (int p0 = 0; p0 < npairs; p0 += 256) {             // stable compaction in pair order (mine_compact_kernel)
     const int pair = p0 + tid;
-    const int sel = pair < npairs ? __hip_atomic_load(&q.selected[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    const int sel = (low && pair < npairs) ? __hip_atomic_load(&q.selected[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
     const bool act = sel >= 0;
     const unsigned long long m = __ballot(act);
     if (lane == 0) wave_tot[wave] = __popcll(m);
@@ -248,9 +264,9 @@ __global__ __launch_bounds__(256) void fused_triplet_loss_fwd_kernel(FusedLossPa
     total = 1;
   }
   __syncthreads();
-  for (int t = total + tid; t < q.max_t; t += 256) { q.loss[t] = 0.f; q.active[t] = 0.f; }
+  for (int t = total + tid; t < q.max_t; t += FUSED_THREADS) { q.loss[t] = 0.f; q.active[t] = 0.f; }
   float s = 0.f;                                         // mean over the live triplets, mean_first_kernel's order
-  for (int t = tid; t < total; t += 256) s += q.loss[t];
+  if (low) for (int t = tid; t < total; t += 256) s += q.loss[t];
   s = wave_sum(s);
   if (lane == 0) part[wave] = s;
   __syncthreads();
@@ -289,6 +305,6 @@ extern "C" int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int
                     (int*)workspace, (float*)workspace + 4,
                     mode == EMBNET_MINE_BATCH_HARD ? n : embnet_mine_max_triplets(p, k)};
   EMBNET_TRACE("embnet::fused_triplet_loss_fwd_kernel", TRACE_BYTES, 4.0 * n * e * (p + 1.0), stream);
-  fused_triplet_loss_fwd_kernel<<<p, 256, 0, (hipStream_t)stream>>>(q);
+  fused_triplet_loss_fwd_kernel<<<p, FUSED_THREADS, 0, (hipStream_t)stream>>>(q);
   return check_launch("fused_triplet_loss_fwd");
 }

@@ -260,6 +260,7 @@ using namespace embnet;
 extern "C" int embnet_triplet_hinge_fwd(const float* y_pred, int t, int e, float margin, float* loss, void* stream) {
   EMBNET_CHECK_ARG(y_pred && loss, "triplet_hinge_fwd: null pointer");
   EMBNET_CHECK_ARG(t > 0 && e > 0, "triplet_hinge_fwd: t=%d e=%d", t, e);
+  EMBNET_TRACE("embnet::triplet_hinge_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
   triplet_hinge_fwd_kernel<<<cdiv(t, 4), 256, 0, S(stream)>>>(y_pred, t, e, margin, loss);
   return check_launch("triplet_hinge_fwd");
 }
@@ -268,6 +269,7 @@ extern "C" int embnet_triplet_hinge_bwd(const float* y_pred, const float* dloss,
                                         float* dy, void* stream) {
   EMBNET_CHECK_ARG(y_pred && dloss && dy, "triplet_hinge_bwd: null pointer");
   EMBNET_CHECK_ARG(t > 0 && e > 0, "triplet_hinge_bwd: t=%d e=%d", t, e);
+  EMBNET_TRACE("embnet::triplet_hinge_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   triplet_hinge_bwd_kernel<<<cdiv(t, 4), 256, 0, S(stream)>>>(y_pred, dloss, t, e, margin, dy);
   return check_launch("triplet_hinge_bwd");
 }
@@ -277,8 +279,11 @@ extern "C" int embnet_triplet_gather_fwd(const float* emb, int n, int e, const i
                                          float* active, float* mean_loss, void* stream) {
   EMBNET_CHECK_ARG(emb && triplets && count && loss && active && mean_loss, "triplet_gather_fwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && e > 0 && max_t > 0, "triplet_gather_fwd: n=%d e=%d max_t=%d", n, e, max_t);
-  triplet_gather_fwd_kernel<<<cdiv(max_t, 4), 256, 0, S(stream)>>>(emb, e, triplets, count, max_t, margin, loss,
-                                                                   active);
+  {
+    EMBNET_TRACE("embnet::triplet_gather_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
+    triplet_gather_fwd_kernel<<<cdiv(max_t, 4), 256, 0, S(stream)>>>(emb, e, triplets, count, max_t, margin, loss, active);
+  }
+  EMBNET_TRACE("embnet::mean_first_kernel", TRACE_BYTES, 0.0, S(stream));
   mean_first_kernel<<<1, 256, 0, S(stream)>>>(loss, count, max_t, mean_loss);
   return check_launch("triplet_gather_fwd");
 }
@@ -289,6 +294,7 @@ extern "C" int embnet_triplet_gather_bwd(const float* emb, int n, int e, const i
   EMBNET_CHECK_ARG(emb && triplets && count && active && demb, "triplet_gather_bwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && e > 0 && max_t > 0, "triplet_gather_bwd: n=%d e=%d max_t=%d", n, e, max_t);
   EMBNET_CHECK_ARG(e <= 4096, "triplet_gather_bwd: encodings_len %d > 4096 unsupported", e);
+  EMBNET_TRACE("embnet::triplet_gather_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   triplet_gather_bwd_kernel<<<n, 256, 0, S(stream)>>>(emb, n, e, triplets, count, max_t, active, upstream, demb);
   return check_launch("triplet_gather_bwd");
 }
@@ -296,6 +302,7 @@ extern "C" int embnet_triplet_gather_bwd(const float* emb, int n, int e, const i
 extern "C" int embnet_contrastive_fwd(const float* y_true, const float* dist, int b, float* loss, void* stream) {
   EMBNET_CHECK_ARG(y_true && dist && loss, "contrastive_fwd: null pointer");
   EMBNET_CHECK_ARG(b > 0, "contrastive_fwd: b=%d", b);
+  EMBNET_TRACE("embnet::contrastive_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
   contrastive_fwd_kernel<<<1, 256, 0, S(stream)>>>(y_true, dist, b, loss);
   return check_launch("contrastive_fwd");
 }
@@ -304,6 +311,7 @@ extern "C" int embnet_contrastive_bwd(const float* y_true, const float* dist, in
                                       float* ddist, void* stream) {
   EMBNET_CHECK_ARG(y_true && dist && ddist, "contrastive_bwd: null pointer");
   EMBNET_CHECK_ARG(b > 0, "contrastive_bwd: b=%d", b);
+  EMBNET_TRACE("embnet::contrastive_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   contrastive_bwd_kernel<<<cdiv(b, 256), 256, 0, S(stream)>>>(y_true, dist, b, upstream, ddist);
   return check_launch("contrastive_bwd");
 }
@@ -311,6 +319,7 @@ extern "C" int embnet_contrastive_bwd(const float* y_true, const float* dist, in
 extern "C" int embnet_accuracy(const float* y_true, const float* dist, int b, float* acc, void* stream) {
   EMBNET_CHECK_ARG(y_true && dist && acc, "accuracy: null pointer");
   EMBNET_CHECK_ARG(b > 0, "accuracy: b=%d", b);
+  EMBNET_TRACE("embnet::accuracy_kernel", TRACE_BYTES, 0.0, S(stream));
   accuracy_kernel<<<1, 256, 0, S(stream)>>>(y_true, dist, b, acc);
   return check_launch("accuracy");
 }
@@ -318,6 +327,7 @@ extern "C" int embnet_accuracy(const float* y_true, const float* dist, int b, fl
 extern "C" int embnet_l2norm_fwd(const float* x, int n, int e, float* y, float* rnorm, void* stream) {
   EMBNET_CHECK_ARG(x && y && rnorm, "l2norm_fwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && e > 0, "l2norm_fwd: n=%d e=%d", n, e);
+  EMBNET_TRACE("embnet::l2norm_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
   l2norm_fwd_kernel<<<cdiv(n, 4), 256, 0, S(stream)>>>(x, n, e, y, rnorm);
   return check_launch("l2norm_fwd");
 }
@@ -326,6 +336,7 @@ extern "C" int embnet_l2norm_bwd(const float* y, const float* rnorm, const float
                                  void* stream) {
   EMBNET_CHECK_ARG(y && rnorm && dy && dx, "l2norm_bwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && e > 0, "l2norm_bwd: n=%d e=%d", n, e);
+  EMBNET_TRACE("embnet::l2norm_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   l2norm_bwd_kernel<<<cdiv(n, 4), 256, 0, S(stream)>>>(y, rnorm, dy, n, e, dx);
   return check_launch("l2norm_bwd");
 }
@@ -333,6 +344,7 @@ extern "C" int embnet_l2norm_bwd(const float* y, const float* rnorm, const float
 extern "C" int embnet_pair_distance_fwd(const float* e1, const float* e2, int b, int e, float* dist, void* stream) {
   EMBNET_CHECK_ARG(e1 && e2 && dist, "pair_distance_fwd: null pointer");
   EMBNET_CHECK_ARG(b > 0 && e > 0, "pair_distance_fwd: b=%d e=%d", b, e);
+  EMBNET_TRACE("embnet::pair_distance_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
   pair_distance_fwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(e1, e2, b, e, dist);
   return check_launch("pair_distance_fwd");
 }
@@ -341,6 +353,7 @@ extern "C" int embnet_pair_distance_bwd(const float* e1, const float* e2, const 
                                         int b, int e, float* de1, float* de2, void* stream) {
   EMBNET_CHECK_ARG(e1 && e2 && dist && ddist && de1 && de2, "pair_distance_bwd: null pointer");
   EMBNET_CHECK_ARG(b > 0 && e > 0, "pair_distance_bwd: b=%d e=%d", b, e);
+  EMBNET_TRACE("embnet::pair_distance_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   pair_distance_bwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(e1, e2, dist, ddist, b, e, de1, de2);
   return check_launch("pair_distance_bwd");
 }
@@ -403,8 +416,15 @@ extern "C" int embnet_softmax_xent_fwd(const float* logits, const float* targets
   EMBNET_CHECK_ARG(logits && targets && prob && row_loss && row_correct && mean_loss && accuracy,
                    "softmax_xent_fwd: null pointer");
   EMBNET_CHECK_ARG(b > 0 && c > 0, "softmax_xent_fwd: b=%d c=%d", b, c);
-  softmax_xent_fwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(logits, targets, b, c, prob, row_loss, row_correct);
-  mean_first_kernel<<<1, 256, 0, S(stream)>>>(row_loss, nullptr, b, mean_loss);
+  {
+    EMBNET_TRACE("embnet::softmax_xent_fwd_kernel", TRACE_BYTES, 0.0, S(stream));
+    softmax_xent_fwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(logits, targets, b, c, prob, row_loss, row_correct);
+  }
+  {
+    EMBNET_TRACE("embnet::mean_first_kernel", TRACE_BYTES, 0.0, S(stream));
+    mean_first_kernel<<<1, 256, 0, S(stream)>>>(row_loss, nullptr, b, mean_loss);
+  }
+  EMBNET_TRACE("embnet::mean_first_kernel", TRACE_BYTES, 0.0, S(stream));
   mean_first_kernel<<<1, 256, 0, S(stream)>>>(row_correct, nullptr, b, accuracy);
   return check_launch("softmax_xent_fwd");
 }
@@ -413,6 +433,7 @@ extern "C" int embnet_softmax_xent_bwd(const float* prob, const float* targets, 
                                        float* dlogits, void* stream) {
   EMBNET_CHECK_ARG(prob && targets && dlogits, "softmax_xent_bwd: null pointer");
   EMBNET_CHECK_ARG(b > 0 && c > 0, "softmax_xent_bwd: b=%d c=%d", b, c);
+  EMBNET_TRACE("embnet::softmax_xent_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
   softmax_xent_bwd_kernel<<<cdiv(b, 4), 256, 0, S(stream)>>>(prob, targets, b, c, upstream, dlogits);
   return check_launch("softmax_xent_bwd");
 }

@@ -187,8 +187,11 @@ extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margi
     hipError_t e = hipMemsetAsync(cand_mask, 0, (size_t)npairs * mask_words * 4, s);
     if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "mine_triplets: memset: %s", hipGetErrorString(e));
   }
-  mine_select_kernel<<<cdiv(npairs, 4), 256, 0, s>>>(dist, n, p, k, margin, mode, seed, selected, cand_mask,
-                                                     mask_words);
+  {
+    EMBNET_TRACE("embnet::mine_select_kernel", TRACE_BYTES, 0.0, s);
+    mine_select_kernel<<<cdiv(npairs, 4), 256, 0, s>>>(dist, n, p, k, margin, mode, seed, selected, cand_mask, mask_words);
+  }
+  EMBNET_TRACE("embnet::mine_compact_kernel", TRACE_BYTES, 0.0, s);
   mine_compact_kernel<<<1, 1024, 0, s>>>(selected, n, p, k, triplets, count);
   return check_launch("mine_triplets");
 }
@@ -198,6 +201,7 @@ extern "C" int embnet_batch_hard(const float* dist, int p, int k, int32_t* tripl
   EMBNET_CHECK_ARG(dist && triplets, "batch_hard: null pointer");
   EMBNET_CHECK_ARG(p >= 2 && k >= 2, "batch_hard: need k_classes>=2 and k_samples>=2 (got %d,%d)", p, k);
   const int n = p * k;
+  EMBNET_TRACE("embnet::batch_hard_kernel", TRACE_BYTES, 0.0, (hipStream_t)stream);
   batch_hard_kernel<<<cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(dist, n, k, triplets, count);
   return check_launch("batch_hard");
 }
