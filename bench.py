@@ -14,8 +14,10 @@ forward -> NxN distance matrix -> mine-and-select -> hinge -> backward -> (RCCL 
 Rank 0 prints ONE JSON line; details go to stderr.
 
 roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
-every 4th timed step; the kernel with the largest total time is reported against the roofline that bounds it — MFMA
-fp32 (157.3 TFLOP/s) for the GEMM-engine kernels with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
+every 4th timed step; the kernel with the largest total time is reported against the roofline that bounds it — for the
+convolution kernels the bf16 MFMA peak (16 x 157.3 TFLOP/s) with the bf16 FLOP they execute (each fp32 product = 6 bf16
+MFMA terms of an exact operand split: 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
+fp32 (157.3 TFLOP/s) for the distance / dense GEMMs with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
 copy rate also given) for the streaming kernels with their algorithmic bytes.
 """
 import argparse
@@ -280,14 +282,14 @@ def main():
         metric = f"images/sec training ({args.backbone}, {args.image}², Siamese contrastive) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), SiameseNet 'l2' head + contrastive_loss, "
                     f"{args.pairs} pairs per GPU (first half same class) = {n_local} images, E={args.encodings_len}, "
-                    f"{args.optimizer}, fp32")
+                    f"{args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
     else:
         label = {"resnet18": "ResNet18", "resnet50": "ResNet50", "efficientnet-b0": "EfficientNet-B0"}.get(args.backbone, args.backbone)
         mining = "batch-hard" if (args.mining in ("hardest", "batch_hard")) else args.mining
         metric = f"images/sec training ({label}, {args.image}², triplet {mining}) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), 107-class P x K sampling, local batch "
                     f"{args.k_classes}x{args.k_samples}={n_local}, E={args.encodings_len}, margin {args.margin}, mining "
-                    f"'{args.mining}' per local batch, {args.optimizer}, fp32")
+                    f"'{args.mining}' per local batch, {args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
     out = {
         "metric": metric, "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
