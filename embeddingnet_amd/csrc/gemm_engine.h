@@ -514,23 +514,28 @@ __device__ __forceinline__ Split4 split4(const float4 v) {
   return s;
 }
 
-// k-contiguous operand: three planes [ROWS][32 k] of bf16, 80-byte row pitch (64 + 16: the 16-byte fragment reads of
-// a 32-row block fall on 16 distinct 16-byte bank slots).  Lane (i = lane&31, h = lane>>5) of k16-step st reads
-// k = 16 st + 8 h .. +7 of row i with one ds_read_b128 per plane — the A/B operand map of v_mfma_f32_32x32x16_bf16.
+// k-contiguous operand: three planes [ROWS][32 k] of bf16, 64-byte rows, the four 16-byte chunks of a row XOR-swizzled
+// with (row >> 2) & 3.  Lane (i = lane&31, h = lane>>5) of k16-step st reads k = 16 st + 8 h .. +7 of row i with one
+// ds_read_b128 per plane — the A/B operand map of v_mfma_f32_32x32x16_bf16; the swizzle puts the 16 lanes of each
+// ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) on 16 distinct 16-byte slots of the 256-byte
+// bank window, and a 16-lane ds_write_b64 group covers two whole rows = 128 contiguous bytes.  (First version: 80-byte
+// pitch, no swizzle — reads conflict-free, but the row pairs of a store overlapped mod 128 B: SQ_LDS_BANK_CONFLICT =
+// 20-33 % of SQ_LDS_IDX_ACTIVE in the forward / data-gradient kernels, 0-1 % in the k-major weight-gradient kernels.)
 template <int ROWS>
 struct TileKC3 {
   using Map = TileKC<ROWS>;
-  static constexpr int PASSES = Map::PASSES, PITCH = 80, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
+  static constexpr int PASSES = Map::PASSES, PITCH = 64, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
+  __device__ static __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> 2) & 3)) << 4); }
   __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      unsigned char* d = s + Map::row_of(tid, p) * PITCH + Map::k_of(tid) * 2;
+      unsigned char* d = s + off(Map::row_of(tid, p), (tid & 7) >> 1) + (tid & 1) * 8;      // k_of(tid) = 4 * (tid & 7)
 #pragma unroll
       for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
     }
   }
   __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
-    const unsigned char* a = s + (r0 + (lane & 31)) * PITCH + (2 * st + (lane >> 5)) * 16;
+    const unsigned char* a = s + off(r0 + (lane & 31), 2 * st + (lane >> 5));
 #pragma unroll
     for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const bf16x8*>(a + q * PLANE);
   }

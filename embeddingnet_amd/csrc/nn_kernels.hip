@@ -114,10 +114,23 @@ __device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float*
       for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, a, b); f(r + rl, q, a, b); f(r + 2 * rl, q, a, b); f(r + 3 * rl, q, a, b); }
       for (; r < r1; r += rl) f(r, q, a, b);
     }
-    sh4[0][threadIdx.x] = a; sh4[1][threadIdx.x] = b;
+    // row-lanes of one wave first (xor butterfly over the lane bits above the column bits), then the <= 4 per-wave
+    // (or per-row-lane, when a wave is one row-lane) sums through LDS: 2 LDS round trips instead of rl - 1 serial ones
+    int groups = g.rl;                                   // partial sums per column left for the LDS step
+    if (g.cl < 64) {
+      for (int o = g.cl; o < 64; o <<= 1) {
+        a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+      }
+      groups = 4;
+      if ((threadIdx.x & 63) < g.cl) { sh4[0][(threadIdx.x >> 6) * g.cl + ci] = a; sh4[1][(threadIdx.x >> 6) * g.cl + ci] = b; }
+    } else {
+      sh4[0][threadIdx.x] = a; sh4[1][threadIdx.x] = b;
+    }
     __syncthreads();
     if (ri == 0 && q < c4) {
-      for (int k = 1; k < g.rl; ++k) {
+      a = sh4[0][ci]; b = sh4[1][ci];
+      for (int k = 1; k < groups; ++k) {
         const float4 oa = sh4[0][k * g.cl + ci], ob = sh4[1][k * g.cl + ci];
         a.x += oa.x; a.y += oa.y; a.z += oa.z; a.w += oa.w;
         b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
 __global__ __launch_bounds__(256) void affine_act_maxpool_fwd4_kernel(
     const float* __restrict__ x, int n, int h, int w, int c4, const float* __restrict__ scale,
     const float* __restrict__ shift, int act, int k, int stride, int pad, int oh, int ow, float* __restrict__ y,
-    uint8_t* __restrict__ argmax) {
+    uint8_t* __restrict__ argmax, float* __restrict__ xwin) {
   const long total = (long)n * oh * ow * c4;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -428,21 +441,24 @@ __global__ __launch_bounds__(256) void affine_act_maxpool_fwd4_kernel(
   const int b = (int)(t / oh);
   const float4 sc = reinterpret_cast<const float4*>(scale)[col], sh = reinterpret_cast<const float4*>(shift)[col];
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  float bx[4] = {0.f, 0.f, 0.f, 0.f};                    // the BN input at the winning tap (backward's reduction reads it)
   int bi[4] = {255, 255, 255, 255};
   for (int dy = 0; dy < k; ++dy)
     for (int dx = 0; dx < k; ++dx) {
       const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
       const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
-      float vv[4] = {0.f, 0.f, 0.f, 0.f};
+      float vv[4] = {0.f, 0.f, 0.f, 0.f}, xx[4] = {0.f, 0.f, 0.f, 0.f};
       if (in) {
         const float4 v = reinterpret_cast<const float4*>(x)[(((long)b * h + ih) * w + iw) * c4 + col];
+        xx[0] = v.x; xx[1] = v.y; xx[2] = v.z; xx[3] = v.w;
         vv[0] = act_apply(act, fmaf(v.x, sc.x, sh.x)); vv[1] = act_apply(act, fmaf(v.y, sc.y, sh.y));
         vv[2] = act_apply(act, fmaf(v.z, sc.z, sh.z)); vv[3] = act_apply(act, fmaf(v.w, sc.w, sh.w));
       }
       const int tap = in ? dy * k + dx : 255;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; }
+      for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; bx[j] = xx[j]; }
     }
+  if (xwin) reinterpret_cast<float4*>(xwin)[i] = make_float4(bx[0], bx[1], bx[2], bx[3]);
   reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
   reinterpret_cast<uint32_t*>(argmax)[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) |
                                            ((uint32_t)bi[3] << 24);
@@ -453,9 +469,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce4_kernel(
     const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ x, long mp, int h, int w,
     int c4, int k, int stride, int pad, int oh, int ow, ColGeom g, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ partial) {
+    const float* __restrict__ xwin, float* __restrict__ partial) {
   col_reduce2_v4(mp, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
     const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[r * c4 + q];
+    float4 xw4 = make_float4(0.f, 0.f, 0.f, 0.f);      // forward kept the winners' inputs: a streaming read, no gather
+    if (xwin) xw4 = reinterpret_cast<const float4*>(xwin)[r * c4 + q];
+    const float xwv[4] = {xw4.x, xw4.y, xw4.z, xw4.w};
     const float4 d = reinterpret_cast<const float4*>(dy)[r * c4 + q];
     const int x_o = (int)(r % ow); const long t = r / ow;
     const int y_o = (int)(t % oh), bb = (int)(t / oh);
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce4_kernel(
       const uint32_t tp = on ? tap : 0u;
       const int ih = min(max(y_o * stride - pad + (int)(tp / (uint32_t)k), 0), h - 1);
       const int iw = min(max(x_o * stride - pad + (int)(tp % (uint32_t)k), 0), w - 1);
-      const float xv = x[((((long)bb * h + ih) * w + iw) * c4 + q) * 4 + j];
+      const float xv = xwin ? xwv[j] : x[((((long)bb * h + ih) * w + iw) * c4 + q) * 4 + j];
       const float dz = on ? act_grad(act, fmaf(xv, scv[j], shv[j]), dd[j]) : 0.f;
       av[j] = dz; bv[j] = dz * ((xv - muv[j]) * rsv[j]);
     }
@@ -783,7 +802,7 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
 
 extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,
                                          int act, int k, int stride, int pad, int oh, int ow, float* y, uint8_t* argmax,
-                                         void* stream) {
+                                         float* xwin, void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && y && argmax, "bn_act_maxpool_fwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k * k < 255 && stride > 0 && pad >= 0 && oh > 0 && ow > 0,
                    "bn_act_maxpool_fwd: bad geometry");
@@ -791,8 +810,8 @@ extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, in
   EMBNET_CHECK_ARG((oh - 1) * stride + k <= h + 2 * pad && (ow - 1) * stride + k <= w + 2 * pad,
                    "bn_act_maxpool_fwd: window leaves the padded image");
   const long total = (long)n * oh * ow * (c / 4);
-  { EMBNET_TRACE("embnet::affine_act_maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 20.0 * total, stream); affine_act_maxpool_fwd4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, scale, shift, act, k, stride,
-                                                                          pad, oh, ow, y, argmax); }
+  { EMBNET_TRACE("embnet::affine_act_maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + (xwin ? 36.0 : 20.0) * total, stream); affine_act_maxpool_fwd4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, scale, shift, act, k, stride,
+                                                                          pad, oh, ow, y, argmax, xwin); }
   return check_launch("bn_act_maxpool_fwd");
 }
 
@@ -803,8 +822,8 @@ extern "C" size_t embnet_bn_act_maxpool_bwd_workspace_bytes(int n, int oh, int o
 extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
                                          int k, int stride, int pad, int oh, int ow, const float* save_mean,
                                          const float* save_rstd, const float* scale, const float* shift, int act,
-                                         int training, float* dx, float* dgamma, float* dbeta, void* workspace,
-                                         size_t workspace_bytes, void* stream) {
+                                         int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(dy && argmax && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_act_maxpool_bwd: null pointer");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_act_maxpool_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "bn_act_maxpool_bwd: bad geometry");
@@ -815,7 +834,7 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
   if (save_mean && save_rstd) {
     const ColGeom g4 = col_geom(mp, c / 4);
     { EMBNET_TRACE("embnet::pool_bn_bwd_reduce4_kernel", TRACE_BYTES, 9.0 * mp * c, stream); pool_bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, x, mp, h, w, c / 4, k, stride, pad, oh, ow, g4,
-                                                                 save_mean, save_rstd, scale, shift, act, (float*)workspace); }
+                                                                 save_mean, save_rstd, scale, shift, act, xwin, (float*)workspace); }
     bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));

@@ -684,16 +684,22 @@ class _BNActMaxPoolFn(torch.autograd.Function):
                                           int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
         arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        # training: keep the BN input at every window's winner, so backward's dgamma/dbeta sums stream instead of gathering
+        xwin = torch.empty_like(y) if training else None
         check(lib.embnet_bn_act_maxpool_fwd(ptr(x), n, h, w, c, stats[2].data_ptr(), stats[3].data_ptr(), int(act), k,
-                                            stride, pad, oh, ow, ptr(y), ptr(arg), stream()))
+                                            stride, pad, oh, ow, ptr(y), ptr(arg), ptr(xwin) if training else None, stream()))
         ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow, int(act), training, gamma is not None)
-        ctx.save_for_backward(x, stats, arg)
+        if training:
+            ctx.save_for_backward(x, stats, arg, xwin)
+        else:
+            ctx.save_for_backward(x, stats, arg)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, stats, arg = ctx.saved_tensors
         n, h, w, c, k, stride, pad, oh, ow, act, training, has_gamma = ctx.cfg
+        x, stats, arg = ctx.saved_tensors[:3]
+        xwin = ctx.saved_tensors[3] if training else None
         lib = _lib.lib()
         dy = _c(dy)
         dx = torch.empty_like(x)
@@ -702,7 +708,8 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         mean = stats[0].data_ptr() if training else None
         rstd = stats[1].data_ptr() if training else None
         check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
-                                            stats[2].data_ptr(), stats[3].data_ptr(), act, int(training), ptr(dx),
+                                            stats[2].data_ptr(), stats[3].data_ptr(), act, int(training),
+                                            ptr(xwin) if training else None, ptr(dx),
                                             dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None

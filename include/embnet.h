@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 4
+#define EMBNET_ABI_VERSION 5
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -235,14 +235,17 @@ int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int
  * bn0 -> relu -> pad -> pool, reference backbones.py:99-104 via image-classifiers).  scale/shift come from
  * embnet_bn_train_fwd / embnet_bn_infer_fwd called with y = NULL.  Backward takes the POOLED gradient and
  * returns dx (w.r.t. the BN input), dgamma, dbeta; the activation tensor and its gradient never exist.
- * c % 4 == 0.  Same results as bn -> maxpool (sums in a different fp32 order). */
+ * c % 4 == 0.  Same results as bn -> maxpool (sums in a different fp32 order).
+ * xwin (optional, [n,oh,ow,c]): forward also stores the BN input at each window's winning tap; handing it to backward
+ * turns the dgamma/dbeta reduction's gather through the arg-max into a streaming read (188 -> ~60 us on the ResNet stem). */
 int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift, int act,
-                              int k, int stride, int pad, int oh, int ow, float* y, uint8_t* argmax, void* stream);
+                              int k, int stride, int pad, int oh, int ow, float* y, uint8_t* argmax, float* xwin,
+                              void* stream);
 size_t embnet_bn_act_maxpool_bwd_workspace_bytes(int n, int oh, int ow, int c);
 int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c, int k,
                               int stride, int pad, int oh, int ow, const float* save_mean, const float* save_rstd,
-                              const float* scale, const float* shift, int act, int training, float* dx, float* dgamma,
-                              float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                              const float* scale, const float* shift, int act, int training, const float* xwin, float* dx,
+                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);
