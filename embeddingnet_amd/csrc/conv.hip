@@ -316,8 +316,11 @@ constexpr int SMEM_FLOATS = CONV_MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? CONV_MAIN
 // Workgroups per CU the LDS image allows (one wave of each on every SIMD) -> the register budget hipcc must keep
 // for the 16-byte-load kernels (the scalar-load variants for odd channel counts would spill)
 // (__launch_bounds__'s second argument is waves per SIMD): 128x128 and 192x64 two, 128x64 three, smaller tiles four.
+#ifndef EMBNET_OCC_12864
+#define EMBNET_OCC_12864 3
+#endif
 template <class G>
-constexpr int CONV_OCC = !EMBNET_CONV_SPLIT ? 1 : (G::BM * G::BN >= 192 * 64 ? 2 : (G::BM * G::BN >= 128 * 64 ? 3 : 4));
+constexpr int CONV_OCC = !EMBNET_CONV_SPLIT ? 1 : (G::BM * G::BN >= 192 * 64 ? 2 : (G::BM * G::BN >= 128 * 64 ? EMBNET_OCC_12864 : 4));
 
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end, float* smem,

@@ -544,16 +544,27 @@ struct TileKC3 {
 // row-contiguous (k-major) operand: three planes [32 k][ROWS] of bf16; the fragment (8 consecutive k of one row per
 // lane) comes from two ds_read_b64_tr_b16 per plane — each 16-lane group reads a 4 k x 16 rows block and receives it
 // transposed (lane 4q+p supplies the address of k-row q, rows 4p..4p+3; lane i receives row i, k-row q in element q).
-// Pitch: 2*ROWS bytes, +64 unless that is already 64 mod 128, so the four k-rows of a block sit on different banks.
+// A 32-lane half reads 64 contiguous bytes of four consecutive k-rows, which must fall on different banks (256-byte
+// window): ROWS = 64 / 128 (128- / 256-byte rows) swizzle the 64-byte slots of a k-row with its k (see off), other sizes
+// pad the pitch to 64 mod 128 bytes.  (Unpadded: 12 / 24 KB per operand instead of 18 / 30.)
 template <int ROWS>
 struct TileKM3 {
   using Map = TileKM<ROWS>;
   static constexpr int PASSES = Map::PASSES;
-  static constexpr int PITCH = 2 * ROWS + ((2 * ROWS) % 128 == 64 ? 0 : 64), PLANE = BK * PITCH, BYTES = 3 * PLANE;
+  static constexpr bool SWZ = ROWS == 64 || ROWS == 128;
+  static constexpr int PITCH = SWZ ? 2 * ROWS : 2 * ROWS + ((2 * ROWS) % 128 == 64 ? 0 : 64);
+  static constexpr int PLANE = BK * PITCH, BYTES = 3 * PLANE;
+  // byte offset of row `row` (a multiple of 4) of k-row k.  128-byte rows: k-rows 0..3 -> slots (0|1) of the windows
+  // [0,128) and [128,256): flip the 64-byte half with bit 1 of k; 256-byte rows: XOR the 64-byte slot with k & 3.
+  __device__ static __forceinline__ int off(int k, int row) {
+    const int b = row * 2;
+    if (!SWZ) return k * PITCH + b;
+    return k * PITCH + (ROWS == 64 ? (b ^ (((k >> 1) & 1) << 6)) : (b ^ ((k & 3) << 6)));
+  }
   __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      unsigned char* d = s + Map::k_of(tid, p) * PITCH + Map::row_of(tid, p) * 2;
+      unsigned char* d = s + off(Map::k_of(tid, p), Map::row_of(tid, p));
 #pragma unroll
       for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
     }
@@ -561,12 +572,13 @@ struct TileKM3 {
   __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
     const int k = 16 * st + 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int row = r0 + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
-    const unsigned char* a = s + k * PITCH + row * 2;
+    const unsigned char* a = s + off(k, row);
+    const unsigned char* a4 = s + off(k + 4, row);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE + 4 * PITCH));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a4 + q * PLANE));
       const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       v[q] = __builtin_bit_cast(bf16x8, w);
     }
