@@ -259,6 +259,7 @@ def main():
         if trace:          # ~250 event pairs per traced step: kept to every 4th step so they cost < 2 % of the timed region
             _lib.trace_enable(i % 4 == 0)
         loss = step()
+    host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # time to ENQUEUE a step (the host runs ahead of the GPU)
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.trace_enable(False)
@@ -271,6 +272,7 @@ def main():
     if rank != 0:
         return
 
+    log(f"  host enqueue {host_ms:.2f} ms/step, step {ms_per_step:.2f} ms ({'GPU' if host_ms < 0.9 * ms_per_step else 'host'}-bound)")
     roofline = None
     if trace:
         roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + 3) // 4, ms_per_step, args.config,
@@ -295,7 +297,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "global_batch": n_local * world,
-                   "parallelism": f"dp{world}", "final_loss": float(loss.item())},
+                   "parallelism": f"dp{world}", "final_loss": float(loss.item()),
+                   "host_enqueue_ms_per_step": round(host_ms, 3)},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

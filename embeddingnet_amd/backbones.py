@@ -173,8 +173,9 @@ class ResNet(nn.Module):
         self.out_channels = cin
 
     def forward(self, x):
-        x = L.bn_act_maxpool(L.input_bn_conv(x, self.bn_data, self.conv0, emit_stats=self.training and EPILOGUE_STATS), self.bn0,
-                             self.pooling0)
+        # conv0's output feeds bn0 only: in training mode (batch statistics) bn0's data gradient sums to zero per channel
+        x = L.bn_act_maxpool(L.input_bn_conv(x, self.bn_data, self.conv0, emit_stats=self.training and EPILOGUE_STATS,
+                                             zero_sum_dy=self.bn0.training), self.bn0, self.pooling0)
         for nm in self._units:
             x = getattr(self, nm)(x)
         return self.bn1(x)

@@ -664,6 +664,82 @@ __global__ __launch_bounds__(256) void tap_contract_kernel(const float* __restri
   if (threadIdx.x == 0) out[ch] = part[0] + part[1] + part[2] + part[3];
 }
 
+// Per-tap sums of a convolution's output gradient when that gradient sums to ZERO over all pixels of every channel
+// (it is the data gradient of a training-mode BatchNormalization: sum dx = 0 identically):
+//   taps[r][s][k] = sum over pixels whose tap (r,s) lies INSIDE the image = - sum over pixels whose tap lies in the padding.
+// Those pixels are border strips: with rows_out(r) = output rows whose tap row r is in the padding and cols_out(s)
+// likewise, the sum is  sum_{y in rows_out(r)} R[y] + sum_{x in cols_out(s)} C[x] - sum_{y,x in both} Q[y][x]  with the
+// line sums R[y] = sum_{n,x} dy, C[x] = sum_{n,y} dy, Q[y][x] = sum_n dy.  For the 7x7/2 ResNet stem that is 4 rows,
+// 3 columns and 12 corners of a 112x112 map: 6 % of the tensor is read.  "Lines" are numbered rows, then columns,
+// then corners (row-major); border rows are [0,yt) and [yb,oh), border columns [0,xl) and [xr,ow).
+struct TapBorder { int oh, ow, k, r, s, stride, pad_t, pad_l, h, w, yt, yb, xl, xr; };
+__device__ __forceinline__ int tb_nrow(const TapBorder& g) { return g.yt + (g.oh - g.yb); }
+__device__ __forceinline__ int tb_ncol(const TapBorder& g) { return g.xl + (g.ow - g.xr); }
+__device__ __forceinline__ int tb_row(const TapBorder& g, int i) { return i < g.yt ? i : g.yb + (i - g.yt); }
+__device__ __forceinline__ int tb_col(const TapBorder& g, int i) { return i < g.xl ? i : g.xr + (i - g.xl); }
+
+// partial[line][image][k]: one workgroup per (line, image); 64 channels x 4 pixel lanes
+__global__ __launch_bounds__(256) void tap_border_lines_kernel(const float* __restrict__ dy, TapBorder g,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int line = blockIdx.x, n = blockIdx.y, nimg = gridDim.y;
+  const int nrow = tb_nrow(g), ncol = tb_ncol(g);
+  int y0, x0, count, step;                                 // pixels (y0, x0) + j * step, j < count (step in pixels)
+  if (line < nrow) { y0 = tb_row(g, line); x0 = 0; count = g.ow; step = 1; }
+  else if (line < nrow + ncol) { y0 = 0; x0 = tb_col(g, line - nrow); count = g.oh; step = g.ow; }
+  else { const int q = line - nrow - ncol; y0 = tb_row(g, q / ncol); x0 = tb_col(g, q % ncol); count = 1; step = 1; }
+  const float* base = dy + (((long)n * g.oh + y0) * g.ow + x0) * g.k;
+  const int lk = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < g.k; k0 += 64) {
+    float acc = 0.f;
+    if (k0 + lk < g.k)
+      for (int j = pl; j < count; j += 4) acc += base[(long)j * step * g.k + k0 + lk];
+    red[pl][lk] = acc;
+    __syncthreads();
+    if (pl == 0 && k0 + lk < g.k)
+      partial[((long)line * nimg + n) * g.k + k0 + lk] = (red[0][lk] + red[1][lk]) + (red[2][lk] + red[3][lk]);
+    __syncthreads();
+  }
+}
+
+// L[line][k] = sum over images, in double, fixed order
+__global__ __launch_bounds__(256) void tap_border_reduce_kernel(const float* __restrict__ partial, int nimg, int k,
+                                                                float* __restrict__ lines) {
+  __shared__ double red[4][64];
+  const int line = blockIdx.x, lk = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < k; k0 += 64) {
+    double acc = 0.0;
+    if (k0 + lk < k)
+      for (int n = pl; n < nimg; n += 4) acc += (double)partial[((long)line * nimg + n) * k + k0 + lk];
+    red[pl][lk] = acc;
+    __syncthreads();
+    if (pl == 0 && k0 + lk < k) lines[(long)line * k + k0 + lk] = (float)((red[0][lk] + red[1][lk]) + (red[2][lk] + red[3][lk]));
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void tap_border_combine_kernel(const float* __restrict__ lines, TapBorder g,
+                                                                 float* __restrict__ taps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.r * g.s * g.k) return;
+  const int kk = i % g.k, t = i / g.k, rr = t / g.s, ss = t - rr * g.s;
+  const int nrow = tb_nrow(g), ncol = tb_ncol(g);
+  float acc = 0.f;
+  for (int a = 0; a < nrow; ++a) {
+    const bool rout = (unsigned)(tb_row(g, a) * g.stride + rr - g.pad_t) >= (unsigned)g.h;
+    if (rout) acc += lines[(long)a * g.k + kk];
+    for (int b = 0; b < ncol; ++b) {
+      const bool cout_ = (unsigned)(tb_col(g, b) * g.stride + ss - g.pad_l) >= (unsigned)g.w;
+      if (a == 0 && cout_) acc += lines[(long)(nrow + b) * g.k + kk];
+      if (rout && cout_) acc -= lines[(long)(nrow + ncol + a * ncol + b) * g.k + kk];
+    }
+  }
+  if (nrow == 0)
+    for (int b = 0; b < ncol; ++b)
+      if ((unsigned)(tb_col(g, b) * g.stride + ss - g.pad_l) >= (unsigned)g.w) acc += lines[(long)b * g.k + kk];
+  taps[i] = -acc;
+}
+
 __global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, float alpha, float* __restrict__ out) {
   if (threadIdx.x || blockIdx.x) return;
   double s = 0.0;
@@ -903,6 +979,63 @@ extern "C" int embnet_tap_contract(const float* w, const float* tap_sums, int ta
   EMBNET_CHECK_ARG(w && tap_sums && out && taps > 0 && c > 0 && k > 0, "tap_contract: bad argument");
   tap_contract_kernel<<<c, 256, 0, S(stream)>>>(w, tap_sums, taps, c, k, out);
   return check_launch("tap_contract");
+}
+
+// border rows / columns of the output map: those with at least one tap in the padding
+static bool make_tap_border(TapBorder& g, int oh, int ow, int k, int r, int s, int stride, int pad_t, int pad_l, int h, int w) {
+  g = TapBorder{oh, ow, k, r, s, stride, pad_t, pad_l, h, w, 0, oh, 0, ow};
+  auto row_out = [&](int y) { return y * stride - pad_t < 0 || y * stride + r - 1 - pad_t >= h; };
+  auto col_out = [&](int x) { return x * stride - pad_l < 0 || x * stride + s - 1 - pad_l >= w; };
+  while (g.yt < oh && row_out(g.yt)) ++g.yt;
+  while (g.yb > g.yt && row_out(g.yb - 1)) --g.yb;
+  while (g.xl < ow && col_out(g.xl)) ++g.xl;
+  while (g.xr > g.xl && col_out(g.xr - 1)) --g.xr;
+  for (int y = g.yt; y < g.yb; ++y) if (row_out(y)) return false;        // (cannot happen for a contiguous image)
+  for (int x = g.xl; x < g.xr; ++x) if (col_out(x)) return false;
+  return true;
+}
+static int tap_border_lines(const TapBorder& g) {
+  const int nrow = g.yt + (g.oh - g.yb), ncol = g.xl + (g.ow - g.xr);
+  return nrow + ncol + nrow * ncol;
+}
+
+extern "C" size_t embnet_tap_border_sums_workspace_bytes(int n, int oh, int ow, int k, int r, int s, int stride, int pad_t,
+                                                         int pad_l, int h, int w) {
+  if (n <= 0 || oh <= 0 || ow <= 0 || r <= 0 || s <= 0 || k <= 0 || stride <= 0) return 0;
+  TapBorder g;
+  if (!make_tap_border(g, oh, ow, k, r, s, stride, pad_t, pad_l, h, w)) return 0;
+  return (size_t)tap_border_lines(g) * ((size_t)n + 1) * k * sizeof(float) + 16;
+}
+
+extern "C" int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, int k, int r, int s, int stride, int pad_t,
+                                      int pad_l, int h, int w, float* taps, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  EMBNET_CHECK_ARG(dy && taps, "tap_border_sums: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && oh > 0 && ow > 0 && k > 0 && r > 0 && s > 0 && stride > 0 && h > 0 && w > 0, "tap_border_sums: bad geometry");
+  TapBorder g;
+  EMBNET_CHECK_ARG(make_tap_border(g, oh, ow, k, r, s, stride, pad_t, pad_l, h, w), "tap_border_sums: border rows not contiguous");
+  const int nlines = tap_border_lines(g);
+  if (nlines == 0) {                                       // no padding at all: every tap sums the whole (zero-sum) map
+    hipError_t e = hipMemsetAsync(taps, 0, (size_t)r * s * k * sizeof(float), S(stream));
+    return e == hipSuccess ? 0 : fail(EMBNET_ELAUNCH, "tap_border_sums: memset: %s", hipGetErrorString(e));
+  }
+  const size_t need = embnet_tap_border_sums_workspace_bytes(n, oh, ow, k, r, s, stride, pad_t, pad_l, h, w);
+  EMBNET_CHECK_ARG(workspace, "tap_border_sums: null workspace");
+  if (workspace_bytes < need) return fail(EMBNET_EWORKSPACE, "tap_border_sums: workspace %zu < %zu", workspace_bytes, need);
+  float* partial = (float*)workspace;
+  float* lines = partial + (size_t)nlines * n * k;
+  {
+    EMBNET_TRACE("embnet::tap_border_lines_kernel", TRACE_BYTES,
+                 4.0 * n * k * ((double)(g.yt + oh - g.yb) * ow + (double)(g.xl + ow - g.xr) * oh), stream);
+    tap_border_lines_kernel<<<dim3(nlines, n), 256, 0, S(stream)>>>(dy, g, partial);
+  }
+  {
+    EMBNET_TRACE("embnet::tap_border_reduce_kernel", TRACE_BYTES, 4.0 * nlines * n * k, stream);
+    tap_border_reduce_kernel<<<nlines, 256, 0, S(stream)>>>(partial, n, k, lines);
+  }
+  EMBNET_TRACE("embnet::tap_border_combine_kernel", TRACE_BYTES, 4.0 * r * s * k, stream);
+  tap_border_combine_kernel<<<cdiv(r * s * k, 256), 256, 0, S(stream)>>>(lines, g, taps);
+  return check_launch("tap_border_sums");
 }
 
 extern "C" int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream) {

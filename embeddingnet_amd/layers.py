@@ -543,7 +543,7 @@ class _InputBNConvFn(torch.autograd.Function):
     _ones = {}
 
     @staticmethod
-    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None):
+    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False):
         x, w = _c(x), _c(w)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -571,7 +571,7 @@ class _InputBNConvFn(torch.autograd.Function):
         check(lib.embnet_conv2d_fwd_f32(
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
             ptr(out_stats), ptr(cws), cws.numel() * 4, stream()))
-        ctx.geom, ctx.c = geom, c
+        ctx.geom, ctx.c, ctx.zero_sum_dy = geom, c, bool(zero_sum_dy)
         ctx.save_for_backward(a, w)
         return y
 
@@ -589,23 +589,32 @@ class _InputBNConvFn(torch.autograd.Function):
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
             None, None, 0, stream()))
         dw = dw_p if cp == c else dw_p[:, :, :c, :].contiguous()
-        key = (a.device, n, h, wd)
-        ones = _InputBNConvFn._ones.get(key)
-        if ones is None:
-            ones = _InputBNConvFn._ones[key] = torch.ones((n, h, wd, 1), device=a.device, dtype=torch.float32)
         taps = torch.empty((r, s, 1, k), device=a.device, dtype=torch.float32)
-        ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, 1, r, s, k, oh, ow), a.device)
-        check(lib.embnet_conv2d_wgrad_f32(
-            ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
-            None, None, 0, stream()))
+        if ctx.zero_sum_dy:
+            # dy is the data gradient of a training-mode BatchNormalization (sums to zero per channel): the per-tap sums
+            # are minus the border strips' sums — 6 % of the tensor instead of a pass over all of it
+            ws = workspace(max(lib.embnet_tap_border_sums_workspace_bytes(n, oh, ow, k, r, s, stride, pt, pl, h, wd), 16), a.device)
+            check(lib.embnet_tap_border_sums(ptr(dy), n, oh, ow, k, r, s, stride, pt, pl, h, wd, ptr(taps), ptr(ws),
+                                             ws.numel() * 4, stream()))
+        else:
+            key = (a.device, n, h, wd)
+            ones = _InputBNConvFn._ones.get(key)
+            if ones is None:
+                ones = _InputBNConvFn._ones[key] = torch.ones((n, h, wd, 1), device=a.device, dtype=torch.float32)
+            ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, 1, r, s, k, oh, ow), a.device)
+            check(lib.embnet_conv2d_wgrad_f32(
+                ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
+                None, None, 0, stream()))
         dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
-        return None, dbeta, None, None, dw, None, None, None, None
+        return None, dbeta, None, None, dw, None, None, None, None, None
 
 
-def input_bn_conv(x, bn, conv, emit_stats=False):
+def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
     """bn (scale=False, no relu) then conv (no bias / activation) on an image batch.
-    emit_stats: as Conv2D.forward (the BatchNormalization behind the conv gets its sums from the epilogue)."""
+    emit_stats: as Conv2D.forward (the BatchNormalization behind the conv gets its sums from the epilogue).
+    zero_sum_dy: the caller vouches that the conv output's ONLY consumer is a BatchNormalization in training mode, whose
+    data gradient sums to zero per channel — bn's beta gradient then needs the border strips of dy only."""
     fusable = (bn.training and not x.requires_grad and bn.gamma is None and not bn.relu and conv.bias is None
                and not conv.relu and torch.is_grad_enabled())
     if not fusable:
@@ -619,7 +628,7 @@ def input_bn_conv(x, bn, conv, emit_stats=False):
         if rows > 0:
             out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
     y = _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum, geom,
-                             out_stats)
+                             out_stats, zero_sum_dy)
     if out_stats is not None:
         y._bn_partials = out_stats
     return y

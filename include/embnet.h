@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 5
+#define EMBNET_ABI_VERSION 6
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -261,6 +261,15 @@ int embnet_scale(const float* x, long total, float alpha, const float* alpha_dev
 /* out[c] = sum_{tap,k} w[tap,c,k] * tap_sums[tap,k]: gradient of a per-channel offset added to a conv
  * input (the zoo ResNet's bn_data beta) from per-tap sums of dy — avoids a full 3-channel dgrad. */
 int embnet_tap_contract(const float* w, const float* tap_sums, int taps, int c, int k, float* out, void* stream);
+/* tap_sums[r,s,k] for embnet_tap_contract when dy[n,oh,ow,k] sums to zero over the pixels of every channel (dy is the
+ * data gradient of a training-mode BatchNormalization: the zoo ResNet's bn0 behind conv0): the sum over the pixels
+ * whose tap (r,s) is inside the image = minus the sum over those whose tap falls into the padding — border strips
+ * only (row sums + column sums - corners), 6 % of the tensor for the 7x7/2 stem.  The caller vouches for the zero-sum
+ * property. */
+size_t embnet_tap_border_sums_workspace_bytes(int n, int oh, int ow, int k, int r, int s, int stride, int pad_t, int pad_l,
+                                              int h, int w);
+int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, int k, int r, int s, int stride, int pad_t, int pad_l,
+                           int h, int w, float* tap_sums, void* workspace, size_t workspace_bytes, void* stream);
 /* y[pixels,cout] = [x[pixels,cin] | 0]: widens 3-channel images to 4 channels for 16-byte stem gathers. */
 int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */

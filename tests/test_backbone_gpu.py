@@ -591,3 +591,39 @@ def test_fused_step_loss_and_grads_vs_oracle(dev):
         den += (pr.grad ** 2).sum().item()
         assert err < 2e-2 and l2 < 5e-3, f"grad {kname}: max-rel {err:.2e}, rel-L2 {l2:.2e}"
     assert (num / den) ** 0.5 < 2e-3, f"global gradient rel-L2 error {(num / den) ** 0.5:.2e}"
+
+
+def test_stem_beta_gradient_from_border_strips(dev):
+    """bn_data's beta gradient through conv0 (layers.input_bn_conv): with zero_sum_dy (conv0's only consumer is a
+    training-mode BatchNormalization, whose data gradient sums to zero per channel) the per-tap sums of dy come from the
+    border strips alone (embnet_tap_border_sums); same gradient as the full per-tap sums, and as the float64 autograd
+    of the plain layers."""
+    from embeddingnet_amd import layers as L
+    gen = torch.Generator().manual_seed(3)
+    n, h, w = 6, 40, 36
+    bn_data = L.BatchNormalization(3, epsilon=2e-5, scale=False).to(dev)
+    conv0 = L.Conv2D(3, 64, 7, strides=2, padding=3, use_bias=False, gen=gen).to(dev)
+    bn0 = L.BatchNormalization(64, epsilon=2e-5, relu=True).to(dev)
+    x = torch.rand((n, h, w, 3), device=dev)
+    up = torch.randn((n, 20, 18, 64), device=dev)
+    grads = {}
+    for flag in (False, True):
+        for m in (bn_data, conv0, bn0):
+            m.zero_grad(set_to_none=True)
+        y = bn0(L.input_bn_conv(x, bn_data, conv0, zero_sum_dy=flag))
+        (y * up).sum().backward()
+        grads[flag] = (bn_data.beta.grad.clone(), conv0.kernel.grad.clone())
+    scale = grads[False][0].abs().max().item()
+    assert (grads[True][0] - grads[False][0]).abs().max().item() <= 2e-5 * max(scale, 1e-6) + 1e-6
+    assert torch.equal(grads[True][1], grads[False][1])
+    # float64 reference of the same three layers
+    xr = x.detach().cpu().double()
+    beta = torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    xm = xr.mean((0, 1, 2)); xv = xr.var((0, 1, 2), unbiased=False)
+    a = (xr - xm) / torch.sqrt(xv + 2e-5) + beta
+    kr = conv0.kernel.detach().cpu().double()
+    yr = F.conv2d(a.permute(0, 3, 1, 2), kr.permute(3, 2, 0, 1), stride=2, padding=3).permute(0, 2, 3, 1)
+    ym = yr.mean((0, 1, 2)); yv = yr.var((0, 1, 2), unbiased=False)
+    out = torch.relu((yr - ym) / torch.sqrt(yv + 2e-5) * bn0.gamma.detach().cpu().double() + bn0.beta.detach().cpu().double())
+    (out * up.cpu().double()).sum().backward()
+    close(grads[True][0], beta.grad, 2e-4, "beta gradient vs float64")
