@@ -914,14 +914,21 @@ static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt
   // measured (EMBNET_WGRAD_BLOCKS sweep on ResNet18 shapes): with few output tiles one round of 3
   // workgroups per CU is best; with many tiles shorter K ranges in 2-3 rounds balance better
 #if EMBNET_CONV_SPLIT
-  // two workgroups per CU: one round (512) for few tiles, two for 25..99, short K ranges beyond (same sweep)
-  long target = tiles >= 100 ? 2048 : (tiles >= 25 ? 1024 : (tiles <= 2 ? 768 : 512));   // stem (2 tiles, 50k K tiles): 768
+  // two workgroups per CU are resident: whole rounds of 512
+  // (tools/exp/wgrad_rounds.py, profiles/r02_wgrad_rounds.txt: with whole rounds, ONE round wins up to 72 tiles, two from 144)
+  long target = tiles >= 100 ? 1024 : (tiles <= 2 ? 768 : 512);   // stem (2 tiles, 50k K tiles): 768
 #else
   long target = tiles >= 100 ? 2048 : (tiles >= 30 ? 1536 : 768);
 #endif
   const long forced_blocks = env_long("EMBNET_WGRAD_BLOCKS", 0);   // tuning aids, read per call
   if (forced_blocks > 0) target = forced_blocks;
+#if EMBNET_CONV_SPLIT
+  // whole rounds: tiles * splits must not spill a few workgroups into an extra round (36 tiles x 15 splits = 540 ran as
+  // two rounds of 512 slots) -> round the split count DOWN
+  long want = target / tiles;
+#else
   long want = (target + tiles - 1) / tiles;
+#endif
   if (want > kt_total / 4) want = kt_total / 4;       // at least 4 k-tiles per split
   if (want < 1) want = 1;
   kt_per_split = cdiv(kt_total, want);
