@@ -730,11 +730,17 @@ static int fair_from(long grid, int tile, bool wgrad) {
 // Plan the remainder split for `tiles` output tiles of bm x bn with kt K-tiles each (see SplitTail).
 // Model: a CU retires one tile per t_tile; whole tiles cost ceil(tiles/256) of those, the split costs
 // floor(tiles/256) + ceil(rem*parts/256)/parts plus the fix-up pass over rem*parts partial tiles.
-static constexpr int NUM_CUS = 256;
 static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, SplitTail& t, size_t* need = nullptr) {
   t.n_full = (int)tiles; t.parts = 1; t.kt_part = kt; t.ws = nullptr;
   if (need) *need = 0;
   static const int knob = (int)env_long("EMBNET_CONV_TAIL", 1);
+  static const int slots_knob = (int)env_long("EMBNET_TAIL_SLOTS", 512);   // granularity of a "round"; 0: 256 x resident(tile)
+  int NUM_CUS = slots_knob;
+  if (slots_knob == 0) {
+    int res = 2;
+    for (int t = 0; t < 5; ++t) if (TILE_BM[t] == bm && TILE_BN[t] == bn) res = TILE_RESIDENT[t];
+    NUM_CUS = 256 * res;
+  }
   const int rem = (int)(tiles % NUM_CUS);
   if (!knob || rem == 0 || tiles < NUM_CUS) return;
   const double t_tile = (double)kt * bm * bn * BK * 2.0 / (0.85 * 146e12 / NUM_CUS);        // seconds
