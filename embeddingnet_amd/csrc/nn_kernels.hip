@@ -206,113 +206,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
   }
 }
 
-// ---- BatchNorm backward in ONE launch (training mode, C % 4 == 0) ----------------------------------------------
-// The two-pass form reads dy and x twice from HBM (reduce: 8 B/element, apply: 12 B/element, + a finalize launch).
-// Here every workgroup keeps its row range for both phases, with two grid-wide barriers in between:
-//   1  partial sums of dz and dz*xhat over its rows  ->  partial[wg][2][c]
-//   -- barrier --   2  workgroup j adds the partials of channels j, j+G, .. in double (bn_bwd_finalize's arithmetic)
-//   -- barrier --   3  dx for its rows: dy and x are re-read while they are still in L2 / the 256 MB Infinity Cache
-// so HBM sees each input once.  The grid (<= 1024 workgroups of 256 threads, 8 KB of LDS, < 64 registers) is always
-// co-resident on the 256 CUs, which is what makes the spin barriers safe.  The barrier counters live in a per-device
-// buffer of the library, are monotonic inside a launch and re-armed by the last workgroup to leave; launches on ONE
-// stream at a time (autograd's backward is).  EMBNET_BN_FUSED_BWD=0 restores the two-pass form.
-static __device__ unsigned g_bnf_sync[4];
-
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have left the CU (write-through L1)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 4) void bn_bwd_fused4_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, long m, int c4, ColGeom g, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-    const float* __restrict__ dx_add, float* __restrict__ partial, float* __restrict__ dbeta, float* __restrict__ dgamma,
-    float* __restrict__ dx) {
-  const unsigned G = gridDim.x;
-  // phase 1: the same column reduction as bn_bwd_reduce4_kernel, over this workgroup's rows
-  col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
-    const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
-    float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
-    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
-    if (relu) {
-      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
-      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
-    }
-    a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
-    b.x = fmaf(dz.x, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(dz.y, (xv.y - mu.y) * rs.y, b.y);
-    b.z = fmaf(dz.z, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(dz.w, (xv.w - mu.w) * rs.w, b.w);
-  });
-  grid_barrier(&g_bnf_sync[0], G);
-  // phase 2: channel sums (bn_bwd_finalize_kernel's arithmetic), channels strided over the workgroups
-  const int c = c4 * 4;
-  for (int col = blockIdx.x; col < c; col += G) {
-    double s, ss;
-    block_partial_sums(partial, (int)G, c, col, s, ss);
-    if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
-    __syncthreads();
-  }
-  grid_barrier(&g_bnf_sync[0], 2 * G);
-  // phase 3: dx over the same rows
-  const float inv_m = 1.f / (float)m;
-  const int ci = threadIdx.x % g.cl, ri = threadIdx.x / g.cl;
-  const long r0 = (long)blockIdx.x * g.rows_per_block, r1 = min(r0 + g.rows_per_block, m);
-  for (int q0 = 0; q0 < c4; q0 += g.cl) {
-    const int q = q0 + ci;
-    if (q >= c4) continue;
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
-    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
-    float4 db, dg;                                       // written by other CUs during this launch: coherent loads
-    db.x = __hip_atomic_load(dbeta + 4 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_m;
-    db.y = __hip_atomic_load(dbeta + 4 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_m;
-    db.z = __hip_atomic_load(dbeta + 4 * q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_m;
-    db.w = __hip_atomic_load(dbeta + 4 * q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * inv_m;
-    dg.x = __hip_atomic_load(dgamma + 4 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    dg.y = __hip_atomic_load(dgamma + 4 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    dg.z = __hip_atomic_load(dgamma + 4 * q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    dg.w = __hip_atomic_load(dgamma + 4 * q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long rl = g.rl;
-    auto one = [&](long r) {
-      const long i = r * c4 + q;
-      const float4 xv = reinterpret_cast<const float4*>(x)[i];
-      float4 dz = reinterpret_cast<const float4*>(dy)[i];
-      if (relu) {
-        dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
-        dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
-      }
-      float4 o;                                          // bn_bwd_apply4_kernel's expression, term for term
-      o.x = sc.x * (dz.x - db.x - (xv.x - mu.x) * rs.x * dg.x * inv_m);
-      o.y = sc.y * (dz.y - db.y - (xv.y - mu.y) * rs.y * dg.y * inv_m);
-      o.z = sc.z * (dz.z - db.z - (xv.z - mu.z) * rs.z * dg.z * inv_m);
-      o.w = sc.w * (dz.w - db.w - (xv.w - mu.w) * rs.w * dg.w * inv_m);
-      if (dx_add) {
-        const float4 a = reinterpret_cast<const float4*>(dx_add)[i];
-        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-      }
-      reinterpret_cast<float4*>(dx)[i] = o;
-    };
-    long r = r0 + ri;
-    for (; r + 3 * rl < r1; r += 4 * rl) { one(r); one(r + rl); one(r + 2 * rl); one(r + 3 * rl); }
-    for (; r < r1; r += rl) one(r);
-  }
-  // re-arm the barrier counter: everyone is past the second barrier once it has bumped the exit counter
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned d = __hip_atomic_fetch_add(&g_bnf_sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == G - 1) {
-      __hip_atomic_store(&g_bnf_sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&g_bnf_sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
+// (A one-launch BatchNorm backward — sums, two spin barriers across a co-resident 1024-workgroup grid, then dx from the
+// still-cached inputs — was built and measured in round 2: 144 us per layer against 27 + 31 us for the two passes
+// (barrier latency, 16 instead of 32 waves per CU, 64-channel finalize on 64 workgroups).  Removed.)
 // mean/var -> scale = gamma*rstd, shift = beta - mean*scale; moving stats updated in place.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int blocks, long m, int c,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -934,15 +830,6 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   // inference-mode statistics: xhat uses the moving stats folded in scale/shift; dgamma then needs them too.
   // We only support parameter gradients in training mode; frozen BN returns dgamma = dbeta sums with xhat from
   // save_mean/save_rstd when given, else zeros.
-  static const bool fused_bwd = env_long("EMBNET_BN_FUSED_BWD", 1) != 0;
-  if (fused_bwd && training && save_mean && save_rstd && (c & 3) == 0 && !bn_scalar()) {
-    ColGeom g4 = col_geom(m, c / 4);                     // <= 1024 workgroups: co-resident at 4 per CU
-    if (g4.blocks > 1024) { g4.blocks = 1024; g4.rows_per_block = (int)((m + 1023) / 1024); g4.blocks = (int)((m + g4.rows_per_block - 1) / g4.rows_per_block); }
-    EMBNET_TRACE("embnet::bn_bwd_fused4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream);
-    bn_bwd_fused4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu,
-                                                           dx_add, partial, dbeta, dgamma, dx);
-    return check_launch("bn_bwd");
-  }
   if (save_mean && save_rstd) {
     if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);

@@ -47,8 +47,10 @@ CONV_CASES = [
     (2, 9, 9, 6, 10, 2, 1, "valid", True, True),      # non-vector channel counts
     (4, 7, 7, 512, 512, 3, 1, 1, False, False),       # deep K (4608)
     (2, 8, 8, 256, 64, 1, 1, "valid", False, False),  # bottleneck 1x1
-    (8, 40, 40, 256, 128, 3, 1, 1, True, True),       # 400 tiles: the 144 left-over tiles are split along K (fwd + dgrad)
-    (5, 61, 59, 128, 64, 3, 1, 1, False, False),      # 282 tiles of 64x64 with a ragged last row tile, tail split
+    (8, 40, 40, 256, 128, 3, 1, 1, True, True),       # 400 tiles of 64x64, fused bias + ReLU
+    (5, 61, 59, 128, 64, 3, 1, 1, False, False),      # 282 tiles of 64x64 with a ragged last row tile
+    (10, 60, 60, 64, 64, 3, 1, 1, True, True),        # 563 tiles of 64x64: the 51 left over after a round of 512 are split along K (fwd + dgrad)
+    (5, 60, 60, 128, 128, 3, 1, 1, False, False),     # 564 tiles (two column tiles): 52 left-over tiles split along K
 ]
 
 
@@ -129,7 +131,7 @@ def test_conv2d_products_are_fp32_accurate(dev, shape):
         assert np.array_equal(got, ref), f"{name}: integer operands must come out exact"
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (8, 40, 40, 256, 128), (2, 9, 9, 6, 10)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (8, 40, 40, 256, 128), (10, 60, 60, 64, 64), (2, 9, 9, 6, 10)])
 def test_conv2d_residual_epilogue(dev, shape):
     """Conv2D(x, residual=r) == Conv2D(x) + r bit for bit (whole tiles, K-split left-over tiles and the scalar
     path), and the Add's gradient reaches r unchanged."""
@@ -182,7 +184,7 @@ def test_deferred_batchnorm_into_conv(dev, shape, k, stride, act):
 
 @pytest.mark.parametrize("shape,k,stride", [((2, 16, 16, 64, 64), 3, 1), ((8, 40, 40, 256, 128), 3, 1),
                                             ((5, 61, 59, 128, 64), 3, 1), ((3, 15, 17, 64, 128), 3, 2),
-                                            ((2, 9, 9, 8, 32), 1, 1)])
+                                            ((2, 9, 9, 8, 32), 1, 1), ((10, 60, 60, 64, 64), 3, 1)])
 def test_conv_epilogue_statistics_feed_batchnorm(dev, shape, k, stride):
     """Conv2D(emit_stats=True) hands the next BatchNormalization its per-channel sums from the conv epilogue
     (whole tiles and K-split left-over tiles, with a residual): same BN output, moving statistics and gradients
@@ -235,7 +237,7 @@ def test_batchnorm_with_skip_folds_the_shortcut_gradient(dev, c):
 
 
 @pytest.mark.parametrize("shape,stride", [((2, 16, 16, 64, 64), 1), ((3, 15, 17, 64, 128), 2), ((8, 40, 40, 256, 128), 1),
-                                          ((2, 9, 9, 6, 10), 2)])
+                                          ((2, 9, 9, 6, 10), 2), ((10, 60, 60, 64, 64), 1)])
 def test_conv_pair_accumulates_the_input_gradient(dev, shape, stride):
     """conv_pair(x, 3x3, 1x1 projection): one node whose backward lets the second dgrad add into the first one's
     output (skipping pixels a strided 1x1 never touches) — same values as two separate convs + autograd's add."""
@@ -257,7 +259,7 @@ def test_conv_pair_accumulates_the_input_gradient(dev, shape, stride):
 
 
 @pytest.mark.parametrize("shape,k,stride", [((2, 16, 16, 64, 64), 1, 1), ((8, 40, 40, 256, 128), 3, 1), ((2, 9, 9, 6, 10), 3, 1),
-                                            ((3, 15, 17, 64, 128), 3, 2)])
+                                            ((3, 15, 17, 64, 128), 3, 2), ((10, 60, 60, 64, 64), 3, 1)])
 def test_conv_with_skip_folds_the_skip_gradient(dev, shape, k, stride):
     """conv(x, with_skip=True) -> (conv(x), x): the gradient of the pass-through copy is added in the data-gradient
     epilogue (whole tiles, K-split tiles, scalar path, strided classes); same as autograd's own accumulation."""
@@ -282,9 +284,9 @@ def test_conv_tail_split_is_planned_for_the_test_shapes():
     """The two big CONV_CASES must really take the remainder-split path (host-side plan, no launch)."""
     from embeddingnet_amd import _lib
     lib = _lib.lib()
-    assert lib.embnet_conv2d_fwd_workspace_bytes(8, 256, 3, 3, 128, 40, 40) > 0
-    assert lib.embnet_conv2d_dgrad_workspace_bytes(8, 40, 40, 256, 3, 3, 128, 1) > 0
-    assert lib.embnet_conv2d_fwd_workspace_bytes(5, 128, 3, 3, 64, 61, 59) > 0
+    assert lib.embnet_conv2d_fwd_workspace_bytes(10, 64, 3, 3, 64, 60, 60) > 0
+    assert lib.embnet_conv2d_dgrad_workspace_bytes(10, 60, 60, 64, 3, 3, 64, 1) > 0
+    assert lib.embnet_conv2d_fwd_workspace_bytes(5, 128, 3, 3, 128, 60, 60) > 0
     assert lib.embnet_conv2d_fwd_workspace_bytes(2, 64, 3, 3, 64, 16, 16) == 0
 
 
