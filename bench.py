@@ -197,7 +197,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     _lib.lib()
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))     # (more ranks than GPUs only in the gloo debug mode)
     torch.cuda.set_device(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     shape = (args.image, args.image, 3)

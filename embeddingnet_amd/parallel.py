@@ -22,7 +22,9 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # EMBNET_DIST_BACKEND=gloo: debugging aid — runs the multi-rank path (broadcasts, bucketed gradient all-reduce) on
+        # GPU tensors without RCCL, e.g. two ranks sharing the one GPU of a test box
+        backend = backend or os.environ.get("EMBNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -191,3 +191,20 @@ def test_frozen_backbone_batchnorm_runs_in_inference_mode():
         base(x)
     h.remove()
     assert torch.equal(feats[0], feats[1]) and ref.shape == emb.shape
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """The N > 1 path of bench.py end to end on GPU tensors (rank-0 broadcast, per-rank class shards, bucketed gradient
+    all-reduce from autograd hooks, max-over-ranks timing) with two ranks sharing this box's one GPU over gloo
+    (EMBNET_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the driver's 8-GPU run uses nccl = RCCL)."""
+    import json
+    env = dict(os.environ, EMBNET_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29546", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--backbone", "resnet18",
+                          "--image", "64", "--k-classes", "8"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 2 * 8 * 4
+    assert d["config"]["parallelism"] == "dp2" and np.isfinite(d["config"]["final_loss"])
