@@ -519,6 +519,29 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply4_kernel(
   const float4 xv = reinterpret_cast<const float4*>(x)[i];
   float g[4] = {0.f, 0.f, 0.f, 0.f};
   const int y_hi = min((ih + pad) / stride, oh - 1), x_hi = min((iw + pad) / stride, ow - 1);
+  if (k <= 2 * stride) {
+    // at most two windows per dimension cover a pixel (3x3/2, 2x2/2): all four candidates are fetched unconditionally
+    // (clamped addresses, masked afterwards) so the loads are in flight together; same accumulation order as the loops
+    uint32_t am[4]; float4 d[4]; bool ok[4]; uint32_t tp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y_o = y_hi - (j >> 1), x_o = x_hi - (j & 1);
+      ok[j] = y_o >= 0 && x_o >= 0 && y_o * stride - pad + k > ih && x_o * stride - pad + k > iw;
+      const int yc = max(y_o, 0), xc = max(x_o, 0);
+      tp[j] = (uint32_t)((ih - (yc * stride - pad)) * k + (iw - (xc * stride - pad)));
+      const long o = (((long)b * oh + yc) * ow + xc) * c4 + q;
+      am[j] = reinterpret_cast<const uint32_t*>(argmax)[o];
+      d[j] = reinterpret_cast<const float4*>(dy)[o];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!ok[j]) continue;
+      g[0] += (am[j] & 0xff) == tp[j] ? d[j].x : 0.f;
+      g[1] += ((am[j] >> 8) & 0xff) == tp[j] ? d[j].y : 0.f;
+      g[2] += ((am[j] >> 16) & 0xff) == tp[j] ? d[j].z : 0.f;
+      g[3] += (am[j] >> 24) == tp[j] ? d[j].w : 0.f;
+    }
+  } else
   for (int y_o = y_hi; y_o >= 0 && y_o * stride - pad + k > ih; --y_o)
     for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
       const uint32_t tap = (uint32_t)((ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad)));

@@ -629,3 +629,34 @@ def test_stem_beta_gradient_from_border_strips(dev):
     out = torch.relu((yr - ym) / torch.sqrt(yv + 2e-5) * bn0.gamma.detach().cpu().double() + bn0.beta.detach().cpu().double())
     (out * up.cpu().double()).sum().backward()
     close(grads[True][0], beta.grad, 2e-4, "beta gradient vs float64")
+
+
+@pytest.mark.parametrize("geom", [(3, 9, 11, 8, 3, 3, 1, 1, 1, 9, 11),          # n, oh, ow, k, r, s, stride, pad_t, pad_l, h, w
+                                  (2, 10, 7, 68, 7, 7, 2, 3, 3, 20, 14),        # the stem's 7x7/2, pad 3
+                                  (2, 6, 6, 5, 5, 5, 2, 1, 2, 12, 11),          # Keras 'same' with asymmetric padding
+                                  (2, 8, 8, 4, 1, 1, 1, 0, 0, 8, 8), (1, 4, 5, 3, 3, 3, 1, 0, 0, 6, 7)])   # no padding
+def test_tap_border_sums_against_brute_force(dev, geom):
+    """embnet_tap_border_sums: taps[r,s,k] = - sum of dy over the pixels whose tap (r,s) falls into the padding (row
+    sums + column sums - corners of the border strips), for any stride / asymmetric padding / channel count; without
+    padding every entry is zero."""
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd.layers import workspace
+    n, oh, ow, k, r, s, stride, pt, pl, h, w = geom
+    rs = np.random.RandomState(4)
+    dy = rs.randn(n, oh, ow, k).astype(np.float32)
+    want = np.zeros((r, s, k))
+    for rr in range(r):
+        for ss in range(s):
+            for y in range(oh):
+                for x in range(ow):
+                    ih, iw = y * stride + rr - pt, x * stride + ss - pl
+                    if not (0 <= ih < h and 0 <= iw < w):
+                        want[rr, ss] -= dy[:, y, x, :].astype(np.float64).sum(0)
+    lib = _lib.lib()
+    d = g(dy, dev)
+    taps = torch.full((r, s, k), 7.0, device=dev)
+    ws = workspace(max(lib.embnet_tap_border_sums_workspace_bytes(n, oh, ow, k, r, s, stride, pt, pl, h, w), 16), dev)
+    _lib.check(lib.embnet_tap_border_sums(_lib.ptr(d), n, oh, ow, k, r, s, stride, pt, pl, h, w, _lib.ptr(taps), _lib.ptr(ws),
+                                          ws.numel() * 4, _lib.stream()))
+    got = taps.cpu().double().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0), (got - want)
