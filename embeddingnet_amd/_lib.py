@@ -76,7 +76,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object:
+    ~8 us per call, 90 calls per ResNet18 step.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -43,7 +43,7 @@ def _side_stream(device):
 def workspace(nbytes, device):
     """Grow-only scratch buffer per device (kernels on one stream run in order, so reuse is safe)."""
     n = max((int(nbytes) + 3) // 4, 256)
-    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _lib.stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
@@ -75,8 +75,8 @@ class _Conv2dFn(torch.autograd.Function):
         stride, pt, pl, oh, ow = geom
         # in_stats [4,C] (mean, rstd, scale, shift of the BatchNormalization in front): the kernels read
         # act(x*scale + shift) on the fly, x being the BN's INPUT (layers.Deferred)
-        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
-        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
+        in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
         if residual is not None:
             if relu:
                 raise _lib.EmbnetError("conv2d: a fused residual add goes with a linear conv (no fused ReLU)")
@@ -113,8 +113,8 @@ class _Conv2dFn(torch.autograd.Function):
             dz = dy
         dx = dw = db = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
-        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
+        in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
 
         def run_wgrad():
             ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
@@ -160,8 +160,8 @@ class _ConvPairFn(torch.autograd.Function):
         x, w1, w2 = _c(x), _c(w1), _c(w2)
         lib = _lib.lib()
         n, h, wd, c = x.shape
-        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
-        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
+        in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
         ys = []
         for w, geom, st in ((w1, geom1, out_stats1), (w2, geom2, None)):
             r, s, c2, k = w.shape
@@ -183,8 +183,8 @@ class _ConvPairFn(torch.autograd.Function):
         x, w1, w2, in_stats = ctx.saved_tensors
         lib = _lib.lib()
         n, h, wd, c = x.shape
-        in_scale = in_stats[2].data_ptr() if in_stats is not None else None
-        in_shift = in_stats[3].data_ptr() if in_stats is not None else None
+        in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
+        in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dws, first = [], True
         for w, geom, dy, need_dw in ((w1, ctx.geoms[0], dy1, ctx.needs_input_grad[1]),
@@ -377,7 +377,7 @@ def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mea
     if partials is not None and tuple(partials.shape[:2]) != (2, c):
         raise _lib.EmbnetError(f"BatchNormalization: statistics partials {tuple(partials.shape)} for {c} channels")
     check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), ptr(y),
-                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                  stats.data_ptr(), (stats.data_ptr() + 4 * stats.shape[1]), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                   ptr(moving_mean), ptr(moving_var), ptr(partials),
                                   partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, stream()))
 
@@ -401,7 +401,7 @@ class _BatchNormFn(torch.autograd.Function):
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, y, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
-                                          int(relu), ptr(y), stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+                                          int(relu), ptr(y), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
         ctx.save_for_backward(x, stats)
         if with_skip:                       # second output: x itself, for the identity shortcut (see backward)
@@ -421,11 +421,11 @@ class _BatchNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-        mean = stats[0].data_ptr() if ctx.training else None
-        rstd = stats[1].data_ptr() if ctx.training else None
-        check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, stats[2].data_ptr(), stats[3].data_ptr(),
-                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), dgb[0].data_ptr(),
-                                dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
+        mean = stats.data_ptr() if ctx.training else None
+        rstd = (stats.data_ptr() + 4 * stats.shape[1]) if ctx.training else None
+        check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
+                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), dgb.data_ptr(),
+                                (dgb.data_ptr() + 4 * dgb.shape[1]), ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
@@ -455,7 +455,7 @@ class _AffineActFn(torch.autograd.Function):
     def forward(ctx, raw, stats, act):
         y = torch.empty_like(raw)
         c = raw.shape[-1]
-        check(_lib.lib().embnet_affine_act(ptr(raw), raw.numel() // c, c, stats[2].data_ptr(), stats[3].data_ptr(),
+        check(_lib.lib().embnet_affine_act(ptr(raw), raw.numel() // c, c, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                            int(act), ptr(y), stream()))
         return y
 
@@ -478,7 +478,7 @@ class _BNDeferFn(torch.autograd.Function):
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
-                                          int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+                                          int(act), None, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = int(act), training, gamma is not None
         ctx.save_for_backward(x, stats)
         ctx.mark_non_differentiable(stats)
@@ -690,12 +690,12 @@ class _BNActMaxPoolFn(torch.autograd.Function):
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
-                                          int(act), None, stats[2].data_ptr(), stats[3].data_ptr(), stream()))
+                                          int(act), None, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
         arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
         # training: keep the BN input at every window's winner, so backward's dgamma/dbeta sums stream instead of gathering
         xwin = torch.empty_like(y) if training else None
-        check(lib.embnet_bn_act_maxpool_fwd(ptr(x), n, h, w, c, stats[2].data_ptr(), stats[3].data_ptr(), int(act), k,
+        check(lib.embnet_bn_act_maxpool_fwd(ptr(x), n, h, w, c, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), int(act), k,
                                             stride, pad, oh, ow, ptr(y), ptr(arg), ptr(xwin) if training else None, stream()))
         ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow, int(act), training, gamma is not None)
         if training:
@@ -714,12 +714,12 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
         ws = workspace(lib.embnet_bn_act_maxpool_bwd_workspace_bytes(n, oh, ow, c), x.device)
-        mean = stats[0].data_ptr() if training else None
-        rstd = stats[1].data_ptr() if training else None
+        mean = stats.data_ptr() if training else None
+        rstd = (stats.data_ptr() + 4 * stats.shape[1]) if training else None
         check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
-                                            stats[2].data_ptr(), stats[3].data_ptr(), act, int(training),
+                                            (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), act, int(training),
                                             ptr(xwin) if training else None, ptr(dx),
-                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(ws), ws.numel() * 4, stream()))
+                                            dgb.data_ptr(), (dgb.data_ptr() + 4 * dgb.shape[1]), ptr(ws), ws.numel() * 4, stream()))
         dgamma = dgb[0] if (has_gamma and ctx.needs_input_grad[1]) else None
         dbeta = dgb[1] if ctx.needs_input_grad[2] else None
         return (dx, dgamma, dbeta) + (None,) * 10
