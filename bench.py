@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="triplet step: do not capture the step into a HIP graph (N = 1)")
     ap.add_argument("--cpu-classes", type=int, default=4)
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -238,8 +239,11 @@ def main():
             opt.step()
             return loss.detach()
     else:
+        # one GPU: the step is captured into a HIP graph after its warm-up steps (the host needs 2-4 ms to enqueue a step;
+        # the small configs are otherwise host-bound); steps whose kernels are being timed run eagerly
         trainer = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin,
-                                 negatives_selection_mode=args.mining, seed=rank, reducer=reducer)
+                                 negatives_selection_mode=args.mining, seed=rank, reducer=reducer,
+                                 graph=(world == 1 and not args.no_graph))
         step = lambda: trainer.step(images)
 
     def barrier():

@@ -54,7 +54,7 @@ def lib():
         for name, (res, argtypes) in parse_header().items():
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, argtypes
-        if l.embnet_abi_version() != 6:
+        if l.embnet_abi_version() != 8:
             raise EmbnetError("libembnet_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -92,8 +92,17 @@ def f32(x):
 
 
 # ---- per-kernel timing (embnet_trace_*: HIP events inside the library around every kernel launch) ----------------
+_trace_on = False
+
+
 def trace_enable(on):
+    global _trace_on
+    _trace_on = bool(on)
     lib().embnet_trace_enable(int(bool(on)))
+
+
+def trace_is_enabled():
+    return _trace_on
 
 
 def trace_reset():

@@ -43,7 +43,7 @@ __device__ __forceinline__ float hinge_term(const float* a, const float* p, cons
 }
 
 struct FusedLossParams {
-  const float* emb; int n, p, k, e; float margin; int mode; uint64_t seed;
+  const float* emb; int n, p, k, e; float margin; int mode; uint64_t seed; const uint64_t* seed_dev;
   int* triplets; int* count; int* selected; float* loss; float* active; float* mean;
   int* ticket; float* pair_term;            // workspace: [1] arrival counter (zero between launches), [slots] hinge terms
   int max_t;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_triplet_loss_fwd_kernel(F
           total += __popcll(__ballot(pred));
         }
         if (total > 0) {
-          const uint32_t u = rng_u32(q.seed, (uint64_t)pair, 0);
+          const uint32_t u = rng_u32(q.seed_dev ? *q.seed_dev : q.seed, (uint64_t)pair, 0);
           const int want = (int)(((uint64_t)u * (uint64_t)total) >> 32);
           int cum = 0;
           for (int x0 = 0; x0 < nneg; x0 += 64) {
@@ -289,7 +289,8 @@ extern "C" size_t embnet_fused_loss_workspace_bytes(int p, int k) {
 }
 
 extern "C" int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int e, float margin, int mode,
-                                             uint64_t seed, int32_t* triplets, int32_t* count, int32_t* selected,
+                                             uint64_t seed, const uint64_t* seed_dev, int32_t* triplets, int32_t* count,
+                                             int32_t* selected,
                                              float* loss, float* active, float* mean_loss, void* workspace,
                                              size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(emb && triplets && count && selected && loss && active && mean_loss && workspace,
@@ -301,7 +302,7 @@ extern "C" int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int
     return fail(EMBNET_EWORKSPACE, "fused_triplet_loss_fwd: workspace %zu < %zu bytes", workspace_bytes,
                 embnet_fused_loss_workspace_bytes(p, k));
   const int n = p * k;
-  FusedLossParams q{emb, n, p, k, e, margin, mode, seed, triplets, count, selected, loss, active, mean_loss,
+  FusedLossParams q{emb, n, p, k, e, margin, mode, seed, seed_dev, triplets, count, selected, loss, active, mean_loss,
                     (int*)workspace, (float*)workspace + 4,
                     mode == EMBNET_MINE_BATCH_HARD ? n : embnet_mine_max_triplets(p, k)};
   EMBNET_TRACE("embnet::fused_triplet_loss_fwd_kernel", TRACE_BYTES, 4.0 * n * e * (p + 1.0), stream);

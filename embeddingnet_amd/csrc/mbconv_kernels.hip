@@ -550,7 +550,9 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restric
 
 // ---- per-sample drop-connect (Dropout with noise_shape (None,1,1,1)), inverted scaling ---------------
 __global__ __launch_bounds__(256) void sample_dropout_kernel(const float* __restrict__ x, long total, long per_sample,
-                                                             float rate, uint64_t seed, float* __restrict__ y) {
+                                                             float rate, uint64_t seed, const uint64_t* __restrict__ seed_add,
+                                                             float* __restrict__ y) {
+  if (seed_add) seed += *seed_add;
   const float keep_scale = 1.f / (1.f - rate);
   const uint32_t thr = (uint32_t)((double)rate * 4294967296.0);
   const long stride = (long)gridDim.x * 256;
@@ -747,11 +749,11 @@ extern "C" int embnet_channel_scale_bwd(const float* x, const float* s, const fl
   return check_launch("channel_scale_bwd");
 }
 
-extern "C" int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed, float* y,
-                                     void* stream) {
+extern "C" int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed,
+                                     const uint64_t* seed_add_dev, float* y, void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0 && per_sample > 0, "sample_dropout: bad argument");
   EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "sample_dropout: rate %f outside [0,1)", rate);
-  { EMBNET_TRACE("embnet::sample_dropout_kernel", TRACE_BYTES, 8.0 * total, stream); sample_dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, per_sample, rate, seed, y); }
+  { EMBNET_TRACE("embnet::sample_dropout_kernel", TRACE_BYTES, 8.0 * total, stream); sample_dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, per_sample, rate, seed, seed_add_dev, y); }
   return check_launch("sample_dropout");
 }
 

@@ -639,7 +639,8 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
 // inverted dropout with a counter-based mask: y = x * keep / (1-rate); the same (seed, index) gives
 // the same mask in backward.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long total, float rate,
-                                                      uint64_t seed, float* __restrict__ y) {
+                                                      uint64_t seed, const uint64_t* __restrict__ seed_add, float* __restrict__ y) {
+  if (seed_add) seed += *seed_add;                         // graph replays: the step count since capture, from device memory
   const float keep_scale = 1.f / (1.f - rate);
   const uint32_t thr = (uint32_t)((double)rate * 4294967296.0);
   const long stride = (long)gridDim.x * 256;
@@ -993,10 +994,11 @@ extern "C" int embnet_scale(const float* x, long total, float alpha, const float
   return check_launch("scale");
 }
 
-extern "C" int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream) {
+extern "C" int embnet_dropout(const float* x, long total, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* y,
+                              void* stream) {
   EMBNET_CHECK_ARG(x && y && total > 0, "dropout: bad argument");
   EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "dropout: rate %f outside [0,1)", rate);
-  { EMBNET_TRACE("embnet::dropout_kernel", TRACE_BYTES, 8.0 * total, stream); dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, y); }
+  { EMBNET_TRACE("embnet::dropout_kernel", TRACE_BYTES, 8.0 * total, stream); dropout_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(x, total, rate, seed, seed_add_dev, y); }
   return check_launch("dropout");
 }
 

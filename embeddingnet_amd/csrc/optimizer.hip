@@ -35,7 +35,10 @@ __device__ __forceinline__ void opt_update(float& w, float g, float& s1, float& 
 
 template <int RULE>
 __global__ __launch_bounds__(256) void opt_step_kernel(const OptTensor* __restrict__ table, const int* __restrict__ chunks,
-                                                       OptCoef k) {
+                                                       OptCoef k, const float* __restrict__ coef_dev) {
+  if (coef_dev) {                                          // step-dependent scalars from device memory: a captured graph replays
+    k.lr = coef_dev[0]; k.b1 = coef_dev[1]; k.b2 = coef_dev[2]; k.eps = coef_dev[3]; k.c1 = coef_dev[4]; k.c2 = coef_dev[5];
+  }
   const int ti = chunks[2 * blockIdx.x];
   const long first = (long)chunks[2 * blockIdx.x + 1] * OPT_CHUNK;
   const OptTensor t = table[ti];
@@ -76,7 +79,8 @@ using namespace embnet;
 extern "C" int embnet_optimizer_chunk_elems(void) { return OPT_CHUNK; }
 
 extern "C" int embnet_optimizer_step(int rule, const void* table, int n_tensors, const int32_t* chunks, int n_chunks,
-                                     float lr, float b1, float b2, float eps, float c1, float c2, void* stream) {
+                                     float lr, float b1, float b2, float eps, float c1, float c2, const float* coef_dev,
+                                     void* stream) {
   EMBNET_CHECK_ARG(table && chunks, "optimizer_step: null pointer");
   EMBNET_CHECK_ARG(n_tensors > 0 && n_chunks > 0, "optimizer_step: empty table");
   EMBNET_CHECK_ARG(rule >= EMBNET_OPT_SGD && rule <= EMBNET_OPT_RADAM_WARM, "optimizer_step: unknown rule %d", rule);
@@ -87,11 +91,11 @@ extern "C" int embnet_optimizer_step(int rule, const void* table, int n_tensors,
   EMBNET_TRACE("embnet::opt_step_kernel", TRACE_BYTES,
                4.0 * n_chunks * OPT_CHUNK * (rule == EMBNET_OPT_SGD ? 3 : (rule == EMBNET_OPT_RMSPROP ? 5 : 7)), s);
   switch (rule) {
-    case EMBNET_OPT_SGD: opt_step_kernel<EMBNET_OPT_SGD><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
-    case EMBNET_OPT_RMSPROP: opt_step_kernel<EMBNET_OPT_RMSPROP><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
-    case EMBNET_OPT_ADAM: opt_step_kernel<EMBNET_OPT_ADAM><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
-    case EMBNET_OPT_RADAM: opt_step_kernel<EMBNET_OPT_RADAM><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
-    default: opt_step_kernel<EMBNET_OPT_RADAM_WARM><<<n_chunks, 256, 0, s>>>(t, chunks, k); break;
+    case EMBNET_OPT_SGD: opt_step_kernel<EMBNET_OPT_SGD><<<n_chunks, 256, 0, s>>>(t, chunks, k, coef_dev); break;
+    case EMBNET_OPT_RMSPROP: opt_step_kernel<EMBNET_OPT_RMSPROP><<<n_chunks, 256, 0, s>>>(t, chunks, k, coef_dev); break;
+    case EMBNET_OPT_ADAM: opt_step_kernel<EMBNET_OPT_ADAM><<<n_chunks, 256, 0, s>>>(t, chunks, k, coef_dev); break;
+    case EMBNET_OPT_RADAM: opt_step_kernel<EMBNET_OPT_RADAM><<<n_chunks, 256, 0, s>>>(t, chunks, k, coef_dev); break;
+    default: opt_step_kernel<EMBNET_OPT_RADAM_WARM><<<n_chunks, 256, 0, s>>>(t, chunks, k, coef_dev); break;
   }
   return check_launch("optimizer_step");
 }

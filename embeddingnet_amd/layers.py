@@ -785,20 +785,26 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
+# Device address of a uint64 "steps since capture" counter while a training step is being captured into a HIP graph
+# (train_step.TripletTrainer sets it): the dropout kernels add it to their seed, so a replay draws the mask an eager
+# step would have drawn at that step.  None outside a capture.
+GRAPH_TICK = None
+
+
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rate, seed):
         x = _c(x)
         y = torch.empty_like(x)
-        check(_lib.lib().embnet_dropout(ptr(x), x.numel(), rate, seed, ptr(y), stream()))
-        ctx.rate, ctx.seed = rate, seed
+        ctx.rate, ctx.seed, ctx.tick = rate, seed, GRAPH_TICK
+        check(_lib.lib().embnet_dropout(ptr(x), x.numel(), rate, seed, ctx.tick, ptr(y), stream()))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        check(_lib.lib().embnet_dropout(ptr(dy), dy.numel(), ctx.rate, ctx.seed, ptr(dx), stream()))
+        check(_lib.lib().embnet_dropout(ptr(dy), dy.numel(), ctx.rate, ctx.seed, ctx.tick, ptr(dx), stream()))
         return dx, None, None
 
 
@@ -937,16 +943,17 @@ class _SampleDropoutFn(torch.autograd.Function):
         x = _c(x)
         y = torch.empty_like(x)
         per = x.numel() // x.shape[0]
-        check(_lib.lib().embnet_sample_dropout(ptr(x), x.numel(), per, rate, seed, ptr(y), stream()))
-        ctx.cfg = (rate, seed, per)
+        tick = GRAPH_TICK
+        check(_lib.lib().embnet_sample_dropout(ptr(x), x.numel(), per, rate, seed, tick, ptr(y), stream()))
+        ctx.cfg = (rate, seed, per, tick)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        rate, seed, per = ctx.cfg
+        rate, seed, per, tick = ctx.cfg
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        check(_lib.lib().embnet_sample_dropout(ptr(dy), dy.numel(), per, rate, seed, ptr(dx), stream()))
+        check(_lib.lib().embnet_sample_dropout(ptr(dy), dy.numel(), per, rate, seed, tick, ptr(dx), stream()))
         return dx, None, None
 
 

@@ -146,7 +146,7 @@ class _FusedTripletLoss(torch.autograd.Function):
     the gather form's (embnet_triplet_gather_bwd), since the outputs are the same."""
 
     @staticmethod
-    def forward(ctx, emb, p, k, margin, mode, seed):
+    def forward(ctx, emb, p, k, margin, mode, seed, seed_dev=None):
         emb = _prep(emb)
         n, e = emb.shape
         lib = _lib.lib()
@@ -156,11 +156,12 @@ class _FusedTripletLoss(torch.autograd.Function):
         count = _new((1,), emb, torch.int32)
         sel = _new((max(p * (k * (k - 1) // 2), 1),), emb, torch.int32)
         loss, act, mean = _new((rows,), emb), _new((rows,), emb), _new((), emb)
-        key = (emb.device.index, torch.cuda.current_stream().cuda_stream, p, k)
+        key = (emb.device.index, stream(), p, k)
         ws = _FUSED_WS.get(key)
         if ws is None:                                      # zero-filled once; the kernel re-arms its counter itself
             ws = _FUSED_WS[key] = torch.zeros(max(lib.embnet_fused_loss_workspace_bytes(p, k) // 4, 8), device=emb.device)
-        check(lib.embnet_fused_triplet_loss_fwd(ptr(emb), p, k, e, f32(margin), code, int(seed) & (2 ** 64 - 1), ptr(trip),
+        check(lib.embnet_fused_triplet_loss_fwd(ptr(emb), p, k, e, f32(margin), code, int(seed) & (2 ** 64 - 1),
+                                                seed_dev, ptr(trip),
                                                 ptr(count), ptr(sel), ptr(loss), ptr(act), ptr(mean), ptr(ws),
                                                 ws.numel() * 4, stream()))
         ctx.save_for_backward(emb, trip, count, act)
@@ -174,12 +175,13 @@ class _FusedTripletLoss(torch.autograd.Function):
         demb = torch.empty_like(emb)
         check(_lib.lib().embnet_triplet_gather_bwd(ptr(emb), n, e, ptr(trip), ptr(count), trip.shape[0], ptr(act),
                                                    ptr(_prep(dmean)), ptr(demb), stream()))
-        return demb, None, None, None, None, None
+        return demb, None, None, None, None, None, None
 
 
-def fused_triplet_loss(emb, k_classes, k_samples, margin, mode, seed=0):
-    """-> (mean loss [autograd], per-triplet losses, triplets [rows,3] int32, count [1] int32); one launch."""
-    return _FusedTripletLoss.apply(emb, int(k_classes), int(k_samples), float(margin), mode, int(seed))
+def fused_triplet_loss(emb, k_classes, k_samples, margin, mode, seed=0, seed_dev=None):
+    """-> (mean loss [autograd], per-triplet losses, triplets [rows,3] int32, count [1] int32); one launch.
+    seed_dev: device address of a uint64 seed that overrides `seed` (graph replays, see train_step.TripletTrainer)."""
+    return _FusedTripletLoss.apply(emb, int(k_classes), int(k_samples), float(margin), mode, int(seed), seed_dev)
 
 
 # --------------------------------------------------------------------------- contrastive / accuracy

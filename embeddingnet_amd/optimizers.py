@@ -36,6 +36,7 @@ class KerasOptimizer(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("one parameter group (the reference sets a single learning rate)")
         self._ptrs, self._table, self._chunks, self._host, self._copied = None, None, None, None, None
+        self.coef_dev = None         # device float[6] the kernel reads its scalars from (set by a graph-capturing trainer)
 
     # -- state ----------------------------------------------------------------------------
     def _slots(self, p):
@@ -94,10 +95,21 @@ class KerasOptimizer(torch.optim.Optimizer):
             ck = [(i, c) for i, p in enumerate(self._tensors) for c in range(-(-p.numel() // ce))]
             self._chunks = torch.tensor(ck, dtype=torch.int32, device=dev)
             self._host = torch.empty((len(rows), 5), dtype=torch.int64).pin_memory()
+        if torch.cuda.is_current_stream_capturing():
+            # a captured step keeps a table (and its pinned source) of its own: replays re-run the upload node, and eager
+            # steps in between must not rewrite what it copies from; no host wait is legal inside a capture either
+            host = getattr(self, "_graph_host", None)     # pinned memory cannot be allocated while capturing: prepare_capture()
+            if host is None or host.shape[0] != len(rows):
+                raise _lib.EmbnetError("KerasOptimizer: call prepare_capture() before capturing a step")
+            host.copy_(torch.from_numpy(np.asarray(rows, dtype=np.uint64).view(np.int64)))
             self._table = torch.empty((len(rows), 5), dtype=torch.int64, device=dev)
+            self._table.copy_(host, non_blocking=True)
+            self._ptrs = ptrs
+            return
         if self._copied is not None:
             self._copied.synchronize()                    # the previous upload still reads the pinned staging rows
         self._host.copy_(torch.from_numpy(np.asarray(rows, dtype=np.uint64).view(np.int64)))
+        self._table = torch.empty((len(rows), 5), dtype=torch.int64, device=dev)
         self._table.copy_(self._host, non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()
@@ -116,8 +128,22 @@ class KerasOptimizer(torch.optim.Optimizer):
         lr = float(self.param_groups[0]["lr"])
         rule, b1, b2, c1, c2 = self._coefficients(lr, self.iterations)
         check(_lib.lib().embnet_optimizer_step(rule, self._table.data_ptr(), len(self._tensors), self._chunks.data_ptr(),
-                                               self._chunks.shape[0], lr, b1, b2, self.eps, c1, c2, _lib.stream()))
+                                               self._chunks.shape[0], lr, b1, b2, self.eps, c1, c2,
+                                               self.coef_dev.data_ptr() if self.coef_dev is not None else None,
+                                               _lib.stream()))
         return loss
+
+    def prepare_capture(self):
+        """Allocate what a captured step() needs that cannot be allocated during stream capture."""
+        self._graph_host = torch.empty((len(self._tensors), 5), dtype=torch.int64).pin_memory()
+        self._ptrs = None                                  # the captured step builds (and keeps) its own table
+
+    def scalars(self, t):
+        """-> (kernel rule, [lr, b1, b2, eps, c1, c2]) of step t (1-based): what step() passes, for a caller that keeps
+        them in device memory (`coef_dev`) across graph replays."""
+        lr = float(self.param_groups[0]["lr"])
+        rule, b1, b2, c1, c2 = self._coefficients(lr, t)
+        return rule, [lr, b1, b2, self.eps, c1, c2]
 
 
 def SGD(params, lr):

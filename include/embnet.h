@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 6
+#define EMBNET_ABI_VERSION 8
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -273,7 +273,8 @@ int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, int k, int r,
 /* y[pixels,cout] = [x[pixels,cin] | 0]: widens 3-channel images to 4 channels for 16-byte stem gathers. */
 int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
-int embnet_dropout(const float* x, long total, float rate, uint64_t seed, float* y, void* stream);
+int embnet_dropout(const float* x, long total, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* y,
+                   void* stream);   /* seed_add_dev (NULL or device uint64): added to seed — a replayed HIP graph draws a new mask per step */
 /* ---- EfficientNet MBConv pieces (backbones.py:84-98, `efficientnet` zoo package) and the siamese 'l1' head ---- */
 /* DepthwiseConv2D: x[n,h,w,c], w[r,s,c] (Keras depthwise_kernel [r,s,c,1]), y[n,oh,ow,c]; padding as conv2d. */
 int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s,
@@ -292,8 +293,8 @@ int embnet_channel_scale_fwd(const float* x, const float* s, int n, int hw, int 
 int embnet_channel_scale_bwd(const float* x, const float* s, const float* dy, int n, int hw, int c, float* dx,
                              float* ds, void* stream);
 /* drop-connect: Dropout with noise_shape (None,1,1,1): one keep/drop decision per sample, inverted scaling. */
-int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed, float* y,
-                          void* stream);
+int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed,
+                          const uint64_t* seed_add_dev, float* y, void* stream);
 /* models.py:218 L1 layer: y = |a - b|. */
 int embnet_absdiff_fwd(const float* a, const float* b, long total, float* y, void* stream);
 int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long total, float* da, float* db,
@@ -313,12 +314,15 @@ int embnet_sumsq(const float* x, long total, float alpha, float* out, void* work
  * active[max_t], mean_loss), so embnet_triplet_gather_bwd is the backward of both.  batch-hard: T = N, one triplet per
  * anchor, `selected` unused; triplets/loss/active must hold N rows.
  * embnet_fused_loss_supported: 1 when N <= 512, k <= 16 and k*(e+N) floats fit 64 KiB of LDS.
- * workspace (embnet_fused_loss_workspace_bytes): zero-filled ONCE by the caller; every launch leaves its counter zeroed. */
+ * workspace (embnet_fused_loss_workspace_bytes): zero-filled ONCE by the caller; every launch leaves its counter zeroed.
+ * seed_dev (NULL or a device uint64): the seed of the random rules read from device memory instead of `seed`, so that
+ * a captured HIP graph of the training step draws new negatives at every replay. */
 int embnet_fused_loss_supported(int p, int k, int e);
 size_t embnet_fused_loss_workspace_bytes(int p, int k);
 int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int e, float margin, int mode, uint64_t seed,
-                                  int32_t* triplets, int32_t* count, int32_t* selected, float* loss, float* active,
-                                  float* mean_loss, void* workspace, size_t workspace_bytes, void* stream);
+                                  const uint64_t* seed_dev, int32_t* triplets, int32_t* count, int32_t* selected,
+                                  float* loss, float* active, float* mean_loss, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ------------------------------------------------------------------ optimizer update
  * utils.py:143-153 get_optimizer(name, lr): `Adam(lr)`, `RMSprop(lr)`, `keras_radam.RAdam(lr)`, else `SGD(lr)`
@@ -336,11 +340,13 @@ int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int e, float m
  *     EMBNET_OPT_ADAM        m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g^2;  w -= c1*m/(sqrt(v)+eps),      c1 = lr*sqrt(1-b2^t)/(1-b1^t)
  *     EMBNET_OPT_RADAM       m, v as Adam;  w -= c1*m/(sqrt(v*c2)+eps),    c1 = lr*r_t/(1-b1^t), c2 = 1/(1-b2^t)   (sma_t >= 5)
  *     EMBNET_OPT_RADAM_WARM  m, v as Adam;  w -= c1*m,                     c1 = lr/(1-b1^t)                          (sma_t < 5)
+ *   coef_dev (NULL or device float[6] = lr, b1, b2, eps, c1, c2): the scalars read from device memory instead of the
+ *           arguments — a captured HIP graph of the training step replays with the step count's current coefficients.
  * HBM-bound: 12 (SGD) .. 28 (Adam/RAdam) bytes per element. */
 enum { EMBNET_OPT_SGD = 0, EMBNET_OPT_RMSPROP = 1, EMBNET_OPT_ADAM = 2, EMBNET_OPT_RADAM = 3, EMBNET_OPT_RADAM_WARM = 4 };
 int embnet_optimizer_chunk_elems(void);
 int embnet_optimizer_step(int rule, const void* table, int n_tensors, const int32_t* chunks, int n_chunks,
-                          float lr, float b1, float b2, float eps, float c1, float c2, void* stream);
+                          float lr, float b1, float b2, float eps, float c1, float c2, const float* coef_dev, void* stream);
 
 #ifdef __cplusplus
 }

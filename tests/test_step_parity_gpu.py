@@ -379,3 +379,37 @@ def test_stage_activations_vs_oracle(dev, name, shape, enc, batch, training):
         assert err < 1e-4, f"{name} stage {s}: {err:.2e}"
     err = (emb.cpu().double() - want_emb).abs().max().item() / want_emb.abs().max().item()
     assert err < 1e-4, f"{name} embedding: {err:.2e}"
+
+
+@pytest.mark.parametrize("backbone,mode,optimizer", [("simple2", "semihard", "radam"), ("resnet18", "hardest", "adam")])
+def test_graph_replay_equals_eager_steps(backbone, mode, optimizer):
+    """TripletTrainer(graph=True): the step captured into a HIP graph and replayed (scalars of the optimizer and the
+    mining seed read from device memory) gives the same losses, triplets and weights, bit for bit, as eager steps —
+    including when eager steps are interleaved (bench.py times its kernels on eager steps)."""
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    dev = torch.device("cuda:0")
+    runs = []
+    for graph in (False, True):
+        base, _ = B.get_backbone((48, 48, 3), encodings_len=32, backbone_name=backbone, backbone_weights=None, seed=5, device=dev)
+        opt = KerasOptimizer([p for p in base.parameters() if p.requires_grad], optimizer, 1e-3)
+        tr = TripletTrainer(base, opt, 6, 3, margin=0.5, negatives_selection_mode=mode, seed=11, graph=graph)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        losses, counts = [], []
+        for i in range(20):
+            x = torch.rand((18, 48, 48, 3), device=dev, generator=gen)
+            if graph and i in (13, 17):
+                _lib.trace_enable(True)                     # forces an eager step between replays
+            losses.append(tr.step(x).clone())
+            _lib.trace_enable(False)
+            counts.append(tr.last_triplets[1].clone())
+        if graph:
+            assert tr._graph is not None, f"the step was not captured: failed={tr._graph_failed} {getattr(tr, '_graph_error', '')} supported={tr._graph_supported(x)}"
+        runs.append((torch.stack(losses), torch.stack(counts), torch.cat([p.detach().reshape(-1) for p in base.parameters()]).clone(),
+                     opt.iterations))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0] - runs[1][0]).abs().max()
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][2], runs[1][2])
+    assert runs[0][3] == runs[1][3] == 20
