@@ -252,7 +252,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    n_warm = args.warmup
+    if args.mode != "siamese" and getattr(trainer, "graph_mode", False):
+        n_warm = max(n_warm, trainer.GRAPH_WARMUP + 2)     # the capture itself (once, after GRAPH_WARMUP eager steps) stays untimed
+    for _ in range(n_warm):
         step()
     trace = rank == 0 and not args.no_kernel_timer
     if trace:
