@@ -13,11 +13,11 @@ python3 bench.py --mining batch_hard --steps 30 --no-cpu-baseline > "$out/bench_
 for c in c1 c3 c5; do
   python3 bench.py --config $c --steps 20 --warmup 5 --cpu-seconds 8 > "$out/bench_$c.json" 2> "$out/bench_$c.err"
 done
-CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph"
 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- $CMD > "$out/trace_bench.json" 2> "$out/trace.err"
 python3 tools/kernel_stats.py "$out"/trace/*/*_kernel_trace.csv 13 "$out/kernel_stats" \
     "rocprofv3 --kernel-trace of \`$CMD\` (13 steps in the trace)" > /dev/null
-PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer"
+PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-graph"
 for c in c2 c5; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- $PCMD --config $c > /dev/null 2> "$out/pmc_fetch_$c.err"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- $PCMD --config $c > /dev/null 2> "$out/pmc_write_$c.err"
