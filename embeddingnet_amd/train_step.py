@@ -34,6 +34,7 @@ class TripletTrainer:
     Needs: the KerasOptimizer, the fused loss path and no gradient reducer (N = 1); anything else, or a failed capture,
     falls back to eager steps.  Steps taken while the kernel trace is on run eagerly."""
     GRAPH_WARMUP = 8
+    # (last_triplets / last_total are the replayed step's own buffers in graph mode: read them before the next step)
 
     def __init__(self, base_model, optimizer, k_classes, k_samples, margin=0.5,
                  negatives_selection_mode="semihard", seed=0, reducer=None, graph=None):
@@ -150,7 +151,7 @@ class TripletTrainer:
         self._since_capture += 1
         self._graph.replay()
         self.last_triplets, self.last_total = self._g_last      # an eager step in between re-bound them
-        return self._gout
+        return self._gout.clone()                               # callers keep per-step losses; the graph's output is one buffer
 
     def step(self, images):
         from . import _lib
