@@ -610,6 +610,25 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
   dx[i] = dy[b * c + col] / (float)hw;
 }
 
+// dx = dx_add + dy/hw broadcast, four channels per thread: the pooled tensor's OTHER consumer (squeeze-and-excite: the
+// channel scaling) hands its gradient in and the sum is written once — no broadcast tensor, no accumulation pass
+__global__ __launch_bounds__(256) void gap_bwd_add4_kernel(const float* __restrict__ dy, const float* __restrict__ dx_add,
+                                                           long total4, int hw, int c4, float* __restrict__ dx) {
+  const float inv = 1.f / (float)hw;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int q = (int)(i % c4);
+    const long b = i / ((long)hw * c4);
+    const float4 g = reinterpret_cast<const float4*>(dy)[b * c4 + q];
+    float4 o = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    if (dx_add) {
+      const float4 a = reinterpret_cast<const float4*>(dx_add)[i];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+}
+
 // ---------------------------------------------------------------- elementwise
 // dz = dy * [y > 0];  optional column sums of dz -> bias gradient partials
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -957,8 +976,15 @@ extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, vo
   return check_launch("gap_fwd");
 }
 
-extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream) {
+extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream) {
   EMBNET_CHECK_ARG(dy && dx && n > 0 && hw > 0 && c > 0, "gap_bwd: bad argument");
+  EMBNET_CHECK_ARG(!dx_add || (c & 3) == 0, "gap_bwd: dx_add needs c %% 4 == 0 (got %d)", c);
+  if ((c & 3) == 0) {
+    const long total4 = (long)n * hw * (c / 4);
+    EMBNET_TRACE("embnet::gap_bwd_add4_kernel", TRACE_BYTES, (dx_add ? 8.0 : 4.0) * n * hw * c, stream);
+    gap_bwd_add4_kernel<<<ew_blocks(total4), 256, 0, S(stream)>>>(dy, dx_add, total4, hw, c / 4, dx);
+    return check_launch("gap_bwd");
+  }
   { EMBNET_TRACE("embnet::gap_bwd_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_bwd_kernel<<<cdiv((long)n * hw * c, 256), 256, 0, S(stream)>>>(dy, n, hw, c, dx); }
   return check_launch("gap_bwd");
 }

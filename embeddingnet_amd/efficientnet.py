@@ -81,7 +81,9 @@ class MBConv(nn.Module):
                 x = self.expand_conv(x, emit_stats=self.training)           # BN sums from the conv epilogue
             x = self.expand_bn(x)
         x = self.bn(self.dwconv(x))
-        s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(self.gap(x)))))
+        # x feeds the pooling and the scaling: the scaling's gradient is folded into the pooling's backward kernel
+        g, x = self.gap(x, with_skip=True)
+        s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(g))))
         x = L.channel_scale(x, s)
         x = self.project_bn(self.project_conv(x, emit_stats=self.training))
         if self.skip:

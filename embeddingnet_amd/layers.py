@@ -736,26 +736,36 @@ def bn_act_maxpool(x, bn, pool):
 
 class _GapFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, with_skip=False):
         x = _c(x)
         n, h, w, c = x.shape
         y = torch.empty((n, c), device=x.device, dtype=torch.float32)
         check(_lib.lib().embnet_gap_fwd(ptr(x), n, h * w, c, ptr(y), stream()))
         ctx.shape = (n, h, w, c)
+        if with_skip:                       # second output: x itself, for the tensor's other consumer (see backward)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
+        """dskip: gradient of the pass-through copy of x (with_skip) — added while the pooled gradient is broadcast,
+        instead of a broadcast tensor plus an autograd accumulation pass."""
         n, h, w, c = ctx.shape
         dy = _c(dy)
+        dskip = _c(dskip) if (dskip is not None and c % 4 == 0) else dskip
         dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
-        check(_lib.lib().embnet_gap_bwd(ptr(dy), n, h * w, c, ptr(dx), stream()))
-        return dx
+        fold = dskip is not None and c % 4 == 0
+        check(_lib.lib().embnet_gap_bwd(ptr(dy), n, h * w, c, ptr(dskip) if fold else None, ptr(dx), stream()))
+        if dskip is not None and not fold:
+            dx = dx + dskip
+        return dx, None
 
 
 class GlobalAveragePooling2D(nn.Module):
-    def forward(self, x):
-        return _GapFn.apply(x)
+    def forward(self, x, with_skip=False):
+        """with_skip=True: returns (gap(x), x) — hand the second value to x's other consumer (squeeze-and-excite: the
+        channel scaling), so that its gradient is added inside the pooling's backward kernel."""
+        return _GapFn.apply(x, with_skip)
 
 
 class Flatten(nn.Module):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 8
+#define EMBNET_ABI_VERSION 9
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -249,7 +249,8 @@ int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const floa
 
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);
-int embnet_gap_bwd(const float* dy, int n, int hw, int c, float* dx, void* stream);
+int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream);   /* dx_add (NULL or
+    [n,hw,c], c % 4 == 0): gradient of x's other consumer, summed in the same pass */
 
 /* Elementwise helpers of the backward pass and the residual blocks. */
 int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void* stream);   /* dz = dy*[y>0] */
