@@ -381,7 +381,8 @@ def test_stage_activations_vs_oracle(dev, name, shape, enc, batch, training):
     assert err < 1e-4, f"{name} embedding: {err:.2e}"
 
 
-@pytest.mark.parametrize("backbone,mode,optimizer", [("simple2", "semihard", "radam"), ("resnet18", "hardest", "adam")])
+@pytest.mark.parametrize("backbone,mode,optimizer", [("simple2", "semihard", "radam"), ("resnet18", "hardest", "adam"),
+                                                     ("efficientnet-b0", "random_hard", "rms_prop")])   # drop-connect seeds
 def test_graph_replay_equals_eager_steps(backbone, mode, optimizer):
     """TripletTrainer(graph=True): the step captured into a HIP graph and replayed (scalars of the optimizer and the
     mining seed read from device memory) gives the same losses, triplets and weights, bit for bit, as eager steps —
@@ -405,6 +406,9 @@ def test_graph_replay_equals_eager_steps(backbone, mode, optimizer):
             losses.append(tr.step(x).clone())
             _lib.trace_enable(False)
             counts.append(tr.last_triplets[1].clone())
+        if backbone == "efficientnet-b0":
+            from embeddingnet_amd import layers as L
+            assert any(isinstance(m, L.DropConnect) and m.rate > 0 and m._step > 0 for m in base.modules())
         if graph:
             assert tr._graph is not None, f"the step was not captured: failed={tr._graph_failed} {getattr(tr, '_graph_error', '')} supported={tr._graph_supported(x)}"
         runs.append((torch.stack(losses), torch.stack(counts), torch.cat([p.detach().reshape(-1) for p in base.parameters()]).clone(),
