@@ -243,7 +243,7 @@ def main():
         # the small configs are otherwise host-bound); steps whose kernels are being timed run eagerly
         trainer = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin,
                                  negatives_selection_mode=args.mining, seed=rank, reducer=reducer,
-                                 graph=(world == 1 and not args.no_graph))
+                                 graph=("auto" if (world == 1 and not args.no_graph) else False))
         step = lambda: trainer.step(images)
 
     def barrier():
@@ -254,17 +254,20 @@ def main():
 
     n_warm = args.warmup
     if args.mode != "siamese" and getattr(trainer, "graph_mode", False):
-        n_warm = max(n_warm, trainer.GRAPH_WARMUP + 2)     # the capture itself (once, after GRAPH_WARMUP eager steps) stays untimed
+        n_warm = max(n_warm, trainer.GRAPH_WARMUP + 8)     # the probe + capture (once, after GRAPH_WARMUP eager steps) stay untimed
     for _ in range(n_warm):
         step()
     trace = rank == 0 and not args.no_kernel_timer
+    # kernels are timed on every 4th step; with the step replayed as a HIP graph those steps run eagerly (host-bound on
+    # the small configs), so every 8th
+    every = 8 if (args.mode != "siamese" and getattr(trainer, "_graph", None) is not None) else 4
     if trace:
         _lib.trace_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if trace:          # ~250 event pairs per traced step: kept to every 4th step so they cost < 2 % of the timed region
-            _lib.trace_enable(i % 4 == 0)
+            _lib.trace_enable(i % every == 0)
         loss = step()
     host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # time to ENQUEUE a step (the host runs ahead of the GPU)
     barrier()
@@ -279,10 +282,14 @@ def main():
     if rank != 0:
         return
 
+    if args.mode != "siamese":
+        log(f"  step mode: {'HIP graph replay' if getattr(trainer, '_graph', None) is not None else 'eager'}"
+            + (f" (capture failed: {trainer._graph_error})" if getattr(trainer, "_graph_failed", False) else "")
+            + (f"  probe: {trainer.graph_probe}" if getattr(trainer, "graph_probe", None) else ""))
     log(f"  host enqueue {host_ms:.2f} ms/step, step {ms_per_step:.2f} ms ({'GPU' if host_ms < 0.9 * ms_per_step else 'host'}-bound)")
     roofline = None
     if trace:
-        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + 3) // 4, ms_per_step, args.config,
+        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + every - 1) // every, ms_per_step, args.config,
                                           _lib.lib().embnet_conv_mfma_terms())
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /

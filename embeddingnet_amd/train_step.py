@@ -33,12 +33,13 @@ class TripletTrainer:
     each replay (dropout layers add a device-side step counter to their seeds); results are bit-identical to eager steps.
     Needs: the KerasOptimizer, the fused loss path and no gradient reducer (N = 1); anything else, or a failed capture,
     falls back to eager steps.  Steps taken while the kernel trace is on run eagerly."""
-    GRAPH_WARMUP = 8
+    GRAPH_WARMUP = 8          # graph='auto' decides here: see _probe
     # (last_triplets / last_total are the replayed step's own buffers in graph mode: read them before the next step)
 
     def __init__(self, base_model, optimizer, k_classes, k_samples, margin=0.5,
                  negatives_selection_mode="semihard", seed=0, reducer=None, graph=None):
-        self.graph_mode = (os.environ.get("EMBNET_GRAPH", "0") == "1") if graph is None else bool(graph)
+        env = os.environ.get("EMBNET_GRAPH", "0")
+        self.graph_mode = ({"1": True, "auto": "auto"}.get(env, False)) if graph is None else (graph if graph == "auto" else bool(graph))
         self._graph, self._graph_failed = None, False
         self.model, self.opt = base_model, optimizer
         self.p, self.k, self.margin, self.mode = int(k_classes), int(k_samples), float(margin), negatives_selection_mode
@@ -153,15 +154,53 @@ class TripletTrainer:
         self.last_triplets, self.last_total = self._g_last      # an eager step in between re-bound them
         return self._gout.clone()                               # callers keep per-step losses; the graph's output is one buffer
 
+    def _probe(self, images):
+        """graph='auto': three eager steps timed on the host (enqueue only) and on the device.  A step whose launches the
+        host enqueues in well under its device time gains nothing from a graph; otherwise the step is captured and three
+        replays are timed against the eager steps — the graph stays only if it is not slower (the replayed step works in
+        a memory pool of its own, and HBM-bound networks have measured up to 1.5x slower in an unlucky one)."""
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); host = 0.0
+        for _ in range(3):
+            h0 = time.perf_counter()
+            self._plain_step(images)
+            host += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / 3
+        self.graph_probe = dict(eager_ms=1e3 * eager, host_ms=1e3 * host / 3)
+        if host / 3 < 0.8 * eager or not self._graph_supported(images):
+            self.graph_mode = False                              # GPU-bound as it is
+            return
+        self._capture(images)
+        if self._graph is None:
+            return
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            self._replay(images)
+        torch.cuda.synchronize()
+        replay = (time.perf_counter() - t0) / 3
+        self.graph_probe["replay_ms"] = 1e3 * replay
+        if replay > 0.97 * eager:                                # no gain: stay eager
+            self._graph, self.graph_mode = None, False
+            self.opt.coef_dev = None
+
     def step(self, images):
         from . import _lib
         if self.graph_mode and not self._graph_failed and not _lib.trace_is_enabled():
             if self._graph is not None and images.shape == self._gx.shape:
                 return self._replay(images)
-            if self._graph is None and self.step_no >= self.GRAPH_WARMUP and self._graph_supported(images):
-                self._capture(images)
-                if self._graph is not None:
+            if self._graph is None and self.step_no >= self.GRAPH_WARMUP:
+                if self.graph_mode == "auto":
+                    self._probe(images)
+                elif self._graph_supported(images):
+                    self._capture(images)
+                if self._graph is not None and images.shape == self._gx.shape:
                     return self._replay(images)
+        return self._plain_step(images)
+
+    def _plain_step(self, images):
         has = hasattr(self.opt, "coef_dev")                   # eager steps pass their scalars by value
         saved = self.opt.coef_dev if has else None
         if has:
