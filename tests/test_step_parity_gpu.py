@@ -417,3 +417,23 @@ def test_graph_replay_equals_eager_steps(backbone, mode, optimizer):
     assert torch.equal(runs[0][1], runs[1][1])
     assert torch.equal(runs[0][2], runs[1][2])
     assert runs[0][3] == runs[1][3] == 20
+
+
+def test_graph_auto_probe_picks_a_mode_and_keeps_training():
+    """graph='auto' (bench.py's default at N = 1): after the warm-up steps the trainer times eager steps on the host and
+    on the device, captures the step only if the host is the limiter, keeps the graph only if its replays are faster,
+    and trains on either way."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    dev = torch.device("cuda:0")
+    base, _ = B.get_backbone((48, 48, 3), encodings_len=32, backbone_name="simple2", backbone_weights=None, seed=5, device=dev)
+    opt = KerasOptimizer([p for p in base.parameters() if p.requires_grad], "adam", 1e-3)
+    tr = TripletTrainer(base, opt, 6, 3, margin=0.5, negatives_selection_mode="hardest", seed=2, graph="auto")
+    gen = torch.Generator(device=dev).manual_seed(1)
+    losses = [tr.step(torch.rand((18, 48, 48, 3), device=dev, generator=gen)).item() for _ in range(24)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert tr.graph_probe["eager_ms"] > 0 and tr.graph_probe["host_ms"] > 0
+    assert (tr._graph is not None) == (tr.graph_mode == "auto")          # a dropped graph leaves eager mode behind
+    if tr._graph is not None:
+        assert tr.graph_probe["replay_ms"] <= 0.97 * tr.graph_probe["eager_ms"]
