@@ -14,9 +14,12 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(16))) float f16_t;
 
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef NW
+#define NW 4                                   // waves per workgroup: 4 -> 128 x 128 tile, 8 -> 256 x 128 (each wave 64 x 64)
+#endif
+constexpr int BM = 32 * NW, BN = 128, BK = 32, NT = 64 * NW;
 constexpr int PITCH = 80;                      // bytes per 32-k bf16 row: 64 + 16 pad, 16-byte fragment reads conflict-free
-constexpr int PLANE = 128 * PITCH;
+constexpr int PLANE_A = BM * PITCH, PLANE_B = BN * PITCH;
 
 __device__ __forceinline__ uint32_t hi_pair(uint32_t a, uint32_t b) {      // {bf16 trunc(a), bf16 trunc(b)}
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
@@ -54,33 +57,44 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uin
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_split(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_split(const float* __restrict__ A, const float* __restrict__ B,
                                                           float* __restrict__ C, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE_A + 3 * PLANE_B];
+  unsigned char* ldsB = lds + 3 * PLANE_A;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int r = lane & 31, h = lane >> 5;
-  float4 ra[4], rb[4];
+  constexpr int PA = BM * 8 / NT, PB = BN * 8 / NT;
+  float4 ra[PA], rb[PB];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i, row = f >> 3, kq = f & 7;
+    for (int i = 0; i < PA; ++i) {
+      const int f = tid + NT * i, row = f >> 3, kq = f & 7;
       ra[i] = *reinterpret_cast<const float4*>(A + (long)(m0 + row) * K + kt * BK + kq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int f = tid + NT * i, row = f >> 3, kq = f & 7;
       rb[i] = *reinterpret_cast<const float4*>(B + (long)(n0 + row) * K + kt * BK + kq * 4);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i, row = f >> 3, kq = f & 7;
+    for (int i = 0; i < PA; ++i) {
+      const int f = tid + NT * i, row = f >> 3, kq = f & 7;
       uint2 p1, p2, p3;
       split4(ra[i], p1, p2, p3);
       unsigned char* d = lds + row * PITCH + kq * 8;
-      *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + PLANE) = p2; *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+      *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + PLANE_A) = p2; *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = p3;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int f = tid + NT * i, row = f >> 3, kq = f & 7;
+      uint2 p1, p2, p3;
       split4(rb[i], p1, p2, p3);
-      d += 3 * PLANE;
-      *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + PLANE) = p2; *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+      unsigned char* d = ldsB + row * PITCH + kq * 8;
+      *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + PLANE_B) = p2; *reinterpret_cast<uint2*>(d + 2 * PLANE_B) = p3;
     }
   };
   f16_t acc[2][2];
@@ -103,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_split(const float* __restric
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          a[i][p] = *reinterpret_cast<const bf8_t*>(lds + p * PLANE + (wm * 64 + i * 32 + r) * PITCH + (2 * s + h) * 16);
-          b[i][p] = *reinterpret_cast<const bf8_t*>(lds + (3 + p) * PLANE + (wn * 64 + i * 32 + r) * PITCH + (2 * s + h) * 16);
+          a[i][p] = *reinterpret_cast<const bf8_t*>(lds + p * PLANE_A + (wm * 64 + i * 32 + r) * PITCH + (2 * s + h) * 16);
+          b[i][p] = *reinterpret_cast<const bf8_t*>(ldsB + p * PLANE_B + (wn * 64 + i * 32 + r) * PITCH + (2 * s + h) * 16);
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -145,7 +159,7 @@ template <int TERMS>
 static void run(int M, int N, int K, const float* dA, const float* dB, float* dC, const std::vector<float>& hA,
                 const std::vector<float>& hB) {
   dim3 grid(N / BN, M / BM);
-  gemm_bf16_split<TERMS><<<grid, 256>>>(dA, dB, dC, M, N, K);
+  gemm_bf16_split<TERMS><<<grid, NT>>>(dA, dB, dC, M, N, K);
   CK(hipDeviceSynchronize());
   std::vector<float> hC((size_t)M * N);
   CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
@@ -163,10 +177,10 @@ static void run(int M, int N, int K, const float* dA, const float* dB, float* dC
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 20; ++w) gemm_bf16_split<TERMS><<<grid, 256>>>(dA, dB, dC, M, N, K);
+  for (int w = 0; w < 20; ++w) gemm_bf16_split<TERMS><<<grid, NT>>>(dA, dB, dC, M, N, K);
   const int it = 30;
   CK(hipEventRecord(e0));
-  for (int w = 0; w < it; ++w) gemm_bf16_split<TERMS><<<grid, 256>>>(dA, dB, dC, M, N, K);
+  for (int w = 0; w < it; ++w) gemm_bf16_split<TERMS><<<grid, NT>>>(dA, dB, dC, M, N, K);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
