@@ -142,6 +142,8 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * accumulation; each fp32 product is formed on the bf16 matrix instruction from an EXACT three-way split of both
  * operands (x = x1 + x2 + x3, six of the nine cross terms; the three dropped are <= 2^-24 |x||y|), which measures
  * no further from an fp64 reference than the fp32 MFMA's fma chain and runs at 16/6 of its rate.
+ * The pieces keep fp32's exponent range (no overflow / underflow beyond fp32's own); an INFINITE operand yields NaN where an
+ * fp32 product would yield inf (inf - inf inside the split) — training has diverged by then either way.
  * embnet_conv_mfma_terms() = bf16 MFMA terms per product in this build (6), or 1 for a build on v_mfma_f32_32x32x2_f32.
  * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
  * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its

@@ -660,3 +660,29 @@ def test_tap_border_sums_against_brute_force(dev, geom):
                                           ws.numel() * 4, _lib.stream()))
     got = taps.cpu().double().numpy()
     assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0), (got - want)
+
+
+def test_conv2d_split_arithmetic_extreme_magnitudes(dev):
+    """The bf16 pieces of the conv kernels' operand split keep fp32's exponent range: activations around 1e-30 and
+    weights around 1e+25 (products around 1e-5), and the reverse, come out as accurately as ordinary magnitudes; zeros
+    and negative zeros stay exact.  (An infinite operand gives NaN, not inf: inf - inf in the split — documented.)"""
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(9)
+    layer = L.Conv2D(64, 64, 3, padding=1, use_bias=False).to(dev)
+    for sx, sw in ((1e-30, 1e25), (1e25, 1e-30), (1.0, 1.0)):
+        x = (rs.randn(2, 10, 10, 64) * sx).astype(np.float32)
+        x[0, :3] = 0.0
+        x[1, 5] = -0.0
+        w = (rs.randn(3, 3, 64, 64) * sw).astype(np.float32)
+        with torch.no_grad():
+            layer.kernel.copy_(g(w, dev))
+        y = layer(g(x, dev)).detach().cpu().double().numpy()
+        ref = F.conv2d(torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1),
+                       padding=1).permute(0, 2, 3, 1).numpy()
+        mag = F.conv2d(torch.tensor(np.abs(x), dtype=torch.float64).permute(0, 3, 1, 2),
+                       torch.tensor(np.abs(w), dtype=torch.float64).permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1).numpy()
+        assert np.isfinite(y).all()
+        assert (np.abs(y - ref) / np.maximum(mag, 1e-300)).max() <= 1e-6, (sx, sw)
+    with torch.no_grad():
+        layer.kernel.zero_()
+    assert torch.count_nonzero(layer(g(x, dev))) == 0
