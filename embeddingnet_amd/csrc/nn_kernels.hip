@@ -590,6 +590,43 @@ __global__ __launch_bounds__(256) void gap_fwd4_kernel(const float* __restrict__
   }
 }
 
+// BatchNorm apply (+ activation) and GlobalAveragePooling of the result in one pass: y = act(x*scale + shift) is written
+// and its per-image channel means come out of the same read (squeeze-and-excite pools the tensor it then scales).
+// Same decomposition as gap_fwd4_kernel (16 channel quads x 16 pixel lanes per workgroup, grid = (c4/16, n)); four
+// pixels per trip so four loads are in flight per lane.
+__global__ __launch_bounds__(256) void affine_act_gap4_kernel(const float* __restrict__ x, int hw, int c4,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              int act, float* __restrict__ y, float* __restrict__ gap) {
+  __shared__ float4 sh[256];
+  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cq = blockIdx.x * 16 + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq < c4) {
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sf = reinterpret_cast<const float4*>(shift)[cq];
+    const float4* xi = reinterpret_cast<const float4*>(x) + (long)n * hw * c4 + cq;
+    float4* yi = reinterpret_cast<float4*>(y) + (long)n * hw * c4 + cq;
+    auto one = [&](const float4 v, int p) {
+      float4 o = make_float4(fmaf(v.x, sc.x, sf.x), fmaf(v.y, sc.y, sf.y), fmaf(v.z, sc.z, sf.z), fmaf(v.w, sc.w, sf.w));
+      if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
+      yi[(long)p * c4] = o;
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    };
+    int p = pl;
+    for (; p + 48 < hw; p += 64) {
+      const float4 v0 = xi[(long)p * c4], v1 = xi[(long)(p + 16) * c4], v2 = xi[(long)(p + 32) * c4], v3 = xi[(long)(p + 48) * c4];
+      one(v0, p); one(v1, p + 16); one(v2, p + 32); one(v3, p + 48);
+    }
+    for (; p < hw; p += 16) one(xi[(long)p * c4], p);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && cq < c4) {
+    for (int k = 1; k < 16; ++k) { const float4 o = sh[k * 16 + cl]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    const float inv = 1.f / (float)hw;
+    reinterpret_cast<float4*>(gap)[(long)n * c4 + cq] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int n, int hw, int c,
                                                       float* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -974,6 +1011,15 @@ extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, vo
   if ((c & 3) == 0) { EMBNET_TRACE("embnet::gap_fwd4_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_fwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, y); }
   else { EMBNET_TRACE("embnet::gap_fwd_kernel", TRACE_BYTES, 4.0 * n * hw * c, stream); gap_fwd_kernel<<<cdiv((long)n * c, 256), 256, 0, S(stream)>>>(x, n, hw, c, y); }
   return check_launch("gap_fwd");
+}
+
+extern "C" int embnet_affine_act_gap(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act,
+                                     float* y, float* gap, void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && y && gap && n > 0 && hw > 0 && c > 0, "affine_act_gap: bad argument");
+  EMBNET_CHECK_ARG((c & 3) == 0, "affine_act_gap: channel count %d not a multiple of 4", c);
+  EMBNET_TRACE("embnet::affine_act_gap4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream);
+  affine_act_gap4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, scale, shift, act, y, gap);
+  return check_launch("affine_act_gap");
 }
 
 extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream) {

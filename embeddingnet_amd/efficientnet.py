@@ -80,9 +80,9 @@ class MBConv(nn.Module):
             else:
                 x = self.expand_conv(x, emit_stats=self.training)           # BN sums from the conv epilogue
             x = self.expand_bn(x)
-        x = self.bn(self.dwconv(x))
-        # x feeds the pooling and the scaling: the scaling's gradient is folded into the pooling's backward kernel
-        g, x = self.gap(x, with_skip=True)
+        # BN + swish and the squeeze-and-excite pooling of its output in one pass; in backward the pooled gradient is
+        # broadcast into the scaling's gradient by one kernel (no accumulation pass)
+        x, g = self.bn(self.dwconv(x), emit_gap=True)
         s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(g))))
         x = L.channel_scale(x, s)
         x = self.project_bn(self.project_conv(x, emit_stats=self.training))

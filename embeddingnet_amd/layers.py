@@ -431,6 +431,55 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class _BNGapFn(torch.autograd.Function):
+    """BatchNormalization (+ activation) that also returns the GlobalAveragePooling of its output, from the same pass
+    (embnet_affine_act_gap): the squeeze-and-excite block pools the tensor this layer writes.  Training or inference
+    statistics as _BatchNormFn; the pooled gradient is broadcast into dy in one kernel before the usual BN backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, partials=None):
+        x = _c(x)
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        if training:
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
+        else:
+            check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
+                                          int(act), None, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), stream()))
+        y = torch.empty_like(x)
+        g = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        check(lib.embnet_affine_act_gap(ptr(x), n, m // n, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(act),
+                                        ptr(y), ptr(g), stream()))
+        ctx.relu, ctx.training, ctx.has_gamma = act, training, gamma is not None
+        ctx.save_for_backward(x, stats)
+        return y, g
+
+    @staticmethod
+    def backward(ctx, dy, dg):
+        x, stats = ctx.saved_tensors
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        dy = _c(dy)
+        if dg is not None:                                  # d(output) = dy + dg / hw, written once
+            dz = torch.empty_like(dy)
+            check(lib.embnet_gap_bwd(ptr(_c(dg)), n, m // n, c, ptr(dy), ptr(dz), stream()))
+            dy = dz
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+        mean = stats.data_ptr() if ctx.training else None
+        rstd = (stats.data_ptr() + 4 * c) if ctx.training else None
+        check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
+                                int(ctx.relu), int(ctx.training), None, ptr(dx), dgb.data_ptr(),
+                                (dgb.data_ptr() + 4 * c), ptr(ws), ws.numel() * 4, stream()))
+        dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
+        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
 class Deferred:
     """A BatchNormalization(+activation) output that has not been written.  `raw` is the BN's input (as an
     autograd alias whose gradient is the gradient of the BN OUTPUT), `stats` [4,C] = mean, rstd, scale, shift,
@@ -515,11 +564,18 @@ class BatchNormalization(nn.Module):
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
 
-    def forward(self, x, defer=False, with_skip=False):
-        """defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
+    def forward(self, x, defer=False, with_skip=False, emit_gap=False):
+        """emit_gap=True (C % 4 == 0): returns (bn(x), GlobalAveragePooling2D(bn(x))) from one pass over the tensor.
+        defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
         affine + activation while gathering their input, and the normalised tensor is never written.
         with_skip=True: returns (bn(x), x) — use the second value for the identity shortcut that also consumes x,
         so that its gradient is added inside the BN backward kernel instead of by an autograd accumulation pass."""
+        if emit_gap:
+            if x.dim() == 4 and x.shape[-1] % 4 == 0:
+                return _BNGapFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                      self.momentum, self.relu, self.training, _partials_of(x, self.training))
+            y = self.forward(x)
+            return y, _GapFn.apply(y)
         if with_skip and not defer:
             return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                       self.momentum, self.relu, self.training, _partials_of(x, self.training), True)

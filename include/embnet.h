@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 9
+#define EMBNET_ABI_VERSION 10
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -250,6 +250,10 @@ int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const floa
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
+/* act(x*scale + shift) -> y AND its per-image channel means -> gap[n,c], one pass (the BatchNormalization + swish in front
+ * of a squeeze-and-excite block, whose pooling reads what the BN writes); scale/shift from embnet_bn_train_fwd(y = NULL). */
+int embnet_affine_act_gap(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act, float* y,
+                          float* gap, void* stream);
 int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);
 int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream);   /* dx_add (NULL or
     [n,hw,c], c % 4 == 0): gradient of x's other consumer, summed in the same pass */

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
-    assert bound.embnet_abi_version() == 9
+    assert bound.embnet_abi_version() == 10
     assert bound.embnet_mine_max_triplets(32, 4) == 192
     assert bound.embnet_pairwise_workspace_bytes(128) == 512
 
