@@ -14,30 +14,11 @@
 // an out-of-range offset and read as 0 (gemm_engine.h).  VEC = 16-byte gathers (channel count % 4 == 0).
 // Roofline: MFMA f32 (157.3 TFLOP/s); algorithmic FLOP = 2 * N*OH*OW * K * R*S*C per pass.
 #include "gemm_engine.h"
+#include "conv_geom.h"
 #include "../../include/embnet.h"
 #include <stdlib.h>
 
 namespace embnet {
-
-struct FastDiv {           // exact n / d for 0 <= n < 2^31, d >= 1
-  uint32_t mul, shift, d;
-  static FastDiv make(uint32_t d) {
-    FastDiv f; f.d = d;
-    uint32_t s = 0; while ((1ull << s) < d) ++s;
-    f.shift = s;
-    f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
-    return f;
-  }
-  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, mul) + n) >> shift; }
-  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
-};
-
-struct ConvGeom {
-  int N, H, W, C, R, S, K, stride, pad_t, pad_l, OH, OW;
-  FastDiv dOHW, dOW, dHW, dW, dC, dK, dS;
-};
-
-constexpr int ROW_INVALID = -(1 << 28);
 
 // Optional per-channel transform of the conv INPUT, applied in registers between the gather and LDS:
 // a = act(x*scale[c] + shift[c]) — the BatchNormalization(+activation) in front of the conv — so the
@@ -54,13 +35,6 @@ __device__ __forceinline__ float4 transform4(float4 v, bool ok, const float4& sc
   return ok ? z : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-
-// gemm-k index kk -> (r, s, inner) with `dinner` the divider of the inner size (C for fwd, K for dgrad)
-__device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const FastDiv& dS, int& r, int& s, int& c) {
-  uint32_t rs, cc; dinner.divmod((uint32_t)kk, rs, cc);
-  uint32_t rr, ss; dS.divmod(rs, rr, ss);
-  r = (int)rr; s = (int)ss; c = (int)cc;
-}
 
 // ---- forward A: rows = output pixels, k = (r,s,c) -------------------------------------------
 template <int ROWS, bool VEC, bool TF = false>
@@ -658,23 +632,6 @@ extern "C" int embnet_debug_set_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(embnet::g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
-
-static int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int k, int stride, int pad_t,
-                     int pad_l, int oh, int ow, const char* who) {
-  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && r > 0 && s > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0,
-                   "%s: non-positive dimension", who);
-  EMBNET_CHECK_ARG(pad_t >= 0 && pad_l >= 0, "%s: negative padding", who);
-  EMBNET_CHECK_ARG((oh - 1) * stride + 1 - pad_t <= h && (ow - 1) * stride + 1 - pad_l <= w,
-                   "%s: output %dx%d reaches outside the %dx%d input", who, oh, ow, h, w);
-  EMBNET_CHECK_ARG((size_t)n * h * w * c * 4 <= MAX_OPERAND_BYTES && (size_t)n * oh * ow * k * 4 <= MAX_OPERAND_BYTES &&
-                   (size_t)r * s * c * k * 4 <= MAX_OPERAND_BYTES,
-                   "%s: a tensor exceeds 2 GiB (buffer-addressed operands): split the batch", who);
-  g.N = n; g.H = h; g.W = w; g.C = c; g.R = r; g.S = s; g.K = k; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
-  g.OH = oh; g.OW = ow;
-  g.dOHW = FastDiv::make(oh * ow); g.dOW = FastDiv::make(ow); g.dHW = FastDiv::make(h * w); g.dW = FastDiv::make(w);
-  g.dC = FastDiv::make(c); g.dK = FastDiv::make(k); g.dS = FastDiv::make(s);
-  return 0;
-}
 
 using G128x128 = Geom<128, 128, 2, 2>;
 using G128x64 = Geom<128, 64, 2, 2>;
