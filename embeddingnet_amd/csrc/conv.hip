@@ -15,6 +15,9 @@
 // Roofline: MFMA f32 (157.3 TFLOP/s); algorithmic FLOP = 2 * N*OH*OW * K * R*S*C per pass.
 #include "gemm_engine.h"
 #include "conv_geom.h"
+#ifndef EMBNET_EXP_HOOKS
+#define EMBNET_EXP_HOOKS 0
+#endif
 #include "../../include/embnet.h"
 #include <stdlib.h>
 
@@ -622,6 +625,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }  // namespace embnet
 
 using namespace embnet;
+
+#if EMBNET_EXP_HOOKS       // experiment builds only (tools/exp/conv_planes.hip)
+// host helper for conv_planes.hip: the fix-up pass over `rem` left-over tiles cut into `parts` partial tiles (SplitTail)
+namespace embnet {
+void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
+                       const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
+                       hipStream_t st) {
+  EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (parts + 1 + (residual ? 1 : 0)), st);
+  tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(ws, parts, bm, bn, wtm, n_full, tiles_n, m, cols, bias, relu,
+                                                           residual, out, stats, stats_rows);
+}
+}  // namespace embnet
+#endif
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -1,4 +1,4 @@
-// Convolution geometry shared by the implicit-GEMM kernels (conv.hip, conv_planes.hip).
+// Convolution geometry of the implicit-GEMM kernels (conv.hip; also used by the experiment tools/exp/conv_planes.hip).
 #pragma once
 #include "common.h"
 
@@ -32,6 +32,11 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
   uint32_t rr, ss; dS.divmod(rs, rr, ss);
   r = (int)rr; s = (int)ss; c = (int)cc;
 }
+
+// conv.hip, experiment builds (-DEMBNET_EXP_HOOKS=1): fix-up pass over left-over tiles computed as K-split partial tiles
+void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
+                       const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
+                       hipStream_t st);
 
 inline int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int k, int stride, int pad_t,
                      int pad_l, int oh, int ow, const char* who) {

@@ -35,9 +35,12 @@ def main():
     vp = ctypes.c_void_p
     l.embnet_split_planes_f32.argtypes = [vp, ctypes.c_long, vp, vp]
     l.embnet_conv2d_fwd_planes.argtypes = [vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, ctypes.c_int, vp]
+    l.embnet_prep_weight_planes.argtypes = [vp] + [ctypes.c_int] * 5 + [vp, vp]
+    l.embnet_conv2d_patch_planes.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, vp, ctypes.c_size_t, vp]
+    l.embnet_conv2d_patch_workspace_bytes.restype = ctypes.c_size_t
     st = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
-    print(f"{'shape':34s} {'library (in-loop split)':>26s} " + " ".join(f"{TILE[t]:>22s}" for t in tiles))
+    print(f"{'shape':34s} {'library (in-loop split)':>26s} " + " ".join(f"{TILE[t]:>22s}" for t in tiles) + f" {'patch 256xN/8w':>22s}")
     for (n, h, w, c, ks, k, s_, pad) in RN18[:a.first]:
         oh, ow = (h + 2 * pad - ks) // s_ + 1, (w + 2 * pad - ks) // s_ + 1
         x = torch.randn((n, h, w, c), device=dev).abs_()
@@ -56,6 +59,15 @@ def main():
         for t in tiles:
             calls.append((TILE[t], lambda t=t: l.embnet_conv2d_fwd_planes(P(xp), P(wp), P(y1), n, h, w, c, ks, ks, k, s_, pad, pad,
                                                                        oh, ow, None, None, t, st)))
+        patch = s_ == 1 and l.embnet_conv2d_patch_supported(n, c, ks, ks, k, s_, oh, ow)
+        if patch:
+            wp2 = torch.empty((3, wt.numel()), device=dev, dtype=torch.int16)
+            assert l.embnet_prep_weight_planes(P(wt), ks, ks, c, k, 0, P(wp2), st) == 0
+            assert torch.equal(wp2, wp), "prep_weight_planes differs from transpose + split"
+            pws = torch.empty(max(l.embnet_conv2d_patch_workspace_bytes(n, c, ks, ks, k, s_, oh, ow), 1024) // 4, device=dev)
+            y2 = torch.empty_like(y0)
+            calls.append(("patch", lambda: l.embnet_conv2d_patch_planes(P(xp), P(wp2), None, P(y2), n, h, w, c, ks, ks, k, pad, pad, oh, ow,
+                                                                        0, None, None, P(pws), pws.numel() * 4, st)))
         # correctness: bit-identical to the unsplit-tail library launch
         assert l.embnet_conv2d_fwd_f32(P(x), P(wt), None, P(y0), n, h, w, c, ks, ks, k, s_, pad, pad, oh, ow, 0, None, None,
                                        None, 0, None, None, 0, st) == 0
@@ -67,6 +79,13 @@ def main():
             if not same:
                 d = (y0 - y1).abs()
                 print(f"  tile {TILE[t]}: NOT bit-identical: max |d| {d.max().item():.3e} (nan: {torch.isnan(y1).sum().item()})")
+        if patch:
+            y2.fill_(float("nan"))
+            assert calls[-1][1]() == 0, l.embnet_last_error()
+            torch.cuda.synchronize()
+            err = ((y2 - y0).abs().max() / y0.abs().max()).item()
+            if not err < 2e-6:
+                print(f"  patch kernel: max |d| / max |y| = {err:.3e} (nan: {torch.isnan(y2).sum().item()})")
         for _ in range(30):
             for _, f in calls:
                 f()
