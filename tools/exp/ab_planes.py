@@ -38,9 +38,13 @@ def main():
     l.embnet_prep_weight_planes.argtypes = [vp] + [ctypes.c_int] * 5 + [vp, vp]
     l.embnet_conv2d_patch_planes.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, vp, ctypes.c_size_t, vp]
     l.embnet_conv2d_patch_workspace_bytes.restype = ctypes.c_size_t
+    l.embnet_split_planes_cm_f32.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp]
+    l.embnet_prep_weight_planes2.argtypes = [vp] + [ctypes.c_int] * 5 + [vp, vp]
+    l.embnet_conv2d_patch2_planes.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, vp, ctypes.c_size_t, vp]
+    l.embnet_conv2d_patch2_workspace_bytes.restype = ctypes.c_size_t
     st = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
-    print(f"{'shape':34s} {'library (in-loop split)':>26s} " + " ".join(f"{TILE[t]:>22s}" for t in tiles) + f" {'patch 256xN/8w':>22s}")
+    print(f"{'shape':34s} {'library (in-loop split)':>26s} " + " ".join(f"{TILE[t]:>22s}" for t in tiles) + f" {'patch 256xN/8w':>22s} {'patch2 8+2 waves':>22s}")
     for (n, h, w, c, ks, k, s_, pad) in RN18[:a.first]:
         oh, ow = (h + 2 * pad - ks) // s_ + 1, (w + 2 * pad - ks) // s_ + 1
         x = torch.randn((n, h, w, c), device=dev).abs_()
@@ -68,6 +72,16 @@ def main():
             y2 = torch.empty_like(y0)
             calls.append(("patch", lambda: l.embnet_conv2d_patch_planes(P(xp), P(wp2), None, P(y2), n, h, w, c, ks, ks, k, pad, pad, oh, ow,
                                                                         0, None, None, P(pws), pws.numel() * 4, st)))
+        patch2 = s_ == 1 and l.embnet_conv2d_patch2_supported(n, c, ks, ks, k, oh, ow)
+        if patch2:
+            xc = torch.empty((3, x.numel()), device=dev, dtype=torch.int16)
+            assert l.embnet_split_planes_cm_f32(P(x), n * h * w, c, P(xc), st) == 0
+            wp3 = torch.empty((3, wt.numel()), device=dev, dtype=torch.int16)
+            assert l.embnet_prep_weight_planes2(P(wt), ks, ks, c, k, 0, P(wp3), st) == 0
+            pws2 = torch.empty(max(l.embnet_conv2d_patch2_workspace_bytes(n, c, ks, ks, k, oh, ow), 1024) // 4, device=dev)
+            y3 = torch.empty_like(y0)
+            calls.append(("patch2", lambda: l.embnet_conv2d_patch2_planes(P(xc), P(wp3), None, P(y3), n, h, w, c, ks, ks, k, pad, pad, oh, ow,
+                                                                          0, None, None, P(pws2), pws2.numel() * 4, st)))
         # correctness: bit-identical to the unsplit-tail library launch
         assert l.embnet_conv2d_fwd_f32(P(x), P(wt), None, P(y0), n, h, w, c, ks, ks, k, s_, pad, pad, oh, ow, 0, None, None,
                                        None, 0, None, None, 0, st) == 0
@@ -79,9 +93,16 @@ def main():
             if not same:
                 d = (y0 - y1).abs()
                 print(f"  tile {TILE[t]}: NOT bit-identical: max |d| {d.max().item():.3e} (nan: {torch.isnan(y1).sum().item()})")
+        if patch2:
+            y3.fill_(float("nan"))
+            assert calls[-1][1]() == 0, l.embnet_last_error()
+            torch.cuda.synchronize()
+            err = ((y3 - y0).abs().max() / y0.abs().max()).item()
+            if not err < 2e-6:
+                print(f"  patch2 kernel: max |d| / max |y| = {err:.3e} (nan: {torch.isnan(y3).sum().item()})")
         if patch:
             y2.fill_(float("nan"))
-            assert calls[-1][1]() == 0, l.embnet_last_error()
+            assert calls[-1 - int(bool(patch2))][1]() == 0, l.embnet_last_error()
             torch.cuda.synchronize()
             err = ((y2 - y0).abs().max() / y0.abs().max()).item()
             if not err < 2e-6:

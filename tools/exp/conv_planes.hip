@@ -495,6 +495,336 @@ __global__ __launch_bounds__(256) void prep_weight_planes_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Patch convolution, second version: what the first one's stamps asked for (profiles/r03_exp_patch_phases.txt: per step
+// 2 500 cycles of MFMA work, 830 cycles of DMA ISSUE with the matrix pipe idle, 1 600 cycles waiting for DMA that had
+// been requested a whole step earlier).
+//  * Operand layouts in HBM made for the consumer: activations CHUNK-MAJOR [plane][C/16][pixels][16] so that consecutive
+//    patch rows are consecutive 32-byte pieces (a 1 KiB DMA = 8 whole cache lines instead of 32 scattered ones), weights
+//    STEP-MAJOR [plane][r][C/16][s][K][16] so that a step's weights are one contiguous block per tap.
+//  * Two LOADER waves (wave 8: weights, wave 9: patches) beside the 8 MFMA waves: the MFMA waves never issue a DMA and
+//    never wait on vmcnt; the loaders' queues hold nothing but their own DMAs, so their counted waits are constants.
+//  * Weight ring of NBS slots, requested NBS - 1 steps ahead; the next chunk's patch is requested at the first step of the
+//    current chunk (R*S/TPS steps ahead).
+// A step is TPS taps of one 16-channel chunk (TPS = 3: a kernel row; TPS = 1: one tap).
+struct ConvPatch2Params {
+  const unsigned short* xp;      // [3][C/16][N*H*W][16] bf16 pieces of the input
+  const unsigned short* wp;      // [3][R][C/16][S][K][16] bf16 pieces of the kernel
+  float* y; const float* bias; const float* residual; float* stats; int stats_rows; int relu;
+  ConvGeom g; unsigned x_plane_bytes, w_plane_bytes;
+  int PH, PW; FastDiv dPHW, dPW;
+  int LR;                        // LDS patch rows (multiple of 32)
+  int n_full, parts, cc_part, n_pieces, grid; float* ws;
+};
+
+struct Patch2Item { int m0, n0, cc_b, cc_e, tile_m; float* part; };
+
+template <int BN>
+__device__ __forceinline__ Patch2Item patch2_item(int item, int n_mine) {
+  typedef const ConvPatch2Params __attribute__((address_space(4)))* kargp;
+  kargp pp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pp));
+  const int b = blockIdx.x, NCC = pp->g.C / 16, tiles_n = (pp->g.K + BN - 1) / BN;
+  Patch2Item t; int id;
+  if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr; }
+  else {
+    id = pp->n_full + b / pp->parts;
+    t.cc_b = (b % pp->parts) * pp->cc_part; t.cc_e = min(NCC, t.cc_b + pp->cc_part);
+    t.part = pp->ws + (long)b * (256 * BN);
+  }
+  t.tile_m = id / tiles_n; t.m0 = t.tile_m * 256; t.n0 = (id % tiles_n) * BN;
+  return t;
+}
+
+__device__ __forceinline__ int patch2_base(int m) {            // padded-image position of output pixel m
+  typedef const ConvPatch2Params __attribute__((address_space(4)))* kargp;
+  kargp pp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pp));
+  FastDiv dOHW, dOW;
+  dOHW.mul = pp->g.dOHW.mul; dOHW.shift = pp->g.dOHW.shift; dOHW.d = pp->g.dOHW.d;
+  dOW.mul = pp->g.dOW.mul; dOW.shift = pp->g.dOW.shift; dOW.d = pp->g.dOW.d;
+  uint32_t n, rem, oh, ow;
+  dOHW.divmod((uint32_t)m, n, rem); dOW.divmod(rem, oh, ow);
+  return (int)n * (pp->PH * pp->PW) + (int)oh * pp->PW + (int)ow;
+}
+
+template <int BN, int R, int S, int TPS, int NBS>
+__global__ __launch_bounds__(640) void conv_patch2_kernel(const ConvPatch2Params p) {
+  using G = GeomN<256, BN, 4, 2>;
+  constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
+  constexpr int SBY = TPS * 3 * BN * 32;                 // one weight slot: TPS taps x 3 planes x BN rows x 32 bytes
+  constexpr int NBI = TPS * 3 * (BN / 32);               // DMA instructions per weight slot
+  static_assert((R * S) % TPS == 0 && SPC >= 2, "steps per chunk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int LR = p.LR, PLP = LR * 32, PB = 3 * PLP;
+  unsigned char* const bslot0 = smem + 2 * PB;
+  const int b = blockIdx.x;
+  const int n_mine = b < p.n_full ? (p.n_full - b + p.grid - 1) / p.grid : 0;
+  const int n_items = n_mine + (b < p.n_pieces ? 1 : 0);
+  if (n_items == 0) return;
+  const int dhalf = (lane & 1) ^ ((lane >> 4) & 1);
+
+  if (wave == 8) {
+    // ---- weight loader: slot (gs % NBS) <- weights of step gs, D steps ahead of the MFMA waves ----------------------
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wp), 0, 3u * p.w_plane_bytes, 0x00020000);
+    const int K = p.g.K, NCC = p.g.C / 16;
+    const unsigned wpb = p.w_plane_bytes;
+    int it = 0; Patch2Item t = patch2_item<BN>(0, n_mine);       // the step being REQUESTED: (it, cc, st)
+    int cc = t.cc_b, st = 0; bool live = true;
+    auto issue = [&](int gs) {
+      unsigned char* slot = bslot0 + (gs % NBS) * SBY;
+#pragma unroll
+      for (int j = 0; j < NBI; ++j) {
+        const int gb = j % (BN / 32), tq = j / (BN / 32), q = tq % 3, tp = tq / 3;
+        const int tap = st * TPS + tp, r = tap / S, s = tap % S;
+        const int row = t.n0 + gb * 32 + (lane >> 1);
+        const unsigned off = (live && row < K) ? 32u * (unsigned)row + 16u * dhalf : OOB;
+        const unsigned so = q * wpb + 32u * (unsigned)(((r * NCC + cc) * S + s) * K);
+        dma16(wr, slot + ((tp * 3 + q) * BN + gb * 32) * 32, off, so);
+      }
+      if (live && ++st == SPC) {
+        st = 0;
+        if (++cc == t.cc_e) {
+          if (++it < n_items) { t = patch2_item<BN>(it, n_mine); cc = t.cc_b; } else live = false;
+        }
+      }
+    };
+    int total = 0;                                               // steps of this workgroup
+    for (int i = 0; i < n_items; ++i) { const Patch2Item q = patch2_item<BN>(i, n_mine); total += (q.cc_e - q.cc_b) * SPC; }
+    for (int gs = 0; gs < D; ++gs) issue(gs);
+    for (int gs = 0; gs < total; ++gs) {
+      // the D - 1 youngest requests may still be in flight: the weights of step gs have landed
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NBI) : "memory");
+      __builtin_amdgcn_s_barrier();                              // #gs: step gs - 1 is done everywhere -> its slot is free
+      issue(gs + D);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (wave == 9) {
+    // ---- patch loader: buffer (gc & 1) <- patch of chunk gc, requested at the first step of chunk gc - 1 -------------
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xp), 0, 3u * p.x_plane_bytes, 0x00020000);
+    const int NG = LR / 32;
+    const unsigned xpb = p.x_plane_bytes, chunk_bytes = 32u * (unsigned)(p.g.N * p.g.H * p.g.W);
+    unsigned poff[16];
+    auto tile_offsets = [&](const Patch2Item& t) {
+      typedef const ConvPatch2Params __attribute__((address_space(4)))* kargp;
+      kargp pp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(pp));
+      FastDiv dPHW, dPW;
+      dPHW.mul = pp->dPHW.mul; dPHW.shift = pp->dPHW.shift; dPHW.d = pp->dPHW.d;
+      dPW.mul = pp->dPW.mul; dPW.shift = pp->dPW.shift; dPW.d = pp->dPW.d;
+      const int P0 = patch2_base(t.m0), N = pp->g.N, H = pp->g.H, W = pp->g.W, pt = pp->g.pad_t, pl = pp->g.pad_l;
+#pragma unroll
+      for (int gI = 0; gI < 16; ++gI) {
+        const int idx = P0 + 32 * gI + (lane >> 1);
+        uint32_t n, rem, py, px;
+        dPHW.divmod((uint32_t)idx, n, rem); dPW.divmod(rem, py, px);
+        const int ih = (int)py - pt, iw = (int)px - pl;
+        const bool ok = gI < NG && (int)n < N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        poff[gI] = ok ? 32u * (unsigned)(((int)n * H + ih) * W + iw) + 16u * dhalf : OOB;
+      }
+    };
+    auto issue = [&](int cc, int gc) {
+      unsigned char* buf = smem + (gc & 1) * PB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI)
+          if (gI < NG) dma16(xr, buf + q * PLP + gI * 1024, poff[gI], q * xpb + (unsigned)cc * chunk_bytes);
+    };
+    int it = 0; Patch2Item t = patch2_item<BN>(0, n_mine);       // the chunk being REQUESTED
+    int cc = t.cc_b; bool live = true;
+    tile_offsets(t);
+    auto advance = [&]() {
+      if (++cc == t.cc_e) {
+        if (++it < n_items) { t = patch2_item<BN>(it, n_mine); cc = t.cc_b; tile_offsets(t); } else live = false;
+      }
+    };
+    issue(cc, 0); advance();
+    int total_chunks = 0;
+    for (int i = 0; i < n_items; ++i) { const Patch2Item q = patch2_item<BN>(i, n_mine); total_chunks += q.cc_e - q.cc_b; }
+    for (int gc = 0; gc < total_chunks; ++gc) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // patch gc has landed (requested a chunk ago)
+      __builtin_amdgcn_s_barrier();                              // first step of chunk gc: chunk gc - 1 is done -> its buffer is free
+      if (live) { issue(cc, gc + 1); advance(); }
+#pragma unroll 1
+      for (int s2 = 1; s2 < SPC; ++s2) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ---- MFMA waves ---------------------------------------------------------------------------------------------------
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  const int K = p.g.K, PW = p.PW, M = p.g.N * p.g.OH * p.g.OW;
+  int gs = 0, gc = 0;
+  f32x16 acc[TM][TN];
+#if EMBNET_PLANES_STAMPS
+  unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_steps = 0;
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_last;
+#endif
+  for (int item = 0; item < n_items; ++item) {
+    const Patch2Item cur = patch2_item<BN>(item, n_mine);
+    int rowidx[TM];
+    {
+      const int P0 = patch2_base(cur.m0);
+#pragma unroll
+      for (int im = 0; im < TM; ++im) {
+        const int m = cur.m0 + wm + im * 32 + (lane & 31);
+        rowidx[im] = m < M ? patch2_base(m) - P0 : 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int cc = cur.cc_b; cc < cur.cc_e; ++cc) {
+      const unsigned char* pbuf = smem + (gc & 1) * PB;
+#pragma unroll 1
+      for (int st = 0; st < SPC; ++st) {
+        PSTAMP(t_comp);
+        __syncthreads();             // barrier #gs: this step's weights (and, at st = 0, this chunk's patch) are in LDS
+        PSTAMP(t_wait);
+#if EMBNET_PLANES_STAMPS
+        ++t_steps;
+#endif
+        const unsigned char* bs = bslot0 + (gs % NBS) * SBY;
+#pragma unroll
+        for (int tp = 0; tp < TPS; ++tp) {
+          const int tap = st * TPS + tp, r = tap / S, s = tap % S;
+          bf16x8 a[TM][3], bb[TN][3];
+#pragma unroll
+          for (int im = 0; im < TM; ++im) {
+            const int idx = rowidx[im] + r * PW + s;
+            const unsigned char* ap = pbuf + idx * 32 + ((h ^ ((idx >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[im][q] = *reinterpret_cast<const bf16x8*>(ap + q * PLP);
+          }
+#pragma unroll
+          for (int in = 0; in < TN; ++in) {
+            const int row = wn + in * 32 + (lane & 31);
+            const unsigned char* bp = bs + (tp * 3 * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bb[in][q] = *reinterpret_cast<const bf16x8*>(bp + q * BN * 32);
+          }
+          mfma_step3<G>(a, bb, acc);
+          if (TPS > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        ++gs;
+      }
+      ++gc;
+    }
+    PSTAMP(t_comp);
+    if (cur.part) {
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr)
+            cur.part[(wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h) * BN + wn + in * 32 + (lane & 31)] = acc[im][in][rr];
+    } else {
+      const bool inner = cur.m0 + 256 <= M && cur.n0 + BN <= K;
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        const int col = cur.n0 + wn + in * 32 + (lane & 31);
+        const bool cok = col < K;
+        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+          const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
+          float v[16];
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) { v[rr] = acc[im][in][rr] + bv; if (p.relu) v[rr] = fmaxf(v[rr], 0.f); }
+          if (inner) {
+            if (p.residual) {
+#pragma unroll
+              for (int rr = 0; rr < 16; ++rr) v[rr] += p.residual[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              p.y[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] = v[rr];
+              s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              if (row < M && cok) {
+                const long o = o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K;
+                if (p.residual) v[rr] += p.residual[o];
+                p.y[o] = v[rr];
+                s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+              }
+            }
+          }
+        }
+        if (p.stats) {
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0 && cok) {
+            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = p.stats_rows;
+            p.stats[(long)col * P + prow] = s1;
+            p.stats[((long)K + col) * P + prow] = s2;
+          }
+        }
+      }
+    }
+    PSTAMP(t_epi);
+  }
+#if EMBNET_PLANES_STAMPS
+  if (g_pstamps && lane == 0) {
+    unsigned long long* d = g_pstamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    d[0] = t_wait; d[1] = 0; d[2] = t_comp; d[3] = t_epi; d[4] = t_steps; d[5] = __builtin_amdgcn_s_memtime() - t_begin;
+  }
+#endif
+}
+
+// fp32 NHWC [pixels][C] -> chunk-major planes [3][C/16][pixels][16] bf16; one thread per (pixel, 4 channels)
+__global__ __launch_bounds__(256) void split_planes_cm_kernel(const float* __restrict__ x, long pixels, int C,
+                                                              unsigned short* __restrict__ planes) {
+  const long total4 = pixels * C / 4, plane = pixels * C;
+  const int c4 = C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long pix = i / c4; const int c = (int)(i % c4) * 4;
+    const Split4 s = split4(reinterpret_cast<const float4*>(x)[i]);
+    const long o = ((long)(c >> 4) * pixels + pix) * 16 + (c & 15);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(planes + q * plane + o) = s.p[q];
+  }
+}
+
+// kernel [R,S,C,K] fp32 -> step-major planes [3][R][Cin/16][S][rows][16] bf16.
+// flip = 0: rows = K, reduction channels = C:  out[r][cc][s][k][j] = w[r, s, 16 cc + j, k]
+// flip = 1: rows = C, reduction channels = K:  out[r][cc][s][c][j] = w[R-1-r, S-1-s, c, 16 cc + j]   (stride-1 data gradient)
+__global__ __launch_bounds__(256) void prep_weight_planes2_kernel(const float* __restrict__ w, int R, int S, int C, int K, int flip,
+                                                                  unsigned short* __restrict__ out) {
+  const int rows = flip ? C : K, red = flip ? K : C, ncc = red / 16;
+  const long total4 = (long)R * S * C * K / 4, plane = (long)R * S * C * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    long e = 4 * i;                                   // output element index [r][cc][s][row][j]
+    const int j = (int)(e % 16); e /= 16;
+    const int row = (int)(e % rows); e /= rows;
+    const int s = (int)(e % S); e /= S;
+    const int cc = (int)(e % ncc); const int r = (int)(e / ncc);
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ch = cc * 16 + j + t;
+      v[t] = flip ? w[((long)((R - 1 - r) * S + (S - 1 - s)) * C + row) * K + ch] : w[((long)(r * S + s) * C + ch) * K + row];
+    }
+    const Split4 sp = split4(make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(out + q * plane + 4 * i) = sp.p[q];
+  }
+}
+
 }  // namespace embnet
 
 using namespace embnet;
@@ -651,4 +981,98 @@ extern "C" int embnet_conv2d_patch_planes(const void* xp, const void* wp, const 
     launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
                       stats, p.stats_rows, st);
   return check_launch("conv2d_patch_planes");
+}
+
+// ---- patch convolution, second version: host side ---------------------------------------------------------------------
+extern "C" int embnet_split_planes_cm_f32(const float* x, long pixels, int c, void* planes, void* stream) {
+  EMBNET_CHECK_ARG(x && planes && pixels > 0 && c > 0 && (c & 15) == 0, "split_planes_cm: need c %% 16 == 0");
+  const long n4 = pixels * c / 4;
+  EMBNET_TRACE("embnet::split_planes_cm_kernel", TRACE_BYTES, 10.0 * pixels * c, stream);
+  split_planes_cm_kernel<<<(int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1), 256, 0, (hipStream_t)stream>>>(x, pixels, c, (unsigned short*)planes);
+  return check_launch("split_planes_cm");
+}
+extern "C" int embnet_prep_weight_planes2(const float* w, int r, int s, int c, int k, int flip, void* planes, void* stream) {
+  EMBNET_CHECK_ARG(w && planes && r > 0 && s > 0 && c > 0 && k > 0, "prep_weight_planes2: bad argument");
+  EMBNET_CHECK_ARG(((flip ? k : c) & 15) == 0, "prep_weight_planes2: reduction channel count %% 16");
+  const long total4 = (long)r * s * c * k / 4;
+  prep_weight_planes2_kernel<<<(int)(total4 / 256 + 1 > 2048 ? 2048 : total4 / 256 + 1), 256, 0, (hipStream_t)stream>>>(
+      w, r, s, c, k, flip, (unsigned short*)planes);
+  return check_launch("prep_weight_planes2");
+}
+
+struct Patch2Plan { int bn, tps, nbs, LR, tiles, n_full, parts, cc_part, n_pieces, grid; size_t lds, ws_bytes; };
+static bool patch2_plan(int n, int c, int r, int s, int k, int oh, int ow, Patch2Plan& pl) {
+  if (!(r == 3 && s == 3) || (c & 15) || (k & 3)) return false;
+  pl.bn = k >= 128 ? 128 : 64;
+  pl.tps = pl.bn == 64 ? 3 : 1;
+  pl.nbs = pl.bn == 64 ? 3 : 6;
+  static const int nbs_knob = (int)env_long("EMBNET_PATCH_NBS", 0);
+  if (nbs_knob > 0) pl.nbs = nbs_knob;
+  pl.LR = patch_rows(n, oh, ow, r, s);
+  if (pl.LR > 512) return false;
+  pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
+  if (pl.lds > 160 * 1024) return false;
+  const long M = (long)n * oh * ow;
+  pl.tiles = cdiv(M, 256) * cdiv(k, pl.bn);
+  static const int grid_knob = (int)env_long("EMBNET_PATCH_GRID", 256);
+  pl.grid = grid_knob;
+  const int ncc = c / 16;
+  pl.n_full = pl.tiles / pl.grid * pl.grid;
+  const int rem = pl.tiles - pl.n_full;
+  pl.parts = 1; pl.cc_part = ncc; pl.n_pieces = 0; pl.ws_bytes = 0;
+  if (rem > 0) {
+    int parts = pl.grid / rem; if (parts > ncc) parts = ncc; if (parts < 1) parts = 1;
+    pl.cc_part = cdiv(ncc, parts); pl.parts = cdiv(ncc, pl.cc_part);
+    if (pl.parts == 1) { pl.n_full = pl.tiles; }
+    else { pl.n_pieces = rem * pl.parts; pl.ws_bytes = (size_t)pl.n_pieces * 256 * pl.bn * 4; }
+  }
+  return true;
+}
+extern "C" int embnet_conv2d_patch2_supported(int n, int c, int r, int s, int k, int oh, int ow) {
+  Patch2Plan pl; return patch2_plan(n, c, r, s, k, oh, ow, pl) ? 1 : 0;
+}
+extern "C" size_t embnet_conv2d_patch2_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
+  Patch2Plan pl; return patch2_plan(n, c, r, s, k, oh, ow, pl) ? pl.ws_bytes : 0;
+}
+
+template <int BN, int TPS, int NBS>
+static void launch_patch2(const ConvPatch2Params& p, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_patch2_kernel<BN, 3, 3, TPS, NBS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  conv_patch2_kernel<BN, 3, 3, TPS, NBS><<<p.grid, 640, lds, st>>>(p);
+}
+
+extern "C" int embnet_conv2d_patch2_planes(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
+                                           int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu,
+                                           const float* residual, float* stats, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  EMBNET_CHECK_ARG(xp && wp && y, "conv2d_patch2_planes: null pointer");
+  Patch2Plan pl;
+  EMBNET_CHECK_ARG(patch2_plan(n, c, r, s, k, oh, ow, pl), "conv2d_patch2_planes: unsupported geometry");
+  ConvPatch2Params p{(const unsigned short*)xp, (const unsigned short*)wp, y, bias, residual, stats, 0, relu};
+  if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, 1, pad_t, pad_l, oh, ow, "conv2d_patch2_planes")) return rc;
+  const long M = (long)n * oh * ow;
+  p.x_plane_bytes = (unsigned)((size_t)n * h * wd * c * 2);
+  p.w_plane_bytes = (unsigned)((size_t)r * s * c * k * 2);
+  p.PH = oh + r - 1; p.PW = ow + s - 1;
+  p.dPHW = FastDiv::make(p.PH * p.PW); p.dPW = FastDiv::make(p.PW);
+  p.LR = pl.LR;
+  p.stats_rows = cdiv(M, 256) * 4;
+  p.grid = pl.grid;
+  if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
+  p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    EMBNET_TRACE_FLOP(pl.bn == 128 ? "conv_patch2<128>" : "conv_patch2<64>", 2.0 * M * k * r * s * c,
+                      6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
+    if (pl.bn == 128) {
+      if (pl.nbs == 6) launch_patch2<128, 1, 6>(p, pl.lds, st); else launch_patch2<128, 1, 4>(p, pl.lds, st);
+    } else {
+      if (pl.nbs == 3) launch_patch2<64, 3, 3>(p, pl.lds, st); else launch_patch2<64, 3, 4>(p, pl.lds, st);
+    }
+  }
+  if (p.n_pieces > 0)
+    launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
+                      stats, p.stats_rows, st);
+  return check_launch("conv2d_patch2_planes");
 }

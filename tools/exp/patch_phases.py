@@ -17,6 +17,11 @@ l.embnet_prep_weight_planes.argtypes = [vp] + [ctypes.c_int] * 5 + [vp, vp]
 l.embnet_conv2d_patch_planes.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, vp, ctypes.c_size_t, vp]
 l.embnet_conv2d_patch_workspace_bytes.restype = ctypes.c_size_t
 l.embnet_debug_set_planes_stamps.argtypes = [vp]
+l.embnet_split_planes_cm_f32.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp]
+l.embnet_prep_weight_planes2.argtypes = [vp] + [ctypes.c_int] * 5 + [vp, vp]
+l.embnet_conv2d_patch2_planes.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, vp, ctypes.c_size_t, vp]
+l.embnet_conv2d_patch2_workspace_bytes.restype = ctypes.c_size_t
+V2 = os.environ.get("PATCH_V", "1") == "2"
 st = torch.cuda.current_stream().cuda_stream
 P = lambda t: t.data_ptr()
 for (n, h, w, c, ks, k, s_, pad) in SHAPES:
@@ -29,7 +34,12 @@ for (n, h, w, c, ks, k, s_, pad) in SHAPES:
     wp = torch.empty((3, wt.numel()), device=dev, dtype=torch.int16)
     l.embnet_prep_weight_planes(P(wt), ks, ks, c, k, 0, P(wp), st)
     pws = torch.empty(max(l.embnet_conv2d_patch_workspace_bytes(n, c, ks, ks, k, s_, oh, ow), 1024) // 4, device=dev)
-    run = lambda: l.embnet_conv2d_patch_planes(P(xp), P(wp), None, P(y), n, h, w, c, ks, ks, k, pad, pad, oh, ow, 0, None, None, P(pws), pws.numel() * 4, st)
+    if V2:
+        xp = torch.empty((3, x.numel()), device=dev, dtype=torch.int16)
+        l.embnet_split_planes_cm_f32(P(x), n * h * w, c, P(xp), st)
+        l.embnet_prep_weight_planes2(P(wt), ks, ks, c, k, 0, P(wp), st)
+        pws = torch.empty(max(l.embnet_conv2d_patch2_workspace_bytes(n, c, ks, ks, k, oh, ow), 1024) // 4, device=dev)
+    run = lambda: (l.embnet_conv2d_patch2_planes if V2 else l.embnet_conv2d_patch_planes)(P(xp), P(wp), None, P(y), n, h, w, c, ks, ks, k, pad, pad, oh, ow, 0, None, None, P(pws), pws.numel() * 4, st)
     for _ in range(20):
         run()
     buf = torch.zeros((256 * 8, 8), device=dev, dtype=torch.int64)
