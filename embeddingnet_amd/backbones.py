@@ -287,12 +287,16 @@ def load_keras_weights(module, weights, strict=True):
             raise KeyError(f"missing weight {k}")
 
 
-def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, params_save_paths, max_epochs=None):
+def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, params_save_paths, max_epochs=None,
+                              distributed=False):
     """Optional softmax pre-training of the backbone (reference backbones.py:128-204, run by
     tools/train.py:164-170 when the config has SOFTMAX_PRETRAINING): GAP -> Dense(n_classes) trained with
     categorical cross-entropy on SimpleDataGenerator batches; LR lr0*decay^floor(epoch/step),
     ReduceLROnPlateau(0.1, patience 20), EarlyStopping(patience 10, restore best), best-only checkpoints
-    under <work_dir>/<project>/pretraining_model/weights/.  Returns the history dict."""
+    under <work_dir>/<project>/pretraining_model/weights/.  Returns the history dict.
+    distributed=True (a torch.distributed world is up): every rank trains on its own batches with the gradients averaged
+    over the ranks (parallel.GradReducer), the monitored values are all-reduced so every rank takes the same schedule /
+    stopping decisions, and rank 0 writes the checkpoints."""
     import os
     from .datagenerators import SimpleDataGenerator
     p = params_softmax
@@ -308,6 +312,12 @@ def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, param
     val_gen = SimpleDataGenerator(data_loader.val_data, data_loader.class_names, **kw) if data_loader.validate else None
     params = [q for q in list(backbone_model.parameters()) + list(head.parameters()) if q.requires_grad]
     opt = p['optimizer'].build(params)
+    reducer, rank0, mean_over_ranks = None, True, float
+    if distributed:
+        import torch.distributed as dist
+        from .parallel import GradReducer, all_reduce_mean, broadcast_model
+        broadcast_model(head)                          # the backbone was broadcast by the caller; the head is built here
+        reducer, rank0, mean_over_ranks = GradReducer(params), dist.get_rank() == 0, all_reduce_mean
     wdir = os.path.join(params_save_paths['work_dir'], params_save_paths['project_name'], 'pretraining_model/weights/')
     os.makedirs(wdir, exist_ok=True)
     best, best_state, since_best, since_reduce, scale = float('inf'), None, 0, 0, 1.0
@@ -320,13 +330,16 @@ def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, param
         ls, ac = [], []
         for _ in range(len(train_gen)):
             (x,), t = train_gen[0]
-            opt.zero_grad(set_to_none=True)
+            opt.zero_grad(set_to_none=True) if reducer is None else reducer.zero()
             loss, acc, _ = ops.softmax_cross_entropy(head(backbone_model(torch.from_numpy(x).to(dev))),
                                                      torch.from_numpy(t).to(dev))
             loss.backward()
+            if reducer is not None:
+                reducer.finish()
             opt.step()
             ls.append(loss.detach()); ac.append(acc)
-        history['loss'].append(float(torch.stack(ls).mean())); history['accuracy'].append(float(torch.stack(ac).mean()))
+        history['loss'].append(mean_over_ranks(float(torch.stack(ls).mean())))
+        history['accuracy'].append(mean_over_ranks(float(torch.stack(ac).mean())))
         monitor = history['loss'][-1]
         if val_gen is not None:
             backbone_model.eval(); head.eval()
@@ -337,23 +350,28 @@ def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, param
                     loss, acc, _ = ops.softmax_cross_entropy(head(backbone_model(torch.from_numpy(x).to(dev))),
                                                              torch.from_numpy(t).to(dev))
                     ls.append(loss); ac.append(acc)
-            history['val_loss'].append(float(torch.stack(ls).mean()))
-            history['val_accuracy'].append(float(torch.stack(ac).mean()))
+            history['val_loss'].append(mean_over_ranks(float(torch.stack(ls).mean())))
+            history['val_accuracy'].append(mean_over_ranks(float(torch.stack(ac).mean())))
             monitor = history['val_loss'][-1]
-        print(f"softmax pre-training epoch {epoch + 1}/{n_epochs}: " +
-              " - ".join(f"{k} {v[-1]:.4f}" for k, v in history.items() if v), flush=True)
+        if rank0:
+            print(f"softmax pre-training epoch {epoch + 1}/{n_epochs}: " +
+                  " - ".join(f"{k} {v[-1]:.4f}" for k, v in history.items() if v), flush=True)
         if monitor < best:
             best, since_best, since_reduce = monitor, 0, 0
             best_state = {k: v.detach().clone() for k, v in backbone_model.state_dict().items()}
-            np.savez(os.path.join(wdir, f"{params_save_paths['project_name']}_{epoch + 1:03d}.npz"),
-                     **{k: v.detach().cpu().numpy() for k, v in keras_weights(backbone_model).items()})
+            if rank0:
+                np.savez(os.path.join(wdir, f"{params_save_paths['project_name']}_{epoch + 1:03d}.npz"),
+                         **{k: v.detach().cpu().numpy() for k, v in keras_weights(backbone_model).items()})
         else:
             since_best += 1; since_reduce += 1
             if since_reduce >= 20:
                 scale *= 0.1; since_reduce = 0
             if since_best >= 10:
-                print('EarlyStopping (restoring best weights)')
+                if rank0:
+                    print('EarlyStopping (restoring best weights)')
                 break
     if best_state is not None:
         backbone_model.load_state_dict(best_state)
+    if reducer is not None:
+        reducer.close()                                # the main training builds its own reducer / gradient buffers
     return history

@@ -6,7 +6,8 @@
 
 namespace embnet {
 
-struct DenseParams { const float* a; const float* b; const float* bias; float* out; int m, n, k; int relu; };
+struct DenseParams { const float* a; const float* b; const float* bias; float* out; int m, n, k; int relu;
+                     int kt_per_split, splits; float* slabs; };
 
 // Y[m,n] = A[m,k] (k contiguous) x B[k,n] (n contiguous)
 template <class G, bool VEC>
@@ -20,7 +21,21 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
   LoadRowsKC<G::BM, VEC> la; la.init(p.a, p.k, p.m, p.k, m0, threadIdx.x);
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.b, p.n, p.n, p.k, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
-  gemm_mainloop<G, TA, TB>(la, lb, 0, (p.k + BK - 1) / BK, smem, acc);
+  const int kt_total = (p.k + BK - 1) / BK;
+  if (p.splits > 1) {
+    // few output tiles and a long reduction (simple2's 12 800 -> 512 head at batch 32 is 8 tiles x 400 K tiles: 8 of 256 CUs
+    // streamed a 26 MB kernel, 176 us): blockIdx.y takes a K range and writes a raw partial slab; dense_splitk_finish_kernel
+    // adds the slabs in order and applies bias / ReLU
+    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
+    gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
+    float* slab = p.slabs + (long)blockIdx.y * p.m * p.n;
+    for_each_acc<G>(acc, [&](int r, int c, float v) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < p.m && col < p.n) slab[(long)row * p.n + col] = v;
+    });
+    return;
+  }
+  gemm_mainloop<G, TA, TB>(la, lb, 0, kt_total, smem, acc);
   for_each_acc<G>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < p.m && col < p.n) {
@@ -29,6 +44,16 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
       p.out[(long)row * p.n + col] = v;
     }
   });
+}
+
+__global__ __launch_bounds__(256) void dense_splitk_finish_kernel(const float* __restrict__ slabs, int splits, long mn, int n,
+                                                                  const float* __restrict__ bias, int relu, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn) return;
+  float v = slabs[i];
+  for (int s = 1; s < splits; ++s) v += slabs[(long)s * mn + i];
+  if (bias) v += bias[i % n];
+  out[i] = relu ? fmaxf(v, 0.f) : v;
 }
 
 // dX[m,n=in] = dY[m,k=out] (k contiguous) x W[n=in][k=out] (k contiguous)
@@ -79,7 +104,8 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 #define LAUNCH_DENSE(KERNEL, p, vec, st)                                                             \
   do {                                                                                               \
-    EMBNET_TRACE("embnet::" #KERNEL, TRACE_FLOP, 2.0 * (p).m * (p).n * (p).k, st);                   \
+    EMBNET_TRACE_FLOP("embnet::" #KERNEL, 2.0 * (p).m * (p).n * (p).k,                               \
+                      4.0 * ((double)(p).m * (p).k + (double)(p).k * (p).n + (double)(p).m * (p).n), st); \
     if ((long)cdiv((p).m, 128) * cdiv((p).n, 128) >= 256) {                                          \
       const int grid = cdiv((p).m, 128) * cdiv((p).n, 128);                                          \
       if (vec) KERNEL<G128, true><<<grid, 256, 0, st>>>(p); else KERNEL<G128, false><<<grid, 256, 0, st>>>(p); \
@@ -89,14 +115,46 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
     }                                                                                                \
   } while (0)
 
+// K split of the forward GEMM: only when the output has too few 64x64 tiles to cover the chip and the reduction is long
+static void dense_fwd_plan(int m, int in, int out, int& splits, int& kt_per_split) {
+  const long tiles = (long)cdiv(m, 64) * cdiv(out, 64);
+  const int kt_total = cdiv(in, BK);
+  splits = 1; kt_per_split = kt_total;
+  if (tiles >= 64 || kt_total < 64) return;          // (a second launch only pays on a long reduction: in >= 2048)
+  long want = 512 / tiles;
+  if (want > kt_total / 4) want = kt_total / 4;
+  if (want < 2) return;
+  kt_per_split = cdiv(kt_total, want);
+  splits = cdiv(kt_total, kt_per_split);
+}
+
+extern "C" size_t embnet_dense_fwd_workspace_bytes(int m, int in, int out) {
+  if (m <= 0 || in <= 0 || out <= 0) return 0;
+  int splits, ktps; dense_fwd_plan(m, in, out, splits, ktps);
+  return splits > 1 ? (size_t)splits * m * out * sizeof(float) : 0;
+}
+
 extern "C" int embnet_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y, int m, int in,
-                                    int out, int relu, void* stream) {
+                                    int out, int relu, void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "dense_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_fwd: m=%d in=%d out=%d", m, in, out);
   EMBNET_CHECK_ARG((size_t)m * in * 4 <= MAX_OPERAND_BYTES && (size_t)in * out * 4 <= MAX_OPERAND_BYTES, "dense: operand exceeds 2 GiB");
-  DenseParams p{x, w, bias, y, m, out, in, relu};
+  DenseParams p{x, w, bias, y, m, out, in, relu, 0, 1, nullptr};
   const bool vec = (in & 3) == 0 && (out & 3) == 0 && al16(x) && al16(w);
-  LAUNCH_DENSE(dense_fwd_kernel, p, vec, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  int splits, ktps; dense_fwd_plan(m, in, out, splits, ktps);
+  if (splits > 1 && workspace && workspace_bytes >= (size_t)splits * m * out * sizeof(float)) {
+    p.splits = splits; p.kt_per_split = ktps; p.slabs = (float*)workspace;
+    const dim3 grid(cdiv(m, 64) * cdiv(out, 64), splits);
+    {
+      EMBNET_TRACE_FLOP("embnet::dense_fwd_kernel", 2.0 * m * out * (double)in, 4.0 * ((double)m * in + (double)in * out + (double)m * out * splits), st);
+      if (vec) dense_fwd_kernel<G64, true><<<grid, 256, 0, st>>>(p); else dense_fwd_kernel<G64, false><<<grid, 256, 0, st>>>(p);
+    }
+    EMBNET_TRACE("embnet::dense_splitk_finish_kernel", TRACE_BYTES, 4.0 * m * out * (splits + 1), st);
+    dense_splitk_finish_kernel<<<cdiv((long)m * out, 256), 256, 0, st>>>(p.slabs, splits, (long)m * out, out, bias, relu, y);
+    return check_launch("dense_fwd");
+  }
+  LAUNCH_DENSE(dense_fwd_kernel, p, vec, st);
   return check_launch("dense_fwd");
 }
 
@@ -104,7 +162,7 @@ extern "C" int embnet_dense_dgrad_f32(const float* dy, const float* w, float* dx
                                       void* stream) {
   EMBNET_CHECK_ARG(dy && w && dx, "dense_dgrad: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_dgrad: m=%d in=%d out=%d", m, in, out);
-  DenseParams p{dy, w, nullptr, dx, m, in, out, 0};
+  DenseParams p{dy, w, nullptr, dx, m, in, out, 0, 0, 1, nullptr};
   const bool vec = (out & 3) == 0 && al16(dy) && al16(w);
   LAUNCH_DENSE(dense_dgrad_kernel, p, vec, (hipStream_t)stream);
   return check_launch("dense_dgrad");
@@ -114,7 +172,7 @@ extern "C" int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw
                                       void* stream) {
   EMBNET_CHECK_ARG(x && dy && dw, "dense_wgrad: null pointer");
   EMBNET_CHECK_ARG(m > 0 && in > 0 && out > 0, "dense_wgrad: m=%d in=%d out=%d", m, in, out);
-  DenseParams p{x, dy, nullptr, dw, in, out, m, 0};
+  DenseParams p{x, dy, nullptr, dw, in, out, m, 0, 0, 1, nullptr};
   const bool vec = (in & 3) == 0 && (out & 3) == 0 && al16(x) && al16(dy);
   LAUNCH_DENSE(dense_wgrad_kernel, p, vec, (hipStream_t)stream);
   return check_launch("dense_wgrad");

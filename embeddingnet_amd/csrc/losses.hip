@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void triplet_gather_bwd_kernel(const float* __
   const int cnt = min(*count, max_t);
   const float g = 2.f * (upstream ? *upstream : 1.f) / (float)max(cnt, 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // each thread owns columns c = tid, tid+256, ... (E <= 4096 -> at most 16 live accumulators)
+  // each thread owns columns c = c0 + tid, + 256, ... of this workgroup's block of 4096 columns (16 live accumulators;
+  // blockIdx.y walks the blocks when E > 4096: the reference's default encodings_len is 4096, backbones.py:13)
+  const int c0 = blockIdx.y * 4096;
   float accv[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) accv[i] = 0.f;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void triplet_gather_bwd_kernel(const float* __
       const float* ea = emb + (long)ma * e; const float* ep = emb + (long)mp * e; const float* en = emb + (long)mn * e;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int c = threadIdx.x + 256 * i;
+        const int c = c0 + threadIdx.x + 256 * i;
         if (c < e) {
           float d = 0.f;
           if (ma == r) d += en[c] - ep[c];
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void triplet_gather_bwd_kernel(const float* __
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int c = threadIdx.x + 256 * i;
+    const int c = c0 + threadIdx.x + 256 * i;
     if (c < e) demb[(long)r * e + c] = g * accv[i];
   }
   (void)n_rows;
@@ -293,9 +295,8 @@ extern "C" int embnet_triplet_gather_bwd(const float* emb, int n, int e, const i
                                          const float* upstream, float* demb, void* stream) {
   EMBNET_CHECK_ARG(emb && triplets && count && active && demb, "triplet_gather_bwd: null pointer");
   EMBNET_CHECK_ARG(n > 0 && e > 0 && max_t > 0, "triplet_gather_bwd: n=%d e=%d max_t=%d", n, e, max_t);
-  EMBNET_CHECK_ARG(e <= 4096, "triplet_gather_bwd: encodings_len %d > 4096 unsupported", e);
-  EMBNET_TRACE("embnet::triplet_gather_bwd_kernel", TRACE_BYTES, 0.0, S(stream));
-  triplet_gather_bwd_kernel<<<n, 256, 0, S(stream)>>>(emb, n, e, triplets, count, max_t, active, upstream, demb);
+  EMBNET_TRACE("embnet::triplet_gather_bwd_kernel", TRACE_BYTES, 8.0 * n * e, S(stream));
+  triplet_gather_bwd_kernel<<<dim3(n, cdiv(e, 4096)), 256, 0, S(stream)>>>(emb, n, e, triplets, count, max_t, active, upstream, demb);
   return check_launch("triplet_gather_bwd");
 }
 

@@ -679,6 +679,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) { a += x[r * c + col]; });
 }
 
+// dz = dy * [y > 0] AND the column sums of dz (the bias gradient of a Conv2D / Dense with a fused ReLU) in one pass over
+// the tensor: the separate relu_bwd + colsum pair read dz back (12 + 4 bytes per element -> 12)
+__global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, long m, int c,
+                                                              ColGeom g, float* __restrict__ dz, float* __restrict__ partial) {
+  col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
+    const long i = r * c + col;
+    const float v = y[i] > 0.f ? dy[i] : 0.f;
+    dz[i] = v; a += v;
+  });
+}
+
+// Sum over several tensors of alpha_t * sum(x_t^2) — all the kernel_regularizer=l2(lambda) terms of a model
+// (backbones.py:22-36) in one launch pair: chunk c = (tensor, 4096-element block) -> partial[c]; one workgroup adds the
+// partials in double, in chunk order (reproducible).
+struct SumsqTensor { const float* x; long n; float alpha; int pad; };
+static_assert(sizeof(SumsqTensor) == 24, "descriptor layout is part of the ABI (include/embnet.h)");
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const SumsqTensor* __restrict__ table, const int* __restrict__ chunks,
+                                                          float* __restrict__ partial) {
+  __shared__ float part[4];
+  const SumsqTensor t = table[chunks[2 * blockIdx.x]];
+  const long first = (long)chunks[2 * blockIdx.x + 1] * 4096, end = min(first + 4096, t.n);
+  float s = 0.f;
+  for (long i = first + threadIdx.x; i < end; i += 256) s = fmaf(t.x[i], t.x[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = t.alpha * (part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ double part[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (float)(part[0] + part[1] + part[2] + part[3]);
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long total,
                                                   float* __restrict__ y) {
   const long stride = (long)gridDim.x * 256;
@@ -1054,6 +1092,18 @@ extern "C" int embnet_colsum(const float* x, long m, int c, float* out, void* wo
   return check_launch("colsum");
 }
 
+extern "C" int embnet_relu_bwd_colsum(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(dy && y && dz && dbias && workspace && m > 0 && c > 0, "relu_bwd_colsum: bad argument");
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "relu_bwd_colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  const ColGeom g = col_geom(m, c);
+  { EMBNET_TRACE("embnet::relu_bwd_colsum_kernel", TRACE_BYTES, 12.0 * m * c, stream);
+    relu_bwd_colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, y, m, c, g, dz, (float*)workspace); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, dbias);
+  return check_launch("relu_bwd_colsum");
+}
+
 extern "C" int embnet_add(const float* a, const float* b, long total, float* y, void* stream) {
   EMBNET_CHECK_ARG(a && b && y && total > 0, "add: bad argument");
   { EMBNET_TRACE("embnet::add_kernel", TRACE_BYTES, 12.0 * total, stream); add_kernel<<<ew_blocks(total), 256, 0, S(stream)>>>(a, b, total, y); }
@@ -1142,6 +1192,17 @@ extern "C" int embnet_pad_channels(const float* x, long pixels, int cin, int cou
   EMBNET_CHECK_ARG(x && y && pixels > 0 && cin > 0 && cout >= cin, "pad_channels: bad argument");
   { EMBNET_TRACE("embnet::pad_channels_kernel", TRACE_BYTES, 4.0 * pixels * (cin + cout), stream); pad_channels_kernel<<<ew_blocks(pixels * cout), 256, 0, S(stream)>>>(x, pixels, cin, cout, y); }
   return check_launch("pad_channels");
+}
+
+extern "C" int embnet_sumsq_chunk_elems(void) { return 4096; }
+extern "C" int embnet_sumsq_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(table && chunks && out && workspace && n_tensors > 0 && n_chunks > 0, "sumsq_multi: bad argument");
+  if (workspace_bytes < (size_t)n_chunks * sizeof(float)) return fail(EMBNET_EWORKSPACE, "sumsq_multi: workspace too small");
+  { EMBNET_TRACE("embnet::sumsq_multi_kernel", TRACE_BYTES, 4.0 * 4096 * n_chunks, stream);
+    sumsq_multi_kernel<<<n_chunks, 256, 0, S(stream)>>>((const SumsqTensor*)table, chunks, (float*)workspace); }
+  sum_partials_kernel<<<1, 256, 0, S(stream)>>>((const float*)workspace, n_chunks, out);
+  return check_launch("sumsq_multi");
 }
 
 extern "C" size_t embnet_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }

@@ -5,13 +5,16 @@
 // rule (ResNet18: 62 tensors, 11.3 M floats).  HBM-bound: 4 B/element x (w r+w, g r, slots r+w) = 12..28 B/element.
 // The scalar coefficients (bias corrections, RAdam's rectifier) are computed on the host in double and passed in;
 // the arithmetic per element is the rule's own order in fp32.
+// l2x2 = 2*lambda of the tensor's kernel_regularizer=l2(lambda) (backbones.py:22-36; 0 for none): the regulariser's
+// gradient 2*lambda*w is added to g here, which is what Keras' loss + regulariser differentiates to, so no separate
+// 2*lambda*w tensors or accumulation launches exist.
 #include "common.h"
 #include "../../include/embnet.h"
 
 namespace embnet {
 
-struct OptTensor { float* w; const float* g; float* s1; float* s2; long n; };
-static_assert(sizeof(OptTensor) == 40, "descriptor layout is part of the ABI (include/embnet.h)");
+struct OptTensor { float* w; const float* g; float* s1; float* s2; long n; float l2x2; int pad; };
+static_assert(sizeof(OptTensor) == 48, "descriptor layout is part of the ABI (include/embnet.h)");
 
 constexpr int OPT_CHUNK = 4096;          // elements per workgroup: 256 threads x 4 float4
 
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const OptTensor* __restri
     for (int it = 0; it < OPT_CHUNK / 1024; ++it) {
       const long i = first + it * 1024 + threadIdx.x * 4;
       float4 w = *reinterpret_cast<const float4*>(t.w + i);
-      const float4 g = *reinterpret_cast<const float4*>(t.g + i);
+      float4 g = *reinterpret_cast<const float4*>(t.g + i);
+      g.x = fmaf(t.l2x2, w.x, g.x); g.y = fmaf(t.l2x2, w.y, g.y); g.z = fmaf(t.l2x2, w.z, g.z); g.w = fmaf(t.l2x2, w.w, g.w);
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       if (S1) a = *reinterpret_cast<const float4*>(t.s1 + i);
       if (S2) b = *reinterpret_cast<const float4*>(t.s2 + i);
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const OptTensor* __restri
   }
   for (long i = first + threadIdx.x; i < end; i += 256) {
     float w = t.w[i], a = S1 ? t.s1[i] : 0.f, b = S2 ? t.s2[i] : 0.f;
-    opt_update<RULE>(w, t.g[i], a, b, k);
+    opt_update<RULE>(w, fmaf(t.l2x2, w, t.g[i]), a, b, k);
     t.w[i] = w;
     if (S1) t.s1[i] = a;
     if (S2) t.s2[i] = b;

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 
 struct PairwiseParams {
   const float* x; const float* nn; float* d; int n, e, squared;
+  int kt_per_split, splits; float* slabs;      // splits > 1: blockIdx.y takes a K range and writes a raw Gram slab
 };
 
 template <class G, bool VEC>
@@ -42,6 +43,19 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   LoadRowsKC<G::BN, VEC> lb; lb.init(p.x, p.e, p.n, p.e, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
+  if (p.splits > 1) {
+    // N <= 256 at the reference's default encodings_len = 4096 (backbones.py:13) is 4..16 tiles walking 128 K tiles each
+    // (98 us): the K range is cut over blockIdx.y, pairwise_finish_kernel adds the slabs and applies the epilogue
+    const int kt_total = (p.e + BK - 1) / BK;
+    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
+    gemm_mainloop<G, TA, TB>(la, lb, kt0, kt1, smem, acc);
+    float* slab = p.slabs + (long)blockIdx.y * p.n * p.n;
+    for_each_acc<G>(acc, [&](int r, int c, float g) {
+      const int row = m0 + r, col = n0 + c;
+      if (row < p.n && col < p.n) slab[(long)row * p.n + col] = g;
+    });
+    return;
+  }
   gemm_mainloop<G, TA, TB>(la, lb, 0, (p.e + BK - 1) / BK, smem, acc);
   stamp(4);
 
@@ -71,6 +85,18 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   });
 }
 
+__global__ __launch_bounds__(256) void pairwise_finish_kernel(const float* __restrict__ slabs, int splits, int n,
+                                                              const float* __restrict__ nn, int squared, float* __restrict__ d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x, nn2 = (long)n * n;
+  if (i >= nn2) return;
+  const int row = (int)(i / n), col = (int)(i % n);
+  float g = slabs[i];
+  for (int s = 1; s < splits; ++s) g += slabs[(long)s * nn2 + i];
+  float v = fmaxf(nn[row] + nn[col] - 2.f * g, 0.f);
+  if (row == col) v = 0.f;
+  d[i] = squared ? v : sqrtf(v);
+}
+
 }  // namespace embnet
 
 using namespace embnet;
@@ -81,7 +107,25 @@ extern "C" int embnet_debug_set_stamps_pairwise(void* buf) {      // diagnostic 
 }
 #endif
 
-extern "C" size_t embnet_pairwise_workspace_bytes(int n) { return n > 0 ? (size_t)n * sizeof(float) : 0; }
+static void pairwise_plan(int n, int e, int& splits, int& kt_per_split) {
+  const int kt_total = cdiv(e, BK);
+  splits = 1; kt_per_split = kt_total;
+  const long tiles = (long)cdiv(n, 64) * cdiv(n, 64);
+  if (n >= 512 || kt_total < 32) return;
+  long want = 256 / tiles;
+  if (want > kt_total / 8) want = kt_total / 8;
+  if (want < 2) return;
+  kt_per_split = cdiv(kt_total, want);
+  splits = cdiv(kt_total, kt_per_split);
+}
+
+// n floats of row norms (+ the Gram slabs of a K-split launch)
+extern "C" size_t embnet_pairwise_workspace_bytes(int n, int e) {
+  if (n <= 0 || e <= 0) return 0;
+  int splits, ktps; pairwise_plan(n, e, splits, ktps);
+  const size_t norms = ((size_t)n * sizeof(float) + 15) / 16 * 16;
+  return norms + (splits > 1 ? (size_t)splits * n * n * sizeof(float) : 0);
+}
 
 extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dist, int squared,
                                         void* workspace, size_t workspace_bytes, void* stream) {
@@ -89,18 +133,30 @@ extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dis
   EMBNET_CHECK_ARG(((reinterpret_cast<uintptr_t>(dist) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
                    "pairwise: dist and workspace must be 16-byte aligned");
   EMBNET_CHECK_ARG(n > 0 && e > 0, "pairwise: n=%d e=%d must be positive", n, e);
-  if (workspace_bytes < embnet_pairwise_workspace_bytes(n))
-    return fail(EMBNET_EWORKSPACE, "pairwise: workspace %zu < %zu bytes", workspace_bytes,
-                embnet_pairwise_workspace_bytes(n));
+  if (workspace_bytes < (size_t)n * sizeof(float))
+    return fail(EMBNET_EWORKSPACE, "pairwise: workspace %zu < %zu bytes", workspace_bytes, (size_t)n * sizeof(float));
   hipStream_t s = (hipStream_t)stream;
   float* nn = (float*)workspace;
   row_sqnorm_kernel<<<cdiv(n, 4), 256, 0, s>>>(x, n, e, nn);
-  PairwiseParams p{x, nn, dist, n, e, squared};
+  PairwiseParams p{x, nn, dist, n, e, squared, 0, 1, nullptr};
   EMBNET_CHECK_ARG((size_t)n * e * 4 <= MAX_OPERAND_BYTES, "pairwise: embedding block exceeds 2 GiB");
   const bool vec = (e & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   using GL = Geom<128, 128, 2, 2>;
   using GS = Geom<64, 64, 2, 2>;
-  EMBNET_TRACE("embnet::pairwise_kernel", TRACE_FLOP, 2.0 * n * n * e, s);
+  int splits, ktps; pairwise_plan(n, e, splits, ktps);
+  if (splits > 1 && workspace_bytes >= embnet_pairwise_workspace_bytes(n, e)) {
+    p.splits = splits; p.kt_per_split = ktps;
+    p.slabs = (float*)((char*)workspace + ((size_t)n * sizeof(float) + 15) / 16 * 16);
+    const dim3 grid(cdiv(n, 64) * cdiv(n, 64), splits);
+    {
+      EMBNET_TRACE_FLOP("embnet::pairwise_kernel", 2.0 * n * n * e, 4.0 * ((double)n * e + (double)n * n * splits), s);
+      if (vec) pairwise_kernel<GS, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GS, false><<<grid, 256, 0, s>>>(p);
+    }
+    EMBNET_TRACE("embnet::pairwise_finish_kernel", TRACE_BYTES, 4.0 * n * n * (splits + 1), s);
+    pairwise_finish_kernel<<<cdiv((long)n * n, 256), 256, 0, s>>>(p.slabs, splits, n, nn, squared, dist);
+    return check_launch("pairwise_dist");
+  }
+  EMBNET_TRACE_FLOP("embnet::pairwise_kernel", 2.0 * n * n * e, 4.0 * ((double)n * e + (double)n * n), s);
   if (n >= 1024) {
     const int grid = cdiv(n, 128) * cdiv(n, 128);
     if (vec) pairwise_kernel<GL, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GL, false><<<grid, 256, 0, s>>>(p);

@@ -51,6 +51,29 @@ def workspace(nbytes, device):
     return buf
 
 
+# Gradient sinks (data-parallel training, parallel.GradReducer.direct): parameter storage address -> (flat-buffer view,
+# notify).  A weight-gradient kernel whose parameter has a sink writes its result straight into the view and returns
+# no gradient to autograd, so no AccumulateGrad `add_` kernel runs for it; `notify` tells the reducer the slot is final.
+# Only valid while every parameter takes part in ONE node per step (the fused TripletTrainer step) — the reducer arms it.
+GRAD_SINKS = {}
+
+
+def _sink(param):
+    """-> (tensor to write the parameter's gradient into, notify-or-None)."""
+    s = GRAD_SINKS.get(param.data_ptr()) if GRAD_SINKS else None
+    if s is None:
+        return torch.empty_like(param), None
+    return s
+
+
+def _done(out, notify):
+    """What a backward returns for a parameter gradient it has produced in `out`."""
+    if notify is None:
+        return out
+    notify()
+    return None
+
+
 def _c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -91,6 +114,7 @@ class _Conv2dFn(torch.autograd.Function):
             in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
+        ctx.bias_ref = bias                 # only its address / shape are used (gradient sink lookup)
         ctx.save_for_backward(x, w, y if relu else None, in_stats)
         if with_skip:                       # second output: x itself, for a skip connection (see backward)
             return y, x.view_as(x)
@@ -106,12 +130,21 @@ class _Conv2dFn(torch.autograd.Function):
         stride, pt, pl, oh, ow = ctx.geom
         dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
+        dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.relu:
             dz = torch.empty_like(dy)
-            check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
+            if want_db:                      # dz and its column sums (the bias gradient) in one pass
+                db, db_note = _sink(ctx.bias_ref)
+                ws = workspace(lib.embnet_colsum_workspace_bytes(dy.numel() // k, k), x.device)
+                check(lib.embnet_relu_bwd_colsum(ptr(dy), ptr(y), dy.numel() // k, k, ptr(dz), ptr(db), ptr(ws),
+                                                 ws.numel() * 4, stream()))
+                db = _done(db, db_note)
+                want_db = False
+            else:
+                check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
         else:
             dz = dy
-        dx = dw = db = None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
         in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
@@ -122,8 +155,9 @@ class _Conv2dFn(torch.autograd.Function):
                     in_scale, in_shift, ctx.in_act)
             check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
 
+        dw_note = None
         if need_dw:
-            dw = torch.empty_like(w)
+            dw, dw_note = _sink(w)
         overlap = OVERLAP_WGRAD and need_dx and need_dw
         if overlap:
             main = torch.cuda.current_stream()
@@ -142,8 +176,12 @@ class _Conv2dFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
             run_wgrad()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dz.view(-1, k))
+        if need_dw:
+            dw = _done(dw, dw_note)
+        if want_db:
+            db, db_note = _sink(ctx.bias_ref)
+            _colsum(dz.view(-1, k), out=db)
+            db = _done(db, db_note)
         if dskip is not None and dx is None and ctx.needs_input_grad[0]:
             dx = dskip
         return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None
@@ -203,11 +241,12 @@ class _ConvPairFn(torch.autograd.Function):
                 first = False
             dw = None
             if need_dw:
-                dw = torch.empty_like(w)
+                dw, note = _sink(w)
                 ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
                 args = (ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
                         in_scale, in_shift, ctx.in_act)
                 check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
+                dw = _done(dw, note)
             dws.append(dw)
         if dx is not None and first:
             dx.zero_()
@@ -238,10 +277,11 @@ def conv_pair(x, conv1, conv2, emit_stats=False):
     return y1, y2
 
 
-def _colsum(x2d):
+def _colsum(x2d, out=None):
     lib = _lib.lib()
     m, c = x2d.shape
-    out = torch.empty((c,), device=x2d.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((c,), device=x2d.device, dtype=torch.float32)
     ws = workspace(lib.embnet_colsum_workspace_bytes(m, c), x2d.device)
     check(lib.embnet_colsum(ptr(x2d), m, c, ptr(out), ptr(ws), ws.numel() * 4, stream()))
     return out
@@ -326,8 +366,12 @@ class _DenseFn(torch.autograd.Function):
         if i != i2:
             raise _lib.EmbnetError(f"dense: input width {i} != kernel rows {i2}")
         y = torch.empty((m, o), device=x.device, dtype=torch.float32)
-        check(_lib.lib().embnet_dense_fwd_f32(ptr(x), ptr(w), ptr(bias), ptr(y), m, i, o, int(relu), stream()))
-        ctx.relu, ctx.has_bias = relu, bias is not None
+        lib = _lib.lib()
+        nws = lib.embnet_dense_fwd_workspace_bytes(m, i, o)          # > 0: few output tiles, long reduction -> K split
+        ws = workspace(nws, x.device) if nws else None
+        check(lib.embnet_dense_fwd_f32(ptr(x), ptr(w), ptr(bias), ptr(y), m, i, o, int(relu), ptr(ws),
+                                       ws.numel() * 4 if nws else 0, stream()))
+        ctx.relu, ctx.has_bias, ctx.bias_ref = relu, bias is not None, bias
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -338,20 +382,30 @@ class _DenseFn(torch.autograd.Function):
         m, i = x.shape
         o = w.shape[1]
         dy = _c(dy)
+        dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.relu:
             dz = torch.empty_like(dy)
-            check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
+            if want_db:
+                db, note = _sink(ctx.bias_ref)
+                ws = workspace(lib.embnet_colsum_workspace_bytes(m, o), x.device)
+                check(lib.embnet_relu_bwd_colsum(ptr(dy), ptr(y), m, o, ptr(dz), ptr(db), ptr(ws), ws.numel() * 4, stream()))
+                db, want_db = _done(db, note), False
+            else:
+                check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
         else:
             dz = dy
-        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             check(lib.embnet_dense_dgrad_f32(ptr(dz), ptr(w), ptr(dx), m, i, o, stream()))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw, note = _sink(w)
             check(lib.embnet_dense_wgrad_f32(ptr(x), ptr(dz), ptr(dw), m, i, o, stream()))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dz)
+            dw = _done(dw, note)
+        if want_db:
+            db, note = _sink(ctx.bias_ref)
+            _colsum(dz, out=db)
+            db = _done(db, note)
         return dx, dw, db, None
 
 
@@ -387,6 +441,20 @@ def _partials_of(x, training):
     return p if (p is not None and p.shape[1] == x.shape[-1]) else None
 
 
+def _bn_grad_targets(ctx, c, device, gamma_idx=1, beta_idx=2):
+    """Where a BatchNormalization backward writes dgamma / dbeta: the parameters' gradient sinks when a data-parallel
+    reducer armed them (layers.GRAD_SINKS), scratch otherwise.  -> (dgamma tensor, dbeta tensor, finish) where
+    finish() returns the (dgamma, dbeta) values to hand back to autograd."""
+    want_g = ctx.has_gamma and ctx.needs_input_grad[gamma_idx]
+    want_b = ctx.needs_input_grad[beta_idx]
+    tg, ng = _sink(ctx.gamma_ref) if want_g else (torch.empty((c,), device=device, dtype=torch.float32), None)
+    tb, nb = _sink(ctx.beta_ref) if want_b else (torch.empty((c,), device=device, dtype=torch.float32), None)
+
+    def finish():
+        return (_done(tg, ng) if want_g else None), (_done(tb, nb) if want_b else None)
+    return tg, tb, finish
+
+
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
@@ -403,6 +471,7 @@ class _BatchNormFn(torch.autograd.Function):
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(relu), ptr(y), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
         if with_skip:                       # second output: x itself, for the identity shortcut (see backward)
             return y, x.view_as(x)
@@ -419,15 +488,14 @@ class _BatchNormFn(torch.autograd.Function):
         dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
         dx = torch.empty_like(x)
-        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats.data_ptr() if ctx.training else None
         rstd = (stats.data_ptr() + 4 * stats.shape[1]) if ctx.training else None
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), dgb.data_ptr(),
-                                (dgb.data_ptr() + 4 * dgb.shape[1]), ptr(ws), ws.numel() * 4, stream()))
-        dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
-        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(ws),
+                                ws.numel() * 4, stream()))
+        dgamma, dbeta = finish()
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -453,6 +521,7 @@ class _BNGapFn(torch.autograd.Function):
         check(lib.embnet_affine_act_gap(ptr(x), n, m // n, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(act),
                                         ptr(y), ptr(g), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = act, training, gamma is not None
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
         return y, g
 
@@ -468,15 +537,14 @@ class _BNGapFn(torch.autograd.Function):
             check(lib.embnet_gap_bwd(ptr(_c(dg)), n, m // n, c, ptr(dy), ptr(dz), stream()))
             dy = dz
         dx = torch.empty_like(x)
-        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats.data_ptr() if ctx.training else None
         rstd = (stats.data_ptr() + 4 * c) if ctx.training else None
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
-                                int(ctx.relu), int(ctx.training), None, ptr(dx), dgb.data_ptr(),
-                                (dgb.data_ptr() + 4 * c), ptr(ws), ws.numel() * 4, stream()))
-        dgamma = dgb[0] if (ctx.has_gamma and ctx.needs_input_grad[1]) else None
-        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+                                int(ctx.relu), int(ctx.training), None, ptr(dx), ptr(tg), ptr(tb), ptr(ws),
+                                ws.numel() * 4, stream()))
+        dgamma, dbeta = finish()
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -529,6 +597,7 @@ class _BNDeferFn(torch.autograd.Function):
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(act), None, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         ctx.relu, ctx.training, ctx.has_gamma = int(act), training, gamma is not None
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
         ctx.mark_non_differentiable(stats)
         return x.view_as(x), stats
@@ -628,6 +697,7 @@ class _InputBNConvFn(torch.autograd.Function):
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
             ptr(out_stats), ptr(cws), cws.numel() * 4, stream()))
         ctx.geom, ctx.c, ctx.zero_sum_dy = geom, c, bool(zero_sum_dy)
+        ctx.beta_ref = beta
         ctx.save_for_backward(a, w)
         return y
 
@@ -644,7 +714,12 @@ class _InputBNConvFn(torch.autograd.Function):
         check(lib.embnet_conv2d_wgrad_f32(
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
             None, None, 0, stream()))
-        dw = dw_p if cp == c else dw_p[:, :, :c, :].contiguous()
+        if cp == c:
+            dw = dw_p
+        else:
+            dw, dw_note = _sink(w)
+            dw.copy_(dw_p[:, :, :c, :])
+            dw = _done(dw, dw_note)
         taps = torch.empty((r, s, 1, k), device=a.device, dtype=torch.float32)
         if ctx.zero_sum_dy:
             # dy is the data gradient of a training-mode BatchNormalization (sums to zero per channel): the per-tap sums
@@ -661,9 +736,9 @@ class _InputBNConvFn(torch.autograd.Function):
             check(lib.embnet_conv2d_wgrad_f32(
                 ptr(ones), ptr(dy), ptr(taps), ptr(ws), ws.numel() * 4, n, h, wd, 1, r, s, k, stride, pt, pl, oh, ow,
                 None, None, 0, stream()))
-        dbeta = torch.empty((c,), device=a.device, dtype=torch.float32)
+        dbeta, db_note = _sink(ctx.beta_ref)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
-        return None, dbeta, None, None, dw, None, None, None, None, None
+        return None, _done(dbeta, db_note), None, None, dw, None, None, None, None, None
 
 
 def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
@@ -754,6 +829,7 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         check(lib.embnet_bn_act_maxpool_fwd(ptr(x), n, h, w, c, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), int(act), k,
                                             stride, pad, oh, ow, ptr(y), ptr(arg), ptr(xwin) if training else None, stream()))
         ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow, int(act), training, gamma is not None)
+        ctx.has_gamma, ctx.gamma_ref, ctx.beta_ref = gamma is not None, gamma, beta
         if training:
             ctx.save_for_backward(x, stats, arg, xwin)
         else:
@@ -768,16 +844,15 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         lib = _lib.lib()
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
         ws = workspace(lib.embnet_bn_act_maxpool_bwd_workspace_bytes(n, oh, ow, c), x.device)
         mean = stats.data_ptr() if training else None
         rstd = (stats.data_ptr() + 4 * stats.shape[1]) if training else None
         check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
                                             (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), act, int(training),
                                             ptr(xwin) if training else None, ptr(dx),
-                                            dgb.data_ptr(), (dgb.data_ptr() + 4 * dgb.shape[1]), ptr(ws), ws.numel() * 4, stream()))
-        dgamma = dgb[0] if (has_gamma and ctx.needs_input_grad[1]) else None
-        dbeta = dgb[1] if ctx.needs_input_grad[2] else None
+                                            ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, stream()))
+        dgamma, dbeta = finish()
         return (dx, dgamma, dbeta) + (None,) * 10
 
 
@@ -917,10 +992,11 @@ class _DepthwiseFn(torch.autograd.Function):
             check(lib.embnet_dwconv2d_dgrad_f32(ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
                                                 stream()))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw, note = _sink(w)
             ws = workspace(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, r, s, oh, ow), x.device)
             check(lib.embnet_dwconv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s,
                                                 stride, pt, pl, oh, ow, stream()))
+            dw = _done(dw, note)
         return dx, dw, None
 
 
@@ -1083,12 +1159,59 @@ def l2_penalty(w, lam):
     return _L2PenaltyFn.apply(w, float(lam))
 
 
-def regularization_loss(module):
-    """Sum of the l2 kernel regularisers declared on Conv2D/Dense layers (Keras adds it to the loss)."""
-    total = None
-    for m in module.modules():
-        lam = getattr(m, "l2", 0.0)
-        if lam and isinstance(m, (Conv2D, Dense)) and m.kernel.requires_grad:
-            term = l2_penalty(m.kernel, lam)
-            total = term if total is None else total + term
-    return total
+def regularized_kernels(module):
+    """[(kernel parameter, lambda)] of the Conv2D / Dense layers that declare kernel_regularizer=l2(lambda)."""
+    return [(m.kernel, float(m.l2)) for m in module.modules()
+            if isinstance(m, (Conv2D, Dense)) and getattr(m, "l2", 0.0) and m.kernel.requires_grad]
+
+
+class _L2MultiFn(torch.autograd.Function):
+    """sum_t lambda_t * sum(w_t^2) over all regularised kernels in ONE launch pair (embnet_sumsq_multi).
+    with_grad=False: the value only — the caller's optimizer adds 2*lambda*w to the gradients itself
+    (KerasOptimizer.set_l2: folded into embnet_optimizer_step), so backward returns nothing."""
+
+    @staticmethod
+    def forward(ctx, with_grad, plan, *kernels):
+        lib = _lib.lib()
+        out = torch.empty((), device=kernels[0].device, dtype=torch.float32)
+        ws = workspace(4 * plan["chunks"].shape[0], out.device)
+        check(lib.embnet_sumsq_multi(plan["table"].data_ptr(), len(kernels), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
+                                     ptr(out), ptr(ws), ws.numel() * 4, stream()))
+        ctx.with_grad, ctx.lams = with_grad, plan["lams"]
+        if with_grad:
+            ctx.save_for_backward(*kernels)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.with_grad:
+            return (None, None) + (None,) * len(ctx.lams)
+        grads = []
+        for w, lam in zip(ctx.saved_tensors, ctx.lams):
+            dw = torch.empty_like(w)
+            check(_lib.lib().embnet_scale(ptr(w), w.numel(), 2.0 * lam, ptr(_c(dout)), ptr(dw), stream()))
+            grads.append(dw)
+        return (None, None) + tuple(grads)
+
+
+def regularization_loss(module, with_grad=True):
+    """Sum of the l2 kernel regularisers declared on Conv2D/Dense layers (Keras adds it to the loss).
+    with_grad=False: value only (see _L2MultiFn)."""
+    import numpy as np
+    ks = regularized_kernels(module)
+    if not ks:
+        return None
+    key = tuple((k.data_ptr(), k.numel(), lam) for k, lam in ks)
+    plan = getattr(module, "_l2_plan", None)
+    if plan is None or plan["key"] != key:               # descriptor table + chunk list, rebuilt only if storage moved
+        dev = ks[0][0].device
+        ce = _lib.lib().embnet_sumsq_chunk_elems()
+        rows = np.zeros((len(ks), 3), dtype=np.int64)
+        for i, (k, lam) in enumerate(ks):
+            rows[i, 0], rows[i, 1] = k.data_ptr(), k.numel()
+            rows[i, 2] = int(np.float32(lam).view(np.uint32))               # {float alpha; int32 pad} in one int64
+        chunks = [(i, c) for i, (k, _) in enumerate(ks) for c in range(-(-k.numel() // ce))]
+        plan = dict(key=key, table=torch.from_numpy(rows).to(dev), lams=[lam for _, lam in ks],
+                    chunks=torch.tensor(chunks, dtype=torch.int32, device=dev))
+        module._l2_plan = plan
+    return _L2MultiFn.apply(bool(with_grad), plan, *[k for k, _ in ks])

@@ -93,6 +93,11 @@ class EmbeddingNet:
             data_labels += [class_name] * len(encods)
         return {'paths': data_paths, 'labels': data_labels, 'encodings': np.squeeze(np.array(data_encodings))}
 
+    def train_embeddings_classifier(self, data_loader, classification_model, max_n_samples=10, shuffle=True):
+        """reference models.py:52-59: fit any scikit-learn style classifier (`.fit(X, y)`) on the training encodings."""
+        encodings = self.generate_encodings(data_loader, max_n_samples=max_n_samples, shuffle=shuffle)
+        classification_model.fit(encodings['encodings'], encodings['labels'])
+
     def save_encodings(self, encoded_training_data, save_folder='./', save_file_name='encodings.pkl'):
         import pickle
         data = {k: v for k, v in encoded_training_data.items() if k != 'knn_classifier'}

@@ -31,7 +31,7 @@ def pairwise_distances(x, squared=False):
     x = _prep(x.detach())
     n, e = x.shape
     lib = _lib.lib()
-    ws = _new((max(lib.embnet_pairwise_workspace_bytes(n) // 4, 1),), x)
+    ws = _new((max(lib.embnet_pairwise_workspace_bytes(n, e) // 4, 1),), x)
     d = _new((n, n), x)
     check(lib.embnet_pairwise_dist_f32(ptr(x), n, e, ptr(d), int(bool(squared)), ptr(ws),
                                        ws.numel() * 4, stream()))

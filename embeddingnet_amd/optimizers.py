@@ -36,6 +36,7 @@ class KerasOptimizer(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("one parameter group (the reference sets a single learning rate)")
         self._ptrs, self._table, self._chunks, self._host, self._copied = None, None, None, None, None
+        self._l2 = {}                # parameter -> lambda of its kernel_regularizer (set_l2): 2*lambda*w joins the gradient in the kernel
         self.coef_dev = None         # device float[6] the kernel reads its scalars from (set by a graph-capturing trainer)
 
     # -- state ----------------------------------------------------------------------------
@@ -46,6 +47,12 @@ class KerasOptimizer(torch.optim.Optimizer):
             if f"slot{i + 1}" not in st:
                 st[f"slot{i + 1}"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st.get("slot1"), st.get("slot2")
+
+    def set_l2(self, kernels):
+        """[(parameter, lambda)]: fold the gradient of kernel_regularizer=l2(lambda) — 2*lambda*w — into the update launch
+        (the caller then adds only the regularisers' VALUE to the loss: layers.regularization_loss(..., with_grad=False))."""
+        self._l2 = {id(p): float(lam) for p, lam in kernels}
+        self._ptrs = None
 
     def state_dict(self):
         d = super().state_dict()
@@ -87,8 +94,9 @@ class KerasOptimizer(torch.optim.Optimizer):
                 raise _lib.EmbnetError("KerasOptimizer: gradients must be dense contiguous fp32")
             s1, s2 = self._slots(p)
             gp = g.data_ptr() if g is not None else 0
+            l2x2 = int(np.float32(2.0 * self._l2.get(id(p), 0.0)).view(np.uint32))      # {float l2x2; int32 pad} as one int64
             rows.append((p.data_ptr(), gp, s1.data_ptr() if s1 is not None else 0,
-                         s2.data_ptr() if s2 is not None else 0, p.numel()))
+                         s2.data_ptr() if s2 is not None else 0, p.numel(), l2x2))
             ptrs.append(gp)
         if self._chunks is None:
             ce = lib.embnet_optimizer_chunk_elems()
@@ -101,7 +109,7 @@ class KerasOptimizer(torch.optim.Optimizer):
             if host is None or host.shape[0] != len(rows):
                 raise _lib.EmbnetError("KerasOptimizer: call prepare_capture() before capturing a step")
             host.copy_(torch.from_numpy(np.asarray(rows, dtype=np.uint64).view(np.int64)))
-            self._table = torch.empty((len(rows), 5), dtype=torch.int64, device=dev)
+            self._table = torch.empty((len(rows), 6), dtype=torch.int64, device=dev)
             self._table.copy_(host, non_blocking=True)
             self._ptrs = ptrs
             return
@@ -109,8 +117,8 @@ class KerasOptimizer(torch.optim.Optimizer):
         # tables, so that the host never waits for the upload of the step before (one table + an event wait kept the host
         # at most one step ahead of the GPU: 5 ms of host time per ResNet18 step went into that wait)
         if not hasattr(self, "_ring"):
-            self._ring = [[torch.empty((len(rows), 5), dtype=torch.int64).pin_memory(),
-                           torch.empty((len(rows), 5), dtype=torch.int64, device=dev), None] for _ in range(4)]
+            self._ring = [[torch.empty((len(rows), 6), dtype=torch.int64).pin_memory(),
+                           torch.empty((len(rows), 6), dtype=torch.int64, device=dev), None] for _ in range(4)]
             self._ring_i = 0
         self._ring_i = (self._ring_i + 1) % len(self._ring)
         slot = self._ring[self._ring_i]
@@ -143,7 +151,7 @@ class KerasOptimizer(torch.optim.Optimizer):
 
     def prepare_capture(self):
         """Allocate what a captured step() needs that cannot be allocated during stream capture."""
-        self._graph_host = torch.empty((len(self._tensors), 5), dtype=torch.int64).pin_memory()
+        self._graph_host = torch.empty((len(self._tensors), 6), dtype=torch.int64).pin_memory()
         self._ptrs = None                                  # the captured step builds (and keeps) its own table
 
     def scalars(self, t):
@@ -152,6 +160,39 @@ class KerasOptimizer(torch.optim.Optimizer):
         lr = float(self.param_groups[0]["lr"])
         rule, b1, b2, c1, c2 = self._coefficients(lr, t)
         return rule, [lr, b1, b2, self.eps, c1, c2]
+
+
+def save_optimizer_state(path, opt, named_params, extra=None):
+    """Optimizer slots keyed by the Keras weight names (backbones.keras_weights order), `iterations`, and `extra` scalars
+    (e.g. the epoch) -> an .npz next to a weights checkpoint, so that --resume_from continues Adam / RAdam / RMSprop where
+    they stopped (the reference's ModelCheckpoint saves the optimizer with the model)."""
+    data = {"__iterations__": np.asarray(opt.iterations), "__rule__": np.asarray(opt.rule)}
+    for k, v in (extra or {}).items():
+        data[f"__extra__{k}"] = np.asarray(v)
+    index = {id(p): name for name, p in named_params.items()}
+    for p, st in opt.state.items():
+        name = index.get(id(p))
+        if name is None:
+            continue
+        for slot in ("slot1", "slot2"):
+            if slot in st:
+                data[f"{name}::{slot}"] = st[slot].detach().cpu().numpy()
+    np.savez(path, **data)
+
+
+def load_optimizer_state(path, opt, named_params):
+    """Inverse of save_optimizer_state; returns the `extra` dict.  Slots of parameters the file does not hold stay zero."""
+    d = np.load(path, allow_pickle=False)
+    if str(d["__rule__"]) != opt.rule:
+        raise _lib.EmbnetError(f"optimizer state is for '{d['__rule__']}', the config builds '{opt.rule}'")
+    opt.iterations = int(d["__iterations__"])
+    for name, p in named_params.items():
+        s1, s2 = opt._slots(p)
+        for slot, t in (("slot1", s1), ("slot2", s2)):
+            if t is not None and f"{name}::{slot}" in d:
+                t.copy_(torch.as_tensor(d[f"{name}::{slot}"]).to(t.device).view_as(t))
+    opt._ptrs = None
+    return {k[len("__extra__"):]: d[k] for k in d.files if k.startswith("__extra__")}
 
 
 def SGD(params, lr):

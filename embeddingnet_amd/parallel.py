@@ -14,8 +14,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, local_rank)."""
+def init_distributed(backend=None, timeout_s=None):
+    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, local_rank).
+    timeout_s (or EMBNET_DIST_TIMEOUT_S): collective timeout — the default (10 min for RCCL) is the watchdog that aborts a
+    rank waiting in a collective while another rank does something long on its own."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -27,7 +29,12 @@ def init_distributed(backend=None):
         backend = backend or os.environ.get("EMBNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        timeout_s = timeout_s or os.environ.get("EMBNET_DIST_TIMEOUT_S")
+        kw = {}
+        if timeout_s:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -96,6 +103,13 @@ class GradReducer:
     no part in a step contributes zeros (its bucket is still reduced, so the ranks stay in step).
     Bucket order: parameters are laid out in the order the FIRST backward produced their gradients (recorded by the
     hooks, rank 0's order broadcast so every rank agrees), so from step 2 on each bucket closes as early as possible.
+    A parameter counts ONCE per step however often its hook fires; for gradient accumulation over several backwards use
+    hold(True) ... hold(False); reduce_all() (a bucket reduced after the first backward would miss the later ones).
+    `direct(True)`: the weight-gradient / BatchNorm / bias kernels write straight into the flat-buffer views
+    (layers.GRAD_SINKS) and report to the reducer themselves, so autograd launches no AccumulateGrad `add_` kernel per
+    parameter — only valid while each parameter receives ONE gradient per step (the fused TripletTrainer step).
+    `hold(True)`: count, but launch no collective (a step being captured into a HIP graph); `reduce_all()` then reduces
+    every bucket in order.
     """
 
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, always_reduce=False):
@@ -109,14 +123,23 @@ class GradReducer:
         self._bucket_bytes = bucket_bytes
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dtype)
+        self._works, self._hold, self._direct = [], False, False
         self._layout(list(reversed(self.params)))           # first guess: reverse definition order
         self._seen, self._ordered = [], False               # hook order of the first backward
-        self._works = []
+        self._fired = set()                                 # parameters already counted in this step
         # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
         # NCCL-only and could not be exercised on the single-GPU development box)
         self._avg = dist.ReduceOp.SUM
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def close(self):
+        """Detach from the parameters (hooks, gradient sinks, .grad views): another reducer may take them over."""
+        self.direct(False)
+        for h in self._handles:
+            h.remove()
+        self._handles = []
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+            p.grad = None
 
     def _layout(self, order, keep=False):
         """Assign flat-buffer slots and buckets in `order`; keep=True carries the current gradients over."""
@@ -140,6 +163,19 @@ class GradReducer:
             self.buckets.append([start, off, pending])
         self.order = list(order)
         self._left = [b[2] for b in self.buckets]
+        if self._direct:
+            self.direct(True)                               # the views moved
+
+    def direct(self, on):
+        from . import layers as L
+        self._direct = bool(on)
+        for p in self.params:
+            L.GRAD_SINKS.pop(p.data_ptr(), None)
+            if on:
+                L.GRAD_SINKS[p.data_ptr()] = (p.grad, (lambda q=p: self._count(q)))
+
+    def hold(self, on):
+        self._hold = bool(on)
 
     def _hook(self, p):
         off, n = self._slot[p]
@@ -147,20 +183,46 @@ class GradReducer:
             view = self.flat[off:off + n].view_as(p)        # the gradient was re-allocated outside the buffer
             view.copy_(p.grad)
             p.grad = view
+        self._count(p)
+
+    def _count(self, p):
+        if p in self._fired:                                # a second gradient for the same parameter in this step
+            return
+        self._fired.add(p)
         if not self._ordered:
             self._seen.append(p)
         b = self._bucket_of[p]
         self._left[b] -= 1
-        if self._left[b] == 0 and self._reduce:
+        if self._left[b] == 0 and self._reduce and not self._hold:
             s, e, _ = self.buckets[b]
             self._works.append(dist.all_reduce(self.flat[s:e], op=self._avg, group=self.group, async_op=True))
 
     def zero(self):
         self.flat.zero_()
         self._left = [b[2] for b in self.buckets]
+        self._fired = set()
+
+    def zero_counts(self):
+        """Re-arm the per-step bookkeeping without touching the buffer (a replayed graph zeroes it itself)."""
+        self._left = [b[2] for b in self.buckets]
+        self._fired = set()
+
+    def reduce_all(self):
+        """All buckets, in order, then wait and average: the gradient exchange of a step whose backward ran with the
+        collectives held back (a replayed HIP graph)."""
+        if self._reduce:
+            for s, e, _ in self.buckets:
+                self._works.append(dist.all_reduce(self.flat[s:e], op=self._avg, group=self.group, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.world > 1 and self._avg == dist.ReduceOp.SUM:
+            self.flat.div_(self.world)
 
     def finish(self):
         """Wait for the outstanding bucket reductions (call after backward, before optimizer.step)."""
+        if self._hold:
+            return
         if self._reduce:
             # parameters whose hook never fired (unused in this step) keep their bucket open; reduce those too
             for b, left in enumerate(self._left):

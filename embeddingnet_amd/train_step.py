@@ -31,8 +31,9 @@ class TripletTrainer:
     ~200 (simple2), for the batch sizes where the host cannot keep up with the GPU.  The step-dependent scalars (the
     optimizer's bias corrections, the mining seed) live in device memory and are refreshed by a 32-byte copy before
     each replay (dropout layers add a device-side step counter to their seeds); results are bit-identical to eager steps.
-    Needs: the KerasOptimizer, the fused loss path and no gradient reducer (N = 1); anything else, or a failed capture,
-    falls back to eager steps.  Steps taken while the kernel trace is on run eagerly."""
+    Needs: the KerasOptimizer and the fused loss path; anything else, or a failed capture, falls back to eager steps.
+    With a gradient reducer (N > 1) the step is two graphs — forward + backward, optimizer — with the bucketed gradient
+    all-reduce issued between them as ordinary collectives.  Steps taken while the kernel trace is on run eagerly."""
     GRAPH_WARMUP = 8          # graph='auto' decides here: see _probe
     # (last_triplets / last_total are the replayed step's own buffers in graph mode: read them before the next step)
 
@@ -48,6 +49,13 @@ class TripletTrainer:
         self.fused_loss = os.environ.get("EMBNET_FUSED_LOSS", "1") == "1"
         if self.mode not in tuple(ops.MINING_MODES) + ("batch_hard",):
             raise KeyError(self.mode)
+        from .optimizers import KerasOptimizer
+        self._keras_opt = isinstance(optimizer, KerasOptimizer)
+        if self._keras_opt:
+            # the regularisers' gradient (2*lambda*w) joins g inside the one optimizer launch; the loss keeps their value
+            optimizer.set_l2(L.regularized_kernels(base_model))
+            if reducer is not None:
+                reducer.direct(True)          # one gradient per parameter and step: kernels write the flat buffer in place
 
     def mine(self, emb):
         with torch.no_grad():
@@ -73,7 +81,7 @@ class TripletTrainer:
         else:
             trip, count = self.mine(emb)
             mean, _ = ops.triplet_gather_loss(emb, trip, count, self.margin)
-        reg = L.regularization_loss(self.model)
+        reg = L.regularization_loss(self.model, with_grad=not self._keras_opt)
         return (mean if reg is None else mean + reg), mean, count
 
     # ---- graph replay ---------------------------------------------------------------------------------------
@@ -81,15 +89,14 @@ class TripletTrainer:
         return getattr(self, "_state", None) is not None and torch.cuda.is_current_stream_capturing()
 
     def _graph_supported(self, images):
-        from .optimizers import KerasOptimizer
-        if self.reducer is not None or not isinstance(self.opt, KerasOptimizer) or not self.fused_loss:
+        if not self._keras_opt or not self.fused_loss:
             return False
         return self.opt.rule != "radam" or self.opt.iterations >= 6      # RAdam switches kernels while it warms up
 
     def _push_state(self):
         """Scalars of the step about to run -> the next slot of a pinned ring -> device (stream-ordered before the replay)."""
         slot = self._ring_pos % self._ring.shape[0]
-        if slot % 128 == 0:                                 # the copy issued 128 steps ago from this half must be done
+        if slot % 128 == 0:                                 # about to overwrite this half: its copies of the previous lap must be done
             ev = self._ring_events[(slot // 128) % 2]
             if ev is not None:
                 ev.synchronize()
@@ -99,9 +106,9 @@ class TripletTrainer:
         self._ring_np[slot, 8:10].view("uint64")[0] = self._since_capture
         row = self._ring[slot]
         self._state.copy_(row, non_blocking=True)
-        if slot % 128 == 127:
+        if slot % 128 == 127:                               # last copy out of this half: its event guards the half's next lap
             ev = torch.cuda.Event(); ev.record()
-            self._ring_events[((slot // 128) + 1) % 2] = ev
+            self._ring_events[(slot // 128) % 2] = ev
         self._ring_pos += 1
 
     def _capture(self, images):
@@ -115,31 +122,48 @@ class TripletTrainer:
         self._gx = torch.empty_like(images)
         self.opt.coef_dev = self._state
         self.opt.prepare_capture()
+        it0, st0 = self.opt.iterations, self.step_no
+        drop_steps = [m._step for m in self._drops]
         try:
             self._gx.copy_(images)
-            it0, st0 = self.opt.iterations, self.step_no
             self.step_no += 1
             self._push_state()
-            drop_steps = [m._step for m in self._drops]
             g = torch.cuda.CUDAGraph()
             L.GRAPH_TICK = self._state.data_ptr() + 32
             try:
-                with torch.cuda.graph(g):
-                    self._gout = self._eager_step(self._gx)
+                if self.reducer is None:
+                    with torch.cuda.graph(g):
+                        self._gout = self._eager_step(self._gx)
+                    self._graph_opt = None
+                else:
+                    # data parallel: forward + backward is one graph (the reducer counts but launches nothing), the gradient
+                    # all-reduce runs between the graphs as ordinary bucketed collectives, the optimizer is a second graph
+                    self.reducer.hold(True)
+                    with torch.cuda.graph(g):
+                        self._gout = self._eager_step(self._gx, with_update=False)
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, pool=g.pool()):
+                        self.opt.step()
+                    self._graph_opt = g2
             finally:
                 L.GRAPH_TICK = None
-            # capturing ran the Python side once without executing anything: the counters advanced, the weights did not
-            self.opt.iterations, self.step_no = it0, st0
-            for m, st in zip(self._drops, drop_steps):
-                m._step = st
+                if self.reducer is not None:
+                    self.reducer.hold(False)
             self._g_last = (self.last_triplets, self.last_total)     # the replayed step's (static) output tensors
             self._graph = g
         except Exception as exc:                                                  # stay correct: eager from here on
             self._graph, self._graph_failed, self._state = None, True, None
             self._graph_error = f"{type(exc).__name__}: {exc}"
             self.opt.coef_dev = None
+            self.opt._ptrs = self.opt._table = None                # they pointed into the failed capture's pool
             import warnings
             warnings.warn(f"TripletTrainer: graph capture failed ({type(exc).__name__}: {exc}); running eager steps")
+        finally:
+            # capturing ran the Python side once without executing anything: the counters advanced, the weights did not —
+            # whether or not the capture succeeded
+            self.opt.iterations, self.step_no = it0, st0
+            for m, st in zip(self._drops, drop_steps):
+                m._step = st
 
     def _replay(self, images):
         self._gx.copy_(images)
@@ -150,7 +174,13 @@ class TripletTrainer:
             if m.training and m.enabled and m.rate > 0:
                 m._step += 1
         self._since_capture += 1
-        self._graph.replay()
+        if self._graph_opt is None:
+            self._graph.replay()
+        else:
+            self.reducer.zero_counts()
+            self._graph.replay()                                # zero the flat buffer, forward, backward
+            self.reducer.reduce_all()                           # bucketed all-reduce, wait, average
+            self._graph_opt.replay()
         self.last_triplets, self.last_total = self._g_last      # an eager step in between re-bound them
         return self._gout.clone()                               # callers keep per-step losses; the graph's output is one buffer
 
@@ -169,11 +199,20 @@ class TripletTrainer:
         torch.cuda.synchronize()
         eager = (time.perf_counter() - t0) / 3
         self.graph_probe = dict(eager_ms=1e3 * eager, host_ms=1e3 * host / 3)
-        if host / 3 < 0.8 * eager or not self._graph_supported(images):
+        want = host / 3 >= 0.8 * eager and self._graph_supported(images)
+        if self.reducer is not None:                             # every rank must take the same branch: the replays hold collectives
+            want = self._agree(want, any_rank=True)
+        if not want:
             self.graph_mode = False                              # GPU-bound as it is
             return
         self._capture(images)
-        if self._graph is None:
+        ok = self._graph is not None
+        if self.reducer is not None:
+            ok = self._agree(ok, any_rank=False)                 # a rank whose capture failed takes everyone back to eager steps
+            if not ok:
+                self._graph, self.graph_mode = None, False
+                self.opt.coef_dev = None
+        if not ok:
             return
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -182,9 +221,21 @@ class TripletTrainer:
         torch.cuda.synchronize()
         replay = (time.perf_counter() - t0) / 3
         self.graph_probe["replay_ms"] = 1e3 * replay
-        if replay > 0.97 * eager:                                # no gain: stay eager
+        keep = replay <= 0.97 * eager
+        if self.reducer is not None:
+            keep = self._agree(keep, any_rank=False)
+        if not keep:                                             # no gain: stay eager
             self._graph, self.graph_mode = None, False
             self.opt.coef_dev = None
+
+    def _agree(self, flag, any_rank):
+        """One decision for all ranks: True if any rank (any_rank) / every rank says so."""
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_world_size(self.reducer.group) > 1):
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=self.reducer.flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if any_rank else dist.ReduceOp.MIN, group=self.reducer.group)
+        return bool(t.item() > 0.5)
 
     def step(self, images):
         from . import _lib
@@ -211,7 +262,7 @@ class TripletTrainer:
             if has:
                 self.opt.coef_dev = saved
 
-    def _eager_step(self, images, count_step=False):
+    def _eager_step(self, images, count_step=False, with_update=True):
         self.model.train()
         if count_step:
             self.step_no += 1
@@ -226,5 +277,6 @@ class TripletTrainer:
         total.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
+        if with_update:
+            self.opt.step()
         return mean.detach()

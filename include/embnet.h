@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 10
+#define EMBNET_ABI_VERSION 11
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -55,8 +55,10 @@ int embnet_trace_get(int i, char* name, int name_cap, float* ms, double* work, i
 
 /* datagenerators.py:219 `pairwise_distances(all_embeddings)` (scikit-learn euclidean):
  * dist[n,n] = sqrt(max(|x_i|^2 + |x_j|^2 - 2 x_i.x_j, 0)), diagonal 0; squared!=0 skips the sqrt.
- * x[n,e].  workspace >= embnet_pairwise_workspace_bytes(n). */
-size_t embnet_pairwise_workspace_bytes(int n);
+ * x[n,e].  workspace >= embnet_pairwise_workspace_bytes(n, e) (row norms + the partial Gram slabs of a K-split launch: a
+ * batch of n < 512 rows at a long e, e.g. the reference's default encodings_len = 4096, is too few tiles to fill the chip
+ * otherwise; a workspace of only n floats is accepted and runs unsplit). */
+size_t embnet_pairwise_workspace_bytes(int n, int e);
 int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dist, int squared,
                              void* workspace, size_t workspace_bytes, void* stream);
 
@@ -194,9 +196,13 @@ int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, v
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
 
-/* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out]. */
+/* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out].
+ * workspace (optional, may be NULL/0): >= embnet_dense_fwd_workspace_bytes lets a forward with few output tiles and a long
+ * reduction (simple2's Flatten -> Dense(512): 12 800 x 512 at batch 32) cut K over workgroups (partial slabs + fixed-order
+ * sum with bias / ReLU); 0 bytes = this shape runs unsplit. */
+size_t embnet_dense_fwd_workspace_bytes(int m, int in, int out);
 int embnet_dense_fwd_f32(const float* x, const float* w, const float* bias, float* y, int m, int in, int out,
-                         int relu, void* stream);
+                         int relu, void* workspace, size_t workspace_bytes, void* stream);
 int embnet_dense_dgrad_f32(const float* dy, const float* w, float* dx, int m, int in, int out, void* stream);
 int embnet_dense_wgrad_f32(const float* x, const float* dy, float* dw, int m, int in, int out, void* stream);
 
@@ -260,6 +266,10 @@ int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, f
 
 /* Elementwise helpers of the backward pass and the residual blocks. */
 int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void* stream);   /* dz = dy*[y>0] */
+/* the same on dy/y[m,c] plus dbias[c] = column sums of dz, one pass (Conv2D / Dense with bias and a fused ReLU);
+ * workspace >= embnet_colsum_workspace_bytes(m, c) */
+int embnet_relu_bwd_colsum(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
+                           size_t workspace_bytes, void* stream);
 size_t embnet_colsum_workspace_bytes(long m, int c);
 int embnet_colsum(const float* x, long m, int c, float* out, void* workspace, size_t workspace_bytes,
                   void* stream);                                                                /* bias grads */
@@ -308,6 +318,13 @@ int embnet_absdiff_bwd(const float* a, const float* b, const float* dy, long tot
                        void* stream);
 
 /* kernel_regularizer=l2(lambda) (backbones.py:22-36): *out = alpha * sum x^2. */
+/* All regularisers of a model in one launch pair: *out = sum_t alpha_t * sum(x_t^2).
+ *   table   device array of n_tensors descriptors, 24 bytes each: { const float* x; int64 n; float alpha; int32 pad; }
+ *   chunks  device int32 [n_chunks][2] = (tensor index, chunk index), chunk = embnet_sumsq_chunk_elems() elements
+ *   workspace >= n_chunks floats. */
+int embnet_sumsq_chunk_elems(void);
+int embnet_sumsq_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
 size_t embnet_sumsq_workspace_bytes(void);
 int embnet_sumsq(const float* x, long total, float alpha, float* out, void* workspace, size_t workspace_bytes,
                  void* stream);
@@ -335,9 +352,11 @@ int embnet_fused_triplet_loss_fwd(const float* emb, int p, int k, int e, float m
  * utils.py:143-153 get_optimizer(name, lr): `Adam(lr)`, `RMSprop(lr)`, `keras_radam.RAdam(lr)`, else `SGD(lr)`
  * with the library defaults — applied by Keras after train.py:160-177's compile/fit.  One launch updates every
  * tensor (multi-tensor apply).
- *   table   device array of n_tensors descriptors, 40 bytes each:
- *             { float* w; const float* g; float* slot1; float* slot2; int64 n; }
+ *   table   device array of n_tensors descriptors, 48 bytes each:
+ *             { float* w; const float* g; float* slot1; float* slot2; int64 n; float l2x2; int32 pad; }
  *           g == NULL: the variable got no gradient this step and is skipped (Keras' behaviour);
+ *           l2x2 = 2*lambda of the variable's kernel_regularizer=l2(lambda) (backbones.py:22-36), 0 for none: the kernel
+ *           uses g + l2x2*w as the gradient (what Keras gets from differentiating loss + regularisers);
  *           slot1/slot2: Adam/RAdam m and v, RMSprop rms (slot2 unused), SGD none — zero-initialised by the caller;
  *   chunks  device int32 [n_chunks][2] = (tensor index, chunk index within it), chunk = embnet_optimizer_chunk_elems()
  *           consecutive elements; every element of every tensor must be covered exactly once;

@@ -508,17 +508,14 @@ def test_backbone_forward_backward_vs_oracle(dev, name, shape, enc, batch):
         assert (num / den) ** 0.5 < 2e-2, f"{name}: global gradient rel-L2 error {(num / den) ** 0.5:.2e}"
         return base, x, bad, total
 
-    # Every layer within 5x the fp32 floor, except (deep nets, tiny late feature maps) a couple of layers where a
-    # ReLU/BN decision flips differently than in the fp32 oracle run.  One such flip EARLY in the net (a stem
-    # max-pool arg-max) moves every gradient by ~1e-3 at once; that depends on the input, an arithmetic error
-    # does not — so the tight bound has to hold for one of three inputs, the loose ones (0.3 per tensor, 2e-2
-    # global L2, 2e-4 on the embeddings) for all that are tried.
-    for seed in (0, 1, 2):
-        base, x, bad, total = one_input(seed)
-        if len(bad) <= max(0, total // 40):
-            break
-    else:
-        raise AssertionError(f"{name}: {bad}")
+    # ONE input.  Every parameter gradient within 5x the float32 oracle's own deviation (+ 1e-4) of the float64 oracle for
+    # at least 95 % of the tensors; the rest (a ReLU / arg-max decision that fell the other way than in the float32 oracle
+    # run moves the few tensors behind it) are printed and stay within the loose bounds above.  The per-STAGE gradient
+    # check (tests/test_round3_gpu.py::test_stage_gradients_vs_oracle) is the one that localises a wiring error.
+    base, x, bad, total = one_input(0)
+    if bad:
+        print(f"{name}: {len(bad)} of {total} gradient tensors beyond 5x the float32 floor: {bad}")
+    assert len(bad) <= total // 20, f"{name}: {len(bad)} of {total} tensors off: {bad}"
     # inference path (moving stats) through Model.predict
     pred = base.predict(x)
     ctx_i = _oracle_from(base, training=False)

@@ -22,9 +22,16 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
-    assert bound.embnet_abi_version() == 10
+    assert bound.embnet_abi_version() == 11
     assert bound.embnet_mine_max_triplets(32, 4) == 192
-    assert bound.embnet_pairwise_workspace_bytes(128) == 512
+    assert bound.embnet_pairwise_workspace_bytes(128, 256) == 512          # row norms only: short reduction, no K split
+    # the reference's default encodings_len = 4096 at a 128-row batch: 4 tiles x 128 K tiles -> K split, partial Gram slabs
+    assert bound.embnet_pairwise_workspace_bytes(128, 4096) == 512 + 16 * 128 * 128 * 4
+    assert bound.embnet_pairwise_workspace_bytes(1024, 4096) == 4096          # enough tiles: unsplit
+    # simple2's Flatten -> Dense(512) at batch 32: 8 output tiles, 400 K tiles -> split; ResNet heads: not
+    assert bound.embnet_dense_fwd_workspace_bytes(32, 12800, 512) == 58 * 32 * 512 * 4
+    assert bound.embnet_dense_fwd_workspace_bytes(128, 512, 128) == 0
+    assert bound.embnet_sumsq_chunk_elems() == 4096 and bound.embnet_optimizer_chunk_elems() == 4096
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -258,6 +265,46 @@ red.zero()
 model(x).pow(2).mean().backward()
 red.finish()
 assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+# a second backward before finish(): every parameter still counts once (no negative bucket counters, no early re-launch)
+red.zero()
+model(x).pow(2).mean().backward()
+model(x).pow(2).mean().backward()
+assert all(l >= 0 for l in red._left), red._left
+red.finish()
+# gradient accumulation proper: hold the collectives while the backwards add up, then exchange everything once
+red.zero(); red.hold(True)
+model(x).pow(2).mean().backward()
+model(x).pow(2).mean().backward()
+red.hold(False); red.reduce_all()
+assert torch.allclose(red.flat, 2 * flat, rtol=1e-5, atol=1e-7)
+# hold(): a captured step's backward counts but launches nothing; reduce_all() then exchanges every bucket
+red.zero(); red.hold(True)
+model(x).pow(2).mean().backward()
+red.finish()
+assert not red._works
+red.hold(False); red.reduce_all()
+assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+# direct(): kernels write the flat-buffer views themselves and notify the reducer (layers.GRAD_SINKS); emulated here by
+# filling the views by hand for the last layer and letting autograd deliver the rest
+from embeddingnet_amd import layers as L
+red.direct(True)
+assert set(L.GRAD_SINKS) == {{p.data_ptr() for p in params}}
+local = Net(); local.load_state_dict(model.state_dict())
+local(x).pow(2).mean().backward()
+red.zero()
+for p in model.b.parameters():
+    p.requires_grad_(False)                                     # autograd no longer produces these two gradients
+model(x).pow(2).mean().backward()
+for p, q in zip(model.b.parameters(), local.b.parameters()):
+    view, notify = L.GRAD_SINKS[p.data_ptr()]
+    view.copy_(q.grad); notify(); notify()                      # (a repeated notify is ignored)
+    p.requires_grad_(True)
+red.finish()
+assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+red.close()
+assert not L.GRAD_SINKS and all(p.grad is None for p in params)
+model(x).pow(2).mean().backward()                               # hooks are gone: plain autograd gradients again
+assert model.a.weight.grad is not None and model.a.weight.grad.data_ptr() != red.flat.data_ptr()
 # scalar all-reduce used for the logged loss / plateau decisions, and the BatchNorm buffer average before a checkpoint
 assert all_reduce_mean(float(rank)) == 0.5
 model.bn.running_mean.fill_(float(rank))
@@ -298,3 +345,101 @@ def test_softmax_oracle_matches_torch_reference():
     np.testing.assert_allclose(grad, zt.grad.numpy(), rtol=1e-10, atol=1e-14)
     np.testing.assert_allclose(prob.sum(1), 1.0, rtol=1e-12)
     assert acc == np.mean(z.argmax(1) == t.argmax(1))
+
+
+def test_plateau_callbacks_follow_keras_semantics():
+    """tools/train.py Plateau = ReduceLROnPlateau(0.1, patience 4, min_delta 1e-4) + EarlyStopping(patience 10) +
+    ModelCheckpoint(save_best_only) with Keras' separate states (reference train.py:82-90)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from tools.train import Plateau
+    p = Plateau()
+    save, stop, lr = p.update(1.0, 0.01)
+    assert save and not stop and lr == 0.01
+    # improvements smaller than min_delta = 1e-4 do not reset ReduceLROnPlateau's wait, but they ARE new bests for the
+    # checkpoint and for early stopping (min_delta 0)
+    lrs, saves = [], []
+    for i in range(4):
+        save, stop, lr = p.update(1.0 - 1e-5 * (i + 1), 0.01)
+        lrs.append(lr); saves.append(save)
+    assert saves == [True] * 4 and not stop
+    assert lrs[:3] == [0.01] * 3 and abs(lrs[3] - 0.001) < 1e-12               # 4th epoch without a >= 1e-4 improvement
+    assert p.rl_wait == 0 and abs(p.scale - 0.1) < 1e-12
+    # no improvement at all: early stop after 10 epochs, one more reduction every 4
+    p = Plateau()
+    p.update(0.5, 1.0)
+    out = [p.update(0.6, 1.0) for _ in range(10)]
+    assert [o[1] for o in out] == [False] * 9 + [True]
+    assert [abs(o[2] - 0.1) < 1e-12 for o in out] == [i in (3, 7) for i in range(10)]
+    assert not any(o[0] for o in out)
+    assert abs(p.scale - 0.01) < 1e-12
+
+
+def test_lr_schedule_overrides_plateau_as_in_the_reference(monkeypatch):
+    """Reference train.py:80-83: the one-argument LearningRateScheduler sets lr = lr0 * decay^floor(epoch/step) at every
+    epoch begin, discarding what ReduceLROnPlateau set at the previous epoch end.  Reproduced by default;
+    TRAIN.plateau_persistent multiplies the schedule by the accumulated plateau factor instead."""
+    from tools.train import Plateau
+    lr0, decay, step = 0.1, 0.5, 2
+
+    def run(persistent):
+        pl, used = Plateau(persistent=persistent), []
+        for epoch in range(7):
+            lr = lr0 * decay ** (epoch // step) * (pl.scale if persistent else 1.0)
+            used.append(lr)
+            pl.update(1.0, lr)                                   # a flat monitor: a reduction after epochs 4 (0-based)
+        return used
+    assert run(False) == [lr0 * decay ** (e // step) for e in range(7)]
+    got = run(True)
+    assert got[:5] == [lr0 * decay ** (e // step) for e in range(5)]
+    assert abs(got[5] - lr0 * decay ** 2 * 0.1) < 1e-15 and abs(got[6] - lr0 * decay ** 3 * 0.1) < 1e-15
+
+
+def test_apply_gpu_ids(monkeypatch):
+    """GENERAL.gpu_ids (reference train.py:121-133): visible devices + one process per listed GPU under torch.distributed.run."""
+    import subprocess as sp
+    import tools.train as T
+    calls = []
+    monkeypatch.setattr(sp, "call", lambda cmd: calls.append(cmd) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.setattr(sys, "argv", ["tools/train.py", "cfg.yml", "--max_epochs", "1"])
+    T.apply_gpu_ids(None)
+    T.apply_gpu_ids("")
+    assert not calls and "HIP_VISIBLE_DEVICES" not in os.environ
+    T.apply_gpu_ids("2")                                         # one id: just the visibility mask
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "2" and not calls
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    with pytest.raises(SystemExit) as e:
+        T.apply_gpu_ids("0, 3,5")
+    assert e.value.code == 0 and os.environ["HIP_VISIBLE_DEVICES"] == "0,3,5"
+    cmd = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=3" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-3:] == ["cfg.yml", "--max_epochs", "1"] and cmd[-4].endswith("tools/train.py")
+    # under a launcher the world is the launcher's: nothing is re-spawned
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    T.apply_gpu_ids("0,1,2")
+    assert not calls
+
+
+def test_optimizer_state_roundtrip(tmp_path):
+    """save_optimizer_state / load_optimizer_state: Adam moments, the step count and extras keyed by Keras weight names."""
+    from embeddingnet_amd.optimizers import KerasOptimizer, load_optimizer_state, save_optimizer_state
+    a, b = torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))
+    named = {"dense/kernel": a, "dense/bias": b}
+    opt = KerasOptimizer([a, b], "adam", 1e-3)
+    for p in (a, b):
+        s1, s2 = opt._slots(p)
+        s1.copy_(torch.randn_like(p)); s2.copy_(torch.rand_like(p))
+    opt.iterations = 17
+    save_optimizer_state(str(tmp_path / "x.opt.npz"), opt, named, extra={"epoch": 3})
+    a2, b2 = torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5))
+    opt2 = KerasOptimizer([a2, b2], "adam", 1e-3)
+    extra = load_optimizer_state(str(tmp_path / "x.opt.npz"), opt2, {"dense/kernel": a2, "dense/bias": b2})
+    assert opt2.iterations == 17 and int(extra["epoch"]) == 3
+    for p, q in ((a, a2), (b, b2)):
+        assert torch.equal(opt.state[p]["slot1"], opt2.state[q]["slot1"]) and torch.equal(opt.state[p]["slot2"], opt2.state[q]["slot2"])
+    from embeddingnet_amd import _lib
+    with pytest.raises(_lib.EmbnetError):
+        load_optimizer_state(str(tmp_path / "x.opt.npz"), KerasOptimizer([a2], "rms_prop", 1e-3), {"dense/kernel": a2})

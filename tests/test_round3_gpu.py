@@ -1,0 +1,384 @@
+"""Round-3 GPU parity tests (all through the C ABI):
+
+  * worst case of the split-arithmetic convolution products (include/embnet.h, embnet_conv_mfma_terms): adversarial
+    mantissas, all-positive operands, K = 576 and 4 608, forward / data gradient / weight gradient — the bound the header
+    states is asserted and the measured bias is recorded next to a float32 convolution's error;
+  * gradients of every STAGE OUTPUT of every backbone against the float64 oracle (the backward twin of
+    test_stage_activations_vs_oracle): a mis-wired tap inside a fused path (conv_pair, with_skip, dx_add, epilogue
+    statistics, stem border strips) shows in its stage, not only in an end-to-end tolerance;
+  * the small-backbone path: fused ReLU-backward + bias gradient, multi-tensor regulariser, regulariser gradient folded
+    into the optimizer launch, K-split dense forward, K-split distance matrix, encodings_len > 4096 in the hinge gradient;
+  * data parallel on one GPU: the reducer's in-place gradients (no AccumulateGrad add kernels) and the two-graph step.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbones as OB
+from oracle import losses as olosses
+from oracle import optimizers as OO
+from oracle import pairwise as opair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def g(a, dev):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+
+
+def _record(name, payload):
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(payload, open(os.path.join(out, name), "w"), indent=1)
+
+
+# ------------------------------------------------------------------------------------------------ split worst case
+SPLIT_BOUND = 2.0 ** -20          # include/embnet.h: dropped terms x2*y3 + x3*y2 + x3*y3 <= 2^-20 |x||y| (truncated pieces)
+
+
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64, 64, 3), (2, 8, 8, 512, 128, 3)], ids=["K576", "K4608"])
+def test_conv_split_worst_case(dev, shape):
+    """Operands whose low 16 mantissa bits are all ones (the second and third bf16 pieces are as large as they can be),
+    all positive (nothing cancels, so the dropped cross terms add up with one sign): |result - float64| must stay within
+    the documented 2^-20 * sum|a||b| plus the fp32 accumulation error of a k-ordered chain, on all three passes.  The
+    measured bias and a float32 CPU convolution's error on the same input go to gpurun_out/r03_split_worst_case_*.json."""
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout, k = shape
+    rs = np.random.RandomState(11)
+
+    def adversarial(*dims):
+        v = rs.uniform(0.5, 2.0, dims).astype(np.float32)
+        return (v.view(np.uint32) | np.uint32(0xFFFF)).view(np.float32)
+
+    x, kern, dy = adversarial(n, h, w, cin), adversarial(k, k, cin, cout) * np.float32(2.0 ** -6), adversarial(n, h, w, cout)
+    kern = (kern.view(np.uint32) | np.uint32(0xFFFF)).view(np.float32)
+
+    def run(dt):
+        xr = torch.tensor(x, dtype=dt, requires_grad=True)
+        kr = torch.tensor(kern, dtype=dt, requires_grad=True)
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), kr.permute(3, 2, 0, 1), padding=k // 2).permute(0, 2, 3, 1)
+        yr.backward(torch.tensor(dy, dtype=dt))
+        return [t.detach().double().numpy() for t in (yr, xr.grad, kr.grad)]
+
+    want, cpu32 = run(torch.float64), run(torch.float32)       # all operands positive: sum|a||b| is the result itself
+    layer = L.Conv2D(cin, cout, k, padding=k // 2, use_bias=False).to(dev)
+    with torch.no_grad():
+        layer.kernel.copy_(g(kern, dev))
+    xt = g(x, dev).requires_grad_(True)
+    y = layer(xt)
+    y.backward(g(dy, dev))
+    got = [t.detach().cpu().double().numpy() for t in (y, xt.grad, layer.kernel.grad)]
+    rec = {"shape": list(shape), "bound": SPLIT_BOUND, "terms": 6}
+    for name, a, c32, ref in zip(("fwd", "dgrad", "wgrad"), got, cpu32, want):
+        rel, rel32 = (a - ref) / ref, (c32 - ref) / ref
+        rec[name] = {"max_abs_rel_err": float(np.abs(rel).max()), "mean_rel_err_bias": float(rel.mean()),
+                     "float32_cpu_conv_max_abs_rel_err": float(np.abs(rel32).max()),
+                     "float32_cpu_conv_mean_rel_err": float(rel32.mean())}
+        # truncation split: every dropped term has the product's sign, so the result may only be LOW, by at most the bound;
+        # on top of it comes fp32 accumulation (a chain of K products: <= K/2 ulp in the worst case, far less in practice)
+        kk = ref.size and (k * k * (cin if name != "wgrad" else 1) * (1 if name != "wgrad" else n * h * w))
+        acc = 2.0 ** -24 * max(np.sqrt(kk), 8.0)
+        assert np.abs(rel).max() <= SPLIT_BOUND + acc, (name, rec[name])
+        assert rel.mean() <= acc, f"{name}: results biased HIGH ({rel.mean():.2e}): the dropped terms can only lower them"
+    _record(f"r03_split_worst_case_K{k * k * cin}.json", rec)
+
+
+# ------------------------------------------------------------------------------------------------ per-stage gradients
+@pytest.mark.parametrize("name,shape,enc,batch", [("simple2", (64, 64, 3), 64, 8), ("resnet18", (64, 64, 3), 64, 8),
+                                                   ("resnet50", (96, 96, 3), 32, 6), ("efficientnet-b0", (64, 64, 3), 32, 6)])
+def test_stage_gradients_vs_oracle(dev, name, shape, enc, batch):
+    """d(loss)/d(stage output) for every stage (residual unit / MBConv block / conv-BN pair / head layer) of a training-mode
+    backward with every fused path on, against the float64 oracle with the same weights.  Tolerance per stage:
+    max(1e-4, 5 x the deviation of the SAME oracle run in float32) of the stage's max |gradient| — ReLU / arg-max
+    decisions that flip in fp32 move a stage's gradient by what they move the float32 oracle's."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.backbones import keras_weights
+    base, _ = B.get_backbone(shape, encodings_len=enc, backbone_name=name, backbone_weights=None, seed=6, device=dev)
+    for m in base.modules():
+        if hasattr(m, "enabled"):
+            m.enabled = False
+    rs = np.random.RandomState(13)
+    x = rs.rand(batch, *shape).astype(np.float32)
+    wgt = rs.randn(batch, enc).astype(np.float32)
+
+    ctx_params = {k: v.detach().cpu().double().clone().requires_grad_(isinstance(v, torch.nn.Parameter) and v.requires_grad)
+                  for k, v in keras_weights(base).items()}
+
+    def oracle(dtype):
+        ctx = OB.Ctx({k: v.detach().to(dtype).clone().requires_grad_(v.requires_grad) for k, v in ctx_params.items()}, training=True)
+        ctx.taps = {}
+        emb = OB.base_model(ctx, torch.tensor(x, dtype=dtype), backbone_name=name, encodings_len=enc)
+        taps = {k: t for k, t in ctx.taps.items() if t.requires_grad}
+        for t in taps.values():
+            t.retain_grad()
+        (emb * torch.tensor(wgt, dtype=dtype)).sum().backward()
+        return {k: t.grad.double() for k, t in taps.items()}
+
+    want, want32 = oracle(torch.float64), oracle(torch.float32)
+    got, hooks = {}, []
+
+    def grab(s):
+        def fwd_hook(mod, inp, out):
+            o = out[0] if isinstance(out, (tuple, list)) else out
+            if torch.is_tensor(o) and o.requires_grad:
+                o.register_hook(lambda grad, s=s: got.__setitem__(s, grad.detach().clone()))
+        return fwd_hook
+    for mname, m in base.named_modules():
+        short = mname.split(".")[-1]
+        if short in want:
+            hooks.append(m.register_forward_hook(grab(short)))
+    base.train()
+    emb = base(g(x, dev))
+    (emb * g(wgt, dev)).sum().backward()
+    for h in hooks:
+        h.remove()
+    assert len(got) >= len(want) - 3, (sorted(got), sorted(want))
+    worst = []
+    for s, t in got.items():
+        ref = want[s]
+        t = t.cpu().double()
+        assert tuple(t.shape) == tuple(ref.shape), (s, t.shape, ref.shape)
+        scale = max(ref.abs().max().item(), 1e-30)
+        err = (t - ref).abs().max().item() / scale
+        floor = (want32[s] - ref).abs().max().item() / scale
+        worst.append((err / max(1e-4, 5 * floor), s, err, floor))
+    worst.sort(reverse=True)
+    bad = [f"{s}: {err:.2e} (float32 oracle {floor:.2e})" for r, s, err, floor in worst if r > 1.0]
+    assert not bad, f"{name}: stage gradients off: {bad[:8]}"
+
+
+# ------------------------------------------------------------------------------------------------ small-backbone path
+def test_relu_bwd_colsum_and_multi_tensor_regulariser(dev):
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd import layers as L
+    lib = _lib.lib()
+    rs = np.random.RandomState(2)
+    for m, c in [(32 * 62 * 62, 32), (32, 512), (1000, 6), (7, 130)]:
+        dy, y = rs.randn(m, c).astype(np.float32), rs.randn(m, c).astype(np.float32)
+        dz, db = torch.empty((m, c), device=dev), torch.empty((c,), device=dev)
+        ws = L.workspace(lib.embnet_colsum_workspace_bytes(m, c), dev)
+        _lib.check(lib.embnet_relu_bwd_colsum(_lib.ptr(g(dy, dev)), _lib.ptr(g(y, dev)), m, c, _lib.ptr(dz), _lib.ptr(db), _lib.ptr(ws),
+                                              ws.numel() * 4, _lib.stream()))
+        want = np.where(y > 0, dy, 0).astype(np.float32)
+        assert np.array_equal(dz.cpu().numpy(), want)
+        np.testing.assert_allclose(db.cpu().numpy(), want.astype(np.float64).sum(0), rtol=2e-5, atol=2e-5 * np.abs(want).sum(0).max())
+    # all kernel regularisers of a model in one launch pair; value only / value + gradient
+    net = torch.nn.Sequential()
+    net.a = L.Conv2D(16, 24, 3, l2=2e-4).to(dev)
+    net.b = L.Dense(5000, 70, l2=1e-3).to(dev)
+    net.c = L.Conv2D(3, 8, 5).to(dev)                        # no regulariser
+    want = sum(lam * float((w.detach().double() ** 2).sum()) for w, lam in ((net.a.kernel, 2e-4), (net.b.kernel, 1e-3)))
+    val = L.regularization_loss(net, with_grad=False)
+    assert abs(val.item() - want) <= 2e-6 * want and not val.requires_grad
+    val = L.regularization_loss(net)
+    (3.0 * val).backward()
+    for w, lam in ((net.a.kernel, 2e-4), (net.b.kernel, 1e-3)):
+        np.testing.assert_allclose(w.grad.cpu().numpy(), 3.0 * 2 * lam * w.detach().cpu().numpy(), rtol=1e-6)
+    assert net.c.kernel.grad is None and L.regularization_loss(torch.nn.Sequential(net.c)) is None
+
+
+@pytest.mark.parametrize("rule", ["sgd", "adam", "radam", "rms_prop"])
+def test_optimizer_folds_the_regulariser_gradient(dev, rule):
+    """KerasOptimizer.set_l2: the update launch uses g + 2*lambda*w for the regularised tensors — the rule applied to the
+    gradient of loss + lambda*sum(w^2), which is what Keras differentiates (oracle: the NumPy rule on that gradient)."""
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    rs = np.random.RandomState(8)
+    shapes, lams = [(3, 3, 16, 8), (5000,), (64, 64), (9,)], [2e-4, 0.0, 1e-3, 5e-2]
+    w0 = [rs.randn(*s) for s in shapes]
+    ws = [torch.nn.Parameter(g(w, dev)) for w in w0]
+    opt = KerasOptimizer(ws, rule, 1e-2)
+    opt.set_l2([(w, lam) for w, lam in zip(ws, lams) if lam])
+    wn = [w.astype(np.float32).astype(np.float64) for w in w0]
+    oo = OO.get_optimizer(rule, 1e-2)
+    for step in range(8):
+        grads = [rs.randn(*s) * 0.1 for s in shapes]
+        for w, gr in zip(ws, grads):
+            w.grad = g(gr, dev)
+        opt.step()
+        oo.step(wn, [gr.astype(np.float32).astype(np.float64) + 2 * lam * w for gr, lam, w in zip(grads, lams, wn)])
+        for i, (w, ref) in enumerate(zip(ws, wn)):
+            err = np.abs(w.detach().cpu().double().numpy() - ref).max() / np.abs(ref).max()
+            assert err < 3e-6, f"{rule} step {step + 1} tensor {i}: {err:.2e}"
+
+
+def test_fused_step_with_keras_optimizer_matches_autograd_regularisers(dev):
+    """The fused step with the regularisers' gradient folded into the optimizer (KerasOptimizer) updates the weights exactly
+    like the same step with the regularisers differentiated by autograd and a plain gradient (torch SGD): same loss, and the
+    same weights after the step up to fp32 rounding of lr * (g + 2 lambda w)."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    res = []
+    x = torch.rand((12, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    for keras in (True, False):
+        base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="simple2", backbone_weights=None, seed=3, device=dev)
+        for m in base.modules():
+            if hasattr(m, "enabled"):
+                m.enabled = False
+        params = [p for p in base.parameters() if p.requires_grad]
+        opt = KerasOptimizer(params, "sgd", 0.05) if keras else torch.optim.SGD(params, lr=0.05)
+        tr = TripletTrainer(base, opt, 4, 3, margin=0.5, negatives_selection_mode="hardest")
+        loss = tr.step(x)
+        res.append((loss.item(), tr.last_total.item(), torch.cat([p.detach().reshape(-1) for p in params]).cpu().double()))
+    assert res[0][0] == res[1][0] and abs(res[0][1] - res[1][1]) <= 1e-6 * abs(res[1][1])
+    assert (res[0][2] - res[1][2]).abs().max().item() <= 2e-7 * res[1][2].abs().max().item()
+
+
+def test_split_k_distance_matrix_and_wide_hinge_gradient(dev):
+    """N <= 256 rows at the reference's default encodings_len = 4096 (and 8192): the K-split distance kernel against the
+    sklearn-arithmetic oracle, and the hinge gradient with more than 4096 columns against the float64 oracle."""
+    from embeddingnet_amd import ops
+    rs = np.random.RandomState(21)
+    for n, e in [(128, 4096), (256, 4096), (36, 8192), (60, 2048)]:
+        x = np.abs(rs.randn(n, e)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        d2 = ops.pairwise_distances(g(x, dev), squared=True).cpu().double().numpy()
+        want = opair.pairwise_distances(x).astype(np.float64) ** 2
+        assert np.abs(d2 - want).max() <= 2e-6 * max(1.0, (e / 512) ** 0.5) + 1e-6, (n, e, np.abs(d2 - want).max())
+        assert np.array_equal(np.diag(d2), np.zeros(n)) and np.array_equal(d2, d2.T)
+    p, k, e = 6, 4, 8192
+    emb = np.abs(rs.randn(p * k, e)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    et = g(emb, dev).requires_grad_(True)
+    dist = ops.pairwise_distances(et.detach())
+    trip, count, _ = ops.mine_triplets(dist, p, k, 0.5, "hardest")
+    mean, _ = ops.triplet_gather_loss(et, trip, count, 0.5)
+    mean.backward()
+    t = trip[: int(count.item())].cpu().numpy()
+    er = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
+    y = torch.cat([er[t[:, 0]], er[t[:, 1]], er[t[:, 2]]], dim=1)
+    a, pp, nn = y[:, :e], y[:, e:2 * e], y[:, 2 * e:]
+    ref = torch.clamp(((a - pp) ** 2).sum(1) - ((a - nn) ** 2).sum(1) + 0.5, min=0).mean()
+    ref.backward()
+    assert abs(mean.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    assert (et.grad.cpu().double() - er.grad).abs().max().item() <= 2e-5 * er.grad.abs().max().item()
+
+
+def test_simple_backbone_at_its_design_size(dev):
+    """`simple` (reference backbones.py:19-41) at 105 x 105, the size SURVEY 8(d) names for it (10x10x3 and 7x7x64 -> 128 at
+    42 x 42 kernels): embeddings and parameter gradients of a training-mode step against the float64 oracle."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.backbones import keras_weights
+    shape, enc, batch = (105, 105, 3), 64, 8
+    base, _ = B.get_backbone(shape, encodings_len=enc, backbone_name="simple", backbone_weights=None, seed=1, device=dev)
+    rs = np.random.RandomState(3)
+    x = rs.rand(batch, *shape).astype(np.float32)
+    wgt = rs.randn(batch, enc).astype(np.float32)
+    base.train()
+    emb = base(g(x, dev))
+    (emb * g(wgt, dev)).sum().backward()
+
+    def oracle(dtype):
+        ctx = OB.Ctx({k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in keras_weights(base).items()}, training=True)
+        e = OB.base_model(ctx, torch.tensor(x, dtype=dtype), backbone_name="simple", encodings_len=enc)
+        (e * torch.tensor(wgt, dtype=dtype)).sum().backward()
+        return e.detach().double(), {k: p.grad.double() for k, p in ctx.params.items() if p.grad is not None}
+    e64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    assert (emb.detach().cpu().double() - e64).abs().max().item() <= 1e-4 * e64.abs().max().item()
+    got = keras_weights(base)
+    for k, ref in g64.items():
+        scale = ref.abs().max().item()
+        err = (got[k].grad.cpu().double() - ref).abs().max().item() / scale
+        floor = (g32[k] - ref).abs().max().item() / scale
+        assert err <= 5 * floor + 1e-4, f"simple@105 grad {k}: {err:.2e} (float32 oracle {floor:.2e})"
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, one GPU
+_DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from embeddingnet_amd import backbones as B
+from embeddingnet_amd.optimizers import KerasOptimizer
+from embeddingnet_amd.parallel import GradReducer, broadcast_model, init_distributed
+from embeddingnet_amd.train_step import TripletTrainer
+rank, world, local = init_distributed()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+out = []
+for mode in ("eager", "graph"):
+    base, _ = B.get_backbone((48, 48, 3), encodings_len=32, backbone_name={backbone!r}, backbone_weights=None, seed=5, device=dev)
+    broadcast_model(base)
+    params = [p for p in base.parameters() if p.requires_grad]
+    opt = KerasOptimizer(params, "adam", 1e-3)
+    red = GradReducer(params, bucket_bytes=1 << 20)
+    tr = TripletTrainer(base, opt, 4, 3, margin=0.5, negatives_selection_mode="hardest", seed=7, reducer=red,
+                        graph=(mode == "graph"))
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)        # every rank its own batches
+    losses = [tr.step(torch.rand((12, 48, 48, 3), device=dev, generator=gen)).clone() for _ in range(14)]
+    if mode == "graph":
+        assert tr._graph is not None and tr._graph_opt is not None, getattr(tr, "_graph_error", "not captured")
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).clone()
+    others = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(others, flat)
+    assert all(torch.equal(o, flat) for o in others), "ranks diverged"
+    out.append((torch.stack(losses), flat))
+    red.close()
+assert torch.equal(out[0][0], out[1][0]), (out[0][0] - out[1][0]).abs().max()
+assert torch.equal(out[0][1], out[1][1])
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("backbone", ["simple2", "resnet18"])
+def test_dp_two_graph_step_equals_eager_over_gloo(tmp_path, backbone):
+    """N > 1 with TripletTrainer(graph=True): forward + backward replayed as one HIP graph, the bucketed gradient all-reduce
+    issued between the graphs, the optimizer as a second graph — losses and weights bit-identical to eager data-parallel
+    steps, ranks identical to each other.  Two ranks share this box's one GPU over gloo (RCCL refuses that)."""
+    script = tmp_path / "w.py"
+    script.write_text(_DP_WORKER.format(root=ROOT, backbone=backbone))
+    port = 29600 + os.getpid() % 300
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   EMBNET_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+
+
+def test_dp_gradients_are_written_in_place(dev):
+    """With the reducer's gradient sinks armed (TripletTrainer + KerasOptimizer) a data-parallel step produces the same
+    flat gradient as plain autograd, and autograd launches NO accumulation (`add`) kernel for the parameters: every
+    weight-gradient / BatchNorm / bias kernel wrote its slot of the flat buffer itself."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd import layers as L
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.parallel import GradReducer
+    from embeddingnet_amd.train_step import TripletTrainer
+    x = torch.rand((12, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    flats = []
+    for direct in (False, True):
+        base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None, seed=2, device=dev)
+        params = [p for p in base.parameters() if p.requires_grad]
+        opt = KerasOptimizer(params, "sgd", 0.0)
+        red = GradReducer(params)
+        tr = TripletTrainer(base, opt, 4, 3, margin=0.5, negatives_selection_mode="hardest", reducer=red)
+        red.direct(direct)
+        tr.step(x)                                          # first step: may re-lay the buffer in first-backward order
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            tr.step(x)
+            torch.cuda.synchronize()
+        adds = [e.key for e in prof.key_averages() if "elementwise" in e.key.lower() and ("add" in e.key.lower() or "CUDAFunctor_add" in e.key)]
+        if direct:
+            assert not adds, adds
+            assert len(L.GRAD_SINKS) == len(params)
+        else:
+            assert adds, "expected autograd's accumulation kernels without the sinks (is the probe still valid?)"
+        flats.append({id_: red.flat[off:off + n].clone() for id_, (off, n) in ((i, red._slot[p]) for i, p in enumerate(params))})
+        red.close()
+    for i in flats[0]:
+        assert torch.equal(flats[0][i], flats[1][i]), i

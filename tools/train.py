@@ -52,23 +52,45 @@ def create_save_folders(params):
 
 
 class Plateau:
-    """ReduceLROnPlateau(factor .1, patience 4) + EarlyStopping(patience 10) + best-only checkpoint."""
+    """The three monitor-driven Keras callbacks of the reference (train.py:82-90), each with its own state as in Keras:
+      ReduceLROnPlateau(factor .1, patience 4): `min_delta` 1e-4 (Keras default, mode 'min': an epoch improves only if
+        value < best - 1e-4), cooldown 0, min_lr 0;  after 4 epochs without that improvement the learning rate is
+        multiplied by 0.1 and the wait restarts;
+      EarlyStopping(patience 10, min_delta 0): stop after 10 epochs without value < best;
+      ModelCheckpoint(save_best_only): save when value < best.
+    update(value, lr) -> (save checkpoint?, stop?, lr after the epoch).
+    NB the reference ALSO installs LearningRateScheduler(lambda epoch: lr0 * decay ** floor(epoch / step)) — a one-argument
+    schedule, which Keras applies at every epoch BEGIN by setting the optimizer's lr outright.  It therefore overwrites
+    whatever ReduceLROnPlateau set at the previous epoch end: in the reference the plateau reduction never reaches a
+    training step (it only shows in the log).  main() reproduces that order; `persistent=True` is this port's opt-in
+    (TRAIN.plateau_persistent) to let reductions accumulate as a multiplier on the schedule instead."""
 
-    def __init__(self):
-        self.best, self.since_best, self.since_reduce, self.scale = float('inf'), 0, 0, 1.0
+    def __init__(self, factor=0.1, patience=4, min_delta=1e-4, stop_patience=10, persistent=False):
+        self.factor, self.patience, self.min_delta, self.stop_patience = factor, patience, min_delta, stop_patience
+        self.persistent, self.scale = persistent, 1.0
+        self.rl_best, self.rl_wait = float('inf'), 0          # ReduceLROnPlateau
+        self.es_best, self.es_wait = float('inf'), 0          # EarlyStopping
+        self.best = float('inf')                              # ModelCheckpoint
 
-    def update(self, value):
-        improved = value < self.best
-        if improved:
-            self.best, self.since_best, self.since_reduce = value, 0, 0
+    def update(self, value, lr=None):
+        if value < self.rl_best - self.min_delta:
+            self.rl_best, self.rl_wait = value, 0
         else:
-            self.since_best += 1
-            self.since_reduce += 1
-            if self.since_reduce >= 4:
-                self.scale *= 0.1
-                self.since_reduce = 0
-                print(f'ReduceLROnPlateau: lr scale -> {self.scale:g}', flush=True)
-        return improved, self.since_best >= 10
+            self.rl_wait += 1
+            if self.rl_wait >= self.patience:
+                self.rl_wait = 0
+                self.scale *= self.factor
+                if lr is not None:
+                    lr = lr * self.factor
+                    print(f'ReduceLROnPlateau reducing learning rate to {lr:g}.', flush=True)
+        if value < self.es_best:
+            self.es_best, self.es_wait = value, 0
+        else:
+            self.es_wait += 1
+        save = value < self.best
+        if save:
+            self.best = value
+        return save, self.es_wait >= self.stop_patience, lr
 
 
 def apply_gpu_ids(gpu_ids):
@@ -134,24 +156,41 @@ def main():
         trainable = model.base_model
     if args.resume_from is not None:
         model.load_model(args.resume_from)            # the mining model IS base_model, so it resumes too
-    if 'softmax' in cfg and rank == 0:                # reference train.py:164-170; one rank trains and writes the
-        from embedding_net.backbones import pretrain_backbone_softmax        # pre-training checkpoints, all receive them
-        pretrain_backbone_softmax(model.backbone_model, data_loader, cfg['softmax'], cfg['general'],
-                                  max_epochs=args.max_epochs)
     broadcast_model(trainable)                        # identical start on every rank: parameters and BN buffers
+    if 'softmax' in cfg:                              # reference train.py:164-170
+        # every rank pre-trains on its own batches with the gradients all-reduced (no rank waits in a collective for the
+        # length of a pre-training: the RCCL watchdog would abort it); rank 0 writes the pre-training checkpoints
+        from embedding_net.backbones import pretrain_backbone_softmax
+        pretrain_backbone_softmax(model.backbone_model, data_loader, cfg['softmax'], cfg['general'],
+                                  max_epochs=args.max_epochs, distributed=world > 1)
+        broadcast_model(trainable)                    # belt and braces: BN moving statistics are rank-local
 
     params = [p for p in trainable.parameters() if p.requires_grad]
     opt = p_train['optimizer'].build(params)
     lr0 = p_train['learning_rate']
+    if args.resume_from is not None:                  # optimizer slots and step count, when the checkpoint has them (Keras'
+        # load_model restores the optimizer with the weights; the epoch count and LR schedule restart, as in the reference)
+        from embeddingnet_amd.backbones import keras_weights
+        from embeddingnet_amd.optimizers import load_optimizer_state
+        opt_path = os.path.splitext(args.resume_from)[0] + '.opt.npz'
+        if os.path.exists(opt_path):
+            extra = load_optimizer_state(opt_path, opt, {k: v for k, v in keras_weights(trainable).items()
+                                                         if isinstance(v, torch.nn.Parameter)})
+            print(f'resumed optimizer state from {opt_path} (iterations {opt.iterations}, saved after epoch {int(extra.get("epoch", 0))})')
     reducer = GradReducer(params) if world > 1 else None
     trainer = None if siamese else TripletTrainer(
         model.base_model, opt, gen_kw['k_classes'], p_gen['k_samples'], margin=p_gen['margin'],
         negatives_selection_mode=p_gen['negatives_selection_mode'], seed=rank, reducer=reducer)
-    plateau, history = Plateau(), {'loss': [], 'val_loss': []}
+    plateau = Plateau(persistent=bool(p_train.get('plateau_persistent', False)))
+    history = {'loss': [], 'val_loss': []}
     n_epochs = min(p_train['n_epochs'], args.max_epochs or p_train['n_epochs'])
 
     for epoch in range(n_epochs):
-        lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size']) * plateau.scale
+        # LearningRateScheduler.on_epoch_begin (reference train.py:80-81): sets the rate outright, which discards the
+        # previous epoch's ReduceLROnPlateau reduction (see Plateau) unless TRAIN.plateau_persistent is set
+        lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size'])
+        if plateau.persistent:
+            lr *= plateau.scale
         for g in opt.param_groups:
             g['lr'] = lr
         trainable.train()
@@ -190,12 +229,19 @@ def main():
             msg += f' - val_loss {value:.4f}'
         if rank == 0:
             print(msg, flush=True)
-        improved, stop = plateau.update(value)        # `value` is the all-reduced mean: same LR scale / stop on every rank
+        improved, stop, lr_end = plateau.update(value, lr)   # `value` is the all-reduced mean: same decisions on every rank
+        for g in opt.param_groups:                    # ReduceLROnPlateau.on_epoch_end (until the scheduler's next epoch begin)
+            g['lr'] = lr_end
         if improved:
             average_buffers(trainable)                # BN moving statistics: mean over the ranks' local batches
         if improved and rank == 0:
             path = os.path.join(paths['weights'], f'epoch_{epoch + 1:03d}.npz')
             model.save_weights(path)
+            from embeddingnet_amd.backbones import keras_weights
+            from embeddingnet_amd.optimizers import save_optimizer_state
+            save_optimizer_state(os.path.splitext(path)[0] + '.opt.npz', opt,
+                                 {k: v for k, v in keras_weights(trainable).items() if isinstance(v, torch.nn.Parameter)},
+                                 extra={'epoch': epoch + 1})
             print(f'{monitor} improved to {value:.5f}, saving model to {path}')
         if stop:
             print('EarlyStopping')
