@@ -666,6 +666,7 @@ class _InputBNConvFn(torch.autograd.Function):
     224x224 map (N=3 of a 32-wide MFMA tile, 3/4 of the taps structurally zero at stride 2)."""
 
     _ones = {}
+    _pads = {}
 
     @staticmethod
     def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False):
@@ -679,10 +680,17 @@ class _InputBNConvFn(torch.autograd.Function):
         if cp != c:
             xp = torch.empty((n, h, wd, cp), device=x.device, dtype=torch.float32)
             check(lib.embnet_pad_channels(ptr(x), m, c, cp, ptr(xp), stream()))
-            zeros = torch.zeros(cp - c, device=x.device)
-            beta_p = torch.cat([beta.detach(), zeros])
-            mm_p, mv_p = torch.cat([moving_mean, zeros]), torch.cat([moving_var, zeros + 1])
-            w_p = torch.nn.functional.pad(w.detach(), (0, 0, 0, cp - c))     # [r,s,cp,k], zero taps for the pad channel
+            # persistent padded copies of the three BN vectors and of the kernel (zero taps / zero offset for the pad
+            # channel), refreshed by plain copies: no cat / pad / fill launches per step
+            key = (beta.data_ptr(), w.data_ptr())
+            pads = _InputBNConvFn._pads.get(key)
+            if pads is None:
+                pads = _InputBNConvFn._pads[key] = (torch.zeros(cp, device=x.device), torch.zeros(cp, device=x.device),
+                                                    torch.ones(cp, device=x.device),
+                                                    torch.zeros((r, s, cp, k), device=x.device))
+            beta_p, mm_p, mv_p, w_p = pads
+            beta_p[:c].copy_(beta.detach()); mm_p[:c].copy_(moving_mean); mv_p[:c].copy_(moving_var)
+            w_p[:, :, :c, :].copy_(w.detach())
         else:
             xp, beta_p, mm_p, mv_p, w_p = x, beta, moving_mean, moving_var, w
         a = torch.empty_like(xp)
@@ -1180,6 +1188,8 @@ class _L2MultiFn(torch.autograd.Function):
         ctx.with_grad, ctx.lams = with_grad, plan["lams"]
         if with_grad:
             ctx.save_for_backward(*kernels)
+        else:
+            ctx.mark_non_differentiable(out)
         return out
 
     @staticmethod

@@ -8,6 +8,11 @@ out=../../build_variants; mkdir -p $out/obj_$name
 rm -f $out/obj_$name/*.o
 extra=""
 if [ "${WITH_PLANES:-0}" = "1" ]; then extra="-DEMBNET_EXP_HOOKS=1"; fi
+# any round-1/2 engine experiment switch selects the diagnostic engine header (tools/exp/gemm_engine_diag.h)
+for a in "$@"; do
+  case "$a" in -DEMBNET_ABLATE*|-DEMBNET_INTERLEAVE*|-DEMBNET_PIN*|-DEMBNET_SETPRIO*|-DEMBNET_SPLIT_DIST*|-DEMBNET_SPLIT_ABLATE*|-DEMBNET_LDS_STAGES*|-DEMBNET_PHASE_PRIO*|-DEMBNET_SPLIT_EARLY*|-DEMBNET_STAMPS*)
+    extra="$extra -DEMBNET_DIAG_ENGINE=1";; esac
+done
 for f in conv pairwise dense; do
   /opt/rocm/bin/hipcc "$@" $extra -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -c $f.hip -o $out/obj_$name/$f.o &
 done

@@ -1,3 +1,5 @@
+// DIAGNOSTIC copy of embeddingnet_amd/csrc/gemm_engine.h as of round 2 (included instead of it under -DEMBNET_DIAG_ENGINE=1):
+// the engine with every experiment switch of rounds 1-2 in its main loops.  Not part of the product build.
 // fp32 MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32, exact f32).
 //
 // One 256-thread workgroup (4 wave64) computes a BM x BN output tile; each wave
@@ -25,15 +27,8 @@
 // steps from a single ds_read_b128 (conflict-free with the +4 pad), a KM tile
 // from four ds_read_b32 of 32 consecutive floats.  Summation order inside a
 // tile differs from plain k order; results are f32-rounding-equivalent.
-//
-// Diagnostic / ablation builds (tools/build_variant.sh -DEMBNET_DIAG_ENGINE=1 ...): the same engine with the round-1/2
-// experiment switches threaded through its main loops (EMBNET_ABLATE, _INTERLEAVE, _PIN, _SETPRIO, _SPLIT_DIST,
-// _SPLIT_ABLATE, _LDS_STAGES, in-loop stamps) lives in tools/exp/gemm_engine_diag.h; this file is the product.
 #pragma once
-#if defined(EMBNET_DIAG_ENGINE)
-#include "../../tools/exp/gemm_engine_diag.h"
-#else
-#include "common.h"
+#include "../../embeddingnet_amd/csrc/common.h"
 
 namespace embnet {
 
@@ -68,8 +63,18 @@ __device__ __forceinline__ void stamp(int) {}
 constexpr unsigned OOB = 0x80000000u;          // byte offset no operand (< 2 GiB) reaches
 constexpr size_t MAX_OPERAND_BYTES = 0x7FFFFFF0ull;
 
-// (opaque(): hook used by the diagnostic engine to pin address arithmetic; identity here)
-__device__ __forceinline__ unsigned opaque(unsigned v) { return v; }
+#ifndef EMBNET_INTERLEAVE
+#define EMBNET_INTERLEAVE 0
+#endif
+// Keeps an address computation unconditional: without it hipcc turns `ok ? offset : OOB` into a branch around the
+// offset arithmetic (s_and_saveexec / s_cbranch_execz per load), which splits the K-tile body into many basic blocks
+// and pins every load in front of the MFMAs.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+#if EMBNET_INTERLEAVE
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 
 // Raw buffer view of one operand tensor.
 struct Buf {
@@ -78,6 +83,10 @@ struct Buf {
     r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
   }
   __device__ __forceinline__ float4 ld4(unsigned off) const {
+#if defined(EMBNET_ABLATE) && EMBNET_ABLATE == 5     // diagnostic: the address arithmetic stays, the load instruction does not
+    asm volatile("" :: "v"(off));
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     // NB: cast the WHOLE vector.  Per-component __builtin_bit_cast(float, v.x) makes hipcc (ROCm 7.2)
     // narrow the load to buffer_load_dword while still consuming v[0:3] — three garbage lanes.
     const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
@@ -211,8 +220,15 @@ struct Geom {
   static_assert(TM >= 1 && TN >= 1, "wave tile below one MFMA");
 };
 
+// LDS stages of the main loop: 2 = double-buffered, software-pipelined loop (one barrier per K tile),
+// 1 = single buffer + register prefetch (two barriers per K tile, half the LDS).
+#ifndef EMBNET_LDS_STAGES
+#define EMBNET_LDS_STAGES 1
+#endif
+constexpr int LDS_STAGES = EMBNET_LDS_STAGES;
+
 template <class TA, class TB>
-constexpr int MAIN_FLOATS = TA::FLOATS + TB::FLOATS;
+constexpr int MAIN_FLOATS = LDS_STAGES * (TA::FLOATS + TB::FLOATS);
 
 template <class G, class TA, class TB>
 __device__ __forceinline__ void load_frags(const float* st, int wm, int wn, int j, int lane,
@@ -223,25 +239,48 @@ __device__ __forceinline__ void load_frags(const float* st, int wm, int wn, int 
   for (int i = 0; i < G::TN; ++i) TB::frag(st + TA::FLOATS, wn + 32 * i, j, lane, b[i]);
 }
 
+#ifndef EMBNET_SETPRIO
+#define EMBNET_SETPRIO 0
+#endif
 // Issue priority by phase.  A workgroup that starts on a CU whose other slots are in their main loops is the
 // youngest wave on each SIMD and gets the left-over issue slots: its prologue (tile decode, first loads) ran 3x
 // longer than on an idle CU (16-22k cycles vs 5k, in-kernel stamps: tools/exp/conv_timeline.py) and its epilogue
 // likewise, during which its slot does no matrix work.  Prologue and epilogue therefore run at priority 3, the
 // main loop at 0: the few hundred vector instructions they hold barely touch the older waves' MFMA stream.
-__device__ __forceinline__ void prio_hi() { __builtin_amdgcn_s_setprio(3); }
-__device__ __forceinline__ void prio_lo() { __builtin_amdgcn_s_setprio(0); }
-// `fair` main loops: priority 3, 2, 1, 0 by quarter of the K range done (see gemm_mainloop)
-__device__ __forceinline__ void prio_by_progress(bool fair, int kt, int kt_begin, int kt_end) {
-  if (!fair) { prio_lo(); return; }
-  const int done = 4 * (kt - kt_begin), span = kt_end - kt_begin;
-  if (done >= 3 * span) __builtin_amdgcn_s_setprio(0);
-  else if (done >= 2 * span) __builtin_amdgcn_s_setprio(1);
-  else if (done >= span) __builtin_amdgcn_s_setprio(2);
+#ifndef EMBNET_PHASE_PRIO
+#define EMBNET_PHASE_PRIO 1
+#endif
+#ifndef EMBNET_ABLATE
+#define EMBNET_ABLATE 0
+#endif
+#ifndef EMBNET_INTERLEAVE
+#define EMBNET_INTERLEAVE 0
+#endif
+__device__ __forceinline__ void prio_hi() {
+#if EMBNET_PHASE_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void prio_lo() {
+#if EMBNET_PHASE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+#ifndef EMBNET_PIN
+#define EMBNET_PIN 0
+#endif
+__device__ __forceinline__ void pin() {
+#if EMBNET_PIN
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 template <class G>
 __device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const float (&b)[G::TN][4],
                                           f32x16 (&acc)[G::TM][G::TN]) {
+#if EMBNET_SETPRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -249,13 +288,26 @@ __device__ __forceinline__ void mfma_step(const float (&a)[G::TM][4], const floa
 #pragma unroll
       for (int in = 0; in < G::TN; ++in)
         acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][t], b[in][t], acc[im][in], 0, 0, 0);
+#if EMBNET_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
-// Main loop (fp32 MFMA).  LA/LB: loaders with .load(kt, regs) and .fix(regs) — fix() runs on the fetched registers just
-// before they go to LDS (one load outstanding per loader, so it may use state load() left); TA/TB: their LDS tile
-// types.  smem holds MAIN_FLOATS<TA,TB> floats: one LDS buffer, the next K tile prefetched into registers under the MFMAs
-// of the current one, two barriers per tile.  (A two-stage LDS, software-pipelined variant measured 3-5 % slower: it
-// costs a resident workgroup per CU; tools/exp/gemm_engine_diag.h keeps it.)
+// Main loop.  LA/LB: loaders with .load(kt, regs) and .fix(regs) — fix() runs on the fetched registers just
+// before they go to LDS (one load outstanding per loader, so it may use state load() left); TA/TB: their LDS
+// tile types.  smem holds
+// MAIN_FLOATS<TA,TB> floats.
+//
+// Two-stage version: K tile kt is consumed from LDS stage (kt&1) in four k-steps of 8 while
+//   * the fragments of the next k-step are read one step ahead (two fragment register sets),
+//   * tile kt+1, fetched into registers during the previous iteration, is written to the other
+//     stage under step 1's MFMAs and the fetch of tile kt+2 is issued right behind it (a whole
+//     iteration of latency cover),
+//   * the single barrier sits between steps 2 and 3: by then every wave's stage writes are long
+//     complete and nobody reads this stage again (step 3's fragments were read before it), and the
+//     first fragments of the next stage are read under step 3's MFMAs.
+// A wave therefore has no point where it waits on LDS or memory with the matrix pipe empty, so the
+// loop does not depend on other workgroups to fill its gaps (few-tile layers run 1-2 waves per SIMD).
 // `fair` (wave-uniform): lower this wave's issue priority as it progresses through its K range (3, 2, 1, 0 by
 // quarter) instead of running the loop at 0.  The SIMD arbitrates oldest-first, so workgroups that start together
 // finish one after the other (4 co-resident 128x64 tiles: 68, 78, 91, 105 us) — fine while new workgroups keep
@@ -280,30 +332,139 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int kt
   }
 
   float4 ra[TA::PASSES], rb[TB::PASSES];
-  float* sA = smem;
-  if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); }
-  stamp(8);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();                       // everyone finished reading the previous tile
+  if constexpr (LDS_STAGES == 2) {
+    constexpr int STAGE = TA::FLOATS + TB::FLOATS;
+    if (kt_begin >= kt_end) return;
+    la.load(kt_begin, ra); lb.load(kt_begin, rb);
+    la.fix(ra); lb.fix(rb);
+    TA::store(smem, ra, tid);
+    TB::store(smem + TA::FLOATS, rb, tid);
+    la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
+    lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
+    __syncthreads();
+    float a0[G::TM][4], b0[G::TN][4], a1[G::TM][4], b1[G::TN][4];
+    load_frags<G, TA, TB>(smem, wm, wn, 0, lane, a0, b0);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const float* sc = smem + cur * STAGE;
+      float* sn = smem + (cur ^ 1) * STAGE;
+      load_frags<G, TA, TB>(sc, wm, wn, 1, lane, a1, b1);
+      pin();
+      mfma_step<G>(a0, b0, acc);
+      pin();
+      load_frags<G, TA, TB>(sc, wm, wn, 2, lane, a0, b0);
+      la.fix(ra); lb.fix(rb);
+      TA::store(sn, ra, tid);
+      TB::store(sn + TA::FLOATS, rb, tid);
+      pin();
+      mfma_step<G>(a1, b1, acc);
+      pin();
+      la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
+      lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+      load_frags<G, TA, TB>(sc, wm, wn, 3, lane, a1, b1);
+      pin();
+      mfma_step<G>(a0, b0, acc);
+      pin();
+      __syncthreads();
+      load_frags<G, TA, TB>(sn, wm, wn, 0, lane, a0, b0);
+      pin();
+      mfma_step<G>(a1, b1, acc);
+      pin();
+      cur ^= 1;
+    }
+  } else {
+    float* sA = smem;
+    if (kt_begin < kt_end) { la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb); }
+    stamp(8);
+#if EMBNET_ABLATE >= 2 && EMBNET_ABLATE != 4
+    // diagnostic builds (wrong results by construction; tools/exp only): 1 = no global loads inside the loop,
+    // 2 = also no LDS writes and no barriers (operand tiles written once), 3 = also no fragment reads (MFMA only)
     TA::store(sA, ra, tid);
     TB::store(sA + TA::FLOATS, rb, tid);
     __syncthreads();
-    prio_by_progress(fair, kt, kt_begin, kt_end);
-    // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
-    // offset out of range, so the loads return zeros and need no branch
-    la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
-    lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+    prio_lo();
+#endif
+#if EMBNET_ABLATE == 3
+    float a3[G::TM][4], b3[G::TN][4];
+    load_frags<G, TA, TB>(sA, wm, wn, 0, lane, a3, b3);
+#endif
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+#if EMBNET_ABLATE < 2 || EMBNET_ABLATE == 4
+      __syncthreads();                       // everyone finished reading the previous tile
+      TA::store(sA, ra, tid);
+      TB::store(sA + TA::FLOATS, rb, tid);
+#if EMBNET_STAMPS
+      if (kt == kt_begin) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(9); }     // lgkmcnt(0): the LDS writes (hence the loads) are done
+#endif
+      __syncthreads();
+#if EMBNET_PHASE_PRIO
+      if (!fair) prio_lo();
+      else {
+        const int done = 4 * (kt - kt_begin), span = kt_end - kt_begin;
+        if (done >= 3 * span) __builtin_amdgcn_s_setprio(0);
+        else if (done >= 2 * span) __builtin_amdgcn_s_setprio(1);
+        else if (done >= span) __builtin_amdgcn_s_setprio(2);
+      }
+#endif
+#if EMBNET_STAMPS
+      if (kt == kt_begin) stamp(3);
+#endif
+#endif
+#if EMBNET_ABLATE == 4                      // diagnostic: same instructions, but every prefetch re-reads the FIRST tile (cache hits)
+      la.load(kt + 1 < kt_end ? kt_begin : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt_begin : PAST, rb);
+#elif EMBNET_ABLATE < 1
+      // prefetch of the next tile, in flight under the MFMAs; past the end the k bound makes every
+      // offset out of range, so the loads return zeros and need no branch
+      if constexpr (!(EMBNET_INTERLEAVE && LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE)) {
+        la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+        lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+      }
+#endif
+#if EMBNET_INTERLEAVE && EMBNET_ABLATE == 0
+      // The prefetch of the next tile is issued pass by pass BEHIND the first three k-steps' MFMAs instead of as a
+      // burst in front of them: a vector-memory instruction holds the SIMD's issue port for ~60+ cycles, and in a
+      // burst the co-resident waves' MFMAs (one due every 64 cycles) queue behind it.  (Ablation, tools/exp: the same
+      // kernels run 12-17 % faster without the loads in the loop, and not at all faster when the loads always hit the
+      // cache — what costs is their issue, not their latency.)  Past the end the k bound puts every offset out of range.
+      if constexpr (LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE) {
+        constexpr int NV = TA::PASSES + TB::PASSES;
+        const int ktn = kt + 1 < kt_end ? kt + 1 : PAST;
 #pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      float a[G::TM][4], b[G::TN][4];
-      load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
-      mfma_step<G>(a, b, acc);
+        for (int j = 0; j < BK / 8; ++j) {
+          float a[G::TM][4], b[G::TN][4];
+          load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
+          mfma_step<G>(a, b, acc);
+          if (j < 3) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = j * NV / 3; v < (j + 1) * NV / 3; ++v) {
+              if (v < TA::PASSES) la.load_pass(ktn, v, ra[v < TA::PASSES ? v : 0]);
+              else lb.load_pass(ktn, v - TA::PASSES, rb[v >= TA::PASSES ? v - TA::PASSES : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        continue;
+      }
+#endif
+#pragma unroll
+      for (int j = 0; j < BK / 8; ++j) {
+#if EMBNET_ABLATE == 3
+        mfma_step<G>(a3, b3, acc);
+        asm volatile("" ::: "memory");
+#else
+        float a[G::TM][4], b[G::TN][4];
+        load_frags<G, TA, TB>(sA, wm, wn, j, lane, a, b);
+        mfma_step<G>(a, b, acc);
+#endif
+      }
+      // loader's register-side transform of the tile just fetched (usually none): here, behind the MFMAs it
+      // overlaps with and outside the barrier pair, not between the barrier and the LDS store
+      la.fix(ra); lb.fix(rb);
     }
-    // loader's register-side transform of the tile just fetched (usually none): here, behind the MFMAs it
-    // overlaps with and outside the barrier pair, not between the barrier and the LDS store
-    la.fix(ra); lb.fix(rb);
+    prio_hi();                               // epilogue
   }
-  prio_hi();                                 // epilogue
 }
 
 // ---- fp32 products from bf16 matrix instructions: exact three-way split, six terms ("bf16x6") -----------------
@@ -346,6 +507,10 @@ __device__ __forceinline__ Split4 split4(const float4 v) {
   }
   Split4 s;
   s.p[0] = make_uint2(hi16_pair(a[0], a[1]), hi16_pair(a[2], a[3]));
+#if defined(EMBNET_SPLIT_ABLATE)             // diagnostic build (wrong results): no residual arithmetic, the packing only
+  s.p[1] = s.p[0]; s.p[2] = s.p[0];
+  return s;
+#endif
   s.p[1] = make_uint2(hi16_pair(b[0], b[1]), hi16_pair(b[2], b[3]));
   s.p[2] = make_uint2(hi16_pair(c[0], c[1]), hi16_pair(c[2], c[3]));
   return s;
@@ -447,11 +612,20 @@ __device__ __forceinline__ void mfma_step3(const bf16x8 (&a)[G::TM][3], const bf
 // Main loop of the split path: one LDS buffer, two barriers per K tile, the split arithmetic (11 VALU ops per pair of
 // elements) on prefetched registers BEHIND the MFMAs and outside the barrier pair, so between the barriers there are
 // only the 8-byte LDS stores.  TA/TB are the fp32 tile types the loaders were written for.
-// The registers are free as soon as they are split, so tile kt+2 is requested right behind the split of tile kt+1
-// (before the barrier pair and the LDS stores of the next iteration), not after them (+1.5 %).
-// Measured and not adopted (tools/exp/gemm_engine_diag.h, profiles/r02_exp_ab_split_*.txt): two register sets in flight
-// (EMBNET_SPLIT_DIST=2: +48..130 registers, a workgroup per CU fewer, 5-30 % slower), rounded instead of truncated
-// pieces (same error, 6-7 % slower).  Round 3: what bounds this loop is the per-CU gather rate / latency.
+// Prefetch distance: the MFMA phase of a K tile is 2.7x shorter than the fp32 loop's (24-48 bf16 MFMAs of 32 cycles
+// per wave: 0.3-0.6 us), shorter than an HBM or L2 round trip, so a tile fetched during tile kt's MFMAs is not there
+// when they end (PMC: matrix pipe 34-42 % busy at distance 1).  DIST = 2 keeps two register sets in flight: tile
+// kt+2 is requested before tile kt's MFMAs and first touched (split) after tile kt+1's.  Loaders whose fix() uses
+// state of their last load() (the optional input transform) stay at distance 1.
+// Measured (tools/exp/ab_conv.py, profiles/r02_exp_ab_split_dist2.txt): DIST = 2 costs 48-130 more registers (352
+// for the 128x128 forward kernel: one workgroup per CU instead of two, 128x64: two instead of three) and is 5-30 %
+// SLOWER on every layer that loses occupancy, 2-3 % faster on the 64x64-tile layers only -> off.
+#ifndef EMBNET_SPLIT_DIST
+#define EMBNET_SPLIT_DIST 1
+#endif
+#ifndef EMBNET_SPLIT_EARLY
+#define EMBNET_SPLIT_EARLY 1
+#endif
 template <class G, class TA, class TB, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int kt_begin, int kt_end,
                                                unsigned char* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false,
@@ -470,27 +644,31 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  if (kt_begin >= kt_end) { prio_hi(); return; }
   Split4 pa[TA::PASSES], pb[TB::PASSES];
   unsigned char* sA = smem;
   unsigned char* sB = smem + SA::BYTES;
-  float4 ra[TA::PASSES], rb[TB::PASSES];
-  auto split_all = [&]() {
+  auto split_all = [&](const float4 (&ra)[TA::PASSES], const float4 (&rb)[TB::PASSES]) {
 #pragma unroll
     for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
 #pragma unroll
     for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
   };
-  la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb);
-  split_all();
-  la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
-  lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto to_lds = [&](int kt) {
     __syncthreads();                         // everyone finished reading the previous tile
     SA::store(sA, pa, tid);
     SB::store(sB, pb, tid);
     __syncthreads();
-    prio_by_progress(fair, kt, kt_begin, kt_end);
+#if EMBNET_PHASE_PRIO
+    if (!fair) prio_lo();
+    else {
+      const int done = 4 * (kt - kt_begin), span = kt_end - kt_begin;
+      if (done >= 3 * span) __builtin_amdgcn_s_setprio(0);
+      else if (done >= 2 * span) __builtin_amdgcn_s_setprio(1);
+      else if (done >= span) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
+  };
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int st = 0; st < BK / 16; ++st) {
       bf16x8 a[G::TM][3], b[G::TN][3];
@@ -500,10 +678,69 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
       for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
       mfma_step3<G>(a, b, acc);
     }
-    la.fix(ra); lb.fix(rb);
-    if (kt + 1 < kt_end) split_all();        // tile kt+1, requested one iteration ago
-    la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
-    lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+  };
+  if (kt_begin >= kt_end) { prio_hi(); return; }
+  if constexpr (EMBNET_SPLIT_DIST == 2 && LA::CAN_INTERLEAVE && LB::CAN_INTERLEAVE) {
+    float4 ra0[TA::PASSES], rb0[TB::PASSES], ra1[TA::PASSES], rb1[TB::PASSES];
+    la.load(kt_begin, ra0); lb.load(kt_begin, rb0);
+    if (kt_begin + 1 < kt_end) { la.load(kt_begin + 1, ra1); lb.load(kt_begin + 1, rb1); }
+    split_all(ra0, rb0);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      to_lds(kt);                                                            // tile kt
+      if (kt + 2 < kt_end) { la.load(kt + 2, ra0); lb.load(kt + 2, rb0); }
+      mfma_tile();
+      if (kt + 1 >= kt_end) break;
+      split_all(ra1, rb1);                                                   // requested one iteration ago
+      to_lds(kt + 1);                                                        // tile kt + 1
+      if (kt + 3 < kt_end) { la.load(kt + 3, ra1); lb.load(kt + 3, rb1); }
+      mfma_tile();
+      if (kt + 2 < kt_end) split_all(ra0, rb0);
+    }
+  } else {
+    float4 ra[TA::PASSES], rb[TB::PASSES];
+    la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb);
+    split_all(ra, rb);
+#if EMBNET_ABLATE >= 2        // diagnostic builds (wrong results; tools/exp): 1 = no global loads in the loop, 2 = also no
+    to_lds(kt_begin);         // split / LDS stores / barriers, 3 = also no fragment reads (MFMA only)
+#endif
+#if EMBNET_ABLATE == 3
+    bf16x8 a3[G::TM][3], b3[G::TN][3];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, 0, lane, a3[i]);
+#pragma unroll
+    for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, 0, lane, b3[i]);
+#endif
+#if EMBNET_SPLIT_EARLY
+    // the registers are free as soon as they are split: request tile kt+2 right behind the split of tile kt+1 (before
+    // the barrier pair and the LDS stores of the next iteration) instead of after them
+    la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
+    lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
+#endif
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+#if EMBNET_ABLATE < 2
+      to_lds(kt);
+#endif
+#if EMBNET_ABLATE == 4        // diagnostic: same instructions, every prefetch re-reads the first tile (cache hits)
+      la.load(kt + 1 < kt_end ? kt_begin : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt_begin : PAST, rb);
+#elif EMBNET_ABLATE < 1 && !EMBNET_SPLIT_EARLY
+      la.load(kt + 1 < kt_end ? kt + 1 : PAST, ra);
+      lb.load(kt + 1 < kt_end ? kt + 1 : PAST, rb);
+#endif
+#if EMBNET_ABLATE == 3
+      mfma_step3<G>(a3, b3, acc); asm volatile("" ::: "memory"); mfma_step3<G>(a3, b3, acc); asm volatile("" ::: "memory");
+#else
+      mfma_tile();
+#endif
+#if EMBNET_ABLATE < 2 || EMBNET_ABLATE == 4
+      la.fix(ra); lb.fix(rb);
+      if (kt + 1 < kt_end) split_all(ra, rb);
+#endif
+#if EMBNET_SPLIT_EARLY
+      la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
+      lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+#endif
+    }
   }
   prio_hi();                                 // epilogue
 }
@@ -576,4 +813,3 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 }  // namespace embnet
-#endif  // EMBNET_DIAG_ENGINE
