@@ -16,7 +16,7 @@ forward -> NxN distance matrix -> mine-and-select -> hinge -> backward -> (RCCL 
 Rank 0 prints ONE JSON line; details go to stderr.
 
 roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
-every 4th timed step; the kernel with the largest total time is reported against the roofline that bounds it — for the
+three of the timed steps; the kernel with the largest total time is reported against the roofline that bounds it — for the
 convolution kernels the bf16 MFMA peak (16 x 157.3 TFLOP/s) with the bf16 FLOP they execute (each fp32 product = 6 bf16
 MFMA terms of an exact operand split: 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
 fp32 (157.3 TFLOP/s) for the distance / dense GEMMs with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
@@ -267,9 +267,11 @@ def main():
     for _ in range(n_warm):
         step()
     trace = rank == 0 and not args.no_kernel_timer
-    # kernels are timed on every 4th step; with the step replayed as a HIP graph those steps run eagerly (host-bound on
-    # the small configs), so every 8th
-    every = 8 if (args.mode != "siamese" and getattr(trainer, "_graph", None) is not None) else 4
+    # kernels are timed on THREE of the timed steps (every `every`-th): a traced step carries two HIP events per launch
+    # (~600 marker packets on a ResNet18 step, each a small bubble on the queue) and runs eagerly even where the step is a
+    # HIP graph, so it is several ms slower than a plain one — at every 4th step that cost 12 % of `value` (r03: 11.65 ms
+    # timed vs 10.19 ms in the untraced sustained leg)
+    every = max(4, (args.steps + 2) // 3)
     if trace:
         _lib.trace_reset()
     barrier()

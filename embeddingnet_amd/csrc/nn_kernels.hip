@@ -99,8 +99,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // Four channels per thread (C % 4 == 0): same two-stage reduction with 16-byte loads; lanes run over
 // channel QUADS.  partial keeps the [block][2][C] layout, so the finalize kernels are shared.
-template <class F>   // F(row, quad, float4& a, float4& b)
-__device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float* __restrict__ partial, F f) {
+struct NoPrep { __device__ __forceinline__ int operator()(int) const { return 0; } };
+// F(row, quad, const K& k, float4& a, float4& b) with k = prep(quad): the per-channel constants of a column are fetched ONCE
+// per thread and column block, not once per row (bn_bwd_reduce4 issued four 16-byte constant loads beside the two data
+// loads of every element: 3.9 TB/s where the apply pass, two constant loads per element, reached 5.3)
+template <class P, class F>
+__device__ __forceinline__ void col_reduce2_v4p(long m, int c4, ColGeom g, float* __restrict__ partial, P prep, F f) {
   __shared__ float4 sh4[2][256];
   const int ci = threadIdx.x % g.cl, ri = threadIdx.x / g.cl;
   const long r0 = (long)blockIdx.x * g.rows_per_block;
@@ -109,10 +113,11 @@ __device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float*
     const int q = q0 + ci;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (q < c4) {                     // four rows per trip (same accumulation order): 8 x 16-byte loads in flight per lane
+      const auto k = prep(q);
       long r = r0 + ri;
       const long rl = g.rl;
-      for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, a, b); f(r + rl, q, a, b); f(r + 2 * rl, q, a, b); f(r + 3 * rl, q, a, b); }
-      for (; r < r1; r += rl) f(r, q, a, b);
+      for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, k, a, b); f(r + rl, q, k, a, b); f(r + 2 * rl, q, k, a, b); f(r + 3 * rl, q, k, a, b); }
+      for (; r < r1; r += rl) f(r, q, k, a, b);
     }
     // row-lanes of one wave first (xor butterfly over the lane bits above the column bits), then the <= 4 per-wave
     // (or per-row-lane, when a wave is one row-lane) sums through LDS: 2 LDS round trips instead of rl - 1 serial ones
@@ -141,6 +146,10 @@ __device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float*
     __syncthreads();
   }
 }
+template <class F>   // F(row, quad, float4& a, float4& b)
+__device__ __forceinline__ void col_reduce2_v4(long m, int c4, ColGeom g, float* __restrict__ partial, F f) {
+  col_reduce2_v4p(m, c4, g, partial, NoPrep(), [&](long r, int q, int, float4& a, float4& b) { f(r, q, a, b); });
+}
 
 __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict__ x, long m, int c4, ColGeom g,
                                                         float* __restrict__ partial) {
@@ -156,11 +165,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
                                                              const float* __restrict__ rstd, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
                                                              float* __restrict__ partial) {
-  col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
+  struct K4 { float4 sc, sh, mu, rs; };
+  col_reduce2_v4p(m, c4, g, partial, [&](int q) {
+    return K4{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q],
+              reinterpret_cast<const float4*>(mean)[q], reinterpret_cast<const float4*>(rstd)[q]};
+  }, [&](long r, int q, const K4& k, float4& a, float4& b) {
     const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
     float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
-    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+    const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs;
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
       dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
@@ -178,19 +190,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ dgamma, int relu, int training,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx) {
   const long stride = (long)gridDim.x * 256;
+  // (the launcher makes the stride a multiple of c4 whenever c4 divides a power of two, so a thread keeps its channel
+  // quad and the six per-channel constants are loaded once; otherwise they are re-read per element)
+  const bool fixed = stride % c4 == 0;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sc = z4, sh = z4, mu = z4, rs = z4, db = z4, dg = z4;
+  auto consts = [&](int q) {
+    sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+    if (training) {
+      mu = reinterpret_cast<const float4*>(mean)[q]; rs = reinterpret_cast<const float4*>(rstd)[q];
+      db = reinterpret_cast<const float4*>(dbeta)[q]; dg = reinterpret_cast<const float4*>(dgamma)[q];
+    }
+  };
+  if (fixed) consts((int)(((long)blockIdx.x * 256 + threadIdx.x) % c4));
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
-    const int q = (int)(i % c4);
+    if (!fixed) consts((int)(i % c4));
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     float4 dz = reinterpret_cast<const float4*>(dy)[i];
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
       dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
     }
     float4 o;
     if (training) {
-      const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
-      const float4 db = reinterpret_cast<const float4*>(dbeta)[q], dg = reinterpret_cast<const float4*>(dgamma)[q];
       o.x = sc.x * (dz.x - db.x * inv_m - (xv.x - mu.x) * rs.x * dg.x * inv_m);
       o.y = sc.y * (dz.y - db.y * inv_m - (xv.y - mu.y) * rs.y * dg.y * inv_m);
       o.z = sc.z * (dz.z - db.z * inv_m - (xv.z - mu.z) * rs.z * dg.z * inv_m);
@@ -250,11 +272,19 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   const long stride = (long)gridDim.x * 256;
   if ((c & 3) == 0) {
     const long n4 = total >> 2;
+    const int c4 = c >> 2;
+    const bool fixed = stride % c4 == 0;                 // a thread keeps its channel quad: scale / shift loaded once
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    if (fixed) {
+      const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+      sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-      const int col = (int)((i * 4) % c);
+      if (!fixed) {
+        const int col = (int)((i * 4) % c);
+        sc = *reinterpret_cast<const float4*>(scale + col); sh = *reinterpret_cast<const float4*>(shift + col);
+      }
       const float4 v = reinterpret_cast<const float4*>(x)[i];
-      const float4 sc = *reinterpret_cast<const float4*>(scale + col);
-      const float4 sh = *reinterpret_cast<const float4*>(shift + col);
       float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
       if (relu) { o.x = act_apply(relu, o.x); o.y = act_apply(relu, o.y); o.z = act_apply(relu, o.z); o.w = act_apply(relu, o.w); }
       reinterpret_cast<float4*>(y)[i] = o;
@@ -881,6 +911,15 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 using namespace embnet;
 #define S(stream) ((hipStream_t)(stream))
 static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+// the same, rounded to a block count whose grid stride (blocks * 256 quads) is a multiple of c4: every thread of a
+// channel-quad kernel then keeps ONE channel quad and loads its per-channel constants once
+static inline int ew_blocks_c4(long total4, int c4) {
+  int b = ew_blocks(total4);
+  int gcd = c4, r = 256; while (r) { const int t = gcd % r; gcd = r; r = t; }
+  const int unit = c4 / gcd;
+  if (unit > 1) b = b < unit ? unit : b / unit * unit;
+  return b;
+}
 
 extern "C" size_t embnet_bn_workspace_bytes(long m, int c) {
   if (m <= 0 || c <= 0) return 0;
@@ -912,7 +951,7 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   { EMBNET_TRACE("embnet::bn_finalize_kernel", TRACE_BYTES, 8.0 * nblocks * c, stream); bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
                                                           save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr); }
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
-    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
+    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
   return check_launch("bn_train_fwd");
 }
 
@@ -922,7 +961,7 @@ extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* g
   EMBNET_CHECK_ARG(x && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_infer_fwd: m=%ld c=%d", m, c);
   bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
-  if (y) { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
+  if (y) { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
   return check_launch("bn_infer_fwd");
 }
 
@@ -930,7 +969,7 @@ extern "C" int embnet_affine_act(const float* x, long m, int c, const float* sca
                                  void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && y, "affine_act: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "affine_act: m=%ld c=%d", m, c);
-  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<ew_blocks(m * c / 4 + 1), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y); }
+  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y); }
   return check_launch("affine_act");
 }
 
@@ -962,7 +1001,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks(m * c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
+    { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
                                                                       save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,

@@ -142,10 +142,17 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
 
 /* Conv2D (backbones.py:21-31, :44-68, zoo ResNet/EfficientNet convs): implicit GEMM.  fp32 in, fp32 out, fp32
  * accumulation; each fp32 product is formed on the bf16 matrix instruction from an EXACT three-way split of both
- * operands (x = x1 + x2 + x3, six of the nine cross terms; the three dropped are <= 2^-24 |x||y|), which measures
- * no further from an fp64 reference than the fp32 MFMA's fma chain and runs at 16/6 of its rate.
- * The pieces keep fp32's exponent range (no overflow / underflow beyond fp32's own); an INFINITE operand yields NaN where an
- * fp32 product would yield inf (inf - inf inside the split) — training has diverged by then either way.
+ * operands by truncation (x = x1 + x2 + x3, 8 significant bits each) as six of the nine cross terms.
+ * ERROR BOUND.  The three dropped terms x2*y3 + x3*y2 + x3*y3 are <= 2^-20 |x||y| in the worst case (the low 16 mantissa
+ * bits of both operands all ones; typically 2^-22) and have the product's sign, so on top of fp32 accumulation a result is
+ * LOW by at most 2^-20 * sum|x||y| — a bias, not zero-mean noise.  Measured on that adversarial input with all-positive
+ * operands (tests/test_round3_gpu.py::test_conv_split_worst_case, profiles/r03_split_worst_case_*.json), relative to
+ * sum|x||y|:  K = 576: 1.5e-6 max / -4.4e-7 mean (a float32 CPU convolution on the same input: 2.1e-6 / -9.4e-7);
+ * K = 4608 forward: 3.3e-5 / -2.2e-5 (float32 CPU: 1.9e-5 / -1.4e-5: fp32 accumulation dominates there), data gradient
+ * 2.3e-6 (6.7e-6), weight gradient 5.8e-7 (1.1e-7).  On operands with random mantissas the error is that of the fp32
+ * MFMA's k-ordered fma chain (test_conv2d_products_are_fp32_accurate); on integer-valued operands results are exact.
+ * The pieces keep fp32's exponent range (no overflow / underflow beyond fp32's own).  INFINITY: an infinite operand yields
+ * NaN where an fp32 product would yield inf (inf - inf inside the split) — training has diverged by then either way.
  * embnet_conv_mfma_terms() = bf16 MFMA terms per product in this build (6), or 1 for a build on v_mfma_f32_32x32x2_f32.
  * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
  * padding; bottom/right follow from oh/ow, which the caller computes: Keras 'valid', 'same' incl. its

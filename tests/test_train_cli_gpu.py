@@ -129,6 +129,11 @@ def test_train_cli_resume_from(tmp_path):
     wdir = tmp_path / "simple2_synthetic" / "weights"
     ckpt = str(wdir / sorted(os.listdir(wdir))[-1])
     resumed = _run_cli(cfg_path, "--max_epochs", "1", "--resume_from", ckpt)
+    # the optimizer's slots and step count travel with the checkpoint (Keras' load_model restores the optimizer too)
+    assert os.path.exists(str(tmp_path / "simple2_synthetic" / "optimizer" / os.path.basename(ckpt)))
+    # (3 epochs x 20 batches when the best epoch was the last one; at least one epoch's worth in any case)
+    it = int(resumed.split("resumed optimizer state")[1].split("iterations ")[1].split(",")[0])
+    assert it >= 20 and it % 20 == 0, it
     loss_of = lambda text, epoch: float(text.split(f"Epoch {epoch}/")[1].split("loss ")[1].split()[0])
     assert loss_of(resumed, 1) < 0.8 * loss_of(first, 1), (loss_of(resumed, 1), loss_of(first, 1))
     cfg = parse_params(str(cfg_path))

@@ -51,6 +51,12 @@ def create_save_folders(params):
     return paths
 
 
+def _optimizer_state_path(weights_path):
+    """<project>/weights/epoch_007.npz -> <project>/optimizer/epoch_007.npz (the weights folder holds weight files only)."""
+    d, f = os.path.split(os.path.abspath(weights_path))
+    return os.path.join(os.path.dirname(d), 'optimizer', f)
+
+
 class Plateau:
     """The three monitor-driven Keras callbacks of the reference (train.py:82-90), each with its own state as in Keras:
       ReduceLROnPlateau(factor .1, patience 4): `min_delta` 1e-4 (Keras default, mode 'min': an epoch improves only if
@@ -172,7 +178,7 @@ def main():
         # load_model restores the optimizer with the weights; the epoch count and LR schedule restart, as in the reference)
         from embeddingnet_amd.backbones import keras_weights
         from embeddingnet_amd.optimizers import load_optimizer_state
-        opt_path = os.path.splitext(args.resume_from)[0] + '.opt.npz'
+        opt_path = _optimizer_state_path(args.resume_from)
         if os.path.exists(opt_path):
             extra = load_optimizer_state(opt_path, opt, {k: v for k, v in keras_weights(trainable).items()
                                                          if isinstance(v, torch.nn.Parameter)})
@@ -239,7 +245,8 @@ def main():
             model.save_weights(path)
             from embeddingnet_amd.backbones import keras_weights
             from embeddingnet_amd.optimizers import save_optimizer_state
-            save_optimizer_state(os.path.splitext(path)[0] + '.opt.npz', opt,
+            os.makedirs(os.path.dirname(_optimizer_state_path(path)), exist_ok=True)
+            save_optimizer_state(_optimizer_state_path(path), opt,
                                  {k: v for k, v in keras_weights(trainable).items() if isinstance(v, torch.nn.Parameter)},
                                  extra={'epoch': epoch + 1})
             print(f'{monitor} improved to {value:.5f}, saving model to {path}')
