@@ -139,13 +139,15 @@ class ResidualUnit(nn.Module):
         # ResNet18 step) but the extra VALU work in the conv / wgrad loaders costs 0.65 ms — measured, kept as a knob.
         # emit_stats: every conv here feeds a BatchNormalization (bn2/bn3, the next unit's bn1, the net's last bn1):
         # its epilogue also produces that BN's per-channel sums, so training reads each activation once less.
+        # planes_for: a BatchNormalization in front of a 3x3 stride-1 conv writes its output also as bf16 planes, which
+        # that conv (forward and data gradient) reads through the patch kernel (csrc/conv_patch.hip).
         d, st = DEFER_BN, self.training and EPILOGUE_STATS
         if self.post:                                    # projection shortcut: conv1 and sc read the same tensor
-            y1, sc = L.conv_pair(self.bn1(x, defer=d), self.conv1, self.sc, emit_stats=st)
+            y1, sc = L.conv_pair(self.bn1(x, defer=d, planes_for=self.conv1), self.conv1, self.sc, emit_stats=st)
         else:                                            # identity shortcut: its gradient joins dx inside bn1's backward
-            a, sc = self.bn1(x, defer=d, with_skip=True)
+            a, sc = self.bn1(x, defer=d, with_skip=True, planes_for=self.conv1)
             y1 = self.conv1(a, emit_stats=st)
-        y = self.bn2(y1, defer=d)
+        y = self.bn2(y1, defer=d, planes_for=self.conv2)
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
         return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d), residual=sc, emit_stats=st)

@@ -15,9 +15,6 @@
 // Roofline: MFMA f32 (157.3 TFLOP/s); algorithmic FLOP = 2 * N*OH*OW * K * R*S*C per pass.
 #include "gemm_engine.h"
 #include "conv_geom.h"
-#ifndef EMBNET_EXP_HOOKS
-#define EMBNET_EXP_HOOKS 0
-#endif
 #include "../../include/embnet.h"
 #include <stdlib.h>
 
@@ -626,8 +623,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 using namespace embnet;
 
-#if EMBNET_EXP_HOOKS       // experiment builds only (tools/exp/conv_planes.hip)
-// host helper for conv_planes.hip: the fix-up pass over `rem` left-over tiles cut into `parts` partial tiles (SplitTail)
+// host helper for conv_patch.hip: the fix-up pass over `rem` left-over tiles cut into `parts` partial tiles (SplitTail)
 namespace embnet {
 void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
                        const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
@@ -637,7 +633,6 @@ void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int 
                                                            residual, out, stats, stats_rows);
 }
 }  // namespace embnet
-#endif
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

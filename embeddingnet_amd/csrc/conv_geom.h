@@ -1,4 +1,4 @@
-// Convolution geometry of the implicit-GEMM kernels (conv.hip; also used by the experiment tools/exp/conv_planes.hip).
+// Convolution geometry shared by conv.hip and conv_patch.hip (and the experiment tools/exp/conv_planes.hip).
 #pragma once
 #include "common.h"
 
@@ -33,7 +33,7 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
   r = (int)rr; s = (int)ss; c = (int)cc;
 }
 
-// conv.hip, experiment builds (-DEMBNET_EXP_HOOKS=1): fix-up pass over left-over tiles computed as K-split partial tiles
+// conv.hip: fix-up pass over left-over tiles computed as K-split partial tiles (used by conv.hip and conv_patch.hip)
 void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
                        const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
                        hipStream_t st);

@@ -1,0 +1,498 @@
+// Stride-1 convolution on PRE-SPLIT operands ("patch" kernel): forward and data gradient of the 3x3 layers that dominate
+// the zoo ResNets (image-classifiers residual units, /root/reference/embedding_net/backbones.py:99-104).
+//
+// Why another conv kernel (round-3 measurements): the implicit-GEMM loop of conv.hip re-gathers every
+// input pixel once per tap and splits it into its three bf16 pieces each time; its K-tile period turned out to be the
+// round trip of the gather (L2 / Infinity-Cache rate per CU, ~2 us under load), not the matrix pipe.  Here
+//  * the three bf16 pieces of every fp32 value ("planes", gemm_engine.h split4) are written ONCE by the tensor's producer
+//    (embnet_affine_act_planes, embnet_bn_bwd's dx_planes) in a CHUNK-MAJOR layout [plane][C/16][pixels][16], and the
+//    kernels' weights once per optimizer step (embnet_conv_weight_planes) STEP-MAJOR [plane][r][C/16][s][K][16];
+//  * a workgroup (256 output pixels x BN channels) keeps a PATCH of the zero-padded input in LDS — the contiguous run of
+//    padded-image positions its pixels' R x S windows cover, 16 channels at a time — and every tap reads its A fragments
+//    from the patch at a constant row offset r*PW + s:  position(n, oh, ow) = n*PH*PW + oh*PW + ow,  PH = OH+R-1, PW = OW+S-1.
+//    Each input value is fetched once per tile instead of R*S times; padding positions are written as zeros by the DMA
+//    (out-of-range buffer offsets), so borders and image-to-image seams need no special case;
+//  * operand tiles reach LDS by LDS-DMA (buffer_load ... lds) issued by two LOADER waves (wave 8: weights, wave 9:
+//    patches) beside the eight MFMA waves: no register staging, no split arithmetic, no ds_write and no vmcnt wait in the
+//    MFMA waves; with the layouts above a 1 KiB DMA covers 8 whole cache lines;
+//  * weight ring of NBS slots requested NBS-1 steps ahead, patch double buffer requested a chunk ahead (a DMA takes ~2 us
+//    to land under load); one s_barrier per step (TPS taps of one 16-channel chunk);
+//  * the workgroup is persistent: it walks its output tiles with the loaders running ahead across tile boundaries;
+//    left-over tiles (tiles mod grid) are cut along the channel chunks into equal pieces, one per workgroup
+//    (raw partial tiles + conv.hip's tail_fixup_kernel).
+// Same pieces and six-term products as gemm_mainloop3 (fp32-exact split, include/embnet.h); the summation order over k is
+// (chunk, r, s, channel) instead of (r, s, channel).  LDS rows are 32 bytes per plane; the two 16-byte halves of a row are
+// swapped when (row >> 3) & 1, which makes any 16 consecutive rows conflict-free for ds_read_b128 whatever the tap shift.
+// Measured (profiles/r03_exp_patch2_ab.txt): 192 / 183 / 202 TFLOP/s fp32-equivalent on the 56x56x64, 28x28x128,
+// 14x14x256 ResNet18 layers where conv.hip's forward kernel reaches 155 / 156 / 183.
+#include "gemm_engine.h"
+#include "conv_geom.h"
+#include "../../include/embnet.h"
+
+namespace embnet {
+namespace patch {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <int BN_>
+struct GeomP {      // 8 MFMA waves as 4 (rows) x 2 (columns); 256 output pixels x BN channels
+  static constexpr int BM = 256, BN = BN_, WAVES_M = 4, WAVES_N = 2, WTM = 64, WTN = BN_ / 2, TM = 2, TN = WTN / 32;
+};
+
+struct PatchParams {
+  const unsigned short* xp;      // [3][C/16][N*H*W][16] bf16 pieces of the input
+  const unsigned short* wp;      // [3][R][C/16][S][K][16] bf16 pieces of the kernel
+  float* y; const float* bias; const float* residual; float* stats; int stats_rows; int relu;
+  ConvGeom g; unsigned x_plane_bytes, w_plane_bytes;
+  int PH, PW; FastDiv dPHW, dPW;
+  int LR;                        // LDS patch rows (multiple of 32)
+  int n_full, parts, cc_part, n_pieces, grid; float* ws;
+};
+
+typedef const PatchParams __attribute__((address_space(4)))* kargp;
+// The kernel's only argument, re-read from the kernel-argument segment where it is needed (scalar loads) instead of being
+// kept in registers across the main loops: per-tile set-up uses a dozen dividers and geometry words.
+__device__ __forceinline__ kargp kargs() {
+  kargp pp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pp));
+  return pp;
+}
+
+struct Item { int m0, n0, cc_b, cc_e, tile_m; float* part; };
+
+template <int BN>
+__device__ __forceinline__ Item work_item(int item, int n_mine) {
+  kargp pp = kargs();
+  const int b = blockIdx.x, NCC = pp->g.C / 16, tiles_n = (pp->g.K + BN - 1) / BN;
+  Item t; int id;
+  if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr; }
+  else {
+    id = pp->n_full + b / pp->parts;
+    t.cc_b = (b % pp->parts) * pp->cc_part; t.cc_e = min(NCC, t.cc_b + pp->cc_part);
+    t.part = pp->ws + (long)b * (256 * BN);
+  }
+  t.tile_m = id / tiles_n; t.m0 = t.tile_m * 256; t.n0 = (id % tiles_n) * BN;
+  return t;
+}
+
+__device__ __forceinline__ int padded_pos(int m) {            // padded-image position of output pixel m
+  kargp pp = kargs();
+  FastDiv dOHW, dOW;
+  dOHW.mul = pp->g.dOHW.mul; dOHW.shift = pp->g.dOHW.shift; dOHW.d = pp->g.dOHW.d;
+  dOW.mul = pp->g.dOW.mul; dOW.shift = pp->g.dOW.shift; dOW.d = pp->g.dOW.d;
+  uint32_t n, rem, oh, ow;
+  dOHW.divmod((uint32_t)m, n, rem); dOW.divmod(rem, oh, ow);
+  return (int)n * (pp->PH * pp->PW) + (int)oh * pp->PW + (int)ow;
+}
+
+template <int BN, int R, int S, int TPS, int NBS>
+__global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
+  using G = GeomP<BN>;
+  constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
+  constexpr int SBY = TPS * 3 * BN * 32;                 // one weight slot: TPS taps x 3 planes x BN rows x 32 bytes
+  constexpr int NBI = TPS * 3 * (BN / 32);               // DMA instructions per weight slot
+  static_assert((R * S) % TPS == 0 && SPC >= 2, "steps per chunk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int LR = p.LR, PLP = LR * 32, PB = 3 * PLP;      // patch plane / patch buffer bytes
+  unsigned char* const bslot0 = smem + 2 * PB;
+  const int b = blockIdx.x;
+  const int n_mine = b < p.n_full ? (p.n_full - b + p.grid - 1) / p.grid : 0;
+  const int n_items = n_mine + (b < p.n_pieces ? 1 : 0);
+  if (n_items == 0) return;
+  const int dhalf = (lane & 1) ^ ((lane >> 4) & 1);      // logical 16-byte half this lane's DMA piece holds
+
+  if (wave == 8) {
+    // ---- weight loader: slot (gs % NBS) <- weights of step gs, D steps ahead of the MFMA waves ----------------------
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wp), 0, 3u * p.w_plane_bytes, 0x00020000);
+    const int K = p.g.K, NCC = p.g.C / 16;
+    const unsigned wpb = p.w_plane_bytes;
+    int it = 0; Item t = work_item<BN>(0, n_mine);               // the step being REQUESTED: (it, cc, st)
+    int cc = t.cc_b, st = 0; bool live = true;
+    unsigned rowoff[BN / 32];                                    // per lane, per 32-row group of the tile: constant per tile
+    auto tile_rows = [&]() {
+#pragma unroll
+      for (int gb = 0; gb < BN / 32; ++gb) {
+        const int row = t.n0 + gb * 32 + (lane >> 1);
+        rowoff[gb] = row < K ? 32u * (unsigned)row + 16u * dhalf : OOB;
+      }
+    };
+    tile_rows();
+    auto issue = [&](int gs) {
+      unsigned char* slot = bslot0 + (gs % NBS) * SBY;
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+        const int tap = st * TPS + tp, r = tap / S, s = tap % S;
+        const unsigned so = 32u * (unsigned)(((r * NCC + cc) * S + s) * K);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int gb = 0; gb < BN / 32; ++gb)
+            dma16(wr, slot + ((tp * 3 + q) * BN + gb * 32) * 32, live ? rowoff[gb] : OOB, q * wpb + so);
+      }
+      if (live && ++st == SPC) {
+        st = 0;
+        if (++cc == t.cc_e) {
+          if (++it < n_items) { t = work_item<BN>(it, n_mine); cc = t.cc_b; tile_rows(); } else live = false;
+        }
+      }
+    };
+    int total = 0;                                               // steps of this workgroup
+    for (int i = 0; i < n_items; ++i) { const Item q = work_item<BN>(i, n_mine); total += (q.cc_e - q.cc_b) * SPC; }
+    for (int gs = 0; gs < D; ++gs) issue(gs);
+    for (int gs = 0; gs < total; ++gs) {
+      // the D - 1 youngest requests may still be in flight: the weights of step gs have landed.  (Past the last step the
+      // loader keeps issuing out-of-range requests — zeros into slots nobody reads — so the count stays a constant.)
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NBI) : "memory");
+      __builtin_amdgcn_s_barrier();                              // #gs: step gs - 1 is done everywhere -> its slot is free
+      issue(gs + D);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (wave == 9) {
+    // ---- patch loader: buffer (gc & 1) <- patch of chunk gc, requested at the first step of chunk gc - 1 -------------
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xp), 0, 3u * p.x_plane_bytes, 0x00020000);
+    const int NG = LR / 32;
+    const unsigned xpb = p.x_plane_bytes, chunk_bytes = 32u * (unsigned)(p.g.N * p.g.H * p.g.W);
+    unsigned poff[16];
+    auto tile_offsets = [&](const Item& t) {
+      kargp pp = kargs();
+      FastDiv dPHW, dPW;
+      dPHW.mul = pp->dPHW.mul; dPHW.shift = pp->dPHW.shift; dPHW.d = pp->dPHW.d;
+      dPW.mul = pp->dPW.mul; dPW.shift = pp->dPW.shift; dPW.d = pp->dPW.d;
+      const int P0 = padded_pos(t.m0), N = pp->g.N, H = pp->g.H, W = pp->g.W, pt = pp->g.pad_t, pl = pp->g.pad_l;
+#pragma unroll
+      for (int gI = 0; gI < 16; ++gI) {
+        const int idx = P0 + 32 * gI + (lane >> 1);
+        uint32_t n, rem, py, px;
+        dPHW.divmod((uint32_t)idx, n, rem); dPW.divmod(rem, py, px);
+        const int ih = (int)py - pt, iw = (int)px - pl;
+        const bool ok = gI < NG && (int)n < N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        poff[gI] = ok ? 32u * (unsigned)(((int)n * H + ih) * W + iw) + 16u * dhalf : OOB;
+      }
+    };
+    auto issue = [&](int cc, int gc) {
+      unsigned char* buf = smem + (gc & 1) * PB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI)
+          if (gI < NG) dma16(xr, buf + q * PLP + gI * 1024, poff[gI], q * xpb + (unsigned)cc * chunk_bytes);
+    };
+    int it = 0; Item t = work_item<BN>(0, n_mine);               // the chunk being REQUESTED
+    int cc = t.cc_b; bool live = true;
+    tile_offsets(t);
+    auto advance = [&]() {
+      if (++cc == t.cc_e) {
+        if (++it < n_items) { t = work_item<BN>(it, n_mine); cc = t.cc_b; tile_offsets(t); } else live = false;
+      }
+    };
+    issue(cc, 0); advance();
+    int total_chunks = 0;
+    for (int i = 0; i < n_items; ++i) { const Item q = work_item<BN>(i, n_mine); total_chunks += q.cc_e - q.cc_b; }
+    for (int gc = 0; gc < total_chunks; ++gc) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // patch gc has landed (requested a chunk ago)
+      __builtin_amdgcn_s_barrier();                              // first step of chunk gc: chunk gc - 1 is done -> its buffer is free
+      if (live) { issue(cc, gc + 1); advance(); }
+#pragma unroll 1
+      for (int s2 = 1; s2 < SPC; ++s2) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ---- MFMA waves ---------------------------------------------------------------------------------------------------
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  const int K = p.g.K, PW = p.PW, M = p.g.N * p.g.OH * p.g.OW;
+  int gs = 0, gc = 0;
+  f32x16 acc[TM][TN];
+  for (int item = 0; item < n_items; ++item) {
+    const Item cur = work_item<BN>(item, n_mine);
+    int rowidx[TM];                                      // patch row of this lane's output pixel(s), tap (0, 0)
+    {
+      const int P0 = padded_pos(cur.m0);
+#pragma unroll
+      for (int im = 0; im < TM; ++im) {
+        const int m = cur.m0 + wm + im * 32 + (lane & 31);
+        rowidx[im] = m < M ? padded_pos(m) - P0 : 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int cc = cur.cc_b; cc < cur.cc_e; ++cc) {
+      const unsigned char* pbuf = smem + (gc & 1) * PB;
+#pragma unroll 1
+      for (int st = 0; st < SPC; ++st) {
+        __syncthreads();             // barrier #gs: this step's weights (and, at st = 0, this chunk's patch) are in LDS
+        const unsigned char* bs = bslot0 + (gs % NBS) * SBY;
+#pragma unroll
+        for (int tp = 0; tp < TPS; ++tp) {
+          const int tap = st * TPS + tp, r = tap / S, s = tap % S;
+          bf16x8 a[TM][3], bb[TN][3];
+#pragma unroll
+          for (int im = 0; im < TM; ++im) {
+            const int idx = rowidx[im] + r * PW + s;
+            const unsigned char* ap = pbuf + idx * 32 + ((h ^ ((idx >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[im][q] = *reinterpret_cast<const bf16x8*>(ap + q * PLP);
+          }
+#pragma unroll
+          for (int in = 0; in < TN; ++in) {
+            const int row = wn + in * 32 + (lane & 31);
+            const unsigned char* bp = bs + (tp * 3 * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bb[in][q] = *reinterpret_cast<const bf16x8*>(bp + q * BN * 32);
+          }
+          mfma_step3<G>(a, bb, acc);
+          if (TPS > 1) __builtin_amdgcn_sched_barrier(0);     // one tap's fragments at a time (all taps' reads hoisted: spills)
+        }
+        ++gs;
+      }
+      ++gc;
+    }
+    // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
+    // lane & 31, so a store instruction writes two 128-byte row segments
+    if (cur.part) {
+      float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr)
+            part[(im * 32 + (rr & 3) + 8 * (rr >> 2)) * BN + in * 32] = acc[im][in][rr];
+    } else {
+      const bool inner = cur.m0 + 256 <= M && cur.n0 + BN <= K;      // wave-uniform: no edge tests on interior tiles
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        const int col = cur.n0 + wn + in * 32 + (lane & 31);
+        const bool cok = col < K;
+        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+          const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
+          float v[16];
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) { v[rr] = acc[im][in][rr] + bv; if (p.relu) v[rr] = fmaxf(v[rr], 0.f); }
+          if (inner) {
+            if (p.residual) {
+#pragma unroll
+              for (int rr = 0; rr < 16; ++rr) v[rr] += p.residual[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              p.y[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] = v[rr];
+              s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              if (row < M && cok) {
+                const long o = o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K;
+                if (p.residual) v[rr] += p.residual[o];
+                p.y[o] = v[rr];
+                s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+              }
+            }
+          }
+        }
+        if (p.stats) {                                    // BatchNorm statistics of the layer that follows (as conv.hip's epilogue)
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0 && cok) {
+            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = p.stats_rows;
+            p.stats[(long)col * P + prow] = s1;
+            p.stats[((long)K + col) * P + prow] = s2;
+          }
+        }
+      }
+    }
+  }
+}
+
+// kernel [R,S,C,K] fp32 -> step-major planes [3][R][red/16][S][rows][16] bf16, one thread per four consecutive elements.
+// flip = 0: rows = K, reduction channels = C:  out[r][cc][s][k][j] = w[r, s, 16 cc + j, k]
+// flip = 1: rows = C, reduction channels = K:  out[r][cc][s][c][j] = w[R-1-r, S-1-s, c, 16 cc + j]   (stride-1 data gradient:
+//           the correlation of dy with the flipped kernel, channel roles swapped)
+struct WPlanesTensor { const float* w; unsigned short* out; int R, S, C, K, flip, pad; };
+static_assert(sizeof(WPlanesTensor) == 40, "descriptor layout is part of the ABI (include/embnet.h)");
+__global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor* __restrict__ table, const int* __restrict__ chunks) {
+  const WPlanesTensor t = table[chunks[2 * blockIdx.x]];
+  const int rows = t.flip ? t.C : t.K, red = t.flip ? t.K : t.C, ncc = red / 16;
+  const long plane = (long)t.R * t.S * t.C * t.K, total4 = plane / 4;
+  const long i = (long)chunks[2 * blockIdx.x + 1] * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i4 = i + u * 256;
+    if (i4 >= total4) return;
+    long e = 4 * i4;                                    // output element index [r][cc][s][row][j]
+    const int j = (int)(e % 16); e /= 16;
+    const int row = (int)(e % rows); e /= rows;
+    const int s = (int)(e % t.S); e /= t.S;
+    const int cc = (int)(e % ncc); const int r = (int)(e / ncc);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = cc * 16 + j + q;
+      v[q] = t.flip ? t.w[((long)((t.R - 1 - r) * t.S + (t.S - 1 - s)) * t.C + row) * t.K + ch]
+                    : t.w[((long)(r * t.S + s) * t.C + ch) * t.K + row];
+    }
+    const Split4 sp = split4(make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
+  }
+}
+
+// fp32 NHWC [pixels][C] -> chunk-major planes [3][C/16][pixels][16] bf16; one thread per (pixel, 4 channels)
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ x, long pixels, int C,
+                                                              unsigned short* __restrict__ planes) {
+  const long total4 = pixels * C / 4, plane = pixels * C;
+  const int c4 = C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long pix = i / c4; const int c = (int)(i % c4) * 4;
+    const Split4 s = split4(reinterpret_cast<const float4*>(x)[i]);
+    const long o = ((long)(c >> 4) * pixels + pix) * 16 + (c & 15);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(planes + q * plane + o) = s.p[q];
+  }
+}
+
+}  // namespace patch
+}  // namespace embnet
+
+using namespace embnet;
+using namespace embnet::patch;
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static int patch_rows(int n, int oh, int ow, int r, int s) {                 // LDS patch rows for 256-pixel tiles
+  const long M = (long)n * oh * ow;
+  const int PH = oh + r - 1, PW = ow + s - 1;
+  auto base = [&](long m) { const long img = m / ((long)oh * ow), rem = m % ((long)oh * ow); return img * PH * PW + (rem / ow) * PW + rem % ow; };
+  long worst = 0;
+  for (long m0 = 0; m0 < M; m0 += 256) {
+    const long m1 = (m0 + 256 < M ? m0 + 256 : M) - 1;
+    const long L = base(m1) - base(m0) + (long)(r - 1) * PW + s;
+    if (L > worst) worst = L;
+  }
+  return (int)((worst + 31) / 32 * 32);
+}
+
+struct Plan { int bn, tps, nbs, LR, tiles, n_full, parts, cc_part, n_pieces, grid; size_t lds, ws_bytes; };
+
+static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int ow, Plan& pl) {
+  static const int enabled = (int)env_long("EMBNET_CONV_PATCH", 1);
+  if (!enabled || stride != 1 || r != 3 || s != 3 || (c & 15) || (k & 3) || n <= 0 || oh <= 0 || ow <= 0) return false;
+  if ((size_t)n * (oh + 2) * (ow + 2) * 32 >= 0x7FFFFFF0ull || (size_t)n * oh * ow * c * 2 >= 0x7FFFFFF0ull / 3) return false;
+  // the geometry's plan is a pure function of its arguments: remember the last few (patch_rows walks every tile)
+  struct Key { int n, c, k, oh, ow; };
+  static thread_local Key keys[8]; static thread_local Plan plans[8]; static thread_local int used = 0, next = 0;
+  for (int i = 0; i < used; ++i)
+    if (keys[i].n == n && keys[i].c == c && keys[i].k == k && keys[i].oh == oh && keys[i].ow == ow) { pl = plans[i]; return pl.bn != 0; }
+  pl = Plan{};
+  pl.bn = k >= 128 ? 128 : 64;
+  pl.tps = pl.bn == 64 ? 3 : 1;
+  pl.nbs = pl.bn == 64 ? 3 : 6;
+  pl.LR = patch_rows(n, oh, ow, r, s);
+  pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
+  if (pl.bn == 128 && pl.lds > 160 * 1024) {             // a long patch (small maps: many image seams per tile): shorter weight ring
+    pl.nbs = 4;
+    pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
+  }
+  bool ok = pl.LR <= 512 && pl.lds <= 160 * 1024;
+  if (ok) {
+    const long M = (long)n * oh * ow;
+    pl.tiles = cdiv(M, 256) * cdiv(k, pl.bn);
+    pl.grid = 256;
+    const int ncc = c / 16;
+    pl.n_full = pl.tiles / pl.grid * pl.grid;
+    const int rem = pl.tiles - pl.n_full;
+    pl.parts = 1; pl.cc_part = ncc; pl.n_pieces = 0; pl.ws_bytes = 0;
+    if (rem > 0) {
+      int parts = pl.grid / rem; if (parts > ncc) parts = ncc; if (parts < 1) parts = 1;
+      pl.cc_part = cdiv(ncc, parts); pl.parts = cdiv(ncc, pl.cc_part);
+      if (pl.parts == 1) { pl.n_full = pl.tiles; }                            // whole tiles: nothing to fix up
+      else { pl.n_pieces = rem * pl.parts; pl.ws_bytes = (size_t)pl.n_pieces * 256 * pl.bn * 4; }
+    }
+  } else {
+    pl.bn = 0;
+  }
+  keys[next] = Key{n, c, k, oh, ow}; plans[next] = pl; next = (next + 1) % 8; if (used < 8) ++used;
+  return ok;
+}
+
+extern "C" int embnet_conv2d_patch_supported(int n, int c, int r, int s, int k, int stride, int oh, int ow) {
+  Plan pl; return make_plan(n, c, r, s, k, stride, oh, ow, pl) ? 1 : 0;
+}
+extern "C" size_t embnet_conv2d_patch_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
+  Plan pl; return make_plan(n, c, r, s, k, 1, oh, ow, pl) ? pl.ws_bytes : 0;
+}
+extern "C" int embnet_conv2d_patch_stats_rows(int n, int oh, int ow) { return cdiv((long)n * oh * ow, 256) * 4; }
+
+extern "C" int embnet_planes_from_f32(const float* x, long pixels, int c, void* planes, void* stream) {
+  EMBNET_CHECK_ARG(x && planes && pixels > 0 && c > 0 && (c & 15) == 0, "planes_from_f32: need c %% 16 == 0");
+  EMBNET_CHECK_ARG((size_t)pixels * c * 2 < 0x7FFFFFF0ull / 3, "planes_from_f32: tensor too large");
+  const long n4 = pixels * c / 4;
+  EMBNET_TRACE("embnet::patch::planes_from_f32_kernel", TRACE_BYTES, 10.0 * pixels * c, stream);
+  planes_from_f32_kernel<<<(int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1), 256, 0, (hipStream_t)stream>>>(x, pixels, c, (unsigned short*)planes);
+  return check_launch("planes_from_f32");
+}
+
+extern "C" int embnet_conv_weight_planes_chunk_elems(void) { return 4096; }
+extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream) {
+  EMBNET_CHECK_ARG(table && chunks && n_tensors > 0 && n_chunks > 0, "conv_weight_planes: bad argument");
+  EMBNET_TRACE("embnet::patch::weight_planes_kernel", TRACE_BYTES, 10.0 * 4096 * n_chunks, stream);
+  weight_planes_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const WPlanesTensor*)table, chunks);
+  return check_launch("conv_weight_planes");
+}
+
+template <int BN, int TPS, int NBS>
+static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  conv_patch_kernel<BN, 3, 3, TPS, NBS><<<p.grid, 640, lds, st>>>(p);
+}
+
+extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
+                                       int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu,
+                                       const float* residual, float* stats, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  EMBNET_CHECK_ARG(xp && wp && y, "conv2d_patch: null pointer");
+  Plan pl;
+  EMBNET_CHECK_ARG(make_plan(n, c, r, s, k, 1, oh, ow, pl), "conv2d_patch: unsupported geometry (see embnet_conv2d_patch_supported)");
+  PatchParams p{(const unsigned short*)xp, (const unsigned short*)wp, y, bias, residual, stats, 0, relu};
+  if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, 1, pad_t, pad_l, oh, ow, "conv2d_patch")) return rc;
+  const long M = (long)n * oh * ow;
+  p.x_plane_bytes = (unsigned)((size_t)n * h * wd * c * 2);
+  p.w_plane_bytes = (unsigned)((size_t)r * s * c * k * 2);
+  p.PH = oh + r - 1; p.PW = ow + s - 1;
+  p.dPHW = FastDiv::make(p.PH * p.PW); p.dPW = FastDiv::make(p.PW);
+  p.LR = pl.LR;
+  p.stats_rows = cdiv(M, 256) * 4;
+  p.grid = pl.grid;
+  if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
+  p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    EMBNET_TRACE_FLOP(pl.bn == 128 ? (pl.nbs == 6 ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6>(embnet::patch::PatchParams)"
+                                                  : "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 4>(embnet::patch::PatchParams)")
+                                   : "void embnet::patch::conv_patch_kernel<64, 3, 3, 3, 3>(embnet::patch::PatchParams)",
+                      2.0 * M * k * r * s * c,
+                      6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
+    if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
+    else launch_patch<64, 3, 3>(p, pl.lds, st);
+  }
+  if (p.n_pieces > 0)
+    launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
+                      stats, p.stats_rows, st);
+  return check_launch("conv2d_patch");
+}

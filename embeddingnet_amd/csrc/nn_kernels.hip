@@ -5,6 +5,7 @@
 // :44-75 (BatchNormalization, Dropout), :110-116 (GlobalAveragePooling2D) and the zoo ResNet blocks.
 // Roofline: HBM.  Algorithmic bytes per element are noted at each kernel.
 #include "common.h"
+#include "gemm_engine.h"        // split4: the three bf16 pieces of an fp32 value (planes for conv_patch.hip)
 #include <stdlib.h>
 #include "../../include/embnet.h"
 
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ dbeta,
                                                             const float* __restrict__ dgamma, int relu, int training,
-                                                            const float* __restrict__ dx_add, float* __restrict__ dx) {
+                                                            const float* __restrict__ dx_add, float* __restrict__ dx,
+                                                            unsigned short* __restrict__ dx_planes) {
   const long stride = (long)gridDim.x * 256;
   // (the launcher makes the stride a multiple of c4 whenever c4 divides a power of two, so a thread keeps its channel
   // quad and the six per-channel constants are loaded once; otherwise they are re-read per element)
@@ -225,6 +227,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
     reinterpret_cast<float4*>(dx)[i] = o;
+    if (dx_planes) {                                     // the same values as bf16 pieces, chunk-major: dy operand of the
+      const long pix = i / c4; const int q = (int)(i - pix * c4);      // patch data gradient of the convolution in front
+      const Split4 s = split4(o);
+      const long e = ((long)(q >> 2) * (total4 / c4) + pix) * 16 + 4 * (q & 3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(dx_planes + k * total4 * 4 + e) = s.p[k];
+    }
   }
 }
 
@@ -760,6 +769,33 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) y[i] = a * x[i];
 }
 
+// y = act(x*scale + shift) written as fp32 (y, optional) AND as the three bf16 pieces of every value in the chunk-major
+// layout conv_patch.hip consumes ([plane][C/16][pixels][16]): the BatchNormalization in front of a patch convolution
+// produces the convolution's operand in its final form, once.  C % 16 == 0; one thread per (pixel, channel quad).
+__global__ __launch_bounds__(256) void affine_act_planes_kernel(const float* __restrict__ x, long pixels, int c4,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int act, float* __restrict__ y, unsigned short* __restrict__ planes) {
+  const long total4 = pixels * c4, plane = total4 * 4, stride = (long)gridDim.x * 256;
+  const bool fixed = stride % c4 == 0;
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+  if (fixed) {
+    const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+    sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const long pix = i / c4; const int q = (int)(i - pix * c4);
+    if (!fixed) { sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q]; }
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
+    if (y) reinterpret_cast<float4*>(y)[i] = o;
+    const Split4 s = split4(o);
+    const long e = ((long)(q >> 2) * pixels + pix) * 16 + 4 * (q & 3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
+  }
+}
+
 // inverted dropout with a counter-based mask: y = x * keep / (1-rate); the same (seed, index) gives
 // the same mask in backward.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long total, float rate,
@@ -973,11 +1009,22 @@ extern "C" int embnet_affine_act(const float* x, long m, int c, const float* sca
   return check_launch("affine_act");
 }
 
+extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                        void* planes, void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && planes, "affine_act_planes: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 15) == 0, "affine_act_planes: m=%ld c=%d (c %% 16 == 0)", m, c);
+  EMBNET_CHECK_ARG((size_t)m * c * 2 < 0x7FFFFFF0ull / 3, "affine_act_planes: tensor too large");
+  EMBNET_TRACE("embnet::affine_act_planes_kernel", TRACE_BYTES, (y ? 14.0 : 10.0) * m * c, stream);
+  affine_act_planes_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
+  return check_launch("affine_act_planes");
+}
+
 extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
                              const float* save_rstd, const float* scale, const float* shift, int relu, int training,
-                             const float* dx_add, float* dx, float* dgamma, float* dbeta, void* workspace,
+                             const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
                              size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(dy && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd: dx_planes needs c %% 16 == 0");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_bwd: m=%ld c=%d", m, c);
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
@@ -1002,7 +1049,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   }
   if ((c & 3) == 0 && !bn_scalar())
     { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
-                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
+                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, (unsigned short*)dx_planes); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }

@@ -13,6 +13,7 @@ momentum .99, eps 1e-3, biased batch variance in training; MaxPool2D() 2x2/2;
 Dropout inverted scaling; l2(lambda) = lambda * sum(w^2) on kernels.
 """
 import math
+import os as _os
 
 import torch
 from torch import nn
@@ -23,7 +24,6 @@ from ._lib import check, ptr, stream
 _WS = {}
 
 
-import os as _os
 # Knob (off): run each conv's wgrad on a side stream beside its dgrad.  Measured on ResNet18/MI355X: +-0 % when
 # joined right after the dgrad (both are MFMA-bound), +1.8 % when the join is deferred to the end of backward so
 # wgrad overlaps the HBM-bound BN-backward kernels — not worth per-kernel timings that no longer mean anything
@@ -74,6 +74,85 @@ def _done(out, notify):
     return None
 
 
+# ---- pre-split operands of the patch convolution (csrc/conv_patch.hip) ------------------------------------------------
+# A BatchNormalization whose output feeds a 3x3 stride-1 Conv2D writes that output ALSO as "planes" (the three bf16 pieces
+# of every value, chunk-major) and hangs them on the tensor (`y._planes`); the Conv2D then runs the patch kernel.  In
+# backward the BatchNormalization behind such a conv writes its input gradient also as planes and leaves them in DY_PLANES
+# under the gradient's address, where the conv's backward picks them up for its data gradient.  Kernel planes are rebuilt
+# when the weights changed: WEIGHT_EPOCH is bumped by KerasOptimizer.step(); other writers show in the tensor version.
+PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
+DY_PLANES = {}
+_ACT_PLANES = {}
+WEIGHT_EPOCH = [0]
+_WPLANES = {}          # kernel storage address -> dict(fwd=, bwd=, epoch=, version=, table=, chunks=)
+
+
+def _wplanes_entry(w):
+    e = _WPLANES.get(w.data_ptr())
+    if e is None or e["shape"] != tuple(w.shape):
+        import numpy as np
+        r, s, c, k = w.shape
+        dev = w.device
+        e = dict(shape=tuple(w.shape), epoch=-1, version=-1,
+                 fwd=torch.empty(3 * w.numel(), dtype=torch.int16, device=dev),
+                 bwd=torch.empty(3 * w.numel(), dtype=torch.int16, device=dev) if k % 16 == 0 else None)
+        rows = [(w.data_ptr(), e["fwd"].data_ptr(), r | (s << 32), c | (k << 32), 0)]
+        if e["bwd"] is not None:
+            rows.append((w.data_ptr(), e["bwd"].data_ptr(), r | (s << 32), c | (k << 32), 1))
+        ce = _lib.lib().embnet_conv_weight_planes_chunk_elems()
+        e["rows"] = rows
+        e["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+        e["chunks"] = torch.tensor([(i, j) for i in range(len(rows)) for j in range(-(-w.numel() // ce))], dtype=torch.int32, device=dev)
+        _WPLANES[w.data_ptr()] = e
+    return e
+
+
+def weight_planes(w, flip):
+    """bf16 planes of a Conv2D kernel for the patch kernel (forward: flip 0, stride-1 data gradient: flip 1), rebuilt
+    (one launch for both) when the kernel changed since they were made."""
+    e = _wplanes_entry(w)
+    if e["epoch"] != WEIGHT_EPOCH[0] or e["version"] != w._version:
+        check(_lib.lib().embnet_conv_weight_planes(e["table"].data_ptr(), len(e["rows"]), e["chunks"].data_ptr(), e["chunks"].shape[0], stream()))
+        e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+    return e["bwd"] if flip else e["fwd"]
+
+
+def refresh_weight_planes(module):
+    """Rebuild the planes of every kernel that has them, in ONE launch (called by the trainer right after the optimizer
+    step, so that the next forward finds them current; inside a captured step this launch is part of the graph)."""
+    import numpy as np
+    ws = [m.kernel for m in module.modules() if isinstance(m, Conv2D) and m.kernel.data_ptr() in _WPLANES]
+    if not ws:
+        return
+    key = tuple(w.data_ptr() for w in ws)
+    plan = getattr(module, "_wplanes_plan", None)
+    if plan is None or plan["key"] != key:
+        rows = [r for w in ws for r in _WPLANES[w.data_ptr()]["rows"]]
+        ce = _lib.lib().embnet_conv_weight_planes_chunk_elems()
+        sizes = [w.numel() for w in ws for _ in _WPLANES[w.data_ptr()]["rows"]]
+        dev = ws[0].device
+        plan = dict(key=key, n=len(rows), table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
+                    chunks=torch.tensor([(i, j) for i, n in enumerate(sizes) for j in range(-(-n // ce))], dtype=torch.int32, device=dev))
+        module._wplanes_plan = plan
+    check(_lib.lib().embnet_conv_weight_planes(plan["table"].data_ptr(), plan["n"], plan["chunks"].data_ptr(), plan["chunks"].shape[0], stream()))
+    for w in ws:
+        e = _WPLANES[w.data_ptr()]
+        e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+def patch_ok(n, h, wd, c, r, s, k, stride, oh, ow):
+    return bool(_lib.lib().embnet_conv2d_patch_supported(n, c, r, s, k, stride, oh, ow))
+
+
+def _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dx_add):
+    """dx[n,h,wd,c] (+ dx_add) = stride-1 data gradient through the patch kernel: the correlation of the dy planes
+    [n,oh,ow,k] with the flipped kernel planes."""
+    lib = _lib.lib()
+    ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, k, r, s, c, h, wd), dx.device)
+    check(lib.embnet_conv2d_patch_f32(ptr(dy_planes), ptr(weight_planes(w, 1)), None, ptr(dx), n, oh, ow, k, r, s, c,
+                                      r - 1 - pt, s - 1 - pl, h, wd, 0, ptr(dx_add), None, ptr(ws), ws.numel() * 4, stream()))
+
+
 def _c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -89,7 +168,9 @@ def same_pad(n, k, s):
 # ----------------------------------------------------------------------------- conv
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False):
+    def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False,
+                planes=None):
+        """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward."""
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
@@ -108,10 +189,17 @@ class _Conv2dFn(torch.autograd.Function):
                 raise _lib.EmbnetError(f"Add: shapes differ {(n, oh, ow, k)} vs {tuple(residual.shape)}")
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         lib = _lib.lib()
-        ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-        check(lib.embnet_conv2d_fwd_f32(
-            ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
-            in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
+        if planes is not None:
+            ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+            check(lib.embnet_conv2d_patch_f32(ptr(planes), ptr(weight_planes(w, 0)), ptr(bias), ptr(y), n, h, wd, c, r, s, k,
+                                              pt, pl, oh, ow, int(relu), ptr(residual), ptr(out_stats), ptr(ws),
+                                              ws.numel() * 4, stream()))
+        else:
+            ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+            check(lib.embnet_conv2d_fwd_f32(
+                ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
+                in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
+        ctx.patch = planes is not None
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
         ctx.bias_ref = bias                 # only its address / shape are used (gradient sink lookup)
@@ -165,13 +253,18 @@ class _Conv2dFn(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 run_wgrad()
+        # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
+        dy_planes = DY_PLANES.pop(dy.data_ptr(), None) if (ctx.patch and not ctx.relu) else None
         if need_dx:
             dx = torch.empty_like(x)
-            # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
-            dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-            check(lib.embnet_conv2d_dgrad_f32(
-                ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
-                dws.numel() * 4, stream()))
+            if dy_planes is not None and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
+                _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dskip)
+            else:
+                # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
+                dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
+                check(lib.embnet_conv2d_dgrad_f32(
+                    ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
+                    dws.numel() * 4, stream()))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
@@ -184,7 +277,7 @@ class _Conv2dFn(torch.autograd.Function):
             db = _done(db, db_note)
         if dskip is not None and dx is None and ctx.needs_input_grad[0]:
             dx = dskip
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -194,7 +287,8 @@ class _ConvPairFn(torch.autograd.Function):
     for autograd to add."""
 
     @staticmethod
-    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1):
+    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1, planes=None):
+        """planes: pre-split planes of x -> the FIRST conv (the 3x3) runs the patch kernel."""
         x, w1, w2 = _c(x), _c(w1), _c(w2)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -207,11 +301,17 @@ class _ConvPairFn(torch.autograd.Function):
                 raise _lib.EmbnetError(f"conv2d: input has {c} channels, kernel expects {c2}")
             stride, pt, pl, oh, ow = geom
             y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-            ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            check(lib.embnet_conv2d_fwd_f32(
-                ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
-                int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
+            if planes is not None and w is w1:
+                ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+                check(lib.embnet_conv2d_patch_f32(ptr(planes), ptr(weight_planes(w, 0)), None, ptr(y), n, h, wd, c, r, s, k,
+                                                  pt, pl, oh, ow, 0, None, ptr(st), ptr(ws), ws.numel() * 4, stream()))
+            else:
+                ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+                check(lib.embnet_conv2d_fwd_f32(
+                    ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
+                    int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
             ys.append(y)
+        ctx.patch = planes is not None
         ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
         ctx.save_for_backward(x, w1, w2, in_stats)
         return ys[0], ys[1]
@@ -233,11 +333,15 @@ class _ConvPairFn(torch.autograd.Function):
             dy = _c(dy)
             r, s, _, k = w.shape
             stride, pt, pl, oh, ow = geom
+            dy_planes = DY_PLANES.pop(dy.data_ptr(), None) if (ctx.patch and w is w1) else None
             if dx is not None:
-                sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-                check(lib.embnet_conv2d_dgrad_f32(
-                    ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
-                    ptr(sc), sc.numel() * 4, stream()))
+                if dy_planes is not None and first and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
+                    _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, None)
+                else:
+                    sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
+                    check(lib.embnet_conv2d_dgrad_f32(
+                        ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
+                        ptr(sc), sc.numel() * 4, stream()))
                 first = False
             dw = None
             if need_dw:
@@ -250,7 +354,7 @@ class _ConvPairFn(torch.autograd.Function):
             dws.append(dw)
         if dx is not None and first:
             dx.zero_()
-        return dx, dws[0], None, dws[1], None, None, None, None
+        return dx, dws[0], None, dws[1], None, None, None, None, None
 
 
 def conv_pair(x, conv1, conv2, emit_stats=False):
@@ -265,15 +369,23 @@ def conv_pair(x, conv1, conv2, emit_stats=False):
         else:
             x, in_stats, in_act = x.raw, x.stats, x.act
     g1, g2 = conv1.geometry(x.shape[1], x.shape[2]), conv2.geometry(x.shape[1], x.shape[2])
+    planes = getattr(x, "_planes", None) if in_stats is None else None
+    if planes is not None and not conv1.patch_capable(x.shape):
+        planes = None
     out_stats = None
     if emit_stats:
         r, s, c, k = conv1.kernel.shape
-        rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, g1[3], g1[4])
+        if planes is not None:
+            rows = _lib.lib().embnet_conv2d_patch_stats_rows(x.shape[0], g1[3], g1[4])
+        else:
+            rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, g1[3], g1[4])
         if rows > 0:
             out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
-    y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats)
+    y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats, planes)
     if out_stats is not None:
         y1._bn_partials = out_stats
+    if planes is not None:
+        y1._wants_dy_planes = True
     return y1, y2
 
 
@@ -343,17 +455,35 @@ class Conv2D(nn.Module):
             else:
                 x, in_stats, in_act = x.raw, x.stats, x.act
         geom = self.geometry(x.shape[1], x.shape[2])
+        planes = getattr(x, "_planes", None) if in_stats is None else None
+        if planes is not None and not self.patch_capable(x.shape):
+            planes = None
         out_stats = None
         if emit_stats:
             r, s, c, k = self.kernel.shape
-            rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
+            if planes is not None:
+                rows = _lib.lib().embnet_conv2d_patch_stats_rows(x.shape[0], geom[3], geom[4])
+            else:
+                rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
             if rows > 0:
                 out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
-        out = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip)
+        out = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
+                              planes)
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
+        if planes is not None and not self.relu:
+            y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
         return (y, out[1]) if with_skip else y
+
+    def patch_capable(self, x_shape):
+        """True when this conv on an input of that shape runs the patch kernel (csrc/conv_patch.hip): 3x3, stride 1,
+        C % 16 == 0, K % 4 == 0 and an LDS budget the library checks."""
+        if self.k != 3 or self.stride != 1 or len(x_shape) != 4 or not PATCH_CONV[0]:
+            return False
+        n, h, w, c = x_shape
+        _, _, _, oh, ow = self.geometry(h, w)
+        return patch_ok(n, h, w, c, 3, 3, self.kernel.shape[3], 1, oh, ow)
 
 
 # ----------------------------------------------------------------------------- dense
@@ -458,18 +588,28 @@ def _bn_grad_targets(ctx, c, device, gamma_idx=1, beta_idx=2):
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
-                with_skip=False):
+                with_skip=False, emit_planes=False, emit_dx_planes=False):
+        """emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
+        address; BatchNormalization.forward hangs them on the tensor).  emit_dx_planes: backward writes dx also as planes
+        into DY_PLANES (the producer of x is a patch conv, whose data gradient reads them)."""
         x = _c(x)
         lib = _lib.lib()
         c = x.shape[-1]
         m = x.numel() // c
         y = torch.empty_like(x)
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        yk = None if emit_planes else y                                      # planes: statistics first, then one pass writing both
         if training:
-            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, y, stats, moving_mean, moving_var, partials)
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, yk, stats, moving_mean, moving_var, partials)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
-                                          int(relu), ptr(y), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
+                                          int(relu), ptr(yk), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
+        if emit_planes:
+            planes = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
+            check(lib.embnet_affine_act_planes(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
+                                               ptr(y), ptr(planes), stream()))
+            _ACT_PLANES[y.data_ptr()] = planes
+        ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
@@ -492,11 +632,17 @@ class _BatchNormFn(torch.autograd.Function):
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats.data_ptr() if ctx.training else None
         rstd = (stats.data_ptr() + 4 * stats.shape[1]) if ctx.training else None
+        planes = None
+        if getattr(ctx, "emit_dx_planes", False):
+            planes = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
+            if len(DY_PLANES) > 64:                  # entries nobody collected (a consumer fell back to the fp32 kernel)
+                DY_PLANES.clear()
+            DY_PLANES[dx.data_ptr()] = planes
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(ws),
+                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
                                 ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNGapFn(torch.autograd.Function):
@@ -542,7 +688,7 @@ class _BNGapFn(torch.autograd.Function):
         mean = stats.data_ptr() if ctx.training else None
         rstd = (stats.data_ptr() + 4 * c) if ctx.training else None
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
-                                int(ctx.relu), int(ctx.training), None, ptr(dx), ptr(tg), ptr(tb), ptr(ws),
+                                int(ctx.relu), int(ctx.training), None, ptr(dx), ptr(tg), ptr(tb), None, ptr(ws),
                                 ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
@@ -633,8 +779,10 @@ class BatchNormalization(nn.Module):
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
 
-    def forward(self, x, defer=False, with_skip=False, emit_gap=False):
-        """emit_gap=True (C % 4 == 0): returns (bn(x), GlobalAveragePooling2D(bn(x))) from one pass over the tensor.
+    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None):
+        """planes_for=<Conv2D>: the conv that consumes the output; when it can run the patch kernel on it
+        (Conv2D.patch_capable) the output is also written as bf16 planes (`y._planes`) in the same pass.
+        emit_gap=True (C % 4 == 0): returns (bn(x), GlobalAveragePooling2D(bn(x))) from one pass over the tensor.
         defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
         affine + activation while gathering their input, and the normalised tensor is never written.
         with_skip=True: returns (bn(x), x) — use the second value for the identity shortcut that also consumes x,
@@ -645,9 +793,18 @@ class BatchNormalization(nn.Module):
                                       self.momentum, self.relu, self.training, _partials_of(x, self.training))
             y = self.forward(x)
             return y, _GapFn.apply(y)
+        want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
+        if planes_for is not None and not defer and planes_for.patch_capable(x.shape):
+            out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                     self.momentum, self.relu, self.training, _partials_of(x, self.training), with_skip,
+                                     True, want_dx_planes)
+            y = out[0] if with_skip else out
+            y._planes = _ACT_PLANES.pop(y.data_ptr())
+            return out
         if with_skip and not defer:
             return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), True)
+                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), True,
+                                      False, want_dx_planes)
         if with_skip:
             return self.forward(x, defer=True), x
         if defer and x.shape[-1] % 4 == 0:
@@ -655,7 +812,8 @@ class BatchNormalization(nn.Module):
                                           self.momentum, self.relu, self.training, _partials_of(x, self.training))
             return Deferred(raw, stats, self.relu)
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                  self.momentum, self.relu, self.training, _partials_of(x, self.training))
+                                  self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
+                                  False, want_dx_planes)
 
 
 class _InputBNConvFn(torch.autograd.Function):

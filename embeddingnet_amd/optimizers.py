@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import check
+from . import layers as L
 
 RULE = {"sgd": 0, "rms_prop": 1, "adam": 2, "radam": 3}
 
@@ -141,6 +142,7 @@ class KerasOptimizer(torch.optim.Optimizer):
         if cur != self._ptrs:
             self._build_table()
         self.iterations += 1
+        L.WEIGHT_EPOCH[0] += 1                             # cached bf16 planes of conv kernels are stale from here on
         lr = float(self.param_groups[0]["lr"])
         rule, b1, b2, c1, c2 = self._coefficients(lr, self.iterations)
         check(_lib.lib().embnet_optimizer_step(rule, self._table.data_ptr(), len(self._tensors), self._chunks.data_ptr(),

@@ -144,6 +144,7 @@ class TripletTrainer:
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, pool=g.pool()):
                         self.opt.step()
+                        L.refresh_weight_planes(self.model)
                     self._graph_opt = g2
             finally:
                 L.GRAPH_TICK = None
@@ -279,4 +280,5 @@ class TripletTrainer:
             self.reducer.finish()
         if with_update:
             self.opt.step()
+            L.refresh_weight_planes(self.model)     # bf16 planes of the patch convs' kernels, one launch (layers.py)
         return mean.detach()

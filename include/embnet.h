@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 11
+#define EMBNET_ABI_VERSION 12
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -203,6 +203,37 @@ int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, v
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
 
+/* ---- stride-1 3x3 convolution on pre-split operands ("patch" kernel, csrc/conv_patch.hip) --------------------------------
+ * The zoo ResNets' 3x3 stride-1 layers (backbones.py:99-104), forward and data gradient, 1.1-1.25x faster than the kernels
+ * above: every fp32 operand value is split into its three bf16 pieces ONCE, by the kernel that produces the tensor, and the
+ * convolution keeps a patch of the padded input in LDS so that each input value is fetched once per output tile instead of
+ * once per tap.  Same six-term products (fp32 accuracy as documented above); summation order (chunk, r, s, channel).
+ *   planes of an activation / gradient x[pixels, c] (c % 16 == 0):  bf16 [3][c/16][pixels][16]  (piece, 16-channel chunk,
+ *     pixel, channel in chunk) — written by embnet_affine_act_planes, by embnet_bn_bwd(dx_planes), or from an fp32 tensor by
+ *     embnet_planes_from_f32;
+ *   planes of a kernel w[r,s,c,k]:  bf16 [3][r][red/16][s][rows][16] — flip 0 (forward: rows = k, reduction channels = c) or
+ *     flip 1 (stride-1 data gradient: rows = c, reduction = k, taps flipped) — written for any number of kernels by ONE launch
+ *     of embnet_conv_weight_planes over a device table of 40-byte descriptors
+ *       { const float* w; void* out; int32 r, s, c, k, flip, pad; }   and a chunk list int32 [n_chunks][2] =
+ *     (tensor index, chunk of embnet_conv_weight_planes_chunk_elems() elements), typically once per optimizer step.
+ * embnet_conv2d_patch_f32: y[n,oh,ow,k] = conv(x planes, w planes) with the epilogue options of embnet_conv2d_fwd_f32 (bias,
+ * relu, residual, stats with P = embnet_conv2d_patch_stats_rows) — and, with dy planes, flip-1 kernel planes, c and k
+ * swapped and pad = kernel - 1 - pad, the data gradient (residual = the gradient of the tensor's other consumer).
+ * embnet_conv2d_patch_supported: 1 for 3x3, stride 1, c % 16 == 0, k % 4 == 0 and a patch that fits LDS. */
+int embnet_conv2d_patch_supported(int n, int c, int r, int s, int k, int stride, int oh, int ow);
+size_t embnet_conv2d_patch_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
+int embnet_conv2d_patch_stats_rows(int n, int oh, int ow);
+int embnet_conv2d_patch_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
+                            int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu, const float* residual,
+                            float* stats, void* workspace, size_t workspace_bytes, void* stream);
+int embnet_planes_from_f32(const float* x, long pixels, int c, void* planes, void* stream);
+int embnet_conv_weight_planes_chunk_elems(void);
+int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);
+/* y (NULL or [m,c]) = act(x*scale + shift) as embnet_affine_act, AND the same values as planes: the BatchNormalization in
+ * front of a patch convolution writes the convolution's operand in its final form. */
+int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                             void* planes, void* stream);
+
 /* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out].
  * workspace (optional, may be NULL/0): >= embnet_dense_fwd_workspace_bytes lets a forward with few output tiles and a long
  * reduction (simple2's Flatten -> Dense(512): 12 800 x 512 at batch 32) cut K over workgroups (partial slabs + fixed-order
@@ -232,7 +263,9 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
  * shortcut of a residual unit), so autograd needs no separate accumulation pass. */
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
-                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                  float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
+/* dx_planes (NULL, or 3*m*c bf16, c % 16 == 0): dx ALSO as the pre-split planes embnet_conv2d_patch_f32 takes (below) —
+ * the gradient of the convolution output in front of this BatchNormalization, i.e. that convolution's data-gradient operand. */
 
 /* y = act(x*scale[c] + shift[c]) on x[m,c]: the apply half of BatchNormalization on its own (scale/shift from
  * bn_train_fwd / bn_infer_fwd with y = NULL), for a deferred BN output whose consumer cannot fuse it. */

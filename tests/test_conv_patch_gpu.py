@@ -1,0 +1,225 @@
+"""Parity of the patch convolution (csrc/conv_patch.hip: pre-split bf16 planes, LDS patch + weight ring) on the GPU,
+through the C ABI:
+
+  * the planes a BatchNormalization writes decode EXACTLY to its fp32 output (the three-way truncation split loses nothing);
+  * forward and stride-1 data gradient against a float64 convolution of the same operands, on every ResNet18/34 3x3
+    geometry class (full tiles, ragged tails, K split across work-groups) and with each epilogue (bias, ReLU, residual,
+    per-channel sums);
+  * the layer path (BatchNormalization(planes_for=conv) -> Conv2D) against the same modules with the patch path switched
+    off (gather kernels), values and all gradients;
+  * a ResNet18 training step with the patch convs against the step with the gather convs.
+
+Reference behaviour being matched: keras Conv2D / BatchNormalization inside image-classifiers' ResNet
+(reference embedding_net/backbones.py:99-104).
+"""
+import numpy as np
+import pytest
+import torch
+
+from embeddingnet_amd import _lib
+from embeddingnet_amd import backbones as B
+from embeddingnet_amd import layers as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    return torch.device("cuda", 0)
+
+
+def planes_of(x):
+    """bf16 planes [3][C/16][pixels][16] of an NHWC fp32 tensor (embnet_planes_from_f32)."""
+    c = x.shape[-1]
+    p = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
+    _lib.check(_lib.lib().embnet_planes_from_f32(x.data_ptr(), x.numel() // c, c, p.data_ptr(), _lib.stream()))
+    return p
+
+
+def decode(planes, shape):
+    """planes -> float64 NHWC (sum of the three bf16 pieces)."""
+    c = shape[-1]
+    m = int(np.prod(shape)) // c
+    raw = planes.cpu().numpy().view(np.uint16).astype(np.uint32).reshape(3, c // 16, m, 16)
+    f = (raw << 16).view(np.float32).astype(np.float64).sum(axis=0)         # [c/16][m][16]
+    return f.transpose(1, 0, 2).reshape(shape)
+
+
+def conv64(x, w, pad):
+    """float64 stride-1 cross-correlation, NHWC x RSCK, zero padding `pad` on every side."""
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(3, 2, 0, 1), padding=pad)
+    return y.permute(0, 2, 3, 1).numpy()
+
+
+def dgrad64(dy, w, pad):
+    r = w.shape[0]
+    wf = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))       # flipped, channels swapped
+    return conv64(dy, wf, r - 1 - pad)
+
+
+def test_planes_decode_exactly(dev):
+    torch.manual_seed(0)
+    x = torch.randn(3, 9, 7, 48, device=dev) * torch.logspace(-6, 6, 48, device=dev)
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-38, 3.0e38], device=dev)
+    p = planes_of(x)
+    torch.cuda.synchronize()
+    assert np.array_equal(decode(p, x.shape), x.cpu().numpy().astype(np.float64))
+
+
+GEOMS = [  # n, h, w, c, k: the ResNet 3x3 stride-1 classes + ragged ones
+    (8, 56, 56, 64, 64),       # 56^2 x 64 (BN=64 tiles)
+    (4, 56, 56, 64, 128),
+    (8, 28, 28, 128, 128),
+    (16, 14, 14, 256, 256),
+    (32, 7, 7, 512, 512),      # few tiles: reduction split across work-groups + fix-up
+    (3, 13, 9, 32, 96),        # ragged rows, K not a multiple of the tile
+    (1, 5, 5, 16, 32),
+    (2, 20, 31, 80, 160),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "x".join(map(str, g)))
+def test_patch_forward_and_data_gradient_vs_float64(dev, geom):
+    n, h, w, c, k = geom
+    lib = _lib.lib()
+    if not lib.embnet_conv2d_patch_supported(n, c, 3, 3, k, 1, h, w):
+        pytest.skip("geometry not served by the patch kernel")
+    rng = np.random.default_rng(sum(geom))
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, c, k)) / np.sqrt(9 * c)).astype(np.float32)
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(wt).to(dev)
+    y = torch.empty((n, h, w, k), device=dev)
+    ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, c, 3, 3, k, h, w), 4) // 4, device=dev)
+    _lib.check(lib.embnet_conv2d_patch_f32(planes_of(xd).data_ptr(), L.weight_planes(wd, 0).data_ptr(), None, y.data_ptr(), n, h, w, c, 3, 3, k,
+                                           1, 1, h, w, 0, None, None, ws.data_ptr(), ws.numel() * 4, _lib.stream()))
+    want = conv64(x.astype(np.float64), wt.astype(np.float64), 1)
+    err = np.abs(y.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 3e-6, err                       # fp32 accumulation over 9*C terms; the split itself is < 2^-20
+
+    if lib.embnet_conv2d_patch_supported(n, k, 3, 3, c, 1, h, w):
+        dy = rng.standard_normal((n, h, w, k)).astype(np.float32)
+        dyd = torch.from_numpy(dy).to(dev)
+        add = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(dev)
+        dx = torch.empty((n, h, w, c), device=dev)
+        L._patch_dgrad(planes_of(dyd), wd, dx, n, h, w, c, 3, 3, k, 1, 1, h, w, add)
+        want = dgrad64(dy.astype(np.float64), wt.astype(np.float64), 1) + add.cpu().numpy()
+        err = np.abs(dx.cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < 3e-6, err
+
+
+@pytest.mark.parametrize("n,h,w,c,k", [(8, 28, 28, 128, 128), (5, 11, 13, 64, 96), (32, 7, 7, 512, 512)])
+def test_patch_epilogues(dev, n, h, w, c, k):
+    """bias + ReLU + residual, and the per-channel sums / sums of squares a following BatchNormalization consumes."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, c, k)) / np.sqrt(9 * c)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    res = rng.standard_normal((n, h, w, k)).astype(np.float32)
+    xd, wd, bd, rd = (torch.from_numpy(a).to(dev) for a in (x, wt, bias, res))
+    rows = lib.embnet_conv2d_patch_stats_rows(n, h, w)
+    ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, c, 3, 3, k, h, w), 4) // 4, device=dev)
+    base = conv64(x.astype(np.float64), wt.astype(np.float64), 1)
+    for relu, use_bias, use_res in [(1, True, True), (0, False, True), (1, True, False)]:
+        y = torch.empty((n, h, w, k), device=dev)
+        stats = torch.full((2, k, rows), float("nan"), device=dev)
+        _lib.check(lib.embnet_conv2d_patch_f32(planes_of(xd).data_ptr(), L.weight_planes(wd, 0).data_ptr(), bd.data_ptr() if use_bias else None,
+                                               y.data_ptr(), n, h, w, c, 3, 3, k, 1, 1, h, w, relu, rd.data_ptr() if use_res else None,
+                                               stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, _lib.stream()))
+        want = base + (bias if use_bias else 0) + (res if use_res else 0)
+        if relu:
+            want = np.maximum(want, 0)
+        got = y.cpu().numpy()
+        assert np.abs(got - want).max() / np.abs(want).max() < 3e-6
+        st = stats.cpu().numpy().astype(np.float64).sum(axis=2)             # [2][K]
+        flat = got.reshape(-1, k).astype(np.float64)
+        assert np.allclose(st[0], flat.sum(0), rtol=1e-5, atol=1e-3 * np.sqrt(flat.shape[0]))
+        assert np.allclose(st[1], (flat ** 2).sum(0), rtol=1e-5)
+
+
+class _Pair(torch.nn.Module):
+    """BatchNormalization(+ReLU) -> 3x3 conv -> BatchNormalization -> 3x3 conv (+ identity shortcut): the pattern of a
+    basic ResNet unit, exercising planes emission in forward AND of the BN input gradient in backward."""
+
+    def __init__(self, c, k, gen):
+        super().__init__()
+        self.bn1 = L.BatchNormalization(c, epsilon=2e-5, relu=True)
+        self.conv1 = L.Conv2D(c, k, 3, padding=1, use_bias=False, kernel_initializer="he_uniform", gen=gen)
+        self.bn2 = L.BatchNormalization(k, epsilon=2e-5, relu=True)
+        self.conv2 = L.Conv2D(k, c, 3, padding=1, use_bias=False, kernel_initializer="he_uniform", gen=gen)
+
+    def forward(self, x):
+        a, sc = self.bn1(x, with_skip=True, planes_for=self.conv1)
+        y = self.bn2(self.conv1(a, emit_stats=True), planes_for=self.conv2)
+        return self.conv2(y, residual=sc, emit_stats=True)
+
+
+@pytest.mark.parametrize("n,h,c,k", [(8, 28, 128, 128), (6, 14, 64, 96)])
+def test_unit_with_planes_equals_unit_on_gather_kernels(dev, n, h, c, k):
+    gen = torch.Generator().manual_seed(3)
+    net = _Pair(c, k, gen).to(dev).train()
+    x0 = torch.randn(n, h, h, c, generator=gen).to(dev)
+    dy = torch.randn(n, h, h, c, generator=gen).to(dev)
+    out = {}
+    for on in (True, False):
+        L.PATCH_CONV[0] = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            assert bool(getattr(y, "_wants_dy_planes", False)) == on
+            y.backward(dy)
+            torch.cuda.synchronize()
+            out[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            L.PATCH_CONV[0] = True
+    assert not L.DY_PLANES                         # every planes tensor left for a consumer was collected
+    for a, b in zip(out[True], out[False]):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert rel < 2e-5, rel                     # same operands and split; fp32 accumulation order differs
+
+
+def test_resnet18_step_patch_on_equals_off(dev):
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    res = {}
+    for on in (True, False):
+        L.PATCH_CONV[0] = on
+        try:
+            torch.manual_seed(0)
+            base, _ = B.get_backbone(input_shape=(64, 64, 3), encodings_len=64, backbone_name="resnet18", embeddings_normalization=True,
+                                     backbone_weights=None, seed=5)
+            base.to(dev)
+            opt = KerasOptimizer(base.parameters(), "adam", 1e-3)
+            tr = TripletTrainer(base, opt, k_classes=4, k_samples=4, margin=0.5, graph=False)
+            imgs = torch.rand(16, 64, 64, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+            losses = [float(tr.step(imgs)) for _ in range(3)]
+            res[on] = (losses, [p.detach().clone() for p in base.parameters()])
+        finally:
+            L.PATCH_CONV[0] = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1.0), (res[True][0], res[False][0])
+    # after three Adam steps (lr 1e-3, step size ~lr whatever the gradient's scale) sign flips of tiny gradients move single
+    # weights by up to 2*lr per step; the bulk must agree
+    num = sum(float((a - b).pow(2).sum()) for a, b in zip(res[True][1], res[False][1]))
+    den = sum(float(b.pow(2).sum()) for b in res[False][1])
+    assert (num / den) ** 0.5 < 2e-3
+
+
+def test_weight_planes_follow_the_weights(dev):
+    """Planes are rebuilt after an in-place weight change (tensor version) and after KerasOptimizer.step (epoch)."""
+    w = torch.randn(3, 3, 32, 64, device=dev)
+    p0 = L.weight_planes(w, 0).clone()
+    assert torch.equal(L.weight_planes(w, 0), p0)
+    w.mul_(2.0)
+    p1 = L.weight_planes(w, 0)
+    torch.cuda.synchronize()
+    assert not torch.equal(p1, p0)
+    # forward layout [3][R][C/16][S][K][16]: decode and compare with the weights
+    raw = p1.cpu().numpy().view(np.uint16).astype(np.uint32).reshape(3, 3, 2, 3, 64, 16)
+    f = (raw << 16).view(np.float32).astype(np.float64).sum(axis=0)          # [r][cc][s][k][j]
+    back = f.transpose(0, 2, 1, 4, 3).reshape(3, 3, 32, 64)                  # [r][s][cc*16+j][k]
+    assert np.array_equal(back, w.cpu().numpy().astype(np.float64))
