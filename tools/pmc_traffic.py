@@ -33,8 +33,7 @@ def wide_loads(kernel):
     if re.search(r"embnet::(conv_|pairwise|cross_dist|dense_)", kernel):
         return ", false" not in kernel                    # the non-VEC instantiations load dwords
     return bool(re.search(r"embnet::\w*4(_sq)?_kernel", kernel)) or "slab_reduce" in kernel or "opt_step" in kernel \
-        or "tail_fixup" in kernel or "affine_act_kernel" in kernel or "embnet::patch::" in kernel or "_planes_kernel" in kernel \
-        or "sumsq_multi" in kernel or "relu_bwd_colsum" in kernel
+        or "tail_fixup" in kernel or "affine_act_kernel" in kernel or "embnet::patch::" in kernel or "_planes_kernel" in kernel
 
 
 def main():
