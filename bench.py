@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="triplet step: do not capture the step into a HIP graph (N = 1)")
+    ap.add_argument("--force-graph", action="store_true", help="triplet step: capture the step whatever the probe would decide (A/B)")
     ap.add_argument("--cpu-classes", type=int, default=4)
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -253,7 +254,7 @@ def main():
         # the small configs are otherwise host-bound); steps whose kernels are being timed run eagerly
         trainer = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin,
                                  negatives_selection_mode=args.mining, seed=rank, reducer=reducer,
-                                 graph=(False if args.no_graph else "auto"))     # N > 1: two graphs around the all-reduce, every
+                                 graph=(False if args.no_graph else True if args.force_graph else "auto"))     # N > 1: two graphs around the all-reduce, every
         # rank takes the same decision (TripletTrainer._agree)
         step = lambda: trainer.step(images)
 

@@ -143,6 +143,36 @@ def test_patch_epilogues(dev, n, h, w, c, k):
         assert np.allclose(st[1], (flat ** 2).sum(0), rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,h,c,k", [(128, 56, 64, 64), (128, 28, 128, 128), (128, 14, 256, 256), (128, 7, 512, 512), (96, 28, 128, 256)])
+def test_patch_at_bench_sizes_vs_gather_kernel_and_repeatable(dev, n, h, c, k):
+    """BASELINE config C2's layers (local batch 128): whole rounds of tiles plus a remainder shared out by chunk units, the
+    tile finished by the workgroup holding its first piece.  Against the gather kernel (itself checked against float64 at
+    small sizes), with the following BatchNormalization's sums, and bit-identical from launch to launch (the pieces are
+    added in a fixed order whatever order they arrive in)."""
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, h, h, c, generator=gen).to(dev)
+    conv = L.Conv2D(c, k, 3, padding=1, use_bias=False, kernel_initializer="he_uniform", gen=gen).to(dev)
+    res = torch.randn(n, h, h, k, generator=gen).to(dev)
+    with torch.no_grad():
+        L.PATCH_CONV[0] = False
+        try:
+            want = conv(x, residual=res, emit_stats=True)
+        finally:
+            L.PATCH_CONV[0] = True
+        x._planes = planes_of(x)
+        outs = [conv(x, residual=res, emit_stats=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert getattr(outs[0], "_wants_dy_planes", False)
+    assert float((outs[0] - want).abs().max() / want.abs().max()) < 5e-6      # two fp32 accumulation orders over up to 4608 terms
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]) and torch.equal(o._bn_partials, outs[0]._bn_partials)
+    m = n * h * h
+    for j, ref in enumerate((want.reshape(m, k).double().sum(0), want.reshape(m, k).double().pow(2).sum(0))):
+        got = outs[0]._bn_partials[j].double().sum(-1)
+        assert float((got - ref).abs().max() / ref.abs().max().clamp_min(1.0)) < 1e-5
+
+
 class _Pair(torch.nn.Module):
     """BatchNormalization(+ReLU) -> 3x3 conv -> BatchNormalization -> 3x3 conv (+ identity shortcut): the pattern of a
     basic ResNet unit, exercising planes emission in forward AND of the BN input gradient in backward."""
