@@ -25,8 +25,6 @@
 // swapped when (row >> 3) & 1, which makes any 16 consecutive rows conflict-free for ds_read_b128 whatever the tap shift.
 // Measured (profiles/r03_exp_patch2_ab.txt): 192 / 183 / 202 TFLOP/s fp32-equivalent on the 56x56x64, 28x28x128,
 // 14x14x256 ResNet18 layers where conv.hip's forward kernel reaches 155 / 156 / 183.
-#include <atomic>
-#include <mutex>
 #include "gemm_engine.h"
 #include "conv_geom.h"
 #include "../../include/embnet.h"
@@ -37,16 +35,6 @@ namespace patch {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// 16-byte buffer accesses at DEVICE scope (cache policy sc1: through the L2, to where every XCD sees them)
-__device__ __forceinline__ void store_dev(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 16);
-}
-__device__ __forceinline__ f32x4 load_dev(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16));
 }
 
 template <int BN_>
@@ -61,8 +49,7 @@ struct PatchParams {
   ConvGeom g; unsigned x_plane_bytes, w_plane_bytes;
   int PH, PW; FastDiv dPHW, dPW;
   int LR;                        // LDS patch rows (multiple of 32)
-  int n_full, rem, units, grid;   // tiles [0, n_full): whole, round-robin; the other `rem` tiles: `units` = rem * C/16 chunk units
-  float* ws; int* sync;          // shared out evenly (work_item); partial tiles; two counters per remainder tile (zero between launches)
+  int n_full, parts, cc_part, n_pieces, grid; float* ws;
 };
 
 typedef const PatchParams __attribute__((address_space(4)))* kargp;
@@ -74,41 +61,18 @@ __device__ __forceinline__ kargp kargs() {
   return pp;
 }
 
-// What a workgroup computes, in order: its whole tiles, then up to two PIECES of remainder tiles.  The remainder tiles' chunk
-// units (tile-major) are dealt out in equal contiguous runs, unit range [b*U/grid, (b+1)*U/grid) to workgroup b; a run is
-// shorter than a tile, so it lies in one tile or straddles one tile boundary: the end of tile t (a partial sum, stored to
-// slab b + t) and the beginning of tile t + 1.  The workgroup holding the BEGINNING of a tile finishes that tile: it computes
-// its piece last, waits for the other pieces' slabs (every other piece is something its owner computes BEFORE the piece it
-// may have to wait for, so nobody waits on a waiter), adds them in workgroup order and runs the epilogue.
-struct Item { int m0, n0, cc_b, cc_e, tile_m, role, t_rel; float* part; };   // role 0: whole tile, 1: partial sum, 2: finishes its tile
-struct Pieces { int n; int t[2], cb[2], ce[2]; };
-
-__device__ __forceinline__ Pieces pieces_of(int b) {
-  kargp pp = kargs();
-  Pieces q; q.n = 0; q.t[0] = q.t[1] = q.cb[0] = q.cb[1] = q.ce[0] = q.ce[1] = 0;
-  const int U = pp->units, NCC = pp->g.C / 16;
-  if (U == 0) return q;
-  const int u0 = (int)((long)b * U / pp->grid), u1 = (int)((long)(b + 1) * U / pp->grid);
-  if (u1 == u0) return q;
-  const int t0 = u0 / NCC, c0 = u0 - t0 * NCC, len = u1 - u0;
-  if (c0 + len <= NCC) { q.n = 1; q.t[0] = t0; q.cb[0] = c0; q.ce[0] = c0 + len; }
-  else { q.n = 2; q.t[0] = t0; q.cb[0] = c0; q.ce[0] = NCC; q.t[1] = t0 + 1; q.cb[1] = 0; q.ce[1] = c0 + len - NCC; }
-  return q;
-}
+struct Item { int m0, n0, cc_b, cc_e, tile_m; float* part; };
 
 template <int BN>
 __device__ __forceinline__ Item work_item(int item, int n_mine) {
   kargp pp = kargs();
-  const int b = blockIdx.x, tiles_n = (pp->g.K + BN - 1) / BN;
+  const int b = blockIdx.x, NCC = pp->g.C / 16, tiles_n = (pp->g.K + BN - 1) / BN;
   Item t; int id;
-  if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = pp->g.C / 16; t.role = 0; t.t_rel = 0; t.part = nullptr; }
+  if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr; }
   else {
-    const Pieces q = pieces_of(b);
-    const int j = item - n_mine;                          // (a run that straddles: the tile END first, the beginning last)
-    t.t_rel = j ? q.t[1] : q.t[0]; t.cc_b = j ? q.cb[1] : q.cb[0]; t.cc_e = j ? q.ce[1] : q.ce[0];   // (selects: no indexed array in scratch)
-    t.role = t.cc_b == 0 ? 2 : 1;
-    id = pp->n_full + t.t_rel;
-    t.part = pp->ws + (long)(b + t.t_rel) * (256 * BN);
+    id = pp->n_full + b / pp->parts;
+    t.cc_b = (b % pp->parts) * pp->cc_part; t.cc_e = min(NCC, t.cc_b + pp->cc_part);
+    t.part = pp->ws + (long)b * (256 * BN);
   }
   t.tile_m = id / tiles_n; t.m0 = t.tile_m * 256; t.n0 = (id % tiles_n) * BN;
   return t;
@@ -138,7 +102,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
   unsigned char* const bslot0 = smem + 2 * PB;
   const int b = blockIdx.x;
   const int n_mine = b < p.n_full ? (p.n_full - b + p.grid - 1) / p.grid : 0;
-  const int n_items = n_mine + pieces_of(b).n;
+  const int n_items = n_mine + (b < p.n_pieces ? 1 : 0);
   if (n_items == 0) return;
   const int dhalf = (lane & 1) ^ ((lane >> 4) & 1);      // logical 16-byte half this lane's DMA piece holds
 
@@ -297,59 +261,16 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
     }
     // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
     // lane & 31, so a store instruction writes two 128-byte row segments
-    // A slab holds a partial tile in ACCUMULATOR order — float4 #(((im*TN + in)*4 + g)*8 + wave)*64 + lane = registers
-    // 4g..4g+3 of block (im, in) — so that writer and reader move it with 16-byte lanes, 1 KiB per instruction.
-    if (cur.role == 1) {
-      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(cur.part, 0, 256 * BN * 4, 0x00020000);
-      const unsigned part = (unsigned)(wave * 64 + lane) * 16u;
+    if (cur.part) {
+      float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 v = {acc[im][in][4 * g4], acc[im][in][4 * g4 + 1], acc[im][in][4 * g4 + 2], acc[im][in][4 * g4 + 3]};
-            store_dev(sr, part + ((im * TN + in) * 4 + g4) * 8192u, v);
-          }
-      // The slab is written with device-scope stores (write-through: the reader may sit on another XCD, whose L2 is not
-      // this one's) and read with device-scope loads, so the hand-over needs no cache write-back / invalidate — a release
-      // fence here writes back this XCD's whole L2 (the output tiles of 32 workgroups) and cost 60-100 us per launch.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores have completed before the signal
-      if (lane == 0) __hip_atomic_fetch_add(p.sync + 2 * cur.t_rel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int rr = 0; rr < 16; ++rr)
+            part[(im * 32 + (rr & 3) + 8 * (rr >> 2)) * BN + in * 32] = acc[im][in][rr];
     } else {
-      if (cur.role == 2 && cur.cc_e < p.g.C / 16) {
-        // the other pieces of this tile: workgroups b+1, b+2, ... while their runs begin inside it, in that (fixed) order
-        kargp pp = kargs();
-        const int U = pp->units, NCC = pp->g.C / 16, tile_end = (cur.t_rel + 1) * NCC;
-        int others = 0;
-        for (int j = b + 1; j < pp->grid && (int)((long)j * U / pp->grid) < tile_end; ++j)
-          others += (int)((long)(j + 1) * U / pp->grid) > (int)((long)j * U / pp->grid);
-        int* cnt = p.sync + 2 * cur.t_rel;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8 * others) __builtin_amdgcn_s_sleep(4);
-        asm volatile("" ::: "memory");
-        for (int j = b + 1; j < pp->grid && (int)((long)j * U / pp->grid) < tile_end; ++j) {
-          if ((int)((long)(j + 1) * U / pp->grid) == (int)((long)j * U / pp->grid)) continue;
-          const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(p.ws + (long)(j + cur.t_rel) * (256 * BN), 0, 256 * BN * 4, 0x00020000);
-          const unsigned part = (unsigned)(wave * 64 + lane) * 16u;
-          constexpr int NV = TM * TN * 4, HB = NV > 8 ? 8 : NV;     // 8 x 16 bytes per lane in flight (16 spill beside the accumulators)
-#pragma unroll
-          for (int i0 = 0; i0 < NV; i0 += HB) {
-            f32x4 v[HB];
-#pragma unroll
-            for (int i = 0; i < HB; ++i) v[i] = load_dev(sr, part + (i0 + i) * 8192u);
-#pragma unroll
-            for (int i = 0; i < HB; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[(i0 + i) / (TN * 4)][((i0 + i) / 4) % TN][4 * ((i0 + i) % 4) + e] += v[i][e];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // the eighth wave through re-arms the tile's counters for the next launch
-        if (lane == 0 && __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7) {
-          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
       const bool inner = cur.m0 + 256 <= M && cur.n0 + BN <= K;      // wave-uniform: no edge tests on interior tiles
 #pragma unroll
       for (int in = 0; in < TN; ++in) {
@@ -466,41 +387,7 @@ static int patch_rows(int n, int oh, int ow, int r, int s) {                 // 
   return (int)((worst + 31) / 32 * 32);
 }
 
-// One workgroup per CU (the LDS footprint allows no more) and never more workgroups than CUs: a workgroup that finishes a
-// remainder tile spin-waits for the other pieces, which is only safe when every workgroup of the launch is resident.
-static int patch_grid() {
-  static int grid = 0;
-  if (!grid) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    grid = cus < 256 ? cus : 256;
-  }
-  return grid;
-}
-
-// Counters of the remainder tiles (two per tile; the kernel leaves them zero): device memory owned by the library, a ring of
-// sets so that launches in flight on different streams do not share one.  Allocated at the first call (not capturable:
-// run one eager step before capturing a graph, as TripletTrainer does).
-static int* sync_counters() {
-  constexpr int SETS = 64, PER_SET = 512;
-  static int* base[16] = {};
-  static std::atomic<unsigned> next{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!base[dev]) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!base[dev]) {
-      int* ptr = nullptr;
-      if (hipMalloc(&ptr, sizeof(int) * SETS * PER_SET) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-      if (hipMemset(ptr, 0, sizeof(int) * SETS * PER_SET) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
-      base[dev] = ptr;
-    }
-  }
-  return base[dev] + (size_t)(next.fetch_add(1) % SETS) * PER_SET;
-}
-
-struct Plan { int bn, tps, nbs, LR, tiles, n_full, rem, grid; size_t lds, ws_bytes; };
+struct Plan { int bn, tps, nbs, LR, tiles, n_full, parts, cc_part, n_pieces, grid; size_t lds, ws_bytes; };
 
 static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int ow, Plan& pl) {
   static const int enabled = (int)env_long("EMBNET_CONV_PATCH", 1);
@@ -525,13 +412,17 @@ static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int
   if (ok) {
     const long M = (long)n * oh * ow;
     pl.tiles = cdiv(M, 256) * cdiv(k, pl.bn);
-    pl.grid = patch_grid();
-    // whole rounds of tiles go round-robin; what is left over (fewer tiles than workgroups) is shared out by chunk units
-    // (work_item above), unless it is a whole round's worth anyway
+    pl.grid = 256;
+    const int ncc = c / 16;
     pl.n_full = pl.tiles / pl.grid * pl.grid;
-    pl.rem = pl.tiles - pl.n_full;
-    if (pl.rem * 10 >= pl.grid * 9) { pl.n_full = pl.tiles; pl.rem = 0; }
-    pl.ws_bytes = pl.rem ? (size_t)(pl.grid + pl.rem) * 256 * pl.bn * 4 : 0;
+    const int rem = pl.tiles - pl.n_full;
+    pl.parts = 1; pl.cc_part = ncc; pl.n_pieces = 0; pl.ws_bytes = 0;
+    if (rem > 0) {
+      int parts = pl.grid / rem; if (parts > ncc) parts = ncc; if (parts < 1) parts = 1;
+      pl.cc_part = cdiv(ncc, parts); pl.parts = cdiv(ncc, pl.cc_part);
+      if (pl.parts == 1) { pl.n_full = pl.tiles; }                            // whole tiles: nothing to fix up
+      else { pl.n_pieces = rem * pl.parts; pl.ws_bytes = (size_t)pl.n_pieces * 256 * pl.bn * 4; }
+    }
   } else {
     pl.bn = 0;
   }
@@ -588,9 +479,8 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
   p.LR = pl.LR;
   p.stats_rows = cdiv(M, 256) * 4;
   p.grid = pl.grid;
-  int* sync = pl.rem ? sync_counters() : nullptr;
-  if (pl.rem && (pl.ws_bytes > workspace_bytes || !workspace || !sync)) { pl.n_full = pl.tiles; pl.rem = 0; }   // whole tiles only
-  p.n_full = pl.n_full; p.rem = pl.rem; p.units = pl.rem * (c / 16); p.ws = (float*)workspace; p.sync = sync;
+  if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
+  p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   {
     EMBNET_TRACE_FLOP(pl.bn == 128 ? (pl.nbs == 6 ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6>(embnet::patch::PatchParams)"
@@ -601,5 +491,8 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
     if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
     else launch_patch<64, 3, 3>(p, pl.lds, st);
   }
+  if (p.n_pieces > 0)
+    launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
+                      stats, p.stats_rows, st);
   return check_launch("conv2d_patch");
 }

@@ -145,10 +145,9 @@ def test_patch_epilogues(dev, n, h, w, c, k):
 
 @pytest.mark.parametrize("n,h,c,k", [(128, 56, 64, 64), (128, 28, 128, 128), (128, 14, 256, 256), (128, 7, 512, 512), (96, 28, 128, 256)])
 def test_patch_at_bench_sizes_vs_gather_kernel_and_repeatable(dev, n, h, c, k):
-    """BASELINE config C2's layers (local batch 128): whole rounds of tiles plus a remainder shared out by chunk units, the
-    tile finished by the workgroup holding its first piece.  Against the gather kernel (itself checked against float64 at
-    small sizes), with the following BatchNormalization's sums, and bit-identical from launch to launch (the pieces are
-    added in a fixed order whatever order they arrive in)."""
+    """BASELINE config C2's layers (local batch 128): whole rounds of tiles plus a remainder cut along the channel chunks
+    (partial tiles + fix-up).  Against the gather kernel (itself checked against float64 at small sizes), with the following
+    BatchNormalization's sums, and bit-identical from launch to launch."""
     lib = _lib.lib()
     gen = torch.Generator().manual_seed(n + h)
     x = torch.randn(n, h, h, c, generator=gen).to(dev)
