@@ -24,6 +24,10 @@ static ColGeom col_geom(long m, int c) {
   int cl = 1; while (cl < c && cl < 256) cl <<= 1;
   g.cl = cl; g.rl = 256 / cl;
   long blocks = (m + (long)g.rl * 16 - 1) / ((long)g.rl * 16);
+  if (blocks < 512) {                                   // small tensors (7x7, 14x14 maps): fewer rows per thread rather than idle CUs —
+    blocks = (m + (long)g.rl * 4 - 1) / ((long)g.rl * 4);  // 196 workgroups read a 25 MB pair of tensors at 2 TB/s, 512+ at 3-4
+    if (blocks > 512) blocks = 512;
+  }
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   g.blocks = (int)blocks;

@@ -166,6 +166,7 @@ class _FusedTripletLoss(torch.autograd.Function):
                                                 ws.numel() * 4, stream()))
         ctx.save_for_backward(emb, trip, count, act)
         ctx.mark_non_differentiable(loss, trip, count)
+        ctx.set_materialize_grads(False)                    # no zero tensors (three fill launches) for the outputs nobody differentiates
         return mean, loss, trip, count
 
     @staticmethod
