@@ -156,8 +156,11 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         if not os.path.exists(tpath):
             continue
         prof = json.load(open(tpath)).get(workload, {})
-        if name in prof.get("kernels", {}):
-            roof["traffic"] = prof["kernels"][name]
+        # rocprofv3 prints a plain kernel with its argument list ("embnet::bn_bwd_apply4_kernel(float const*, ...)"), the
+        # library's trace names it without; template instantiations carry the same text in both
+        key = name if name in prof.get("kernels", {}) else next((k for k in prof.get("kernels", {}) if k.startswith(name + "(")), None)
+        if key is not None:
+            roof["traffic"] = prof["kernels"][key]
             roof["traffic_source"] = f"profiles/{tfile} [{workload}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["traffic_algorithmic"], 1), 2)
             break
