@@ -21,7 +21,8 @@ from . import ops
 
 def default_device():
     import os
-    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # one process per GPU: LOCAL_RANK picks it (more ranks than GPUs only in the gloo debug mode, parallel.init_distributed)
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
 
 
 class Model(nn.Module):

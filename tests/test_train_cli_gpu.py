@@ -63,6 +63,30 @@ def test_train_cli_softmax_pretraining(tmp_path):
     assert os.listdir(tmp_path / "simple2_synthetic" / "pretraining_model" / "weights")
 
 
+def test_train_cli_softmax_pretraining_two_ranks(tmp_path):
+    """The same config as a 2-process data-parallel run (both ranks on the box's one GPU over gloo; RCCL refuses two ranks
+    per device): pre-training runs on EVERY rank under the gradient reducer — nobody waits in a collective for rank 0 —
+    then the triplet stage; rank 0 writes the checkpoints, and the ranks end with identical weights."""
+    cfg = open(os.path.join(ROOT, "configs", "simple2_softmax_synthetic.yml")).read().replace("work_dirs/",
+                                                                                              str(tmp_path) + "/")
+    cfg_path = tmp_path / "cfg.yml"
+    cfg_path.write_text(cfg)
+    env = dict(os.environ, EMBNET_DIST_BACKEND="gloo", EMBNET_DUMP_FINAL_WEIGHTS=str(tmp_path / "final_rank"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "tools", "train.py"),
+                          str(cfg_path), "--synthetic", "10", "--max_epochs", "2"], capture_output=True, text=True, timeout=900,
+                         env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "softmax pre-training epoch 2/2" in out.stdout and "Epoch 2/2" in out.stdout
+    assert os.listdir(tmp_path / "simple2_synthetic" / "pretraining_model" / "weights")
+    w0, w1 = np.load(str(tmp_path / "final_rank") + "0.npz"), np.load(str(tmp_path / "final_rank") + "1.npz")
+    assert set(w0.files) == set(w1.files) and len(w0.files) > 10
+    for k in w0.files:
+        if "moving_" in k:
+            continue                                   # BatchNorm statistics are local to a rank (as the reference: no SyncBN)
+        assert np.array_equal(w0[k], w1[k]), k
+
+
 def test_grad_reducer_over_rccl_single_rank():
     """The DP reducer on the real backend (nccl = RCCL), world size 1: hooks fire, buckets are
     all-reduced asynchronously on RCCL's stream, finish() orders them before the optimizer, and the

@@ -127,7 +127,7 @@ def main():
     apply_gpu_ids(cfg['general'].get('gpu_ids'))
     paths = create_save_folders(cfg['general'])
     rank, world, local = init_distributed()
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % max(torch.cuda.device_count(), 1))    # (ranks > GPUs only in the gloo debug mode)
     torch.cuda.set_device(dev)
     p_model['device'] = dev
     # every rank builds the same dataset and the same initial model; what differs per rank is what it samples
@@ -255,6 +255,9 @@ def main():
             break
     if rank == 0:
         np.savez(os.path.join(paths['plots'], 'history.npz'), **{k: np.asarray(v) for k, v in history.items()})
+    dump = os.environ.get('EMBNET_DUMP_FINAL_WEIGHTS')     # diagnostics: EVERY rank's final weights -> <prefix><rank>.npz
+    if dump:                                               # (data-parallel ranks must end with identical trainable weights)
+        model.save_weights(f'{dump}{rank}.npz')
     return history
 
 
