@@ -110,9 +110,14 @@ class GradReducer:
     parameter — only valid while each parameter receives ONE gradient per step (the fused TripletTrainer step).
     `hold(True)`: count, but launch no collective (a step being captured into a HIP graph); `reduce_all()` then reduces
     every bucket in order.
+    Bucket sizes: ~bucket_bytes each (xGMI is point-to-point: few, large messages), except that the gradients produced LAST
+    in backward (the first layers' — tail_bytes of them) get a bucket of their own: every earlier bucket's all-reduce overlaps
+    the rest of backward, but the final bucket's is fully exposed in front of the optimizer, so it should be a small,
+    latency-sized message rather than whatever remainder the cutting left (ResNet18: 45 MB = 16 + 16 + 12 + 0.7 MB instead
+    of 32 + 13).  On RCCL the mean is taken by the collective itself (ReduceOp.AVG); other backends sum and scale once.
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, always_reduce=False):
+    def __init__(self, params, bucket_bytes=16 << 20, process_group=None, always_reduce=False, tail_bytes=1 << 20):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradReducer: no trainable parameters")
@@ -120,7 +125,7 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())   # always_reduce: test hook
         dev, dtype = self.params[0].device, self.params[0].dtype
-        self._bucket_bytes = bucket_bytes
+        self._bucket_bytes, self._tail_bytes = bucket_bytes, tail_bytes
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dtype)
         self._works, self._hold, self._direct = [], False, False
@@ -130,6 +135,8 @@ class GradReducer:
         # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
         # NCCL-only and could not be exercised on the single-GPU development box)
         self._avg = dist.ReduceOp.SUM
+        if self._reduce and dist.get_backend(process_group) == "nccl" and os.environ.get("EMBNET_DP_AVG", "1") == "1":
+            self._avg = dist.ReduceOp.AVG                   # RCCL averages inside the collective: no scaling pass over the buffer
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def close(self):
@@ -147,7 +154,17 @@ class GradReducer:
         self.buckets, self._bucket_of, self._slot = [], {}, {}
         off, start, pending = 0, 0, 0
         per_bucket = max(self._bucket_bytes // self.flat.element_size(), 1)
-        for p in order:
+        # where the final (exposed) bucket starts: the trailing parameters that together stay within tail_bytes
+        tail_from, acc_tail = len(order), 0
+        for i in range(len(order) - 1, 0, -1):
+            acc_tail += order[i].numel() * self.flat.element_size()
+            if acc_tail > self._tail_bytes:
+                break
+            tail_from = i
+        for i, p in enumerate(order):
+            if i == tail_from and pending:                  # close the running bucket in front of the tail
+                self.buckets.append([start, off, pending])
+                start, pending = off, 0
             n = p.numel()
             self._slot[p] = (off, n)
             p.grad = self.flat[off:off + n].view_as(p)

@@ -315,6 +315,23 @@ print("rank", rank, "ok")
 """
 
 
+def test_grad_reducer_final_bucket_is_small():
+    """The gradients produced last in backward get a bucket of their own (its all-reduce is the exposed one)."""
+    import torch
+    from embeddingnet_amd.parallel import GradReducer
+    sizes = [300_000, 200_000, 100_000, 50_000, 3_000, 2_000, 500]           # backward order after reversal below
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in reversed(sizes)]
+    red = GradReducer(params, bucket_bytes=1 << 20, tail_bytes=32 << 10)        # 262 144 floats per bucket, 8 192-float tail
+    lens = [e - s for s, e, _ in red.buckets]
+    assert sum(lens) == sum(sizes) and lens[-1] == 3_000 + 2_000 + 500, lens     # the tail: the last parameters within 32 KiB
+    assert lens[:-1] == [300_000, 300_000, 50_000], lens
+    assert [b[2] for b in red.buckets] == [1, 2, 1, 3]
+    for p in params:                                                            # views still tile the flat buffer exactly
+        off, n = red._slot[p]
+        assert p.grad.data_ptr() == red.flat.data_ptr() + 4 * off and n == p.numel()
+    red.close()
+
+
 def test_grad_reducer_gloo_world2(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER.format(root=ROOT))
