@@ -4,12 +4,15 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from embeddingnet_amd import _lib, layers as L
 from test_conv_patch_gpu import planes_of
 dev = torch.device('cuda', 0); lib = _lib.lib()
+import os
+ZEROS = os.environ.get('ZEROS', '0') == '1'          # all-zero operands: what the same instruction stream does when the data costs no power
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(56, 64, 64), (28, 128, 128), (14, 256, 256), (7, 512, 512)]
 if len(sys.argv) > 2:
     SHAPES = [SHAPES[int(sys.argv[2])]]
 for (h, c, k) in SHAPES:
     x = torch.randn(N, h, h, c, device=dev); w = torch.randn(3, 3, c, k, device=dev) * 0.05
+    if ZEROS: x.zero_(); w.zero_()
     xp = planes_of(x); wp = L.weight_planes(w, 0)
     y = torch.empty(N, h, h, k, device=dev)
     wsb = lib.embnet_conv2d_patch_workspace_bytes(N, c, 3, 3, k, h, h)
