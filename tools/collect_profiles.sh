@@ -8,6 +8,15 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 rm -rf "$out" && mkdir -p "$out"
+# HBM traffic counters first: the bench lines below look their dominant kernel up in profiles/rNN_pmc_traffic.json
+PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-graph --settle-seconds 0 --sustain-seconds 0"
+for c in c2 c1 c1s c3 c5; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- $PCMD --config $c > /dev/null 2> "$out/pmc_fetch_$c.err"
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- $PCMD --config $c > /dev/null 2> "$out/pmc_write_$c.err"
+  python3 tools/pmc_traffic.py "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_traffic.json" $c "$PCMD --config $c" > "$out/pmc_traffic_$c.txt"
+  rm -rf "$out/pmc_fetch" "$out/pmc_write"
+done
+cp "$out/pmc_traffic.json" "$root/profiles/${tag}_pmc_traffic.json"
 python3 bench.py > "$out/bench_c2.json" 2> "$out/bench_c2.err"
 python3 bench.py --mining batch_hard --steps 30 --no-cpu-baseline > "$out/bench_c2_batch_hard.json" 2> "$out/bench_c2_batch_hard.err"
 for c in c1 c1s c3 c5; do
@@ -18,13 +27,6 @@ CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --settl
 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- $CMD > "$out/trace_bench.json" 2> "$out/trace.err"
 python3 tools/kernel_stats.py "$out"/trace/*/*_kernel_trace.csv 13 "$out/kernel_stats" \
     "rocprofv3 --kernel-trace of \`$CMD\` (13 steps in the trace)" > /dev/null
-PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-graph --settle-seconds 0 --sustain-seconds 0"
-for c in c2 c1 c1s c3 c5; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- $PCMD --config $c > /dev/null 2> "$out/pmc_fetch_$c.err"
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- $PCMD --config $c > /dev/null 2> "$out/pmc_write_$c.err"
-  python3 tools/pmc_traffic.py "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_traffic.json" $c "$PCMD --config $c" > "$out/pmc_traffic_$c.txt"
-  rm -rf "$out/pmc_fetch" "$out/pmc_write"
-done
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$out/pmc_mfma" -- $PCMD > /dev/null 2> "$out/pmc_mfma.err"
 python3 tools/pmc_mfma_clock.py "$out/pmc_mfma" "$out/pmc_mfma_clock.md" "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES of \`$PCMD\`" > /dev/null
 rm -rf "$out/pmc_mfma" "$out"/trace/*/*agent_info.csv
