@@ -288,6 +288,7 @@ def load_keras_weights(module, weights, strict=True):
             t.copy_(torch.as_tensor(np.asarray(weights[k]), dtype=t.dtype).reshape(t.shape))
         elif strict:
             raise KeyError(f"missing weight {k}")
+    L.WEIGHT_EPOCH[0] += 1               # cached bf16 planes of conv kernels are stale
 
 
 def pretrain_backbone_softmax(backbone_model, data_loader, params_softmax, params_save_paths, max_epochs=None,

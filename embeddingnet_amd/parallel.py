@@ -63,6 +63,8 @@ def broadcast_model(module, src=0, process_group=None):
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
+    from . import layers as L
+    L.WEIGHT_EPOCH[0] += 1               # (written through .data: the parameters' version counters did not move)
 
 
 def average_buffers(module, process_group=None):
