@@ -167,10 +167,12 @@ constexpr int DW_TW = 4;
 // FLIP = false: forward correlation  y[oh,ow] = sum x[oh*ST+r-pt, ow*ST+s-pl] * w[r,s]
 // FLIP = true (ST = 1 only): the same loop as the stride-1 DATA GRADIENT: dx = correlate(dy, flipped w) with pads
 // KS-1-pt / KS-1-pl — the launcher swaps the roles (g.H/W = size of the tensor read, g.OH/OW = size written).
-template <int KS, int ST, bool FLIP>
+// TW output columns per thread: 8 where the row is wide enough (5x5 stride 1: 60 + 25 loads per 8 outputs instead of 40 + 25
+// per 4; the kernels run at the rate the L1 takes requests, not at the HBM rate), 4 otherwise.
+template <int KS, int ST, bool FLIP, int TW>
 __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           DwGeom g, float* __restrict__ y) {
-  constexpr int TW = DW_TW, NX = (TW - 1) * ST + KS;
+  constexpr int NX = (TW - 1) * ST + KS;
   const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW;
   const long total = (long)g.N * g.OH * wb_n * c4;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -594,6 +596,15 @@ static int make_dw(DwGeom& g, int n, int h, int w, int c, int r, int s, int stri
   return 0;
 }
 
+template <int KS, int ST, bool FLIP>
+static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st) {
+  static const int forced = (int)env_long("EMBNET_DW_TW", 0);            // 4 / 8: A/B
+  // eight columns per thread unless that wastes more than an eighth of a row the four-column blocks tile exactly
+  const bool wide = forced ? forced == 8 : (g.OW >= 7 && cdiv(g.OW, 8) * 8 <= cdiv(g.OW, 4) * 4 + g.OW / 8);
+  if (wide) dwconv_row4_kernel<KS, ST, FLIP, 8><<<cdiv((long)g.N * g.OH * cdiv(g.OW, 8) * (g.C / 4), 256), 256, 0, st>>>(x, w, g, y);
+  else dwconv_row4_kernel<KS, ST, FLIP, 4><<<cdiv((long)g.N * g.OH * cdiv(g.OW, 4) * (g.C / 4), 256), 256, 0, st>>>(x, w, g, y);
+}
+
 // EMBNET_DW_ROWS=0 falls back to the per-pixel kernels (A/B)
 static bool dw_rows() { static const bool on = env_long("EMBNET_DW_ROWS", 1) != 0; return on; }
 
@@ -605,12 +616,11 @@ extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y,
   const long total = (long)n * oh * ow * c;
   const int grid4 = cdiv(total / 4, 256);
   if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
-    const int gridr = cdiv((long)n * oh * cdiv(ow, DW_TW) * (c / 4), 256);
     EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream);
-    if (r == 3 && stride == 1) dwconv_row4_kernel<3, 1, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
-    else if (r == 3) dwconv_row4_kernel<3, 2, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
-    else if (stride == 1) dwconv_row4_kernel<5, 1, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
-    else dwconv_row4_kernel<5, 2, false><<<gridr, 256, 0, S(stream)>>>(x, w, g, y);
+    if (r == 3 && stride == 1) launch_dw_rows<3, 1, false>(x, w, g, y, S(stream));
+    else if (r == 3) launch_dw_rows<3, 2, false>(x, w, g, y, S(stream));
+    else if (stride == 1) launch_dw_rows<5, 1, false>(x, w, g, y, S(stream));
+    else launch_dw_rows<5, 2, false>(x, w, g, y, S(stream));
     return check_launch("dwconv2d_fwd");
   }
   if ((c & 3) == 0 && r == s && r == 3) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
@@ -633,8 +643,8 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
                  4.0 * total + 4.0 * n * oh * ow * c, stream);
     if (stride == 1) {         // correlation of dy with the flipped kernel: the forward loop with the roles swapped
       const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
-      if (r == 3) dwconv_row4_kernel<3, 1, true><<<gridr, 256, 0, S(stream)>>>(dy, w, gf, dx);
-      else dwconv_row4_kernel<5, 1, true><<<gridr, 256, 0, S(stream)>>>(dy, w, gf, dx);
+      if (r == 3) launch_dw_rows<3, 1, true>(dy, w, gf, dx, S(stream));
+      else launch_dw_rows<5, 1, true>(dy, w, gf, dx, S(stream));
     } else if (r == 3) {
       if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<3, 1><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
       else dwconv_dgrad4_s2_row_kernel<3, 0><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx);
