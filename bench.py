@@ -277,7 +277,7 @@ def main():
     # windows of 20 until the window time has stopped improving (two windows in a row less than 0.5 % faster than the one
     # before; at most --settle-seconds), all ranks together, then time
     settle_steps, settle_t0, prev, flat = 0, time.perf_counter(), None, 0
-    while args.settle_seconds > 0 and time.perf_counter() - settle_t0 < args.settle_seconds:
+    while args.settle_seconds > 0:
         barrier()
         w0 = time.perf_counter()
         for _ in range(20):
@@ -286,11 +286,11 @@ def main():
         cur = time.perf_counter() - w0
         settle_steps += 20
         flat = flat + 1 if (prev is not None and cur >= 0.995 * prev) else 0
-        done = flat >= 2
-        if world > 1:                                         # one decision for all ranks (the steps hold collectives)
-            t = torch.tensor([0.0 if done else 1.0], device=dev)
+        done = flat >= 2 or time.perf_counter() - settle_t0 >= args.settle_seconds
+        if world > 1:       # ONE decision for all ranks, time-out included (the steps hold collectives: a rank that left the
+            t = torch.tensor([1.0 if done else 0.0], device=dev)    # loop alone would leave the others waiting in one)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            done = t.item() < 0.5
+            done = t.item() > 0.5
         prev = cur
         if done:
             break
