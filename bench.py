@@ -16,7 +16,7 @@ forward -> NxN distance matrix -> mine-and-select -> hinge -> backward -> (RCCL 
 Rank 0 prints ONE JSON line; details go to stderr.
 
 roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
-three of the timed steps; the kernel with the largest total time is reported against the roofline that bounds it — for the
+one to three of the timed steps (by the length of the timed region); the kernel with the largest total time is reported against the roofline that bounds it — for the
 convolution kernels the bf16 MFMA peak (16 x 157.3 TFLOP/s) with the bf16 FLOP they execute (each fp32 product = 6 bf16
 MFMA terms of an exact operand split: 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
 fp32 (157.3 TFLOP/s) for the distance / dense GEMMs with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
@@ -295,18 +295,21 @@ def main():
         if done:
             break
     trace = rank == 0 and not args.no_kernel_timer
-    # kernels are timed on THREE of the timed steps (every `every`-th): a traced step carries two HIP events per launch
-    # (~600 marker packets on a ResNet18 step, each a small bubble on the queue) and runs eagerly even where the step is a
-    # HIP graph, so it is several ms slower than a plain one — at every 4th step that cost 12 % of `value` (r03: 11.65 ms
-    # timed vs 10.19 ms in the untraced sustained leg)
-    every = max(4, (args.steps + 2) // 3)
+    # kernels are timed on a FEW of the timed steps: a traced step carries two HIP events per launch (~600 marker packets on
+    # a ResNet18 step, each a small bubble on the queue) and runs eagerly even where the step is a HIP graph, so it is slower
+    # than a plain one — at every 4th step that cost 12 % of `value` (r03: 11.65 ms timed vs 10.19 ms in the untraced leg).
+    # A traced C2 step costs ~1.4 ms more than a plain one (13 121 images/s timed with three of 50 steps traced vs 13 235 in
+    # the untraced leg), so the number of traced steps follows the length of the timed region: 1 below 40 steps, 2 below
+    # 80, else 3 — spread evenly, never the first step.
+    n_traced = 1 if args.steps < 40 else 2 if args.steps < 80 else 3
+    traced_at = {(j + 1) * args.steps // (n_traced + 1) for j in range(n_traced)}
     if trace:
         _lib.trace_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if trace:          # ~250 event pairs per traced step: kept to every 4th step so they cost < 2 % of the timed region
-            _lib.trace_enable(i % every == 0)
+        if trace:
+            _lib.trace_enable(i in traced_at)
         loss = step()
     host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # time to ENQUEUE a step (the host runs ahead of the GPU)
     barrier()
@@ -351,7 +354,7 @@ def main():
     log(f"  host enqueue {host_ms:.2f} ms/step, step {ms_per_step:.2f} ms ({'GPU' if host_ms < 0.9 * ms_per_step else 'host'}-bound)")
     roofline = None
     if trace:
-        roofline, _ = roofline_from_trace(_lib.trace_records(), (args.steps + every - 1) // every, ms_per_step, args.config,
+        roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at), ms_per_step, args.config,
                                           _lib.lib().embnet_conv_mfma_terms())
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
