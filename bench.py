@@ -123,7 +123,8 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         log(f"  {name[:104]:104s} x{d['launches'] // traced_steps:3d}/step  avg {1e3 * d['ms'] / d['launches']:8.1f} us  "
             f"{rate:8.1f} {'TFLOP/s' if d['unit'] == 0 else 'GB/s'}  {d['ms'] / traced_steps:6.3f} ms/step")
     total_ms = sum(d["ms"] for d in by.values()) / traced_steps
-    log(f"  traced kernels total {total_ms:.2f} ms of {ms_per_step:.2f} ms per step ({traced_steps} traced steps)")
+    log(f"  traced kernels total {total_ms:.2f} ms of {ms_per_step:.2f} ms per step ({traced_steps} traced steps, "
+        f"{sum(d['launches'] for d in by.values()) // max(traced_steps, 1)} library launches per step)")
     name, d = table[0]
     avg_us = 1e3 * d["ms"] / d["launches"]
     if d["unit"] == 0:
