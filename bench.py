@@ -31,6 +31,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU BEFORE anything here touches the GPU (a
+    process that has initialised HIP must never re-execute itself), relay rank 0's JSON line, return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    kids = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                     stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = kids[0].communicate()
+    rcs = [k.wait() for k in kids]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return next((rc for rc in rcs if rc), 0)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _n = next((int(a.split("=")[1]) if "=" in a else int(sys.argv[i + 2]) for i, a in enumerate(sys.argv[1:])
+               if a == "--gpus" or a.startswith("--gpus=")), 1)
+    if _n > 1:
+        sys.exit(spawn_ranks(_n))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -123,7 +152,7 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         log(f"  {name[:104]:104s} x{d['launches'] // traced_steps:3d}/step  avg {1e3 * d['ms'] / d['launches']:8.1f} us  "
             f"{rate:8.1f} {'TFLOP/s' if d['unit'] == 0 else 'GB/s'}  {d['ms'] / traced_steps:6.3f} ms/step")
     total_ms = sum(d["ms"] for d in by.values()) / traced_steps
-    log(f"  traced kernels total {total_ms:.2f} ms of {ms_per_step:.2f} ms per step ({traced_steps} traced steps, "
+    log(f"  traced kernels total {total_ms:.2f} ms per traced step; an untraced step takes {ms_per_step:.2f} ms ({traced_steps} traced steps, "
         f"{sum(d['launches'] for d in by.values()) // max(traced_steps, 1)} library launches per step)")
     name, d = table[0]
     avg_us = 1e3 * d["ms"] / d["launches"]
@@ -149,7 +178,8 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBPS, 4)}
     roof.update(launches=d["launches"], avg_us=round(avg_us, 1), traffic_algorithmic=round(d["bytes"] / d["launches"]),
-                share_of_step=round(d["ms"] / traced_steps / ms_per_step, 4))
+                share_of_traced_kernel_time=round(d["ms"] / traced_steps / total_ms, 4),
+                traced_kernel_ms_per_step=round(total_ms, 3))
     # measured HBM bytes per launch (PMC counters, separate rocprofv3 passes): only from a profile of THIS workload
     roof["traffic"] = None
     for tfile in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # newest profile that has this workload and kernel
@@ -192,6 +222,11 @@ def main():
     ap.add_argument("--cpu-classes", type=int, default=4)
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--pool", type=int, default=0,
+                    help="resident synthetic batches cycled step by step (0 = as many as fit ~10 GB of HBM, 8..1024): one "
+                         "batch stepped on for hundreds of steps is memorised, mining then finds nothing and every "
+                         "gradient is exactly zero — a dead problem, not a training step")
+    ap.add_argument("--allow-dead", action="store_true", help="print the line even if the timed region saw loss 0 / the fallback triplet")
     ap.add_argument("--settle-seconds", type=float, default=6.0,
                     help="after the W warm-up steps: keep stepping (untimed) until the step time is steady, at most this long")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
@@ -206,6 +241,10 @@ def main():
     from embeddingnet_amd.parallel import GradReducer, broadcast_model, init_distributed
     from embeddingnet_amd.train_step import TripletTrainer
     from embeddingnet_amd.utils import get_optimizer
+
+    def pool_size(n_images):
+        per = 4 * n_images * args.image * args.image * 3
+        return args.pool if args.pool > 0 else int(min(1024, max(8, (10 << 30) // per)))
 
     rank, world, local = init_distributed()
     if world != args.gpus:
@@ -229,23 +268,28 @@ def main():
         model = net.model
         params = [p for p in net.base_model.parameters() if p.requires_grad]      # the 'l2' head has no weights of its own
         n_local = 2 * args.pairs
-        x1 = torch.rand((args.pairs,) + shape, generator=gen, device=dev)       # resident in HBM
-        x2 = torch.rand((args.pairs,) + shape, generator=gen, device=dev)
+        pool = pool_size(n_local)
+        x1s = [torch.rand((args.pairs,) + shape, generator=gen, device=dev) for _ in range(pool)]       # resident in HBM
+        x2s = [torch.rand((args.pairs,) + shape, generator=gen, device=dev) for _ in range(pool)]
         y = (torch.arange(args.pairs, device=dev) < args.pairs // 2).float().reshape(-1, 1)   # datagenerators.py:345-374
     else:
         model, _ = B.get_backbone(shape, encodings_len=args.encodings_len, backbone_name=args.backbone,
                                   backbone_weights=None, seed=0, device=dev)
         params = [p for p in model.parameters() if p.requires_grad]
         n_local = args.k_classes * args.k_samples
-        images = torch.rand((n_local,) + shape, generator=gen, device=dev)     # resident in HBM
+        pool = pool_size(n_local)
+        batches = [torch.rand((n_local,) + shape, generator=gen, device=dev) for _ in range(pool)]     # resident in HBM
     broadcast_model(model)                                    # identical start on every rank (parameters + BN buffers)
     opt = get_optimizer(args.optimizer, args.lr).build(params)
     reducer = GradReducer(params) if world > 1 else None
 
+    tick = [0]                       # steps taken so far: step i runs on resident batch i mod pool
     if args.mode == "siamese":
         model.train()
 
         def step():
+            x1, x2 = x1s[tick[0] % pool], x2s[tick[0] % pool]
+            tick[0] += 1
             reducer.zero() if reducer is not None else opt.zero_grad(set_to_none=True)
             loss = contrastive_loss(y, model([x1, x2])[0])
             loss.backward()
@@ -260,7 +304,9 @@ def main():
                                  negatives_selection_mode=args.mining, seed=rank, reducer=reducer,
                                  graph=(False if args.no_graph else True if args.force_graph else "auto"))     # N > 1: two graphs around the all-reduce, every
         # rank takes the same decision (TripletTrainer._agree)
-        step = lambda: trainer.step(images)
+        def step():
+            tick[0] += 1
+            return trainer.step(batches[(tick[0] - 1) % pool])
 
     def barrier():
         torch.cuda.synchronize()
@@ -306,12 +352,19 @@ def main():
     traced_at = {(j + 1) * args.steps // (n_traced + 1) for j in range(n_traced)}
     if trace:
         _lib.trace_reset()
+    # liveness record of the timed region, kept on the device (no host sync inside a step): every step's loss and number
+    # of mined triplets — two 4-byte device copies per step
+    loss_log = torch.zeros(args.steps, device=dev)
+    count_log = torch.zeros(args.steps, device=dev, dtype=torch.int32)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if trace:
             _lib.trace_enable(i in traced_at)
         loss = step()
+        loss_log[i].copy_(loss)
+        if args.mode != "siamese":
+            count_log[i].copy_(trainer.last_triplets[1][0])
     host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # time to ENQUEUE a step (the host runs ahead of the GPU)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -345,6 +398,21 @@ def main():
         t[rank] = host_ms
         dist.all_reduce(t)
         host_all = [round(v, 3) for v in t.tolist()]
+    # a dead problem (hinge 0 on the reference's fallback triplet, datagenerators.py:246-250: every gradient exactly zero)
+    # is not a training step: refuse to report a throughput for it — on every rank (each mines its own shard)
+    losses, counts = loss_log.tolist(), count_log.tolist()
+    live = dict(loss_first_timed=losses[0], loss_last_timed=losses[-1], loss_min_timed=min(losses),
+                active_triplets_min=(min(counts) if args.mode != "siamese" else None),
+                active_triplets_mean=(round(sum(counts) / len(counts), 1) if args.mode != "siamese" else None),
+                resident_batches=pool)
+    dead = min(losses) <= 0.0 or (args.mode != "siamese" and min(counts) <= 1)
+    if world > 1:
+        t = torch.tensor([1.0 if dead else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dead = t.item() > 0.5
+    if dead and not args.allow_dead:
+        raise SystemExit(f"bench: the timed region ran on a dead problem ({live}): loss 0 / fallback triplet means all-zero "
+                         "gradients; no throughput is reported for it (raise --pool, or --allow-dead for an A/B)")
     if rank != 0:
         return
 
@@ -363,7 +431,7 @@ def main():
     if args.mode == "siamese":
         metric = f"images/sec training ({args.backbone}, {args.image}², Siamese contrastive) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), SiameseNet 'l2' head + contrastive_loss, "
-                    f"{args.pairs} pairs per GPU (first half same class) = {n_local} images, E={args.encodings_len}, "
+                    f"{args.pairs} pairs per GPU (first half same class) = {n_local} images, {pool} resident batches cycled, E={args.encodings_len}, "
                     f"{args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
     else:
         label = {"resnet18": "ResNet18", "resnet50": "ResNet50", "efficientnet-b0": "EfficientNet-B0"}.get(args.backbone, args.backbone)
@@ -372,14 +440,14 @@ def main():
         mining = "batch-hard" if (args.mining in ("hardest", "batch_hard")) else args.mining
         metric = f"images/sec training ({label}, {args.image}², triplet {mining}) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), 107-class P x K sampling, local batch "
-                    f"{args.k_classes}x{args.k_samples}={n_local}, E={args.encodings_len}, margin {args.margin}, mining "
+                    f"{args.k_classes}x{args.k_samples}={n_local} ({pool} resident batches cycled), E={args.encodings_len}, margin {args.margin}, mining "
                     f"'{args.mining}' per local batch, {args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
     out = {
         "metric": metric, "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "global_batch": n_local * world,
-                   "parallelism": f"dp{world}", "final_loss": float(loss.item()),
+                   "parallelism": f"dp{world}", "final_loss": float(loss.item()), **live,
                    "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_ms_per_step_by_rank": host_all,
                    "step_mode": ("siamese eager" if args.mode == "siamese" else
                                  ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),

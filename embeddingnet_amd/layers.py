@@ -837,7 +837,6 @@ class _InputBNConvFn(torch.autograd.Function):
     224x224 map (N=3 of a 32-wide MFMA tile, 3/4 of the taps structurally zero at stride 2)."""
 
     _ones = {}
-    _pads = {}
 
     @staticmethod
     def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False):
@@ -853,12 +852,16 @@ class _InputBNConvFn(torch.autograd.Function):
             check(lib.embnet_pad_channels(ptr(x), m, c, cp, ptr(xp), stream()))
             # persistent padded copies of the three BN vectors and of the kernel (zero taps / zero offset for the pad
             # channel), refreshed by plain copies: no cat / pad / fill launches per step
-            key = (beta.data_ptr(), w.data_ptr())
-            pads = _InputBNConvFn._pads.get(key)
-            if pads is None:
-                pads = _InputBNConvFn._pads[key] = (torch.zeros(cp, device=x.device), torch.zeros(cp, device=x.device),
-                                                    torch.ones(cp, device=x.device),
-                                                    torch.zeros((r, s, cp, k), device=x.device))
+            # (kept on the kernel Parameter object, like its planes: an address-keyed cache would hand a new model the pads
+            # of a freed one whose storage it inherited, and never evict)
+            pads = getattr(w, "_embnet_stem_pads", None)
+            if pads is None or pads[3].shape != (r, s, cp, k) or pads[3].device != x.device:
+                pads = (torch.zeros(cp, device=x.device), torch.zeros(cp, device=x.device),
+                        torch.ones(cp, device=x.device), torch.zeros((r, s, cp, k), device=x.device))
+                try:
+                    w._embnet_stem_pads = pads
+                except AttributeError:
+                    pass
             beta_p, mm_p, mv_p, w_p = pads
             beta_p[:c].copy_(beta.detach()); mm_p[:c].copy_(moving_mean); mv_p[:c].copy_(moving_var)
             w_p[:, :, :c, :].copy_(w.detach())

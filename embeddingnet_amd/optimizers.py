@@ -188,7 +188,10 @@ def load_optimizer_state(path, opt, named_params):
     if str(d["__rule__"]) != opt.rule:
         raise _lib.EmbnetError(f"optimizer state is for '{d['__rule__']}', the config builds '{opt.rule}'")
     opt.iterations = int(d["__iterations__"])
+    mine = {id(q) for g in opt.param_groups for q in g["params"]}
     for name, p in named_params.items():
+        if id(p) not in mine:                   # frozen / foreign parameters: no slots, no keys in opt.state
+            continue
         s1, s2 = opt._slots(p)
         for slot, t in (("slot1", s1), ("slot2", s2)):
             if t is not None and f"{name}::{slot}" in d:

@@ -4,9 +4,11 @@ The reference has no gradient exchange at all (its multi-GPU switch, tools/train
 replicates the mining predict()), so this is build-defined: every rank runs the fused
 step on its own whole classes (mining stays local: no cross-GPU negatives), and the ONLY collective
 is the all-reduce of the flat fp32 gradient, issued bucket by bucket from autograd hooks so it
-overlaps the rest of backward.  Buckets are ~32 MB slices of one contiguous buffer: xGMI is
-point-to-point (7 links x ~153 GB/s), a ring step is bound by one link, so few large messages beat
-many small ones; ResNet18's 45 MB gradient goes out as two.
+overlaps the rest of backward.  Buckets are ~16 MB slices of one contiguous buffer plus a small
+final one (xGMI is point-to-point, 7 links x ~153 GB/s: a ring step is bound by one link, so few
+large messages beat many small ones, and the last, exposed message should be latency-sized);
+ResNet18's 45 MB gradient goes out as 16 + 16 + 12 + 0.7 MB.  Every slot starts on a 16-byte
+boundary (the kernels that write gradients in place use 16-byte stores).
 """
 import os
 
@@ -128,18 +130,41 @@ class GradReducer:
         self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())   # always_reduce: test hook
         dev, dtype = self.params[0].device, self.params[0].dtype
         self._bucket_bytes, self._tail_bytes = bucket_bytes, tail_bytes
-        total = sum(p.numel() for p in self.params)
+        # every slot starts on a 16-byte boundary: the weight-gradient / BatchNorm kernels that write the views in place
+        # (direct) store and load them as float4; the zero padding rides along in the all-reduce
+        total = sum(self._pad(p.numel()) for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dtype)
         self._works, self._hold, self._direct = [], False, False
         self._layout(list(reversed(self.params)))           # first guess: reverse definition order
         self._seen, self._ordered = [], False               # hook order of the first backward
         self._fired = set()                                 # parameters already counted in this step
-        # SUM + one in-place scale of the flat buffer (works on every backend; ReduceOp.AVG is
-        # NCCL-only and could not be exercised on the single-GPU development box)
+        # default: SUM + one in-place scale of the flat buffer (works on every backend); on RCCL the mean is taken inside
+        # the collective (ReduceOp.AVG is NCCL/RCCL-only), checked once against sum-and-scale on the first real exchange
         self._avg = dist.ReduceOp.SUM
+        self._avg_checked = False
         if self._reduce and dist.get_backend(process_group) == "nccl" and os.environ.get("EMBNET_DP_AVG", "1") == "1":
             self._avg = dist.ReduceOp.AVG                   # RCCL averages inside the collective: no scaling pass over the buffer
+            if self.world > 1 and not self._avg_matches_sum_and_scale(dev):
+                import warnings
+                warnings.warn("GradReducer: ReduceOp.AVG disagrees with sum-and-scale on this RCCL; using SUM + scale")
+                self._avg = dist.ReduceOp.SUM
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _avg_matches_sum_and_scale(self, dev):
+        """One-time self-check of the in-collective mean (a collective: every rank constructs its reducer at the same
+        point): a rank-dependent vector averaged by ReduceOp.AVG against the same vector summed and scaled.  Both results
+        are identical on all ranks, so all ranks take the same decision."""
+        rank = dist.get_rank(self.group)
+        t = torch.arange(1024, device=dev, dtype=torch.float32) * (0.37 + rank) - 11.0 * rank
+        a, b = t.clone(), t.clone()
+        dist.all_reduce(a, op=dist.ReduceOp.AVG, group=self.group)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        self._avg_checked = True
+        return bool(torch.allclose(a, b / self.world, rtol=1e-6, atol=1e-6))
+
+    @staticmethod
+    def _pad(n, quantum=4):
+        return (n + quantum - 1) // quantum * quantum
 
     def close(self):
         """Detach from the parameters (hooks, gradient sinks, .grad views): another reducer may take them over."""
@@ -173,7 +198,7 @@ class GradReducer:
             if keep:
                 p.grad.copy_(old[p])
             self._bucket_of[p] = len(self.buckets)
-            off += n
+            off += self._pad(n)
             pending += 1
             if off - start >= per_bucket:
                 self.buckets.append([start, off, pending])

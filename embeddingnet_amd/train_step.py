@@ -246,8 +246,19 @@ class TripletTrainer:
             if self._graph is None and self.step_no >= self.GRAPH_WARMUP:
                 if self.graph_mode == "auto":
                     self._probe(images)
-                elif self._graph_supported(images):
-                    self._capture(images)
+                else:
+                    # graph=True: with a reducer every rank must take the same branch at every fork (a rank that steps
+                    # eagerly issues its bucket all-reduces as the buckets close, a replaying rank in index order)
+                    want = self._graph_supported(images)
+                    if self.reducer is not None:
+                        want = self._agree(want, any_rank=False)
+                    if want:
+                        self._capture(images)
+                        if self.reducer is not None and not self._agree(self._graph is not None, any_rank=False):
+                            self._graph, self.graph_mode = None, False     # somebody's capture failed: everyone eager
+                            self.opt.coef_dev = None
+                    elif self.reducer is not None:
+                        self.graph_mode = False
                 if self._graph is not None and images.shape == self._gx.shape:
                     return self._replay(images)
         return self._plain_step(images)
@@ -276,6 +287,7 @@ class TripletTrainer:
         total, mean, count = self.loss(images)
         self.last_total = total.detach()        # triplet mean + kernel regularisers (what Keras reports as `loss`)
         total.backward()
+        L.DY_PLANES.clear()                     # gradient planes nobody collected (a consumer that fell back to the fp32 kernel)
         if self.reducer is not None:
             self.reducer.finish()
         if with_update:

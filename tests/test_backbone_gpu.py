@@ -509,13 +509,13 @@ def test_backbone_forward_backward_vs_oracle(dev, name, shape, enc, batch):
         return base, x, bad, total
 
     # ONE input.  Every parameter gradient within 5x the float32 oracle's own deviation (+ 1e-4) of the float64 oracle for
-    # at least 95 % of the tensors; the rest (a ReLU / arg-max decision that fell the other way than in the float32 oracle
+    # at least 97.5 % of the tensors; the rest (a ReLU / arg-max decision that fell the other way than in the float32 oracle
     # run moves the few tensors behind it) are printed and stay within the loose bounds above.  The per-STAGE gradient
     # check (tests/test_round3_gpu.py::test_stage_gradients_vs_oracle) is the one that localises a wiring error.
     base, x, bad, total = one_input(0)
     if bad:
         print(f"{name}: {len(bad)} of {total} gradient tensors beyond 5x the float32 floor: {bad}")
-    assert len(bad) <= total // 20, f"{name}: {len(bad)} of {total} tensors off: {bad}"
+    assert len(bad) <= max(total // 40, 1), f"{name}: {len(bad)} of {total} tensors off: {bad}"
     # inference path (moving stats) through Model.predict
     pred = base.predict(x)
     ctx_i = _oracle_from(base, training=False)

@@ -241,7 +241,13 @@ for step in range(3):
     if step == 0:                                               # layout now follows the first backward's hook order:
         assert red.order[0] is model.b.bias or red.order[0] is model.b.weight, "last layer's gradients come first"
         assert red.order[-1] is model.unused.bias or red.order[-1] is model.unused.weight, "never-fired parameters last"
-flat = red.flat.clone()
+def packed():                                                   # the slots without their 16-byte alignment padding
+    return torch.cat([red.flat[o:o + n] for o, n in (red._slot[p] for p in red.order)])
+for p in params:                                                # every slot on a 16-byte boundary, padding stays zero
+    assert red._slot[p][0] % 4 == 0 and p.grad.data_ptr() % 16 == red.flat.data_ptr() % 16
+assert red.flat.numel() > sum(p.numel() for p in params), "this net has odd-sized parameters: the buffer must be padded"
+assert float(red.flat.abs().sum()) == float(packed().abs().sum())
+flat = packed()
 # reference: mean over ranks of the local gradients, computed without the reducer
 ref = Net()
 ref.load_state_dict(model.state_dict())
@@ -264,7 +270,7 @@ for p in params:
 red.zero()
 model(x).pow(2).mean().backward()
 red.finish()
-assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+assert torch.allclose(packed(), flat, rtol=1e-5, atol=1e-7)
 # a second backward before finish(): every parameter still counts once (no negative bucket counters, no early re-launch)
 red.zero()
 model(x).pow(2).mean().backward()
@@ -276,14 +282,14 @@ red.zero(); red.hold(True)
 model(x).pow(2).mean().backward()
 model(x).pow(2).mean().backward()
 red.hold(False); red.reduce_all()
-assert torch.allclose(red.flat, 2 * flat, rtol=1e-5, atol=1e-7)
+assert torch.allclose(packed(), 2 * flat, rtol=1e-5, atol=1e-7)
 # hold(): a captured step's backward counts but launches nothing; reduce_all() then exchanges every bucket
 red.zero(); red.hold(True)
 model(x).pow(2).mean().backward()
 red.finish()
 assert not red._works
 red.hold(False); red.reduce_all()
-assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+assert torch.allclose(packed(), flat, rtol=1e-5, atol=1e-7)
 # direct(): kernels write the flat-buffer views themselves and notify the reducer (layers.GRAD_SINKS); emulated here by
 # filling the views by hand for the last layer and letting autograd deliver the rest
 from embeddingnet_amd import layers as L
@@ -300,7 +306,7 @@ for p, q in zip(model.b.parameters(), local.b.parameters()):
     view.copy_(q.grad); notify(); notify()                      # (a repeated notify is ignored)
     p.requires_grad_(True)
 red.finish()
-assert torch.allclose(red.flat, flat, rtol=1e-5, atol=1e-7)
+assert torch.allclose(packed(), flat, rtol=1e-5, atol=1e-7)
 red.close()
 assert not L.GRAD_SINKS and all(p.grad is None for p in params)
 model(x).pow(2).mean().backward()                               # hooks are gone: plain autograd gradients again

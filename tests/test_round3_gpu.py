@@ -347,7 +347,7 @@ print("rank", rank, "ok")
 """
 
 
-@pytest.mark.parametrize("backbone", ["simple2", "resnet18"])
+@pytest.mark.parametrize("backbone", ["simple2", "resnet18", "efficientnet-b0"])
 def test_dp_two_graph_step_equals_eager_over_gloo(tmp_path, backbone):
     """N > 1 with TripletTrainer(graph=True): forward + backward replayed as one HIP graph, the bucketed gradient all-reduce
     issued between the graphs, the optimizer as a second graph — losses and weights bit-identical to eager data-parallel

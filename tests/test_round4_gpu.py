@@ -1,0 +1,141 @@
+"""Round-4 GPU tests: the state a bench must never time (the reference's fallback triplet with hinge 0), bench.py's
+liveness record and its self-spawned ranks, data-parallel EfficientNet (odd-sized parameters in the flat gradient buffer).
+
+Oracle = test infrastructure (oracle/*.py); every device result goes through the C ABI of libembnet_hip.so.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mining as omining
+from oracle import optimizers as OO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs an MI355X"
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ the fallback step
+@pytest.mark.parametrize("rule", ["adam", "radam", "sgd"])
+def test_fallback_step_has_exactly_zero_gradients(dev, rule):
+    """/root/reference/embedding_net/datagenerators.py:246-250: when mining selects nothing, ONE triplet is emitted (last
+    pair of the last class + the first negative).  If that triplet's hinge is 0 the step's loss is 0, every gradient is
+    EXACTLY zero, and the weights move only by what the optimizer's moment slots still hold (oracle: the NumPy rule fed
+    zero gradients).  Forced here with a margin no distance on the unit sphere can violate."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    p, k, lr = 4, 3, 1e-3
+    base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None, seed=11, device=dev)
+    params = [q for q in base.parameters() if q.requires_grad]
+    opt = KerasOptimizer(params, rule, lr)
+    tr = TripletTrainer(base, opt, p, k, margin=0.5, negatives_selection_mode="hardest")
+    gen = torch.Generator(device=dev).manual_seed(21)
+    oo = OO.get_optimizer(rule, lr)
+    for _ in range(7):                                  # live steps: the moment slots fill up (RAdam passes its warm-up)
+        loss = tr.step(torch.rand((p * k, 64, 64, 3), device=dev, generator=gen))
+        assert loss.item() > 0 and int(tr.last_triplets[1].item()) > 1
+        oo.t += 1
+    # hand the oracle the device's slots (float64 copies), then both take the dead step
+    names = {"adam": ("m", "v"), "radam": ("m", "v"), "sgd": ()}[rule]
+    for i, q in enumerate(params):
+        st = opt.state.get(q, {})
+        for slot, nm in zip(("slot1", "slot2"), names):
+            oo.slots[(i, nm)] = st[slot].detach().cpu().double().numpy().copy()
+    before = [q.detach().cpu().double().numpy().copy() for q in params]
+    tr.margin = -10.0
+    x = torch.rand((p * k, 64, 64, 3), device=dev, generator=gen)
+    loss = tr.step(x)
+    trip, count = tr.last_triplets
+    n = p * k
+    assert int(count.item()) == 1 and trip[0].tolist() == [n - 2, n - 1, 0], (count, trip[0])
+    want = omining.mine_triplets(np.ones((n, n), np.float32) - np.eye(n, dtype=np.float32), p, k, -10.0, "hardest")
+    assert want["fallback"] and want["triplets"].tolist() == [trip[0].tolist()]
+    assert loss.item() == 0.0 and tr.last_total.item() == 0.0
+    for q in params:
+        assert q.grad is not None and float(q.grad.abs().max()) == 0.0, "a dead step must have exactly zero gradients"
+    ref = [w.copy() for w in before]
+    oo.step(ref, [np.zeros_like(w) for w in ref])
+    moved = 0.0
+    for q, w0, w1 in zip(params, before, ref):
+        got = q.detach().cpu().double().numpy()
+        moved = max(moved, float(np.abs(w1 - w0).max()))
+        assert np.abs(got - w1).max() <= 3e-6 * max(np.abs(w1).max(), 1e-30) + 1e-12
+    assert (moved == 0.0) == (rule == "sgd"), "momentum rules keep moving on their slots, plain SGD stands still"
+
+
+# ------------------------------------------------------------------------------------------------ bench.py
+def _bench(*extra, env=None, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                          "--settle-seconds", "0", "--sustain-seconds", "0", *extra], capture_output=True, text=True,
+                         timeout=timeout, env=dict(os.environ, **(env or {})))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_reports_a_live_problem_and_refuses_a_dead_one():
+    """The timed region must run on live gradients: bench.py cycles resident batches, records every timed step's loss and
+    mined-triplet count on the device, prints them, and exits non-zero without a JSON line if any timed step had loss 0 or
+    only the fallback triplet (forced here by an unviolable margin)."""
+    out, d = _bench("--config", "c1", "--pool", "4")
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    c = d["config"]
+    assert c["resident_batches"] == 4 and c["loss_first_timed"] > 0 and c["loss_min_timed"] > 0 and c["active_triplets_min"] > 1
+    assert "4 resident batches" in c["workload"]
+    out, d = _bench("--config", "c1", "--margin", "-10")
+    assert out.returncode != 0 and d is None and "dead problem" in out.stderr, out.stderr[-2000:]
+    out, d = _bench("--config", "c1", "--margin", "-10", "--allow-dead")
+    assert out.returncode == 0 and d["config"]["loss_min_timed"] == 0.0 and d["config"]["active_triplets_min"] == 1
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher on the command line, the form of the driver's N = 1 command): the parent
+    spawns one child per rank BEFORE touching the GPU and relays rank 0's JSON line.  Two ranks share this box's one GPU
+    over gloo (RCCL refuses two ranks per device)."""
+    out, d = _bench("--gpus", "2", "--backbone", "resnet18", "--image", "64", "--k-classes", "8",
+                    env={"EMBNET_DIST_BACKEND": "gloo"})
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 8 * 4 and d["config"]["parallelism"] == "dp2"
+    assert len(d["config"]["host_enqueue_ms_per_step_by_rank"]) == 2 and d["config"]["loss_min_timed"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ DP with odd-sized slots
+def test_dp_efficientnet_gradients_in_place(dev):
+    """EfficientNet-B0 has parameters whose size is not a multiple of 4 (squeeze-excite reduce biases of 6 / 10 elements):
+    the flat gradient buffer keeps every slot on a 16-byte boundary, so the kernels that write gradients in place (16-byte
+    stores) accept every slot, and the in-place gradients equal plain autograd's."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.parallel import GradReducer
+    from embeddingnet_amd.train_step import TripletTrainer
+    x = torch.rand((12, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    flats = []
+    for direct in (False, True):
+        base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="efficientnet-b0", backbone_weights=None, seed=2, device=dev)
+        for m in base.modules():
+            if hasattr(m, "enabled"):
+                m.enabled = False                               # dropout / drop-connect off: both runs see the same graph
+        params = [p for p in base.parameters() if p.requires_grad]
+        assert any(p.numel() % 4 for p in params)
+        opt = KerasOptimizer(params, "sgd", 0.0)
+        red = GradReducer(params)
+        tr = TripletTrainer(base, opt, 4, 3, margin=0.5, negatives_selection_mode="hardest", reducer=red)
+        red.direct(direct)
+        tr.step(x)
+        tr.step(x)
+        for p in params:
+            assert p.grad.data_ptr() % 16 == 0
+        flats.append([red.flat[off:off + n].clone() for off, n in (red._slot[p] for p in params)])
+        red.close()
+    for a, b in zip(*flats):
+        assert torch.equal(a, b)
