@@ -227,8 +227,6 @@ def main():
                          "batch stepped on for hundreds of steps is memorised, mining then finds nothing and every "
                          "gradient is exactly zero — a dead problem, not a training step")
     ap.add_argument("--allow-dead", action="store_true", help="print the line even if the timed region saw loss 0 / the fallback triplet")
-    ap.add_argument("--settle-seconds", type=float, default=6.0,
-                    help="after the W warm-up steps: keep stepping (untimed) until the step time is steady, at most this long")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="after the timed region: keep stepping this long (untimed for `value`) and report the steady-state ms/step")
     args = ap.parse_args()
@@ -319,28 +317,9 @@ def main():
         n_warm = max(n_warm, trainer.GRAPH_WARMUP + 8)     # the probe + capture (once, after GRAPH_WARMUP eager steps) stay untimed
     for _ in range(n_warm):
         step()
-    # settle (untimed): the first ~2 s of stepping run measurably slower than the steady state (r03, ResNet18: 11.3 ms per
-    # step right after 10 warm-up steps, 10.75 after 60, 10.1 after 200 and in every later window) — keep stepping in
-    # windows of 20 until the window time has stopped improving (two windows in a row less than 0.5 % faster than the one
-    # before; at most --settle-seconds), all ranks together, then time
-    settle_steps, settle_t0, prev, flat = 0, time.perf_counter(), None, 0
-    while args.settle_seconds > 0:
-        barrier()
-        w0 = time.perf_counter()
-        for _ in range(20):
-            step()
-        barrier()
-        cur = time.perf_counter() - w0
-        settle_steps += 20
-        flat = flat + 1 if (prev is not None and cur >= 0.995 * prev) else 0
-        done = flat >= 2 or time.perf_counter() - settle_t0 >= args.settle_seconds
-        if world > 1:       # ONE decision for all ranks, time-out included (the steps hold collectives: a rank that left the
-            t = torch.tensor([1.0 if done else 0.0], device=dev)    # loop alone would leave the others waiting in one)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            done = t.item() > 0.5
-        prev = cur
-        if done:
-            break
+    # (round 3 had an untimed "settle" phase here: it was the single resident batch being memorised — loss 0, all-zero
+    # gradients, a cooler chip — not a clock ramp.  On live gradients it changes nothing: profiles/r04_ab_bench_c2_live*.json,
+    # 11.065 ms/step with it, 11.05 without.  Removed.)
     trace = rank == 0 and not args.no_kernel_timer
     # kernels are timed on a FEW of the timed steps: a traced step carries two HIP events per launch (~600 marker packets on
     # a ResNet18 step, each a small bubble on the queue) and runs eagerly even where the step is a HIP graph, so it is slower
@@ -452,7 +431,6 @@ def main():
                    "step_mode": ("siamese eager" if args.mode == "siamese" else
                                  ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),
                    "mining": getattr(args, "mining", None) if args.mode != "siamese" else None,
-                   "settle_steps_after_warmup": settle_steps,
                    "sustained": sustained,
                    "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
                    "sustained_over_timed": round(sustained["ms_per_step"] / ms_per_step, 4) if sustained else None},

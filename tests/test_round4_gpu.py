@@ -77,7 +77,7 @@ def test_fallback_step_has_exactly_zero_gradients(dev, rule):
 # ------------------------------------------------------------------------------------------------ bench.py
 def _bench(*extra, env=None, timeout=900):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-                          "--settle-seconds", "0", "--sustain-seconds", "0", *extra], capture_output=True, text=True,
+                          "--sustain-seconds", "0", *extra], capture_output=True, text=True,
                          timeout=timeout, env=dict(os.environ, **(env or {})))
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     return out, (json.loads(lines[-1]) if lines else None)

@@ -9,7 +9,7 @@ out=$root/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 rm -rf "$out" && mkdir -p "$out"
 # HBM traffic counters first: the bench lines below look their dominant kernel up in profiles/rNN_pmc_traffic.json
-PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-graph --settle-seconds 0 --sustain-seconds 0"
+PCMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-graph --sustain-seconds 0"
 for c in c2 c1 c1s c3 c5; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- $PCMD --config $c > /dev/null 2> "$out/pmc_fetch_$c.err"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- $PCMD --config $c > /dev/null 2> "$out/pmc_write_$c.err"
@@ -23,7 +23,7 @@ for c in c1 c1s c3 c5; do
   python3 bench.py --config $c --steps 20 --warmup 5 --cpu-seconds 8 > "$out/bench_$c.json" 2> "$out/bench_$c.err"
 done
 EMBNET_CONV_PATCH=0 python3 bench.py --no-cpu-baseline > "$out/bench_c2_gather_convs.json" 2> "$out/bench_c2_gather_convs.err"
-CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --settle-seconds 0 --sustain-seconds 0"
+CMD="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --sustain-seconds 0"
 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- $CMD > "$out/trace_bench.json" 2> "$out/trace.err"
 python3 tools/kernel_stats.py "$out"/trace/*/*_kernel_trace.csv 13 "$out/kernel_stats" \
     "rocprofv3 --kernel-trace of \`$CMD\` (13 steps in the trace)" > /dev/null
