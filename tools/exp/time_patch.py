@@ -20,12 +20,20 @@ for (h, c, k) in SHAPES:
     def run():
         _lib.check(lib.embnet_conv2d_patch_f32(xp.data_ptr(), wp.data_ptr(), None, y.data_ptr(), N, h, h, c, 3, 3, k, 1, 1, h, h, 0, None, None,
                                                ws.data_ptr(), ws.numel() * 4, _lib.stream()))
-    for _ in range(10): run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50): run()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 50
     fl = 2.0 * N * h * h * k * 9 * c
-    print(f"n{N} {h}x{h}x{c}->{k}: {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  workspace {wsb >> 20} MiB", flush=True)
+    # WAVES="8 4": one-process A/B of the MFMA wave count (EMBNET_PATCH_WAVES is read at every launch), interleaved rounds
+    variants = os.environ.get('WAVES', '8').split()
+    best = {v: [] for v in variants}
+    for rnd in range(3 if len(variants) > 1 else 1):
+        for v in variants:
+            os.environ['EMBNET_PATCH_WAVES'] = v
+            for _ in range(10): run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50): run()
+            e1.record(); torch.cuda.synchronize()
+            best[v].append(e0.elapsed_time(e1) * 1e3 / 50)
+    for v in variants:
+        us = sorted(best[v])[len(best[v]) // 2]
+        print(f"n{N} {h}x{h}x{c}->{k} waves {v}: {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  (rounds: {' '.join(f'{u:.1f}' for u in best[v])})  workspace {wsb >> 20} MiB", flush=True)
