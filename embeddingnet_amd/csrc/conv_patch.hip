@@ -37,15 +37,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)lds, 16, (int)voff, (int)soff, 0, 0);
 }
 
-// 256 output pixels x BN channels per workgroup, on NW MFMA waves (+ the two loader waves):
-//   NW = 8: 4 (rows) x 2 (columns) waves of 64 x BN/2 — 12 fragment reads per 24 MFMAs at BN = 128 (0.5 ds_read_b128 per MFMA)
-//   NW = 4: 2 x 2 waves of 128 x BN/2 (BN = 128: 18 reads per 48 MFMAs = 0.375, half the barrier participants, 128
-//           accumulator registers) or 4 x 1 waves of 64 x 64 (BN = 64: 12 reads per 24 MFMAs instead of 9 per 12)
-template <int BN_, int NW_ = 8>
-struct GeomP {
-  static constexpr int BM = 256, BN = BN_, NW = NW_;
-  static constexpr int WAVES_N = NW_ == 8 ? 2 : (BN_ == 128 ? 2 : 1), WAVES_M = NW_ / WAVES_N;
-  static constexpr int WTM = BM / WAVES_M, WTN = BN_ / WAVES_N, TM = WTM / 32, TN = WTN / 32;
+template <int BN_>
+struct GeomP {      // 8 MFMA waves as 4 (rows) x 2 (columns); 256 output pixels x BN channels
+  static constexpr int BM = 256, BN = BN_, WAVES_M = 4, WAVES_N = 2, WTM = 64, WTN = BN_ / 2, TM = 2, TN = WTN / 32;
 };
 
 struct PatchParams {
@@ -94,9 +88,9 @@ __device__ __forceinline__ int padded_pos(int m) {            // padded-image po
   return (int)n * (pp->PH * pp->PW) + (int)oh * pp->PW + (int)ow;
 }
 
-template <int BN, int R, int S, int TPS, int NBS, int NW = 8>
-__global__ __launch_bounds__(64 * (NW + 2)) void conv_patch_kernel(const PatchParams p) {
-  using G = GeomP<BN, NW>;
+template <int BN, int R, int S, int TPS, int NBS>
+__global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
+  using G = GeomP<BN>;
   constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
   constexpr int SBY = TPS * 3 * BN * 32;                 // one weight slot: TPS taps x 3 planes x BN rows x 32 bytes
   constexpr int NBI = TPS * 3 * (BN / 32);               // DMA instructions per weight slot
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void conv_patch_kernel(const PatchPa
   if (n_items == 0) return;
   const int dhalf = (lane & 1) ^ ((lane >> 4) & 1);      // logical 16-byte half this lane's DMA piece holds
 
-  if (wave == NW) {
+  if (wave == 8) {
     // ---- weight loader: slot (gs % NBS) <- weights of step gs, D steps ahead of the MFMA waves ----------------------
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wp), 0, 3u * p.w_plane_bytes, 0x00020000);
     const int K = p.g.K, NCC = p.g.C / 16;
@@ -160,7 +154,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void conv_patch_kernel(const PatchPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-  if (wave == NW + 1) {
+  if (wave == 9) {
     // ---- patch loader: buffer (gc & 1) <- patch of chunk gc, requested at the first step of chunk gc - 1 -------------
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xp), 0, 3u * p.x_plane_bytes, 0x00020000);
     const int NG = LR / 32;
@@ -315,13 +309,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void conv_patch_kernel(const PatchPa
         }
         if (p.stats) {                                    // BatchNorm statistics of the layer that follows (as conv.hip's epilogue)
           s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-          if (h == 0 && cok) {                  // four partial rows per tile whatever the wave grid (the fix-up kernel's bands)
-            constexpr int RPW = 4 / G::WAVES_M;
-            const long prow = (long)cur.tile_m * 4 + (wave / G::WAVES_N) * RPW, P = p.stats_rows;
+          if (h == 0 && cok) {
+            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = p.stats_rows;
             p.stats[(long)col * P + prow] = s1;
             p.stats[((long)K + col) * P + prow] = s2;
-#pragma unroll
-            for (int z = 1; z < RPW; ++z) { p.stats[(long)col * P + prow + z] = 0.f; p.stats[((long)K + col) * P + prow + z] = 0.f; }
           }
         }
       }
@@ -464,11 +455,11 @@ extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const
   return check_launch("conv_weight_planes");
 }
 
-template <int BN, int TPS, int NBS, int NW = 8>
+template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  conv_patch_kernel<BN, 3, 3, TPS, NBS, NW><<<p.grid, 64 * (NW + 2), lds, st>>>(p);
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  conv_patch_kernel<BN, 3, 3, TPS, NBS><<<p.grid, 640, lds, st>>>(p);
 }
 
 extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
@@ -497,11 +488,6 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
                                    : "void embnet::patch::conv_patch_kernel<64, 3, 3, 3, 3>(embnet::patch::PatchParams)",
                       2.0 * M * k * r * s * c,
                       6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
-    const char* nwe = getenv("EMBNET_PATCH_WAVES");            // experiment switch (A/B in one process): 4 MFMA waves
-    if (nwe && nwe[0] == '4') {
-      if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6, 4>(p, pl.lds, st); else launch_patch<128, 1, 4, 4>(p, pl.lds, st); }
-      else launch_patch<64, 3, 3, 4>(p, pl.lds, st);
-    } else
     if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
     else launch_patch<64, 3, 3>(p, pl.lds, st);
   }
