@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "embnet.h")
 _lib = None
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
-           "uint64_t": ctypes.c_uint64, "void": None}
+           "uint64_t": ctypes.c_uint64, "double": ctypes.c_double, "void": None}
 
 
 class EmbnetError(RuntimeError):
@@ -54,7 +54,7 @@ def lib():
         for name, (res, argtypes) in parse_header().items():
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, argtypes
-        if l.embnet_abi_version() != 12:
+        if l.embnet_abi_version() != 13:
             raise EmbnetError("libembnet_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -74,8 +74,16 @@ class Seq(nn.Module):
             setattr(self, k, m)
 
     def forward(self, x):
-        for k in self._order:
-            x = getattr(self, k)(x)
+        # a Conv2D directly followed by a training-mode BatchNormalization (simple2's conv -> ReLU -> BN blocks) hands it the
+        # per-channel sums from its epilogue (bias and ReLU applied): the BN does not read the tensor for its statistics
+        mods = [getattr(self, k) for k in self._order]
+        for i, m in enumerate(mods):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, L.Conv2D) and isinstance(nxt, L.BatchNormalization) and nxt.training and EPILOGUE_STATS
+                    and torch.is_grad_enabled()):
+                x = m(x, emit_stats=True)
+            else:
+                x = m(x)
         return x
 
 

@@ -619,6 +619,65 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+
+// The same sum for MANY weight gradients in one launch (embnet_slab_reduce_multi): a training step's backward leaves the
+// split-K slabs of every conv layer in buffers of their own and adds them up once, before the optimizer (or before a
+// bucket's all-reduce), instead of with one ~8 us launch per layer (ResNet18: 21, simple2: 7).  chunks = (tensor index,
+// block of 32 float4 columns) per workgroup; per element the summation order is slab_reduce_kernel's, so the result is
+// bit-identical to the per-layer launches.
+struct SlabTensor { const float* slabs; float* out; long n; int splits; int first_block; };
+static_assert(sizeof(SlabTensor) == 32, "descriptor layout is part of the ABI (include/embnet.h)");
+constexpr int SLAB_BATCH = 112;                      // descriptors per launch: they travel as the kernel argument (< 4 KiB), so
+struct SlabBatch { SlabTensor t[SLAB_BATCH]; int n; int pad; };    // a captured HIP graph holds them by value — no table in memory
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabBatch) {
+  // read the descriptors straight from the kernel-argument segment (uniform addresses: scalar loads); indexing the by-value
+  // argument dynamically would make the compiler copy all of it to scratch first
+  typedef const SlabBatch __attribute__((address_space(4)))* kargb;
+  kargb pb = (kargb)__builtin_amdgcn_kernarg_segment_ptr();
+  int lo = 0, hi = pb->n - 1;                        // the tensor whose block range holds this workgroup
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)blockIdx.x >= pb->t[mid].first_block) lo = mid; else hi = mid - 1; }
+  SlabTensor t;
+  t.slabs = pb->t[lo].slabs; t.out = pb->t[lo].out; t.n = pb->t[lo].n; t.splits = pb->t[lo].splits; t.first_block = pb->t[lo].first_block;
+  const int blk = (int)blockIdx.x - t.first_block;
+  const long n = t.n; const int splits = t.splits;
+  if (n & 3) {                       // scalar path: this workgroup owns 128 consecutive elements
+    const long i = (long)blk * 128 + (threadIdx.x & 127);
+    if (threadIdx.x < 128 && i < n) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += t.slabs[(long)k * n + i];
+      t.out[i] = s;
+    }
+    return;
+  }
+  __shared__ float4 part[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long n4 = n >> 2, i4 = (long)blk * 32 + col;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  if (i4 < n4) {
+    const float4* src = reinterpret_cast<const float4*>(t.slabs) + i4;
+    int k = grp;
+    for (; k + 8 < splits; k += 16) {
+      const float4 u = src[(long)k * n4], v = src[(long)(k + 8) * n4];
+      a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    }
+    if (k < splits) { const float4 u = src[(long)k * n4]; a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w; }
+  }
+  part[grp][col] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (grp == 0 && i4 < n4) {
+    float4 r[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r[g] = part[g][col];
+#define EMBNET_ADD4(p, q) make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w)
+    const float4 s01 = EMBNET_ADD4(r[0], r[1]), s23 = EMBNET_ADD4(r[2], r[3]), s45 = EMBNET_ADD4(r[4], r[5]),
+                 s67 = EMBNET_ADD4(r[6], r[7]);
+    const float4 lo = EMBNET_ADD4(s01, s23), hi = EMBNET_ADD4(s45, s67);
+    reinterpret_cast<float4*>(t.out)[i4] = EMBNET_ADD4(lo, hi);
+#undef EMBNET_ADD4
+  }
+}
+
 }  // namespace embnet
 
 using namespace embnet;
@@ -983,6 +1042,36 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
   return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
                     stream,
                     true, true);
+}
+
+extern "C" int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow) {
+  if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0) return 0;
+  int tile, splits, ktps;
+  wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, splits, ktps);
+  return splits;
+}
+
+extern "C" int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream) {
+  EMBNET_CHECK_ARG(host_table && n_tensors > 0, "slab_reduce_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const SlabTensor* src = (const SlabTensor*)host_table;
+  for (int first = 0; first < n_tensors; first += SLAB_BATCH) {
+    SlabBatch b{};
+    b.n = n_tensors - first < SLAB_BATCH ? n_tensors - first : SLAB_BATCH;
+    int blocks = 0; double bytes = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.t[i] = src[first + i];
+      EMBNET_CHECK_ARG(b.t[i].slabs && b.t[i].out && b.t[i].n > 0 && b.t[i].splits > 0, "slab_reduce_multi: bad descriptor %d", first + i);
+      EMBNET_CHECK_ARG((b.t[i].n & 3) || !((((uintptr_t)b.t[i].slabs) | ((uintptr_t)b.t[i].out)) & 15),
+                       "slab_reduce_multi: descriptor %d needs 16-byte aligned slabs and out", first + i);
+      b.t[i].first_block = blocks;
+      blocks += (int)((b.t[i].n + 127) / 128);
+      bytes += 4.0 * b.t[i].n * (b.t[i].splits + 1);
+    }
+    EMBNET_TRACE("embnet::slab_reduce_multi_kernel", TRACE_BYTES, bytes, st);
+    slab_reduce_multi_kernel<<<blocks, 256, 0, st>>>(b);
+  }
+  return check_launch("slab_reduce_multi");
 }
 
 // The same in two calls — split-K GEMM into the slabs, then the fixed-order slab sum — so a caller can

@@ -241,6 +241,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
   }
 }
 
+// BatchNorm backward apply for a BN whose INPUT is the output of a Conv2D / Dense with a fused ReLU (the small backbones'
+// conv -> ReLU -> BN blocks, /root/reference/embedding_net/backbones.py:44-68): the ReLU's backward and the bias gradient in
+// the same pass.  x >= 0 is the ReLU's output, so its mask is (x > 0):  dz = dx * [x > 0]  is what the producer's data /
+// weight gradients need, and the bias gradient is the column sum of dz.  A column-reduction kernel (rows by block, as the
+// statistics passes) that writes dz on the way: replaces bn_bwd_apply4 + relu_bwd_colsum (12 + 12 -> 16 bytes per element).
+__global__ __launch_bounds__(256) void bn_bwd_apply_inrelu4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   long m, int c4, ColGeom g, float inv_m,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                                   int relu, int training, float* __restrict__ dz_out,
+                                                                   float* __restrict__ partial) {
+  struct K6 { float4 sc, sh, mu, rs, db, dg; };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  col_reduce2_v4p(m, c4, g, partial, [&](int q) {
+    K6 k{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q], z4, z4, z4, z4};
+    if (training) {
+      k.mu = reinterpret_cast<const float4*>(mean)[q]; k.rs = reinterpret_cast<const float4*>(rstd)[q];
+      k.db = reinterpret_cast<const float4*>(dbeta)[q]; k.dg = reinterpret_cast<const float4*>(dgamma)[q];
+    }
+    return k;
+  }, [&](long r, int q, const K6& k, float4& a, float4&) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
+    float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
+    const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs, db = k.db, dg = k.dg;
+    if (relu) {
+      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
+      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
+    }
+    float4 o;
+    if (training) {                                      // (the arithmetic of bn_bwd_apply4_kernel, term for term)
+      o.x = sc.x * (dz.x - db.x * inv_m - (xv.x - mu.x) * rs.x * dg.x * inv_m);
+      o.y = sc.y * (dz.y - db.y * inv_m - (xv.y - mu.y) * rs.y * dg.y * inv_m);
+      o.z = sc.z * (dz.z - db.z * inv_m - (xv.z - mu.z) * rs.z * dg.z * inv_m);
+      o.w = sc.w * (dz.w - db.w * inv_m - (xv.w - mu.w) * rs.w * dg.w * inv_m);
+    } else {
+      o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
+    }
+    o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f; o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
+    reinterpret_cast<float4*>(dz_out)[r * c4 + q] = o;
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+  });
+}
+
 // (A one-launch BatchNorm backward — sums, two spin barriers across a co-resident 1024-workgroup grid, then dx from the
 // still-cached inputs — was built and measured in round 2: 144 us per layer against 27 + 31 us for the two passes
 // (barrier latency, 16 instead of 32 waves per CU, 64-channel finalize on 64 workgroups).  Removed.)
@@ -1058,6 +1102,31 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
   return check_launch("bn_bwd");
+}
+
+extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                    const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                    float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(dy && x && scale && shift && dz && dgamma && dbeta && dbias && workspace, "bn_bwd_inrelu: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0, "bn_bwd_inrelu: m=%ld c=%d (c %% 4 == 0 required)", m, c);
+  EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd_inrelu: training needs saved statistics");
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "bn_bwd_inrelu: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  float* partial = (float*)workspace;
+  const ColGeom g4 = col_geom(m, c / 4);
+  if (save_mean && save_rstd) {
+    { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial); }
+    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
+  } else {
+    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
+    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+  }
+  { EMBNET_TRACE("embnet::bn_bwd_apply_inrelu4_kernel", TRACE_BYTES, 12.0 * m * c, stream);
+    bn_bwd_apply_inrelu4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, 1.f / (float)m, save_mean, save_rstd, scale, shift,
+                                                               dbeta, dgamma, relu, training, dz, partial); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias);
+  return check_launch("bn_bwd_inrelu");
 }
 
 extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,

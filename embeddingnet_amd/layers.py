@@ -51,6 +51,59 @@ def workspace(nbytes, device):
     return buf
 
 
+# Deferred weight-gradient slab sums.  conv2d_wgrad splits its pixel reduction over workgroups into fp32 slabs and adds
+# them up with a second, launch-sized kernel (7-10 us each: 21 per ResNet18 step, 7 per simple2 step).  While SLAB_DEFER[0] is
+# set (TripletTrainer does, around backward) the split-K kernel writes into a slab buffer of the layer's own, the sum is
+# queued, and flush_slab_reduces() adds ALL queued gradients up in one launch (embnet_slab_reduce_multi; same summation
+# order, bit-identical) — before the optimizer, or before a gradient bucket's all-reduce.  Nothing else may read a queued
+# dw before the flush; outside the trainer the flag is off and every wgrad finishes in place.
+SLAB_DEFER = [False]
+SLAB_DEFER_ENABLED = [_os.environ.get("EMBNET_SLAB_DEFER", "1") != "0"]      # [False]: per-layer slab sums everywhere (A/B)
+_SLAB_PENDING = []          # (slab buffer, dw, elements, splits)
+_SLAB_BUFS = {}             # kernel storage address -> slab buffer (scratch: any stale content is overwritten before use)
+
+
+def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0):
+    """dw[r,s,c,k] = weight gradient of a convolution (embnet_conv2d_wgrad_f32), its slab sum deferred when SLAB_DEFER."""
+    if SLAB_DEFER[0]:
+        splits = lib.embnet_conv2d_wgrad_splits(n, c, r, s, k, oh, ow)
+        if splits > 1:
+            need = lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4
+            buf = _SLAB_BUFS.get(w.data_ptr())
+            if buf is None or buf.numel() < need or buf.device != x.device:
+                if len(_SLAB_BUFS) > 512:
+                    _SLAB_BUFS.clear()
+                buf = _SLAB_BUFS[w.data_ptr()] = torch.empty(need, dtype=torch.float32, device=x.device)
+            check(lib.embnet_conv2d_wgrad_slabs_f32(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
+                                                    stride, pt, pl, oh, ow, in_scale, in_shift, in_act, stream()))
+            # (an alias of dw, not dw itself: autograd adopts a returned gradient as .grad only while nobody else holds that
+            # tensor object — a second reference would make it clone the still-unreduced buffer)
+            _SLAB_PENDING.append((buf, dw.detach(), r * s * c * k, splits, w))
+            return
+    ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+    check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl,
+                                      oh, ow, in_scale, in_shift, in_act, stream()))
+
+
+def flush_slab_reduces():
+    """One launch for the slab sums queued since the last flush (no-op when nothing is queued)."""
+    if not _SLAB_PENDING:
+        return
+    import numpy as np
+    rows = np.asarray([(b.data_ptr(), d.data_ptr(), n, sp) for b, d, n, sp, _ in _SLAB_PENDING], dtype=np.int64)
+    check(_lib.lib().embnet_slab_reduce_multi(rows.ctypes.data, len(_SLAB_PENDING), stream()))
+    for _, d, _, _, w in _SLAB_PENDING:                     # a gradient autograd copied instead of adopting: bring it up to date
+        g = getattr(w, "grad", None)
+        if g is not None and g.data_ptr() != d.data_ptr() and g.shape == d.shape and not _in_flat_buffer(w, d):
+            g.copy_(d)
+    _SLAB_PENDING.clear()
+
+
+def _in_flat_buffer(w, d):
+    s = GRAD_SINKS.get(w.data_ptr()) if GRAD_SINKS else None
+    return s is not None and s[0].data_ptr() == d.data_ptr()
+
+
 # Gradient sinks (data-parallel training, parallel.GradReducer.direct): parameter storage address -> (flat-buffer view,
 # notify).  A weight-gradient kernel whose parameter has a sink writes its result straight into the view and returns
 # no gradient to autograd, so no AccumulateGrad `add_` kernel runs for it; `notify` tells the reducer the slot is final.
@@ -82,6 +135,14 @@ def _done(out, notify):
 # when the weights changed: WEIGHT_EPOCH is bumped by KerasOptimizer.step(); other writers show in the tensor version.
 # A DY_PLANES entry holds the gradient tensor beside its planes: while the entry lives that address cannot pass to another
 # tensor, and autograd cannot accumulate a second gradient into it in place (it does so only into buffers nobody else holds).
+# conv -> ReLU -> BatchNormalization blocks (the small backbones, reference backbones.py:44-68): a Conv2D with a fused ReLU
+# and a bias tags its output (`y._relu_conv = (bias,)`); the training-mode BatchNormalization that reads it then runs its
+# backward with the ReLU's backward folded in (embnet_bn_bwd_inrelu: dz = dx * [x > 0] and the bias gradient, one pass) and
+# leaves (dz alias, dbias) in RELU_DONE under dz's address; the conv's backward finds its incoming gradient there and skips
+# its own relu_bwd_colsum pass.  A conv whose output has a second consumer never finds the entry (autograd hands it the SUM,
+# another tensor) and masks again — harmless, dz is already zero where the mask is.
+FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
+RELU_DONE = {}
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
 DY_PLANES = {}
 _ACT_PLANES = {}
@@ -233,7 +294,13 @@ class _Conv2dFn(torch.autograd.Function):
         dskip = _c(dskip) if dskip is not None else None
         dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.relu:
+        done = RELU_DONE.pop(dy.data_ptr(), None) if (ctx.relu and RELU_DONE) else None
+        if done is not None and done[0].shape == dy.shape:
+            dz = dy                          # the BatchNormalization behind this conv already applied the ReLU mask ...
+            if want_db:                      # ... and summed the bias gradient (into the bias' sink when it has one)
+                db = _done(done[1], done[2])
+                want_db = False
+        elif ctx.relu:
             dz = torch.empty_like(dy)
             if want_db:                      # dz and its column sums (the bias gradient) in one pass
                 db, db_note = _sink(ctx.bias_ref)
@@ -251,10 +318,7 @@ class _Conv2dFn(torch.autograd.Function):
         in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
 
         def run_wgrad():
-            ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            args = (ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
-                    in_scale, in_shift, ctx.in_act)
-            check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
+            conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act)
 
         dw_note = None
         if need_dw:
@@ -359,10 +423,7 @@ class _ConvPairFn(torch.autograd.Function):
             dw = None
             if need_dw:
                 dw, note = _sink(w)
-                ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-                args = (ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow,
-                        in_scale, in_shift, ctx.in_act)
-                check(lib.embnet_conv2d_wgrad_f32(*args, stream()))
+                conv_wgrad(lib, x, dy, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act)
                 dw = _done(dw, note)
             dws.append(dw)
         if dx is not None and first:
@@ -487,6 +548,8 @@ class Conv2D(nn.Module):
             y._bn_partials = out_stats
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
+        if self.relu and self.bias is not None and FUSE_RELU_BN[0] and self.kernel.shape[3] % 4 == 0 and residual is None:
+            y._relu_conv = (self.bias,)        # see RELU_DONE
         return (y, out[1]) if with_skip else y
 
     def patch_capable(self, x_shape):
@@ -601,7 +664,7 @@ def _bn_grad_targets(ctx, c, device, gamma_idx=1, beta_idx=2):
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
-                with_skip=False, emit_planes=False, emit_dx_planes=False):
+                with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None):
         """emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
         address; BatchNormalization.forward hangs them on the tensor).  emit_dx_planes: backward writes dx also as planes
         into DY_PLANES (the producer of x is a patch conv, whose data gradient reads them)."""
@@ -623,6 +686,7 @@ class _BatchNormFn(torch.autograd.Function):
                                                ptr(y), ptr(planes), stream()))
             _ACT_PLANES[y.data_ptr()] = planes
         ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
+        ctx.in_relu_bias = in_relu_bias if (in_relu_bias is not None and not with_skip and c % 4 == 0) else None
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
@@ -651,11 +715,22 @@ class _BatchNormFn(torch.autograd.Function):
             if len(DY_PLANES) > 64:                  # entries nobody collected (a consumer fell back to the fp32 kernel)
                 DY_PLANES.clear()
             DY_PLANES[dx.data_ptr()] = (planes, dx)
-        check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
-                                ws.numel() * 4, stream()))
+        if ctx.in_relu_bias is not None and planes is None and dskip is None:
+            # x is the output of a conv with a fused ReLU: its backward (mask + bias gradient) rides on this pass
+            (bias,) = ctx.in_relu_bias
+            db, db_note = _sink(bias)
+            check(lib.embnet_bn_bwd_inrelu(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
+                                           (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training), ptr(dx),
+                                           ptr(tg), ptr(tb), ptr(db), ptr(ws), ws.numel() * 4, stream()))
+            if len(RELU_DONE) > 64:
+                RELU_DONE.clear()
+            RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
+        else:
+            check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
+                                    int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
+                                    ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNGapFn(torch.autograd.Function):
@@ -824,9 +899,10 @@ class BatchNormalization(nn.Module):
             raw, stats = _BNDeferFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                           self.momentum, self.relu, self.training, _partials_of(x, self.training))
             return Deferred(raw, stats, self.relu)
+        in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled()) else None
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                   self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
-                                  False, want_dx_planes)
+                                  False, want_dx_planes, in_relu_bias)
 
 
 class _InputBNConvFn(torch.autograd.Function):

@@ -238,6 +238,8 @@ class GradReducer:
         b = self._bucket_of[p]
         self._left[b] -= 1
         if self._left[b] == 0 and self._reduce and not self._hold:
+            from . import layers as L
+            L.flush_slab_reduces()                          # queued weight-gradient sums must land before the bucket leaves
             s, e, _ = self.buckets[b]
             self._works.append(dist.all_reduce(self.flat[s:e], op=self._avg, group=self.group, async_op=True))
 

@@ -286,7 +286,15 @@ class TripletTrainer:
             self.opt.zero_grad(set_to_none=True)
         total, mean, count = self.loss(images)
         self.last_total = total.detach()        # triplet mean + kernel regularisers (what Keras reports as `loss`)
-        total.backward()
+        # weight-gradient slab sums: queued, one launch for all (layers.conv_wgrad).  Needs every dw to stay untouched until
+        # the flush: a fresh .grad (zero_grad(set_to_none)) or the reducer's in-place sinks — not an AccumulateGrad add_
+        L.SLAB_DEFER[0] = L.SLAB_DEFER_ENABLED[0] and (self.reducer is None or self.reducer._direct)
+        try:
+            total.backward()
+        finally:
+            L.SLAB_DEFER[0] = False
+            L.flush_slab_reduces()              # (with a reducer: what its buckets have not flushed already)
+        L.RELU_DONE.clear()
         L.DY_PLANES.clear()                     # gradient planes nobody collected (a consumer that fell back to the fp32 kernel)
         if self.reducer is not None:
             self.reducer.finish()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 12
+#define EMBNET_ABI_VERSION 13
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -199,6 +199,16 @@ int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, v
                                    int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
                                    int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
                                    void* stream);
+/* Split count of conv2d_wgrad's plan for a geometry (1 = the kernel writes dw itself, no slabs). */
+int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow);
+/* The slab sums of MANY weight gradients in one launch (a step's backward runs embnet_conv2d_wgrad_slabs_f32 into
+ * per-layer slab buffers and adds them up once, before the optimizer / a bucket's all-reduce).
+ * host_table: HOST array of n_tensors descriptors { const float* slabs; float* out; int64 n; int32 splits; int32 reserved }
+ * (32 bytes; device pointers inside): out[i] = sum_s slabs[s*n + i], in embnet_conv2d_wgrad_reduce_f32's order
+ * (bit-identical).  The descriptors travel as kernel arguments (112 per launch), so nothing has to stay alive for a
+ * captured graph.  slabs and out 16-byte aligned when n % 4 == 0. */
+int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream);
+
 /* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
@@ -264,6 +274,12 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                   float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm backward for a BN whose input x is the output of a layer with a fused ReLU (conv -> ReLU -> BN, the small
+ * backbones' block): dz = d(x) * [x > 0] (the gradient the producer's data / weight gradients consume, ReLU backward
+ * included) and dbias[c] = column sums of dz (the producer's bias gradient), in the pass that computes d(x).  c % 4 == 0. */
+int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                         const float* scale, const float* shift, int relu, int training, float* dz, float* dgamma,
+                         float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 /* dx_planes (NULL, or 3*m*c bf16, c % 16 == 0): dx ALSO as the pre-split planes embnet_conv2d_patch_f32 takes (below) —
  * the gradient of the convolution output in front of this BatchNormalization, i.e. that convolution's data-gradient operand. */
 

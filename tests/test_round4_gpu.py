@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from embeddingnet_amd import _lib
 from oracle import mining as omining
 from oracle import optimizers as OO
 
@@ -139,3 +140,85 @@ def test_dp_efficientnet_gradients_in_place(dev):
         red.close()
     for a, b in zip(*flats):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ deferred slab sums
+@pytest.mark.parametrize("backbone,shape", [("resnet18", (64, 64, 3)), ("simple2", (64, 64, 3))])
+def test_deferred_slab_sums_are_bit_identical(dev, backbone, shape):
+    """The weight gradients' split-K slab sums queued during backward and added up by ONE launch
+    (embnet_slab_reduce_multi) equal the per-layer sums bit for bit: same loss, gradients and updated weights."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd import layers as L
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    x = torch.rand((12,) + shape, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    res, launches = [], []
+    for defer in (False, True):
+        L.SLAB_DEFER_ENABLED[0] = defer
+        try:
+            base, _ = B.get_backbone(shape, encodings_len=32, backbone_name=backbone, backbone_weights=None, seed=4, device=dev)
+            for m in base.modules():
+                if hasattr(m, "enabled"):
+                    m.enabled = False
+            params = [p for p in base.parameters() if p.requires_grad]
+            tr = TripletTrainer(base, KerasOptimizer(params, "adam", 1e-3), 4, 3, margin=0.5, negatives_selection_mode="hardest")
+            tr.step(x)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            loss = tr.step(x)
+            torch.cuda.synchronize()
+            names = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+        finally:
+            L.SLAB_DEFER_ENABLED[0] = True
+        launches.append((sum("slab_reduce_kernel" in n for n in names), sum("slab_reduce_multi" in n for n in names)))
+        res.append((loss.clone(), [p.grad.clone() for p in params], [p.detach().clone() for p in params]))
+    # (the ResNet stem's padded-kernel gradient is consumed at once and keeps its own slab sum)
+    assert launches[0][0] >= 3 and launches[0][1] == 0 and launches[1][0] <= 1 and launches[1][1] == 1, launches
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ conv -> ReLU -> BN blocks
+@pytest.mark.parametrize("shape,k,cout", [((4, 20, 20, 32), 3, 32), ((3, 17, 15, 16), 5, 64), ((2, 9, 9, 64), 4, 128)])
+def test_relu_backward_fused_into_batchnorm_backward(dev, shape, k, cout):
+    """conv(+bias, ReLU) -> BatchNormalization (simple2's block, reference backbones.py:44-68): with the ReLU's backward and
+    the bias gradient folded into the BN backward pass (embnet_bn_bwd_inrelu) and the BN statistics taken from the conv
+    epilogue, outputs and all gradients equal the unfused chain — dx, dW, dgamma, dbeta bit for bit where the arithmetic is
+    the same, the bias gradient and the epilogue statistics within fp32 summation-order differences — and the fused path
+    launches no relu_bwd_colsum / bn_stats kernel."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_RELU_BN[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(3)
+            conv = L.Conv2D(shape[-1], cout, k, activation="relu", gen=gen).to(dev)
+            with torch.no_grad():
+                conv.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+            bn = L.BatchNormalization(cout).to(dev).train()
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, cout)); bn.beta.copy_(torch.linspace(-0.2, 0.2, cout))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y = bn(conv(xt, emit_stats=fuse))
+            y.backward(torch.sin(y.detach() * 2))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(y=y.detach(), dx=xt.grad, dW=conv.kernel.grad, db=conv.bias.grad, dgamma=bn.gamma.grad, dbeta=bn.beta.grad,
+                             mm=bn.moving_mean.clone())
+        finally:
+            L.FUSE_RELU_BN[0] = True
+            L.RELU_DONE.clear()
+    assert any("relu_bwd_colsum" in n for n in names[False]) and any("bn_stats" in n for n in names[False])
+    assert not any("relu_bwd" in n or "bn_stats" in n for n in names[True]), names[True]
+    assert any("bn_bwd_apply_inrelu4" in n for n in names[True])
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (key, (a - b).abs().max().item(), scale)
+    # the masked gradient itself is exact: dx / dW are computed from identical dz values when the statistics agree; with the
+    # epilogue statistics they differ in the last bits only
+    assert not L.RELU_DONE
