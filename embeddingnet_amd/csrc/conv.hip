@@ -520,6 +520,35 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
 
 struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; int stagger; };
 
+// The weight gradient on the 16x16x32 MFMA shape (gemm_engine.h, "K32"): same tiles, loaders, slabs and summation order per
+// output element over k tiles; inside a k tile the 32 pixels are summed by one instruction per term instead of two.
+template <class G>
+__device__ __forceinline__ void conv_wgrad_k32_body(const ConvWgradParams& p) {
+  using TA = TileKM<G::BM>;
+  using TB = TileKM<G::BN>;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
+  prio_hi();
+  const int M = p.g.R * p.g.S * p.g.C, Kg = p.g.N * p.g.OH * p.g.OW;
+  const int tiles_n = (p.g.K + G::BN - 1) / G::BN;
+  const int tiles = ((M + G::BM - 1) / G::BM) * tiles_n;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  if (split >= p.splits) return;
+  const int m0 = (tile / tiles_n) * G::BM, n0 = (tile % tiles_n) * G::BN;
+  const int kt_total = (Kg + BK - 1) / BK;
+  const int kt0 = split * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
+  LoadConvWgradA<G::BM, true, false> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
+  LoadRowsKM<G::BN, true> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
+  f32x4 acc[G::TM][G::TN][4];
+  gemm_mainloop3_k32<G, TA, TB>(la, lb, kt0, kt1, reinterpret_cast<unsigned char*>(smem), acc, (int)blockIdx.x >= p.fair_from);
+  float* out = p.out + (long)split * M * p.g.K;
+  for_each_acc16_row4<G>(acc, smem, [&](int r, int c, float4 v) {
+    const int row = m0 + r, col = n0 + c;
+    if (row < M && col < p.g.K) *reinterpret_cast<float4*>(out + (long)row * p.g.K + col) = v;
+  });
+}
+template <class G>
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_k32_kernel(ConvWgradParams p) { conv_wgrad_k32_body<G>(p); }
+
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
 template <class G, bool VA, bool VB, bool TF>
 __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
@@ -803,6 +832,8 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
     default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
   }
 
+static bool wgrad_k32() { static const bool v = env_long("EMBNET_WGRAD_K32", 1) != 0; return v; }
+
 extern "C" int embnet_conv_mfma_terms(void) { return EMBNET_CONV_SPLIT ? 6 : 1; }
 
 extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
@@ -1018,11 +1049,27 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
                    "conv2d_wgrad: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
   p.tf = InputTransform{in_scale, in_shift, in_act};
   if (do_main) {
-    EMBNET_TRACE_FLOP(conv_kernel_name(in_scale ? "conv_wgrad_tf_kernel" : "conv_wgrad_kernel", "ConvWgradParams", tile,
+    // 16x16x32 MFMA shape for the weight gradient (both operands k-major: same fragment reads and matrix cycles as
+    // 32x32x16, but the chip clocks higher on it under load): 1-6 % faster per layer, profiles/r04_exp_wgrad_k32.txt.
+    // EMBNET_WGRAD_K32=0: the 32x32x16 kernels (A/B).
+    static const bool k32 = wgrad_k32();
+    char k32name[160];
+    snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
+    EMBNET_TRACE_FLOP((!in_scale && va && vb && k32 && !p.xcd_order) ? k32name :
+                      conv_kernel_name(in_scale ? "conv_wgrad_tf_kernel" : "conv_wgrad_kernel", "ConvWgradParams", tile,
                                        (in_scale || (va && vb)) ? "true, true" : (vb ? "false, true" : "false, false")),
                       2.0 * n * oh * ow * (double)k * rows,
                       4.0 * ((double)n * h * wd * c + (double)n * oh * ow * k + (double)rows * k * p.splits), st);
     if (in_scale) { LAUNCH_WGRAD(conv_wgrad_tf_kernel, true, true) }
+    else if (va && vb && k32 && !p.xcd_order) {
+      switch (tile) {
+        case 0: conv_wgrad_k32_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
+        case 1: conv_wgrad_k32_kernel<G128x64><<<grid, 256, 0, st>>>(p); break;
+        case 2: conv_wgrad_k32_kernel<G128x32><<<grid, 256, 0, st>>>(p); break;
+        case 4: conv_wgrad_k32_kernel<G192x64><<<grid, 256, 0, st>>>(p); break;
+        default: conv_wgrad_k32_kernel<G64x64><<<grid, 256, 0, st>>>(p); break;
+      }
+    }
     else if (va && vb) { LAUNCH_WGRAD(conv_wgrad_kernel, true, true) }
     else if (vb) { LAUNCH_WGRAD(conv_wgrad_kernel, false, true) }
     else { LAUNCH_WGRAD(conv_wgrad_kernel, false, false) }
@@ -1112,8 +1159,11 @@ extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd,
   } else if (kind == 2) {
     int tile, sp, kt;
     wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
-    snprintf(buf, sizeof buf, "void embnet::conv_wgrad_kernel<embnet::Geom<%s>, %s, %s>(embnet::ConvWgradParams)",
-             geoms[tile], ((k & 3) == 0) ? t : "false", tk);
+    if (((c | k) & 3) == 0 && wgrad_k32())
+      snprintf(buf, sizeof buf, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", geoms[tile]);
+    else
+      snprintf(buf, sizeof buf, "void embnet::conv_wgrad_kernel<embnet::Geom<%s>, %s, %s>(embnet::ConvWgradParams)",
+               geoms[tile], ((k & 3) == 0) ? t : "false", tk);
   } else {
     buf[0] = 0;
   }

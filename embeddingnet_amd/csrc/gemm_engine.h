@@ -393,8 +393,10 @@ struct TileKM3 {
   static constexpr int PLANE = BK * PITCH, BYTES = 3 * PLANE;
   // byte offset of row `row` (a multiple of 4) of k-row k.  128-byte rows: k-rows 0..3 -> slots (0|1) of the windows
   // [0,128) and [128,256): flip the 64-byte half with bit 1 of k; 256-byte rows: XOR the 64-byte slot with k & 3.
+  // (bit 3 of k also flips the 32-byte half: the K = 32 fragments of frag16 read k-rows 8 apart in one 32-lane pass; the
+  // K = 16 fragments never mix the two values of bit 3 in a pass, so they do not notice)
   __device__ static __forceinline__ int off(int k, int row) {
-    const int b = row * 2;
+    const int b = (row * 2) ^ (((k >> 3) & 1) << 5);
     if (!SWZ) return k * PITCH + b;
     return k * PITCH + (ROWS == 64 ? (b ^ (((k >> 1) & 1) << 6)) : (b ^ ((k & 3) << 6)));
   }
@@ -409,6 +411,22 @@ struct TileKM3 {
   __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
     const int k = 16 * st + 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int row = r0 + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+    const unsigned char* a = s + off(k, row);
+    const unsigned char* a4 = s + off(k + 4, row);
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a4 + q * PLANE));
+      const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      v[q] = __builtin_bit_cast(bf16x8, w);
+    }
+  }
+  // the A/B operand of v_mfma_f32_16x16x32_bf16 for rows r0 .. r0+15 over ALL 32 k of the tile: lane (i = lane & 15,
+  // g = lane >> 4) receives k = 8g .. 8g+7 of row r0 + i, again from two transposed reads per plane (k-rows 8g+0..3, 8g+4..7)
+  __device__ static __forceinline__ void frag16(const unsigned char* s, int r0, int lane, bf16x8 (&v)[3]) {
+    const int k = 8 * (lane >> 4) + ((lane & 15) >> 2);
+    const int row = r0 + 4 * (lane & 3);
     const unsigned char* a = s + off(k, row);
     const unsigned char* a4 = s + off(k + 4, row);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
@@ -506,6 +524,128 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
     lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
   }
   prio_hi();                                 // epilogue
+}
+
+// ---- the same six-term products on v_mfma_f32_16x16x32_bf16 ("K32") ------------------------------------------------------
+// Same matrix-pipe cycles per FLOP as the 32x32x16 form, same fragment-read count when BOTH operands are k-major (two
+// transposed reads per 16 rows x 32 k and plane, against two per 32 rows x 16 k), but the chip holds a higher clock on this
+// shape under load (HIP guide rule 28 / microarchitecture guide 'DVFS give-back' item 7: 1.12-1.15 x on random data in bare
+// loops).  A wave's WTM x WTN tile is (2 TM) x (2 TN) blocks of 16 x 16, four accumulator registers each:
+// acc[im][in][sm * 2 + sn] is the block at rows 32 im + 16 sm, columns 32 in + 16 sn; C/D map: col = lane & 15,
+// row = 4 * (lane >> 4) + r.  One K tile (32 k) is one step.
+template <class G>
+using Acc16 = f32x4[G::TM][G::TN][4];
+
+template <class G, class SA, class SB>
+__device__ __forceinline__ void mfma_tile3_k32(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
+                                               f32x4 (&acc)[G::TM][G::TN][4]) {
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  bf16x8 a[2 * G::TM][3];
+#pragma unroll
+  for (int i = 0; i < 2 * G::TM; ++i) SA::frag16(sA, wm + 16 * i, lane, a[i]);
+#pragma unroll
+  for (int j = 0; j < 2 * G::TN; ++j) {
+    bf16x8 b[3];
+    SB::frag16(sB, wn + 16 * j, lane, b);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2 * G::TM; ++i)
+        acc[i >> 1][j >> 1][(i & 1) * 2 + (j & 1)] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[t]], b[PB[t]], acc[i >> 1][j >> 1][(i & 1) * 2 + (j & 1)], 0, 0, 0);
+  }
+}
+
+// gemm_mainloop3 on the K32 form; both tiles k-major (the weight-gradient GEMM).
+template <class G, class TA, class TB, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop3_k32(const LA& la, const LB& lb, int kt_begin, int kt_end,
+                                                   unsigned char* smem, f32x4 (&acc)[G::TM][G::TN][4], bool fair = false,
+                                                   bool zero_acc = true) {
+  using SA = typename SplitTile<TA>::type;
+  using SB = typename SplitTile<TB>::type;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  constexpr int PAST = 1 << 24;
+  if (zero_acc) {
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][b][r] = 0.f;
+  }
+  if (kt_begin >= kt_end) { prio_hi(); return; }
+  Split4 pa[TA::PASSES], pb[TB::PASSES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + SA::BYTES;
+  float4 ra[TA::PASSES], rb[TB::PASSES];
+  auto split_all = [&]() {
+#pragma unroll
+    for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
+#pragma unroll
+    for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
+  };
+  la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb);
+  split_all();
+  la.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, ra);
+  lb.load(kt_begin + 1 < kt_end ? kt_begin + 1 : PAST, rb);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    SA::store(sA, pa, tid);
+    SB::store(sB, pb, tid);
+    __syncthreads();
+    prio_by_progress(fair, kt, kt_begin, kt_end);
+    mfma_tile3_k32<G, SA, SB>(sA, sB, wm, wn, lane, acc);
+    la.fix(ra); lb.fix(rb);
+    if (kt + 1 < kt_end) split_all();
+    la.load(kt + 2 < kt_end ? kt + 2 : PAST, ra);
+    lb.load(kt + 2 < kt_end ? kt + 2 : PAST, rb);
+  }
+  prio_hi();
+}
+
+// for_each_acc_row4 for the K32 accumulators (same staging, same callback)
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc16_row4(const f32x4 (&acc)[G::TM][G::TN][4], float* smem, F&& f) {
+  constexpr int LDW = G::WTN + 4, LPR = G::WTN / 4, RPI = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+  float* s = smem + wave * 32 * LDW;
+  __syncthreads();
+#pragma unroll
+  for (int im = 0; im < G::TM; ++im) {
+#pragma unroll
+    for (int in = 0; in < G::TN; ++in)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          s[((b >> 1) * 16 + 4 * (lane >> 4) + r) * LDW + in * 32 + (b & 1) * 16 + (lane & 15)] = acc[im][in][b][r];
+#pragma unroll
+    for (int rr = 0; rr < 32; rr += RPI) {
+      const int row = rr + lane / LPR, c4 = (lane % LPR) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(&s[row * LDW + c4]);
+      f(wm + 32 * im + row, wn + c4, v);
+    }
+  }
+}
+
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc16(const f32x4 (&acc)[G::TM][G::TN][4], F&& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+#pragma unroll
+  for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < G::TN; ++in)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          f(wm + 32 * im + (b >> 1) * 16 + 4 * (lane >> 4) + r, wn + 32 * in + (b & 1) * 16 + (lane & 15), acc[im][in][b][r]);
 }
 
 // Walk the accumulators: f(row_in_tile, col_in_tile, value) for this lane's elements.

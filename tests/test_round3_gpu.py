@@ -56,7 +56,7 @@ def test_conv_split_worst_case(dev, shape):
     an all-positive sum), so the bound asserted is the one include/embnet.h states: the dropped terms' 2^-20 * sum|a||b| on
     top of fp32 accumulation, with "fp32 accumulation" priced at twice what a float32 CPU convolution shows on the same
     input — for the largest error and for the mean error (the bias), on all three passes.  The measured numbers go to
-    gpurun_out/r03_split_worst_case_*.json (copied to profiles/)."""
+    gpurun_out/r04_split_worst_case_*.json (copied to profiles/)."""
     from embeddingnet_amd import layers as L
     n, h, w, cin, cout, k = shape
     rs = np.random.RandomState(11)
@@ -92,7 +92,7 @@ def test_conv_split_worst_case(dev, shape):
         r = rec[name]
         assert r["max_abs_rel_err"] <= SPLIT_BOUND + 2 * r["float32_cpu_conv_max_abs_rel_err"] + 2.0 ** -23, (name, r)
         assert abs(r["mean_rel_err_bias"]) <= SPLIT_BOUND + 2 * abs(r["float32_cpu_conv_mean_rel_err"]) + 2.0 ** -23, (name, r)
-    _record(f"r03_split_worst_case_K{k * k * cin}.json", rec)
+    _record(f"r04_split_worst_case_K{k * k * cin}.json", rec)
 
 
 # ------------------------------------------------------------------------------------------------ per-stage gradients

@@ -12,7 +12,7 @@ reference to 1e-4 relative"):
 Mining decisions are made on fp32 embeddings on the device and on f64-derived embeddings in the oracle; where the two
 pick differently the test requires the two candidates to be a borderline tie of the reference's own loss values
 (|difference| < 2e-5) and then lets the oracle train on the device's triplets, so the curves stay comparable for all
-20 steps.  Both curves are written to gpurun_out/r03_loss_curve_<case>.json (copied to profiles/ by hand).
+20 steps.  Both curves are written to gpurun_out/r04_loss_curve_<case>.json (copied to profiles/ by hand).
 """
 import json
 import os
@@ -43,7 +43,7 @@ def g(a, dev):
 def _save_curve(name, payload):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        json.dump(payload, open(os.path.join(out, f"r03_loss_curve_{name}.json"), "w"), indent=1)
+        json.dump(payload, open(os.path.join(out, f"r04_loss_curve_{name}.json"), "w"), indent=1)
 
 
 def _dataset(n_classes, per_class, shape, seed):
@@ -149,7 +149,7 @@ def test_keras_optimizer_rules_vs_oracle(dev, rule):
 #       both take the step on the same batch: mining equal (or a borderline tie), loss and total loss within 1e-4
 #       relative (north_star), updated weights equal within the gradient's fp32 bound — for all 20 steps;
 #   (2) free-running: device curve, a float64 oracle and a float32 oracle that never see the device's weights, all
-#       three recorded (profiles/r03_loss_curve_*.json): the device leaves the float64 curve the way the float32 oracle
+#       three recorded (profiles/r04_loss_curve_*.json): the device leaves the float64 curve the way the float32 oracle
 #       does — in jumps, whenever a ReLU / arg-max decision falls the other way.  Asserted for the first three
 #       steps only (1e-4 at step 0, then max(2e-3, 30 x the float32 oracle's largest deviation so far)).
 STEPS = 20
