@@ -1052,7 +1052,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     // 16x16x32 MFMA shape for the weight gradient (both operands k-major: same fragment reads and matrix cycles as
     // 32x32x16, but the chip clocks higher on it under load): 1-6 % faster per layer, profiles/r04_exp_wgrad_k32.txt.
     // EMBNET_WGRAD_K32=0: the 32x32x16 kernels (A/B).
-    static const bool k32 = wgrad_k32();
+    // (not the 128x64 tile: at three workgroups per CU its K32 form spills 9 registers in the loop — the ResNet stem's
+    // weight gradient ran 455-472 us on it against 300-320, profiles/r04_bench_kernel_stats.md)
+    const bool k32 = wgrad_k32() && tile != 1;
     char k32name[160];
     snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
     EMBNET_TRACE_FLOP((!in_scale && va && vb && k32 && !p.xcd_order) ? k32name :
@@ -1064,7 +1066,6 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     else if (va && vb && k32 && !p.xcd_order) {
       switch (tile) {
         case 0: conv_wgrad_k32_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
-        case 1: conv_wgrad_k32_kernel<G128x64><<<grid, 256, 0, st>>>(p); break;
         case 2: conv_wgrad_k32_kernel<G128x32><<<grid, 256, 0, st>>>(p); break;
         case 4: conv_wgrad_k32_kernel<G192x64><<<grid, 256, 0, st>>>(p); break;
         default: conv_wgrad_k32_kernel<G64x64><<<grid, 256, 0, st>>>(p); break;
@@ -1159,7 +1160,7 @@ extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd,
   } else if (kind == 2) {
     int tile, sp, kt;
     wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
-    if (((c | k) & 3) == 0 && wgrad_k32())
+    if (((c | k) & 3) == 0 && wgrad_k32() && tile != 1)
       snprintf(buf, sizeof buf, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", geoms[tile]);
     else
       snprintf(buf, sizeof buf, "void embnet::conv_wgrad_kernel<embnet::Geom<%s>, %s, %s>(embnet::ConvWgradParams)",

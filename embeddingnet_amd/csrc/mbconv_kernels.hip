@@ -219,6 +219,73 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
     if (ow0 + q < g.OW) yo[(long)q * c4] = acc[q];
 }
 
+// The same loop for TWO output rows per thread (oh0, oh0 + 1): the (KS + ST) input rows the pair needs are each fetched once
+// and feed both outputs — the kernel runs at the rate the L1 takes requests (header above), and this form issues
+// (6*12 + 50) image + weight loads per 16 outputs of a 5x5 stride-1 layer against (5*12 + 25) per 8, and (4*10 + 18) per 16
+// against (3*10 + 9) per 8 for 3x3.  A real loop over the input rows (one row's loads in flight; unrolled, hipcc hoists
+// every row's loads: 330-490 VGPRs), so the kernel row of an (input row, output row) pair is a run-time, wave-uniform
+// index and the weights are loaded where they are used (L1 hits), as in the one-row kernel.
+template <int KS, int ST, bool FLIP, int TW>
+__global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            DwGeom g, float* __restrict__ y) {
+  constexpr int NX = (TW - 1) * ST + KS, TH = 2, NR = (TH - 1) * ST + KS;
+  const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW, hb_n = (g.OH + TH - 1) / TH;
+  const long total = (long)g.N * hb_n * wb_n * c4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % c4);
+  long t = i / c4;
+  const int ow0 = (int)(t % wb_n) * TW; t /= wb_n;
+  const int oh0 = (int)(t % hb_n) * TH;
+  const int n = (int)(t / hb_n);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 acc[TH][TW];
+#pragma unroll
+  for (int a = 0; a < TH; ++a)
+#pragma unroll
+    for (int q = 0; q < TW; ++q) acc[a][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int iw0 = ow0 * ST - g.pad_l, ih0 = oh0 * ST - g.pad_t;
+#pragma unroll 1
+  for (int ir = 0; ir < NR; ++ir) {
+    const int ih = ih0 + ir;
+    const bool rok = (unsigned)ih < (unsigned)g.H;
+    const long rbase = ((long)n * g.H + (rok ? ih : 0)) * g.W;
+    float4 xr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int iw = iw0 + j;
+      const bool ok = rok && (unsigned)iw < (unsigned)g.W;
+      xr[j] = x4[ok ? (rbase + iw) * c4 + cq : 0];
+      if (!ok) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int a = 0; a < TH; ++a) {
+      const int r = ir - a * ST;                        // kernel row of this input row for output row oh0 + a (wave-uniform)
+      if (r >= 0 && r < KS) {
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+          const float4 k4 = w4[(FLIP ? (KS - 1 - r) * KS + (KS - 1 - s_) : r * KS + s_) * c4 + cq];
+#pragma unroll
+          for (int q = 0; q < TW; ++q) {
+            const float4 v = xr[q * ST + s_];
+            acc[a][q].x = fmaf(v.x, k4.x, acc[a][q].x); acc[a][q].y = fmaf(v.y, k4.y, acc[a][q].y);
+            acc[a][q].z = fmaf(v.z, k4.z, acc[a][q].z); acc[a][q].w = fmaf(v.w, k4.w, acc[a][q].w);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < TH; ++a) {
+    if (oh0 + a >= g.OH) break;
+    float4* yo = reinterpret_cast<float4*>(y) + (((long)n * g.OH + oh0 + a) * g.OW + ow0) * c4 + cq;
+#pragma unroll
+    for (int q = 0; q < TW; ++q)
+      if (ow0 + q < g.OW) yo[(long)q * c4] = acc[a][q];
+  }
+}
+
 // Stride-2 data gradient: dx[ih,iw] = sum over (r,s) with (ih+pt-r) and (iw+pl-s) even of dy[(ih+pt-r)/2, (iw+pl-s)/2] * w[r,s].
 // Block of 4 dx columns starting at a multiple of 4, so which taps are live in each column only depends on the column's
 // offset t and the parity PLP of pad_l: s = s0(t) + 2b with s0 = (t + PLP) & 1, and the dy column is
@@ -601,6 +668,13 @@ static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, floa
   static const int forced = (int)env_long("EMBNET_DW_TW", 0);            // 4 / 8: A/B
   // eight columns per thread unless that wastes more than an eighth of a row the four-column blocks tile exactly
   const bool wide = forced ? forced == 8 : (g.OW >= 7 && cdiv(g.OW, 8) * 8 <= cdiv(g.OW, 4) * 4 + g.OW / 8);
+  static const int rows2 = (int)env_long("EMBNET_DW_ROWS2", 1);          // 0: one output row per thread (A/B)
+  if (rows2 && g.OH >= 2) {                                               // two output rows per thread
+    const long units = (long)g.N * cdiv(g.OH, 2) * (g.C / 4);
+    if (wide) dwconv_row4x2_kernel<KS, ST, FLIP, 8><<<cdiv(units * cdiv(g.OW, 8), 256), 256, 0, st>>>(x, w, g, y);
+    else dwconv_row4x2_kernel<KS, ST, FLIP, 4><<<cdiv(units * cdiv(g.OW, 4), 256), 256, 0, st>>>(x, w, g, y);
+    return;
+  }
   if (wide) dwconv_row4_kernel<KS, ST, FLIP, 8><<<cdiv((long)g.N * g.OH * cdiv(g.OW, 8) * (g.C / 4), 256), 256, 0, st>>>(x, w, g, y);
   else dwconv_row4_kernel<KS, ST, FLIP, 4><<<cdiv((long)g.N * g.OH * cdiv(g.OW, 4) * (g.C / 4), 256), 256, 0, st>>>(x, w, g, y);
 }

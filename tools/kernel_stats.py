@@ -13,7 +13,11 @@ def main():
     path, steps, prefix = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     title = sys.argv[4] if len(sys.argv) > 4 else path
     agg = collections.OrderedDict()
+    skipped = 0.0
     for r in csv.DictReader(open(path)):
+        if "distribution_elementwise" in r["Kernel_Name"]:       # torch.rand filling the resident batch pool at start-up: not a step
+            skipped += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+            continue
         d = agg.setdefault(r["Kernel_Name"], [0, 0.0])
         d[0] += 1
         d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
@@ -25,7 +29,8 @@ def main():
         for k, (n, us) in rows:
             w.writerow([k, n, round(us, 1), round(us / n, 2), round(100 * us / total, 2)])
     with open(prefix + ".md", "w") as f:
-        f.write(f"# {title}\n\nSum of kernel time: {total / steps / 1e3:.3f} ms per step over {steps} steps.\n\n")
+        f.write(f"# {title}\n\nSum of kernel time: {total / steps / 1e3:.3f} ms per step over {steps} steps"
+                f" (start-up torch.rand kernels of the resident batch pool left out: {skipped / 1e3:.2f} ms in all).\n\n")
         f.write("| kernel | calls/step | avg us | ms/step | % |\n|---|---|---|---|---|\n")
         for k, (n, us) in rows[:40]:
             f.write(f"| `{k[:110]}` | {n / steps:.4g} | {us / n:.1f} | {us / steps / 1e3:.3f} | {100 * us / total:.1f} |\n")
