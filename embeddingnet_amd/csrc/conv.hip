@@ -798,6 +798,27 @@ static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, Split
     NUM_CUS = 256 * res;
   }
   const int rem = (int)(tiles % NUM_CUS);
+  if (knob && tiles < NUM_CUS) {
+    // A launch that does not even fill one round (the small backbones' layers at batch 32, the 7x7 maps): every CU runs at
+    // most a workgroup or two, and the launch lasts as long as ONE workgroup's K chain — kt tiles at the gather's round trip
+    // (~1.5 us) each, with nothing to overlap it with.  Cut every tile's K range into parts (more, shorter chains side by
+    // side; raw partial tiles + the fix-up launch).  EMBNET_SMALL_SPLIT=0: off (A/B).
+    static const int small = (int)env_long("EMBNET_SMALL_SPLIT", 1);
+    static const int small_wgs = (int)env_long("EMBNET_SMALL_SPLIT_WGS", 768);
+    if (!small || kt < 6 || bm * bn > 128 * 64) return;
+    int parts = (int)(small_wgs / tiles);
+    if (parts > kt / 3) parts = kt / 3;
+    if (parts > 32) parts = 32;
+    if (parts < 2) return;
+    const int kt_part = cdiv(kt, parts);
+    parts = cdiv(kt, kt_part);
+    if (parts < 2) return;
+    const size_t bytes = (size_t)tiles * parts * bm * bn * 4;
+    if (need) *need = bytes;
+    if (bytes > ws_bytes) return;
+    t.n_full = 0; t.parts = parts; t.kt_part = kt_part;
+    return;
+  }
   if (!knob || rem == 0 || tiles < NUM_CUS) return;
   const double t_tile = (double)kt * bm * bn * BK * 2.0 / (0.85 * 146e12 / NUM_CUS);        // seconds
   const double tile_bytes = (double)bm * bn * 4;
