@@ -804,7 +804,7 @@ static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, Split
     // (~1.5 us) each, with nothing to overlap it with.  Cut every tile's K range into parts (more, shorter chains side by
     // side; raw partial tiles + the fix-up launch).  EMBNET_SMALL_SPLIT=0: off (A/B).
     static const int small = (int)env_long("EMBNET_SMALL_SPLIT", 1);
-    static const int small_wgs = (int)env_long("EMBNET_SMALL_SPLIT_WGS", 768);
+    static const int small_wgs = (int)env_long("EMBNET_SMALL_SPLIT_WGS", 512);
     if (!small || kt < 6 || bm * bn > 128 * 64) return;
     int parts = (int)(small_wgs / tiles);
     if (parts > kt / 3) parts = kt / 3;
