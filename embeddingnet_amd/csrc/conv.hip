@@ -522,7 +522,7 @@ struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g
 
 // The weight gradient on the 16x16x32 MFMA shape (gemm_engine.h, "K32"): same tiles, loaders, slabs and summation order per
 // output element over k tiles; inside a k tile the 32 pixels are summed by one instruction per term instead of two.
-template <class G>
+template <class G, bool TF>
 __device__ __forceinline__ void conv_wgrad_k32_body(const ConvWgradParams& p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
@@ -536,7 +536,7 @@ __device__ __forceinline__ void conv_wgrad_k32_body(const ConvWgradParams& p) {
   const int m0 = (tile / tiles_n) * G::BM, n0 = (tile % tiles_n) * G::BN;
   const int kt_total = (Kg + BK - 1) / BK;
   const int kt0 = split * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, kt_total);
-  LoadConvWgradA<G::BM, true, false> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
+  LoadConvWgradA<G::BM, true, TF> la; la.init(p.x, p.g, m0, threadIdx.x, p.tf);
   LoadRowsKM<G::BN, true> lb; lb.init(p.dy, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x4 acc[G::TM][G::TN][4];
   gemm_mainloop3_k32<G, TA, TB>(la, lb, kt0, kt1, reinterpret_cast<unsigned char*>(smem), acc, (int)blockIdx.x >= p.fair_from);
@@ -547,7 +547,10 @@ __device__ __forceinline__ void conv_wgrad_k32_body(const ConvWgradParams& p) {
   });
 }
 template <class G>
-__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_k32_kernel(ConvWgradParams p) { conv_wgrad_k32_body<G>(p); }
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_k32_kernel(ConvWgradParams p) { conv_wgrad_k32_body<G, false>(p); }
+// (the input-transform form: x is the INPUT of the BatchNormalization in front, act(x*scale + shift) applied in the loader)
+template <class G>
+__global__ __launch_bounds__(256) void conv_wgrad_k32_tf_kernel(ConvWgradParams p) { conv_wgrad_k32_body<G, true>(p); }
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
 template <class G, bool VA, bool VB, bool TF>
@@ -1078,12 +1081,21 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     const bool k32 = wgrad_k32() && tile != 1;
     char k32name[160];
     snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
-    EMBNET_TRACE_FLOP((!in_scale && va && vb && k32 && !p.xcd_order) ? k32name :
+    if (in_scale) snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_tf_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
+    EMBNET_TRACE_FLOP(((in_scale || (va && vb)) && k32 && !p.xcd_order) ? k32name :
                       conv_kernel_name(in_scale ? "conv_wgrad_tf_kernel" : "conv_wgrad_kernel", "ConvWgradParams", tile,
                                        (in_scale || (va && vb)) ? "true, true" : (vb ? "false, true" : "false, false")),
                       2.0 * n * oh * ow * (double)k * rows,
                       4.0 * ((double)n * h * wd * c + (double)n * oh * ow * k + (double)rows * k * p.splits), st);
-    if (in_scale) { LAUNCH_WGRAD(conv_wgrad_tf_kernel, true, true) }
+    if (in_scale && k32 && !p.xcd_order) {              // same arithmetic as the plain K32 kernels: deferred BN stays bit-identical
+      switch (tile) {
+        case 0: conv_wgrad_k32_tf_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
+        case 2: conv_wgrad_k32_tf_kernel<G128x32><<<grid, 256, 0, st>>>(p); break;
+        case 4: conv_wgrad_k32_tf_kernel<G192x64><<<grid, 256, 0, st>>>(p); break;
+        default: conv_wgrad_k32_tf_kernel<G64x64><<<grid, 256, 0, st>>>(p); break;
+      }
+    }
+    else if (in_scale) { LAUNCH_WGRAD(conv_wgrad_tf_kernel, true, true) }
     else if (va && vb && k32 && !p.xcd_order) {
       switch (tile) {
         case 0: conv_wgrad_k32_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;

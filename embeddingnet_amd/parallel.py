@@ -157,10 +157,14 @@ class GradReducer:
         rank = dist.get_rank(self.group)
         t = torch.arange(1024, device=dev, dtype=torch.float32) * (0.37 + rank) - 11.0 * rank
         a, b = t.clone(), t.clone()
-        dist.all_reduce(a, op=dist.ReduceOp.AVG, group=self.group)
+        ok = True
+        try:
+            dist.all_reduce(a, op=dist.ReduceOp.AVG, group=self.group)
+        except Exception:                   # a build without AVG raises on every rank alike (argument check, no communication)
+            ok = False
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
         self._avg_checked = True
-        return bool(torch.allclose(a, b / self.world, rtol=1e-6, atol=1e-6))
+        return ok and bool(torch.allclose(a, b / self.world, rtol=1e-6, atol=1e-6))
 
     @staticmethod
     def _pad(n, quantum=4):
