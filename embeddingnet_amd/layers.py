@@ -65,8 +65,13 @@ _SLAB_BUFS = {}             # kernel storage address -> slab buffer (scratch: an
 
 def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0):
     """dw[r,s,c,k] = weight gradient of a convolution (embnet_conv2d_wgrad_f32), its slab sum deferred when SLAB_DEFER."""
-    if SLAB_DEFER[0]:
-        splits = lib.embnet_conv2d_wgrad_splits(n, c, r, s, k, oh, ow)
+    # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
+    if SLAB_DEFER[0] and (getattr(w, "grad", None) is None or (GRAD_SINKS and w.data_ptr() in GRAD_SINKS)):
+        if any(e[4] is w for e in _SLAB_PENDING):               # the same kernel a second time in one backward (shared layer):
+            flush_slab_reduces()                                # finish the first gradient, compute this one in place
+            splits = 1
+        else:
+            splits = lib.embnet_conv2d_wgrad_splits(n, c, r, s, k, oh, ow)
         if splits > 1:
             need = lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4
             buf = _SLAB_BUFS.get(w.data_ptr())
@@ -715,7 +720,7 @@ class _BatchNormFn(torch.autograd.Function):
             if len(DY_PLANES) > 64:                  # entries nobody collected (a consumer fell back to the fp32 kernel)
                 DY_PLANES.clear()
             DY_PLANES[dx.data_ptr()] = (planes, dx)
-        if ctx.in_relu_bias is not None and planes is None and dskip is None:
+        if getattr(ctx, "in_relu_bias", None) is not None and planes is None and dskip is None:
             # x is the output of a conv with a fused ReLU: its backward (mask + bias gradient) rides on this pass
             (bias,) = ctx.in_relu_bias
             db, db_note = _sink(bias)

@@ -288,7 +288,9 @@ class TripletTrainer:
         self.last_total = total.detach()        # triplet mean + kernel regularisers (what Keras reports as `loss`)
         # weight-gradient slab sums: queued, one launch for all (layers.conv_wgrad).  Needs every dw to stay untouched until
         # the flush: a fresh .grad (zero_grad(set_to_none)) or the reducer's in-place sinks — not an AccumulateGrad add_
-        L.SLAB_DEFER[0] = L.SLAB_DEFER_ENABLED[0] and (self.reducer is None or self.reducer._direct)
+        # and ONE gradient contribution per parameter (the regularisers' gradient folded into the KerasOptimizer launch, not
+        # added by autograd)
+        L.SLAB_DEFER[0] = L.SLAB_DEFER_ENABLED[0] and self._keras_opt and (self.reducer is None or self.reducer._direct)
         try:
             total.backward()
         finally:

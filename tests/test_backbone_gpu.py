@@ -287,7 +287,11 @@ def test_conv_tail_split_is_planned_for_the_test_shapes():
     assert lib.embnet_conv2d_fwd_workspace_bytes(10, 64, 3, 3, 64, 60, 60) > 0
     assert lib.embnet_conv2d_dgrad_workspace_bytes(10, 60, 60, 64, 3, 3, 64, 1) > 0
     assert lib.embnet_conv2d_fwd_workspace_bytes(5, 128, 3, 3, 128, 60, 60) > 0
-    assert lib.embnet_conv2d_fwd_workspace_bytes(2, 64, 3, 3, 64, 16, 16) == 0
+    # a launch below one round (8 tiles here) cuts EVERY tile's K range over several workgroups (round 4: plan_tail's small-launch
+    # split): parts x tiles x 64 x 64 x 4 bytes, parts <= kt / 3 = 6
+    small = lib.embnet_conv2d_fwd_workspace_bytes(2, 64, 3, 3, 64, 16, 16)
+    assert small > 0 and small % (8 * 64 * 64 * 4) == 0 and 2 <= small // (8 * 64 * 64 * 4) <= 6
+    assert lib.embnet_conv2d_fwd_workspace_bytes(1, 8, 1, 1, 8, 4, 4) == 0            # one K tile: nothing to cut
 
 
 def test_conv2d_wgrad_splitk_large(dev):
