@@ -31,7 +31,9 @@
 // _SPLIT_ABLATE, _LDS_STAGES, in-loop stamps) lives in tools/exp/gemm_engine_diag.h; this file is the product.
 #pragma once
 #if defined(EMBNET_DIAG_ENGINE)
-#include "../../tools/exp/gemm_engine_diag.h"
+// The diagnostic copy of this header (round-1/2 experiment switches) is frozen at round 3: it lacks the K32 main loop and the
+// k-major swizzle bit conv.hip needs since round 4.  To rebuild those experiment variants check out a round-3 tree (f78adeb).
+#error "tools/exp/gemm_engine_diag.h is the round-3 engine; build the diagnostic variants from a round-3 checkout"
 #else
 #include "common.h"
 
