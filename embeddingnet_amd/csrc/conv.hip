@@ -856,7 +856,9 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
     default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
   }
 
-static bool wgrad_k32() { static const bool v = env_long("EMBNET_WGRAD_K32", 1) != 0; return v; }
+// Off by default: 1-6 % faster per layer back to back (profiles/r04_exp_wgrad_k32.txt), 2 % SLOWER inside the training step
+// (same box, alternating runs: 123.9-124.9 vs 121.7-122.1 us for the 128x128 tile, step time equal) — see DESIGN 3.12.
+static bool wgrad_k32() { static const bool v = env_long("EMBNET_WGRAD_K32", 0) != 0; return v; }
 
 extern "C" int embnet_conv_mfma_terms(void) { return EMBNET_CONV_SPLIT ? 6 : 1; }
 
@@ -1074,8 +1076,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   p.tf = InputTransform{in_scale, in_shift, in_act};
   if (do_main) {
     // 16x16x32 MFMA shape for the weight gradient (both operands k-major: same fragment reads and matrix cycles as
-    // 32x32x16, but the chip clocks higher on it under load): 1-6 % faster per layer, profiles/r04_exp_wgrad_k32.txt.
-    // EMBNET_WGRAD_K32=0: the 32x32x16 kernels (A/B).
+    // 32x32x16): EMBNET_WGRAD_K32=1 (experiment; see wgrad_k32()).
     // (not the 128x64 tile: at three workgroups per CU its K32 form spills 9 registers in the loop — the ResNet stem's
     // weight gradient ran 455-472 us on it against 300-320, profiles/r04_bench_kernel_stats.md)
     const bool k32 = wgrad_k32() && tile != 1;
