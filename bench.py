@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=os.environ.get("BCFG", "c2"), choices=sorted(CONFIGS))
     ap.add_argument("--mode", default=None, choices=["triplet", "siamese"])
     ap.add_argument("--backbone", default=None)
     ap.add_argument("--image", type=int, default=None)

@@ -743,7 +743,7 @@ using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 
 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
-static int pick_tile(long m, int ncols, bool strided_dgrad = false) {
+static int pick_tile(long m, int ncols, bool strided_dgrad = false, long kdepth = 0) {
   const int forced = (int)env_long("EMBNET_CONV_TILE", -1);    // tuning aid (tools/exp/tile_sweep.py), read per call
   if (forced >= 0) return forced;
   // Measured on ResNet18 shapes (tools/kernel_bench.py, EMBNET_CONV_TILE sweep): workgroups all take the
@@ -763,7 +763,13 @@ static int pick_tile(long m, int ncols, bool strided_dgrad = false) {
 #else
   if (cdiv(m, 128) * cdiv(ncols, 128) >= 4 * 768 && ncols >= 128) return 0;
 #endif
-  return (cdiv(m, 128) * cdiv(ncols, 64) >= 1024) ? 1 : 3;
+  // long reductions (7x7 / 10x10 kernels of the small backbones: 100-200 K tiles) amortise the bigger tile's operand traffic
+  // over more MFMAs, so 128x64 pays from fewer tiles: `simple`@105 conv2 (882 tiles, K = 3136 / 6272) 1.648 -> 1.587 ms/step
+  const long need = (kdepth >= 96 * BK && !strided_dgrad) ? 512 : 1024;
+  // a launch of fewer than 512 small tiles gets its K range cut over workgroups anyway (plan_tail): with >= 32 K tiles to cut,
+  // half as many 128x64 tiles, each cut finer, beat 64x64 tiles (`simple`@105 conv3 forward 61 -> 41 us, data gradient 67 -> 53)
+  if (!strided_dgrad && kdepth >= 32 * BK && cdiv(m, 64) * cdiv(ncols, 64) < 512) return 1;
+  return (cdiv(m, 128) * cdiv(ncols, 64) >= need) ? 1 : 3;
 }
 static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
 // workgroups of each tile type a CU holds at once (registers / LDS; measured with in-kernel stamps)
@@ -865,7 +871,7 @@ extern "C" int embnet_conv_mfma_terms(void) { return EMBNET_CONV_SPLIT ? 6 : 1; 
 extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;
   const long M = (long)n * oh * ow;
-  const int tile = pick_tile(M, k);
+  const int tile = pick_tile(M, k, false, (long)r * s * c);
   SplitTail t; size_t need;
   plan_tail((long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]), cdiv((long)r * s * c, BK), TILE_BM[tile], TILE_BN[tile],
             0, t, &need);
@@ -876,7 +882,7 @@ extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, 
 extern "C" int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;
   const long M = (long)n * oh * ow;
-  const int tile = pick_tile(M, k);
+  const int tile = pick_tile(M, k, false, (long)r * s * c);
   return cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
 }
 
@@ -893,7 +899,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_fwd")) return rc;
   const long M = (long)n * oh * ow;
   hipStream_t st = (hipStream_t)stream;
-  const int tile = pick_tile(M, k);
+  const int tile = pick_tile(M, k, false, (long)r * s * c);
   const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const bool vec = (c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w) && (!bias || aligned16(bias));
   EMBNET_CHECK_ARG(!in_scale || (vec && aligned16(in_scale) && aligned16(in_shift)),
@@ -928,7 +934,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
 extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride) {
   if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || stride != 1 || ((c | k) & 3)) return 0;
   const long M = (long)n * h * wd;
-  const int tile = pick_tile(M, c);
+  const int tile = pick_tile(M, c, false, (long)r * s * k);
   SplitTail t; size_t need;
   plan_tail((long)cdiv(M, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]), cdiv((long)r * s * k, BK), TILE_BM[tile], TILE_BN[tile],
             0, t, &need);
@@ -964,7 +970,7 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
       if (m > max_m) max_m = m;
     }
   hipStream_t st = (hipStream_t)stream;
-  const int tile = pick_tile(max_m * stride * stride, c, stride > 1);
+  const int tile = pick_tile(max_m * stride * stride, c, stride > 1, (long)r * s * k);
   const long tiles = (long)cdiv(max_m, TILE_BM[tile]) * cdiv(c, TILE_BN[tile]);
   const bool vec = (k & 3) == 0 && aligned16(dy) && aligned16(w);
   // stride 1 = one class whose rows are the input pixels in order, so the fix-up writes dx[row*C + col]
@@ -1186,11 +1192,11 @@ extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd,
   const char* tk = (k & 3) == 0 ? "true" : "false";
   if (kind == 0) {
     snprintf(buf, sizeof buf, "void embnet::conv_fwd_kernel<embnet::Geom<%s>, %s>(embnet::ConvFwdParams)",
-             geoms[pick_tile((long)n * oh * ow, k)], ((c | k) & 3) == 0 ? "true" : "false");
+             geoms[pick_tile((long)n * oh * ow, k, false, (long)r * s * c)], ((c | k) & 3) == 0 ? "true" : "false");
   } else if (kind == 1) {
     long max_m = (long)n * ((h + 0) / 1) * wd;         // same tile choice as the launcher (all classes together)
     snprintf(buf, sizeof buf, "void embnet::conv_dgrad_kernel<embnet::Geom<%s>, %s>(embnet::ConvDgradParams)",
-             geoms[pick_tile(max_m, c, oh < h)], tk);
+             geoms[pick_tile(max_m, c, oh < h, (long)r * s * k)], tk);
   } else if (kind == 2) {
     int tile, sp, kt;
     wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
