@@ -66,7 +66,10 @@ _SLAB_BUFS = {}             # kernel storage address -> slab buffer (scratch: an
 def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0):
     """dw[r,s,c,k] = weight gradient of a convolution (embnet_conv2d_wgrad_f32), its slab sum deferred when SLAB_DEFER."""
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
-    if SLAB_DEFER[0] and (getattr(w, "grad", None) is None or (GRAD_SINKS and w.data_ptr() in GRAD_SINKS)):
+    # (only for a leaf kernel: the gradient of a derived one — the channel-padded kernel of an image conv — is consumed by the
+    # next backward node at once)
+    if SLAB_DEFER[0] and w.grad_fn is None and \
+            (getattr(w, "grad", None) is None or (GRAD_SINKS and w.data_ptr() in GRAD_SINKS)):
         if any(e[4] is w for e in _SLAB_PENDING):               # the same kernel a second time in one backward (shared layer):
             flush_slab_reduces()                                # finish the first gradient, compute this one in place
             splits = 1
@@ -493,6 +496,37 @@ def he_uniform_(t, gen):
     return t.uniform_(-lim, lim, generator=gen)
 
 
+class _PadKernelFn(torch.autograd.Function):
+    """kernel [R,S,C,K] -> [R,S,Cp,K] with zero input channels appended (forward) / gradient of the first C channels (backward):
+    lets a conv whose input has 3 channels run the 16-byte-gather kernels on a 4-channel copy of the image."""
+
+    @staticmethod
+    def forward(ctx, w, cp):
+        r, s, c, k = w.shape
+        wp = torch.zeros((r, s, cp, k), device=w.device, dtype=torch.float32)
+        wp[:, :, :c, :].copy_(w)
+        ctx.c = c
+        return wp
+
+    @staticmethod
+    def backward(ctx, dwp):
+        return dwp[:, :, :ctx.c, :].contiguous(), None
+
+
+def pad_channels(x, cp):
+    """NHWC image batch with C channels -> the same with zero channels appended up to cp (no gradient)."""
+    x = _c(x.detach())
+    n, h, w, c = x.shape
+    xp = torch.empty((n, h, w, cp), device=x.device, dtype=torch.float32)
+    check(_lib.lib().embnet_pad_channels(ptr(x), n * h * w, c, cp, ptr(xp), stream()))
+    return xp
+
+
+# a first-layer conv on a 3-channel image with a large kernel (the `simple` backbone's 10x10x3 -> 64,
+# /root/reference/embedding_net/backbones.py:21-22) runs the scalar-gather kernels: 82 TFLOP/s forward, 80 weight gradient
+PAD_INPUT_CONV = [_os.environ.get("EMBNET_PAD_INPUT_CONV", "1") != "0"]
+
+
 class Conv2D(nn.Module):
     """Keras Conv2D.  padding: 'valid' | 'same' | int (a ZeroPadding2D(p) in front of a valid conv)."""
 
@@ -534,19 +568,25 @@ class Conv2D(nn.Module):
             else:
                 x, in_stats, in_act = x.raw, x.stats, x.act
         geom = self.geometry(x.shape[1], x.shape[2])
+        kernel = self.kernel
+        if (PAD_INPUT_CONV[0] and in_stats is None and x.shape[-1] % 4 and not x.requires_grad and kernel.shape[3] % 4 == 0
+                and kernel.shape[0] * kernel.shape[1] * kernel.shape[2] >= 128 and residual is None and not with_skip):
+            cp = (x.shape[-1] + 3) // 4 * 4           # image input, large kernel: 4-channel copy, 16-byte gathers
+            x = pad_channels(x, cp)
+            kernel = _PadKernelFn.apply(kernel, cp)
         planes = getattr(x, "_planes", None) if in_stats is None else None
         if planes is not None and not self.patch_capable(x.shape):
             planes = None
         out_stats = None
         if emit_stats:
-            r, s, c, k = self.kernel.shape
+            r, s, c, k = kernel.shape
             if planes is not None:
                 rows = _lib.lib().embnet_conv2d_patch_stats_rows(x.shape[0], geom[3], geom[4])
             else:
                 rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
             if rows > 0:
                 out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
-        out = _Conv2dFn.apply(x, self.kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
+        out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
                               planes)
         y = out[0] if with_skip else out
         if out_stats is not None:
