@@ -523,7 +523,8 @@ def pad_channels(x, cp):
 
 
 # a first-layer conv on a 3-channel image with a large kernel (the `simple` backbone's 10x10x3 -> 64,
-# /root/reference/embedding_net/backbones.py:21-22) runs the scalar-gather kernels: 82 TFLOP/s forward, 80 weight gradient
+# /root/reference/embedding_net/backbones.py:21-22) or on a large batch of large images (EfficientNet's 3x3 stride-2 stem at
+# 224x224 x 256: 234 + 309 us forward + weight gradient) runs the scalar-gather kernels: 18-82 TFLOP/s
 PAD_INPUT_CONV = [_os.environ.get("EMBNET_PAD_INPUT_CONV", "1") != "0"]
 
 
@@ -570,7 +571,8 @@ class Conv2D(nn.Module):
         geom = self.geometry(x.shape[1], x.shape[2])
         kernel = self.kernel
         if (PAD_INPUT_CONV[0] and in_stats is None and x.shape[-1] % 4 and not x.requires_grad and kernel.shape[3] % 4 == 0
-                and kernel.shape[0] * kernel.shape[1] * kernel.shape[2] >= 128 and residual is None and not with_skip):
+                and (kernel.shape[0] * kernel.shape[1] * kernel.shape[2] >= 128 or x.numel() // x.shape[-1] >= (1 << 20))
+                and residual is None and not with_skip):
             cp = (x.shape[-1] + 3) // 4 * 4           # image input, large kernel: 4-channel copy, 16-byte gathers
             x = pad_channels(x, cp)
             kernel = _PadKernelFn.apply(kernel, cp)
