@@ -466,3 +466,15 @@ def test_optimizer_state_roundtrip(tmp_path):
     from embeddingnet_amd import _lib
     with pytest.raises(_lib.EmbnetError):
         load_optimizer_state(str(tmp_path / "x.opt.npz"), KerasOptimizer([a2], "rms_prop", 1e-3), {"dense/kernel": a2})
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_and_relays_the_worst_exit_code():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two ranks (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set) before touching any GPU and returns the worst child exit code.  Without a GPU every rank joins the
+    gloo world and then stops with the product's 'needs an MI355X' message: a non-zero exit, no JSON line, both ranks heard."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.stderr.count("needs an MI355X") == 2, out.stderr[-2000:]
