@@ -120,7 +120,8 @@ static void dense_fwd_plan(int m, int in, int out, int& splits, int& kt_per_spli
   const long tiles = (long)cdiv(m, 64) * cdiv(out, 64);
   const int kt_total = cdiv(in, BK);
   splits = 1; kt_per_split = kt_total;
-  if (tiles >= 64 || kt_total < 64) return;          // (a second launch only pays on a long reduction: in >= 2048)
+  static const int min_kt = (int)env_long("EMBNET_DENSE_SPLIT_MIN_KT", 8);    // (8: C5 30.96 -> 30.73 ms in the step; the gate's Dense layers have 15-36 K tiles on 4 output tiles)
+  if (tiles >= 64 || kt_total < min_kt) return;      // (round 1: only for in >= 2048; the chain of K tiles at <= 1 workgroup per CU is what a launch lasts)
   long want = 512 / tiles;
   if (want > kt_total / 4) want = kt_total / 4;
   if (want < 2) return;
