@@ -994,7 +994,10 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 
 using namespace embnet;
 #define S(stream) ((hipStream_t)(stream))
-static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+static inline int ew_blocks(long total) {
+  static const long cap = env_long("EMBNET_EW_BLOCKS", 4096);      // grid cap of the grid-stride elementwise kernels (sweep: DESIGN 3.12)
+  long b = (total + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
 // the same, rounded to a block count whose grid stride (blocks * 256 quads) is a multiple of c4: every thread of a
 // channel-quad kernel then keeps ONE channel quad and loads its per-channel constants once
 static inline int ew_blocks_c4(long total4, int c4) {
