@@ -78,12 +78,22 @@ class Seq(nn.Module):
         # per-channel sums from its epilogue (bias and ReLU applied): the BN does not read the tensor for its statistics.
         # (The other direction — the BN's affine applied in the NEXT conv's loader, bn(x, defer=True) — was measured on
         # simple2: 0.878 -> 0.943 ms/step; the transform kernels cost more than the four apply launches they remove.)
+        # A Dropout directly behind a BatchNormalization (bn3 -> drop1, bn6 -> drop2) is applied by the BatchNormalization's
+        # own kernels (same mask, same arithmetic): two forward and two backward launches off simple2's dependency chain.
         mods = [getattr(self, k) for k in self._order]
+        skip = False
         for i, m in enumerate(mods):
+            if skip:
+                skip = False
+                continue
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if (isinstance(m, L.Conv2D) and isinstance(nxt, L.BatchNormalization) and nxt.training and EPILOGUE_STATS
                     and torch.is_grad_enabled()):
                 x = m(x, emit_stats=True)
+            elif (isinstance(m, L.BatchNormalization) and isinstance(nxt, L.Dropout) and nxt.active()
+                    and L.FUSE_DROPOUT_BN[0]):
+                x = m(x, dropout=nxt)
+                skip = True
             else:
                 x = m(x)
         return x

@@ -11,6 +11,25 @@
 
 namespace embnet {
 
+// Inverted dropout riding on another pass (the BatchNormalization in front of a Dropout layer, simple2's bn3 / bn6,
+// /root/reference/embedding_net/backbones.py:55,66): the mask of embnet_dropout — keep element i iff
+// rng_u32(seed, i, 1) >= thr — applied to the value in registers; thr == 0 switches it off.
+struct DropArg { uint64_t seed; const uint64_t* seed_add; uint32_t thr; float keep_scale; };
+static DropArg drop_arg(float rate, uint64_t seed, const uint64_t* seed_add) {
+  DropArg d{seed, seed_add, 0u, 1.f};
+  if (rate > 0.f) { d.thr = (uint32_t)((double)rate * 4294967296.0); d.keep_scale = 1.f / (1.f - rate); }
+  return d;
+}
+__device__ __forceinline__ uint64_t drop_seed(const DropArg& d) { return d.seed + (d.seed_add ? *d.seed_add : 0ull); }
+__device__ __forceinline__ float4 drop4(const DropArg& d, uint64_t seed, long i4, float4 v) {   // elements 4*i4 .. 4*i4+3
+  const uint64_t e = (uint64_t)i4 * 4;
+  v.x = rng_u32(seed, e, 1) >= d.thr ? v.x * d.keep_scale : 0.f;
+  v.y = rng_u32(seed, e + 1, 1) >= d.thr ? v.y * d.keep_scale : 0.f;
+  v.z = rng_u32(seed, e + 2, 1) >= d.thr ? v.z * d.keep_scale : 0.f;
+  v.w = rng_u32(seed, e + 3, 1) >= d.thr ? v.w * d.keep_scale : 0.f;
+  return v;
+}
+
 static bool bn_scalar() { static const bool v = env_long("EMBNET_BN_SCALAR", 0) != 0; return v; }   // A/B knob
 
 // ---------------------------------------------------------------- column reductions over [M, C]
@@ -169,14 +188,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
                                                              long m, int c4, ColGeom g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const DropArg drop) {
   struct K4 { float4 sc, sh, mu, rs; };
+  const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
   col_reduce2_v4p(m, c4, g, partial, [&](int q) {
     return K4{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q],
               reinterpret_cast<const float4*>(mean)[q], reinterpret_cast<const float4*>(rstd)[q]};
   }, [&](long r, int q, const K4& k, float4& a, float4& b) {
     const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
     float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
+    if (drop.thr) dz = drop4(drop, dseed, r * c4 + q, dz);   // dy of the Dropout behind this layer -> dy of the layer
     const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs;
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
@@ -252,9 +273,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_inrelu4_kernel(const float* 
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                                    int relu, int training, float* __restrict__ dz_out,
-                                                                   float* __restrict__ partial) {
+                                                                   float* __restrict__ partial, const DropArg drop) {
   struct K6 { float4 sc, sh, mu, rs, db, dg; };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
   col_reduce2_v4p(m, c4, g, partial, [&](int q) {
     K6 k{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q], z4, z4, z4, z4};
     if (training) {
@@ -265,6 +287,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_inrelu4_kernel(const float* 
   }, [&](long r, int q, const K6& k, float4& a, float4&) {
     const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
     float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
+    if (drop.thr) dz = drop4(drop, dseed, r * c4 + q, dz);
     const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs, db = k.db, dg = k.dg;
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
@@ -325,8 +348,9 @@ __global__ __launch_bounds__(256) void bn_infer_prepare_kernel(int c, const floa
 // y = [relu](x*scale[c] + shift[c])   (8 B/elem)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, long total, int c,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int relu, float* __restrict__ y) {
+                                                         int relu, float* __restrict__ y, const DropArg drop) {
   const long stride = (long)gridDim.x * 256;
+  const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
   if ((c & 3) == 0) {
     const long n4 = total >> 2;
     const int c4 = c >> 2;
@@ -344,13 +368,15 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       const float4 v = reinterpret_cast<const float4*>(x)[i];
       float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
       if (relu) { o.x = act_apply(relu, o.x); o.y = act_apply(relu, o.y); o.z = act_apply(relu, o.z); o.w = act_apply(relu, o.w); }
+      if (drop.thr) o = drop4(drop, dseed, i, o);
       reinterpret_cast<float4*>(y)[i] = o;
     }
   } else {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
       const int col = (int)(i % c);
-      float o = fmaf(x[i], scale[col], shift[col]);
-      y[i] = act_apply(relu, o);
+      float o = act_apply(relu, fmaf(x[i], scale[col], shift[col]));
+      if (drop.thr) o = rng_u32(dseed, (uint64_t)i, 1) >= drop.thr ? o * drop.keep_scale : 0.f;
+      y[i] = o;
     }
   }
 }
@@ -1038,7 +1064,7 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
   { EMBNET_TRACE("embnet::bn_finalize_kernel", TRACE_BYTES, 8.0 * nblocks * c, stream); bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
                                                           save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr); }
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
-    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
+    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y, DropArg{0, nullptr, 0u, 1.f}); }
   return check_launch("bn_train_fwd");
 }
 
@@ -1048,7 +1074,7 @@ extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* g
   EMBNET_CHECK_ARG(x && moving_mean && moving_var && scale && shift, "bn_infer_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_infer_fwd: m=%ld c=%d", m, c);
   bn_infer_prepare_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(c, gamma, beta, moving_mean, moving_var, eps, scale, shift);
-  if (y) { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y); }
+  if (y) { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y, DropArg{0, nullptr, 0u, 1.f}); }
   return check_launch("bn_infer_fwd");
 }
 
@@ -1056,8 +1082,17 @@ extern "C" int embnet_affine_act(const float* x, long m, int c, const float* sca
                                  void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && y, "affine_act: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "affine_act: m=%ld c=%d", m, c);
-  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y); }
+  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y, DropArg{0, nullptr, 0u, 1.f}); }
   return check_launch("affine_act");
+}
+
+extern "C" int embnet_affine_act_dropout(const float* x, long m, int c, const float* scale, const float* shift, int act, float rate,
+                                         uint64_t seed, const uint64_t* seed_add_dev, float* y, void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && y, "affine_act_dropout: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0, "affine_act_dropout: m=%ld c=%d", m, c);
+  EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "affine_act_dropout: rate %f outside [0,1)", rate);
+  { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, act, y, drop_arg(rate, seed, seed_add_dev)); }
+  return check_launch("affine_act_dropout");
 }
 
 extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
@@ -1088,7 +1123,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   if (save_mean && save_rstd) {
     if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);
-      { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial); }
+      { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, DropArg{0, nullptr, 0u, 1.f}); }
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
     } else {
       { EMBNET_TRACE("embnet::bn_bwd_reduce_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial); }
@@ -1107,10 +1142,10 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
   return check_launch("bn_bwd");
 }
 
-extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,
-                                    const float* save_rstd, const float* scale, const float* shift, int relu, int training,
-                                    float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
+                              const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                              float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream, const DropArg drop) {
   EMBNET_CHECK_ARG(dy && x && scale && shift && dz && dgamma && dbeta && dbias && workspace, "bn_bwd_inrelu: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0, "bn_bwd_inrelu: m=%ld c=%d (c %% 4 == 0 required)", m, c);
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd_inrelu: training needs saved statistics");
@@ -1119,7 +1154,7 @@ extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int
   float* partial = (float*)workspace;
   const ColGeom g4 = col_geom(m, c / 4);
   if (save_mean && save_rstd) {
-    { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial); }
+    { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, drop); }
     bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
@@ -1127,9 +1162,27 @@ extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int
   }
   { EMBNET_TRACE("embnet::bn_bwd_apply_inrelu4_kernel", TRACE_BYTES, 12.0 * m * c, stream);
     bn_bwd_apply_inrelu4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, 1.f / (float)m, save_mean, save_rstd, scale, shift,
-                                                               dbeta, dgamma, relu, training, dz, partial); }
+                                                               dbeta, dgamma, relu, training, dz, partial, drop); }
   colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias);
   return check_launch("bn_bwd_inrelu");
+}
+
+extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                    const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                    float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return bn_bwd_inrelu_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dz, dgamma, dbeta, dbias, workspace,
+                            workspace_bytes, stream, DropArg{0, nullptr, 0u, 1.f});
+}
+
+extern "C" int embnet_bn_bwd_inrelu_dropout(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                            const float* save_rstd, const float* scale, const float* shift, int relu,
+                                            int training, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* dz,
+                                            float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "bn_bwd_inrelu_dropout: rate %f outside [0,1)", rate);
+  return bn_bwd_inrelu_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dz, dgamma, dbeta, dbias, workspace,
+                            workspace_bytes, stream, drop_arg(rate, seed, seed_add_dev));
 }
 
 extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,

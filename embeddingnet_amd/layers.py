@@ -149,6 +149,8 @@ def _done(out, notify):
 # leaves (dz alias, dbias) in RELU_DONE under dz's address; the conv's backward finds its incoming gradient there and skips
 # its own relu_bwd_colsum pass.  A conv whose output has a second consumer never finds the entry (autograd hands it the SUM,
 # another tensor) and masks again — harmless, dz is already zero where the mask is.
+# a Dropout directly behind a BatchNormalization rides on the BatchNormalization's kernels (backbones.Seq); 0: separate passes
+FUSE_DROPOUT_BN = [__import__("os").environ.get("EMBNET_FUSE_DROPOUT_BN", "1") == "1"]
 FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
 RELU_DONE = {}
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
@@ -711,8 +713,10 @@ def _bn_grad_targets(ctx, c, device, gamma_idx=1, beta_idx=2):
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
-                with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None):
-        """emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
+                with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None, dropout=None):
+        """dropout=(rate, seed): a Dropout layer directly behind this one rides on its passes (embnet_affine_act_dropout,
+        embnet_bn_bwd_inrelu_dropout; the mask and arithmetic of embnet_dropout).
+        emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
         address; BatchNormalization.forward hangs them on the tensor).  emit_dx_planes: backward writes dx also as planes
         into DY_PLANES (the producer of x is a patch conv, whose data gradient reads them)."""
         x = _c(x)
@@ -721,7 +725,7 @@ class _BatchNormFn(torch.autograd.Function):
         m = x.numel() // c
         y = torch.empty_like(x)
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
-        yk = None if emit_planes else y                                      # planes: statistics first, then one pass writing both
+        yk = None if (emit_planes or dropout) else y                         # planes / dropout: statistics first, then one pass
         if training:
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, yk, stats, moving_mean, moving_var, partials)
         else:
@@ -732,6 +736,12 @@ class _BatchNormFn(torch.autograd.Function):
             check(lib.embnet_affine_act_planes(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
                                                ptr(y), ptr(planes), stream()))
             _ACT_PLANES[y.data_ptr()] = planes
+        ctx.dropout = None
+        if dropout:
+            rate, seed = dropout
+            ctx.dropout = (rate, seed, GRAPH_TICK)
+            check(lib.embnet_affine_act_dropout(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
+                                                rate, seed, GRAPH_TICK, ptr(y), stream()))
         ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
         ctx.in_relu_bias = in_relu_bias if (in_relu_bias is not None and not with_skip and c % 4 == 0) else None
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
@@ -762,13 +772,25 @@ class _BatchNormFn(torch.autograd.Function):
             if len(DY_PLANES) > 64:                  # entries nobody collected (a consumer fell back to the fp32 kernel)
                 DY_PLANES.clear()
             DY_PLANES[dx.data_ptr()] = (planes, dx)
-        if getattr(ctx, "in_relu_bias", None) is not None and planes is None and dskip is None:
+        drop = getattr(ctx, "dropout", None)
+        inrelu = getattr(ctx, "in_relu_bias", None) is not None and planes is None and dskip is None
+        if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
+            dyd = torch.empty_like(dy)
+            check(lib.embnet_dropout(ptr(dy), dy.numel(), drop[0], drop[1], drop[2], ptr(dyd), stream()))
+            dy = dyd
+        if inrelu:
             # x is the output of a conv with a fused ReLU: its backward (mask + bias gradient) rides on this pass
             (bias,) = ctx.in_relu_bias
             db, db_note = _sink(bias)
-            check(lib.embnet_bn_bwd_inrelu(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
-                                           (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training), ptr(dx),
-                                           ptr(tg), ptr(tb), ptr(db), ptr(ws), ws.numel() * 4, stream()))
+            if drop is not None:
+                check(lib.embnet_bn_bwd_inrelu_dropout(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
+                                                       (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training),
+                                                       drop[0], drop[1], drop[2], ptr(dx), ptr(tg), ptr(tb), ptr(db), ptr(ws),
+                                                       ws.numel() * 4, stream()))
+            else:
+                check(lib.embnet_bn_bwd_inrelu(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
+                                               (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training), ptr(dx),
+                                               ptr(tg), ptr(tb), ptr(db), ptr(ws), ws.numel() * 4, stream()))
             if len(RELU_DONE) > 64:
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
@@ -777,7 +799,7 @@ class _BatchNormFn(torch.autograd.Function):
                                     int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
                                     ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNGapFn(torch.autograd.Function):
@@ -914,8 +936,10 @@ class BatchNormalization(nn.Module):
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
 
-    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None):
-        """planes_for=<Conv2D>: the conv that consumes the output; when it can run the patch kernel on it
+    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None):
+        """dropout=<Dropout>: the Dropout layer that consumes the output, applied in this layer's passes when it is active
+        (plain path only; the caller then skips the Dropout module).
+        planes_for=<Conv2D>: the conv that consumes the output; when it can run the patch kernel on it
         (Conv2D.patch_capable) the output is also written as bf16 planes (`y._planes`) in the same pass.
         emit_gap=True (C % 4 == 0): returns (bn(x), GlobalAveragePooling2D(bn(x))) from one pass over the tensor.
         defer=True (consumers are Conv2D layers): only the statistics are computed; the convs apply the
@@ -949,7 +973,7 @@ class BatchNormalization(nn.Module):
         in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled()) else None
         return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                   self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
-                                  False, want_dx_planes, in_relu_bias)
+                                  False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
 
 
 class _InputBNConvFn(torch.autograd.Function):
@@ -1261,8 +1285,19 @@ class Dropout(nn.Module):
         super().__init__()
         self.rate, self.seed, self.enabled, self._step = rate, seed, True, 0
 
+    def active(self):
+        return bool(self.training and self.enabled and self.rate > 0)
+
+    def take(self):
+        """(rate, seed) of this call's mask for a layer that applies the dropout in its own passes (BatchNormalization
+        (dropout=...)); None when the layer is inactive.  Advances the mask counter exactly as forward() does."""
+        if not self.active():
+            return None
+        self._step += 1
+        return self.rate, (self.seed << 32) + self._step
+
     def forward(self, x):
-        if not (self.training and self.enabled and self.rate > 0):
+        if not self.active():
             return x
         self._step += 1
         return _DropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)

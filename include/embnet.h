@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 13
+#define EMBNET_ABI_VERSION 14
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -348,6 +348,16 @@ int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
 int embnet_dropout(const float* x, long total, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* y,
                    void* stream);   /* seed_add_dev (NULL or device uint64): added to seed — a replayed HIP graph draws a new mask per step */
+/* A Dropout layer directly behind a BatchNormalization (simple2's bn3 -> drop1, bn6 -> drop2: backbones.py:52-55,63-66)
+ * riding on the BatchNormalization's passes, with embnet_dropout's mask and arithmetic (bit-identical to the two
+ * layers run separately):  forward  y = dropout(act(x*scale + shift));  backward  embnet_bn_bwd_inrelu with
+ * dy := dropout_backward(dy) applied as dy is read. */
+int embnet_affine_act_dropout(const float* x, long m, int c, const float* scale, const float* shift, int act, float rate,
+                              uint64_t seed, const uint64_t* seed_add_dev, float* y, void* stream);
+int embnet_bn_bwd_inrelu_dropout(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                 const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                 float rate, uint64_t seed, const uint64_t* seed_add_dev, float* dz, float* dgamma,
+                                 float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 /* ---- EfficientNet MBConv pieces (backbones.py:84-98, `efficientnet` zoo package) and the siamese 'l1' head ---- */
 /* DepthwiseConv2D: x[n,h,w,c], w[r,s,c] (Keras depthwise_kernel [r,s,c,1]), y[n,oh,ow,c]; padding as conv2d. */
 int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s,

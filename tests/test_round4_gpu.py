@@ -222,3 +222,47 @@ def test_relu_backward_fused_into_batchnorm_backward(dev, shape, k, cout):
     # the masked gradient itself is exact: dx / dW are computed from identical dz values when the statistics agree; with the
     # epilogue statistics they differ in the last bits only
     assert not L.RELU_DONE
+
+
+# ------------------------------------------------------------------------------------------------ BN -> Dropout
+@pytest.mark.parametrize("image,inrelu", [(64, True), (40, True), (64, False)])
+def test_dropout_behind_batchnorm_rides_on_its_kernels(dev, image, inrelu):
+    """simple2's bn3 -> drop1 and bn6 -> drop2 (reference backbones.py:52-55,63-66): with the Dropout applied inside the
+    BatchNormalization's forward apply and backward passes (embnet_affine_act_dropout, embnet_bn_bwd_inrelu_dropout) the
+    backbone's output and every gradient equal the separate-layer chain BIT FOR BIT (same counter-based mask, same
+    multiply), over two steps (the mask counter advances the same way), and no dropout kernel is launched for them.
+    inrelu=False: the ReLU backward is not fused into the BN backward, so the Dropout backward runs as a pass in front of it."""
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd import layers as L
+    x = torch.rand((6, image, image, 3), device=dev)
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_DROPOUT_BN[0] = fuse
+        L.FUSE_RELU_BN[0] = inrelu
+        try:
+            base, _ = B.get_backbone((image, image, 3), encodings_len=32, backbone_name="simple2", backbone_weights=None, seed=5)
+            base = base.to(dev).train()
+            out = []
+            _lib.trace_reset(); _lib.trace_enable(True)
+            for step in range(2):
+                for p in base.parameters():
+                    p.grad = None
+                y = base(x)
+                y.backward(torch.cos(y.detach() * 3 + step))
+                out.append([y.detach().clone()] + [p.grad.clone() for p in base.parameters()])
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = out
+        finally:
+            L.FUSE_DROPOUT_BN[0] = True
+            L.FUSE_RELU_BN[0] = True
+            L.RELU_DONE.clear()
+    n_sep, n_fused = (sum("dropout_kernel" in n for n in names[f]) for f in (False, True))
+    # two steps x (3 Dropout layers forward + backward); fused: only the head's Dropout (behind a Dense) keeps its kernel,
+    # plus — without the fused ReLU backward — the two backward passes in front of the BN backward
+    assert n_sep == 12 and n_fused == (4 if inrelu else 8), (n_sep, n_fused)
+    for sa, sb in zip(res[False], res[True]):
+        for a, b in zip(sa, sb):
+            assert torch.equal(a, b)
+    assert not torch.equal(res[True][0][0], res[True][1][0])          # a new mask each step

@@ -26,6 +26,14 @@ RN50 = [(128, 56, 56, 64, 1, 256, 1, 0), (128, 56, 56, 256, 1, 64, 1, 0), (128, 
         (128, 14, 14, 1024, 1, 256, 1, 0), (128, 7, 7, 2048, 1, 512, 1, 0), (128, 7, 7, 512, 1, 2048, 1, 0)]
 
 
+# every 1x1 geometry of a Keras ResNet50 at C3's 512 images per step (stride on the block's first 1x1 conv), with its count
+RN50_1X1 = [(512, 56, 56, 64, 1, 64, 1, 0), (512, 56, 56, 64, 1, 256, 1, 0), (512, 56, 56, 256, 1, 64, 1, 0),
+            (512, 56, 56, 256, 1, 128, 2, 0), (512, 56, 56, 256, 1, 512, 2, 0), (512, 28, 28, 128, 1, 512, 1, 0),
+            (512, 28, 28, 512, 1, 128, 1, 0), (512, 28, 28, 512, 1, 256, 2, 0), (512, 28, 28, 512, 1, 1024, 2, 0),
+            (512, 14, 14, 256, 1, 1024, 1, 0), (512, 14, 14, 1024, 1, 256, 1, 0), (512, 14, 14, 1024, 1, 512, 2, 0),
+            (512, 14, 14, 1024, 1, 2048, 2, 0), (512, 7, 7, 512, 1, 2048, 1, 0), (512, 7, 7, 2048, 1, 512, 1, 0)]
+
+
 def load(path):
     l = ctypes.CDLL(os.path.abspath(path))
     for name, (res, argtypes) in _lib.parse_header().items():
@@ -45,7 +53,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [(os.path.basename(p).replace(".so", ""), load(p)) for p in a.libs]
-    shapes = {"rn18": RN18, "rn50": RN50}.get(a.shapes) or [tuple(int(v) for v in a.shapes.split(","))]
+    shapes = {"rn18": RN18, "rn50": RN50, "rn50_1x1": RN50_1X1}.get(a.shapes) or [tuple(int(v) for v in a.shapes.split(","))]
     st = torch.cuda.current_stream().cuda_stream
     P = lambda t: t.data_ptr()
     tot = {nm: {} for nm, _ in libs}
@@ -96,6 +104,9 @@ def main():
                 us = statistics.median(times[nm])
                 tot[nm][kind] = tot[nm].get(kind, 0.0) + us
                 line += f" {us:9.1f} us {flop / us / 1e6:6.1f} TF"
+            # floors: the pass's compulsory HBM bytes at 5 TB/s (what the streaming kernels reach), its FLOP at 200 TFLOP/s fp32-eq
+            byts = 4.0 * {"fwd": x.numel() + y.numel(), "dgrad": dy.numel() + dx.numel(), "wgrad": x.numel() + dy.numel()}[kind]
+            line += f"   floors: hbm {byts / 5e6:7.1f} us  mfma {flop / 200e6:7.1f} us"
             print(line, flush=True)
     for kind in ("fwd", "dgrad", "wgrad"):
         if any(kind in tot[nm] for nm in tot):
