@@ -413,20 +413,41 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;  // this lane's column quad: sum, sum of squares over its rows
-    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
-      const int row = m0 + r, col = n0 + c;
-      if (row < M && col < p.g.K) {
-        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.residual) {                                  // the Add layer behind the conv (residual units)
-          const float4 q = *reinterpret_cast<const float4*>(p.residual + (long)row * p.g.K + col);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        *reinterpret_cast<float4*>(p.y + (long)row * p.g.K + col) = v;
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
-      }
-    });
+    // what the epilogue adds, fetched for all of the lane's rows before the staging loop (gemm_engine.h, EpiIdx)
+    constexpr int NJ = EpiIdx<G>::NJ;
+    const int ecol = n0 + epi_col<G>();
+    const bool cok = ecol < p.g.K;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && cok) bv = *reinterpret_cast<const float4*>(p.bias + ecol);
+    float4 res[G::TM][NJ];
+    if (p.residual) {                                      // the Add layer behind the conv (residual units)
+#pragma unroll
+      for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          res[im][j] = *reinterpret_cast<const float4*>(p.residual + (long)min(m0 + epi_row<G>(im, j), M - 1) * p.g.K + (cok ? ecol : 0));
+#pragma unroll
+      for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) settle(res[im][j]);
+    }
+    settle(bv);
+    auto emit = [&](int im, int j, int row, int col, float4 v) {
+      if (p.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.residual) { const float4 q = res[im][j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      *reinterpret_cast<float4*>(p.y + (long)row * p.g.K + col) = v;
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+    };
+    if (m0 + G::BM <= M && n0 + G::BN <= p.g.K) {          // interior tile (wave-uniform): straight-line stores, no edge tests
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 v) { emit(im, j, m0 + r, n0 + c, v); });
+    } else {
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 v) {
+        const int row = m0 + r, col = n0 + c;
+        if (row < M && col < p.g.K) emit(im, j, row, col, v);
+      });
+    }
     if (p.stats) {
       // BatchNorm statistics of the layer that follows, while the tile is in registers: every wave writes the
       // column sums of its WTM-row band as partial (tile_m*WAVES_M + wave_m) of stats[2][K][P]; the BN
@@ -489,19 +510,39 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   const int st = p.g.stride;
   if ((p.g.C & 3) == 0) {                                // 16-byte row stores
-    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 v) {
-      const int row = m0 + r, col = n0 + c;
-      if (row < M && col < p.g.C) {
+    // output addresses of the lane's rows and — the gradient through the tensor's other consumer (in dx or apart) — what is
+    // added to them, fetched before the staging loop (gemm_engine.h, EpiIdx)
+    constexpr int NJ = EpiIdx<G>::NJ;
+    const int ecol = n0 + epi_col<G>();
+    const bool cok = ecol < p.g.C;
+    long base[G::TM][NJ];
+    float4 res[G::TM][NJ];
+#pragma unroll
+    for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
         uint32_t n, rem, hc, wc;
-        cg.dHWc.divmod((uint32_t)row, n, rem); cg.dWc.divmod(rem, hc, wc);
-        const long base = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
-        if (p.accumulate) {                                // the gradient through the tensor's other consumer (in dx or apart)
-          const float4 o = *reinterpret_cast<const float4*>(p.add_src + base + col);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        *reinterpret_cast<float4*>(p.dx + base + col) = v;
+        cg.dHWc.divmod((uint32_t)min(m0 + epi_row<G>(im, j), M - 1), n, rem); cg.dWc.divmod(rem, hc, wc);
+        base[im][j] = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
+        if (p.accumulate) res[im][j] = *reinterpret_cast<const float4*>(p.add_src + base[im][j] + (cok ? ecol : 0));
       }
-    });
+    if (p.accumulate) {
+#pragma unroll
+      for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) settle(res[im][j]);
+    }
+    auto emit = [&](int im, int j, int col, float4 v) {
+      if (p.accumulate) { const float4 o = res[im][j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *reinterpret_cast<float4*>(p.dx + base[im][j] + col) = v;
+    };
+    if (m0 + G::BM <= M && n0 + G::BN <= p.g.C) {          // interior tile (wave-uniform): straight-line stores, no edge tests
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int, int c, float4 v) { emit(im, j, n0 + c, v); });
+    } else {
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 v) {
+        if (m0 + r < M && n0 + c < p.g.C) emit(im, j, n0 + c, v);
+      });
+    }
     stamp(5);
     return;
   }

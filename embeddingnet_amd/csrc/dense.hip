@@ -36,10 +36,18 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseParams p) {
     return;
   }
   gemm_mainloop<G, TA, TB>(la, lb, 0, kt_total, smem, acc);
-  for_each_acc<G>(acc, [&](int r, int c, float v) {
+  float bcol[G::TN];                                     // the lane's bias values, one per column block, before the walk
+#pragma unroll
+  for (int in = 0; in < G::TN; ++in) {
+    const int col = n0 + ((threadIdx.x >> 6) % G::WAVES_N) * G::WTN + 32 * in + (threadIdx.x & 31);
+    bcol[in] = (p.bias && col < p.n) ? p.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int in = 0; in < G::TN; ++in) settle(bcol[in]);
+  for_each_acc_idx<G>(acc, [&](int, int in, int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < p.m && col < p.n) {
-      if (p.bias) v += p.bias[col];
+      if (p.bias) v += bcol[in];
       if (p.relu) v = fmaxf(v, 0.f);
       p.out[(long)row * p.n + col] = v;
     }
@@ -51,7 +59,15 @@ __global__ __launch_bounds__(256) void dense_splitk_finish_kernel(const float* _
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= mn) return;
   float v = slabs[i];
-  for (int s = 1; s < splits; ++s) v += slabs[(long)s * mn + i];
+  int s = 1;
+  for (; s + 8 <= splits; s += 8) {                      // eight slab values in flight, added in slab order
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[(long)(s + u) * mn + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; s < splits; ++s) v += slabs[(long)s * mn + i];
   if (bias) v += bias[i % n];
   out[i] = relu ? fmaxf(v, 0.f) : v;
 }

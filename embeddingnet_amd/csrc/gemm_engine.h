@@ -665,6 +665,21 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[G::TM][G::TN], 
         f(wm + 32 * im + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wn + 32 * in + (lane & 31), acc[im][in][r]);
 }
 
+// Same walk with the block indices: f(im, in, row, col, value) — im / in are constants after unrolling, so values the
+// epilogue adds per column block (bias) can sit in a register array loaded before the walk.
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc_idx(const f32x16 (&acc)[G::TM][G::TN], F&& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
+#pragma unroll
+  for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < G::TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        f(im, in, wm + 32 * im + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), wn + 32 * in + (lane & 31), acc[im][in][r]);
+}
+
 // Same walk, but as 16-byte row pieces: each wave stages one 32-row band of its sub-tile through a
 // private LDS region ([32][WTN+4]) and reads it back row-major, so the caller can issue
 // global_store_dwordx4 (256 contiguous bytes per 16 lanes) instead of one dword per lane — 4x fewer
@@ -676,8 +691,30 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[G::TM][G::TN], 
 template <class G>
 constexpr int EPI_FLOATS = 4 * 32 * (G::WTN + 4);
 
-template <class G, class F>
-__device__ __forceinline__ void for_each_acc_row4(const f32x16 (&acc)[G::TM][G::TN], float* smem, F&& f) {
+// The lane's share of the tile in that epilogue: NJ row quads per 32-row block, all in ONE column quad —
+//   row(im, j) = epi_row<G>(im, j),  column = epi_col<G>()      (tile-relative; im < G::TM, j < EpiIdx<G>::NJ).
+// An epilogue that ADDS something read from memory (bias, the residual tensor, the other gradient of a skip connection,
+// row / column norms) loads it for all its (im, j) BEFORE the staging loop: written inside the per-row callback, under
+// the edge test, each load is followed by s_waitcnt vmcnt(0) — 16 serial memory round trips per tile (the generated code
+// of the round-1..3 epilogues: 30 us of a 1x1 convolution's tile whose main loop is 4..16 K tiles).
+// settle(v): a use + redefinition of v the compiler cannot see through.  Placed after the pre-loop loads (in straight-line
+// code) it takes their s_waitcnt ONCE; without it the wait is re-inserted at every use inside the staging loop — the uses
+// sit in divergent edge-test branches, so the "load still pending" state survives each merge — as s_waitcnt vmcnt(0),
+// which on gfx9 also waits for the previous iteration's STORE: 16 serial store round trips per tile.
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void settle(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+template <class G> struct EpiIdx { static constexpr int LPR = G::WTN / 4, RPI = 64 / LPR, NJ = 32 / RPI; };
+template <class G> __device__ __forceinline__ int epi_row(int im, int j) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return (wave / G::WAVES_N) * G::WTM + 32 * im + j * EpiIdx<G>::RPI + lane / EpiIdx<G>::LPR;
+}
+template <class G> __device__ __forceinline__ int epi_col() {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return (wave % G::WAVES_N) * G::WTN + (lane % EpiIdx<G>::LPR) * 4;
+}
+
+template <class G, class F>     // f(im, j, tile row, tile column, float4): im, j are compile-time constants after unrolling
+__device__ __forceinline__ void for_each_acc_row4_idx(const f32x16 (&acc)[G::TM][G::TN], float* smem, F&& f) {
   constexpr int LDW = G::WTN + 4, LPR = G::WTN / 4, RPI = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
@@ -691,12 +728,17 @@ __device__ __forceinline__ void for_each_acc_row4(const f32x16 (&acc)[G::TM][G::
       for (int r = 0; r < 16; ++r)
         s[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDW + in * 32 + (lane & 31)] = acc[im][in][r];
 #pragma unroll
-    for (int rr = 0; rr < 32; rr += RPI) {
-      const int row = rr + lane / LPR, c4 = (lane % LPR) * 4;
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int row = j * RPI + lane / LPR, c4 = (lane % LPR) * 4;
       const float4 v = *reinterpret_cast<const float4*>(&s[row * LDW + c4]);
-      f(wm + 32 * im + row, wn + c4, v);
+      f(im, j, wm + 32 * im + row, wn + c4, v);
     }
   }
+}
+
+template <class G, class F>
+__device__ __forceinline__ void for_each_acc_row4(const f32x16 (&acc)[G::TM][G::TN], float* smem, F&& f) {
+  for_each_acc_row4_idx<G>(acc, smem, [&](int, int, int r, int c, float4 v) { f(r, c, v); });
 }
 
 // Sum a per-lane float4 over the lanes that share a column quad after for_each_acc_row4 (lane % LPR equal).

@@ -60,18 +60,36 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseParams p) {
   stamp(4);
 
   if ((p.n & 3) == 0) {                                  // 16-byte row stores of the matrix
-    for_each_acc_row4<G>(acc, smem, [&](int r, int c, float4 g) {
-      const int row = m0 + r, col = n0 + c;
-      if (row < p.n && col < p.n) {
-        const float nr = p.nn[row];
-        const float4 nc = *reinterpret_cast<const float4*>(p.nn + col);
-        float o[4] = {fmaxf(nr + nc.x - 2.f * g.x, 0.f), fmaxf(nr + nc.y - 2.f * g.y, 0.f),
-                      fmaxf(nr + nc.z - 2.f * g.z, 0.f), fmaxf(nr + nc.w - 2.f * g.w, 0.f)};
+    // the squared norms of the lane's rows and of its column quad, fetched before the staging loop (gemm_engine.h, EpiIdx)
+    constexpr int NJ = EpiIdx<G>::NJ;
+    const int ecol = n0 + epi_col<G>();
+    const float4 nc0 = *reinterpret_cast<const float4*>(p.nn + (ecol < p.n ? ecol : 0));
+    float nrow[G::TM][NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { if (row == col + j) o[j] = 0.f; if (!p.squared) o[j] = sqrtf(o[j]); }
-        *reinterpret_cast<float4*>(p.d + (long)row * p.n + col) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-    });
+    for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) nrow[im][j] = p.nn[min(m0 + epi_row<G>(im, j), p.n - 1)];
+    float4 nc = nc0;
+    settle(nc);
+#pragma unroll
+    for (int im = 0; im < G::TM; ++im)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) settle(nrow[im][j]);
+    auto emit = [&](int im, int j, int row, int col, float4 g) {
+      const float nr = nrow[im][j];
+      float o[4] = {fmaxf(nr + nc.x - 2.f * g.x, 0.f), fmaxf(nr + nc.y - 2.f * g.y, 0.f),
+                    fmaxf(nr + nc.z - 2.f * g.z, 0.f), fmaxf(nr + nc.w - 2.f * g.w, 0.f)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { if (row == col + q) o[q] = 0.f; if (!p.squared) o[q] = sqrtf(o[q]); }
+      *reinterpret_cast<float4*>(p.d + (long)row * p.n + col) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    if (m0 + G::BM <= p.n && n0 + G::BN <= p.n) {          // interior tile (wave-uniform): straight-line stores, no edge tests
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 g) { emit(im, j, m0 + r, n0 + c, g); });
+    } else {
+      for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 g) {
+        if (m0 + r < p.n && n0 + c < p.n) emit(im, j, m0 + r, n0 + c, g);
+      });
+    }
     stamp(5);
     return;
   }
