@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
 template <int KS, int ST>
 __global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      DwGeom g, int cq_lanes, int units_per_block,
-                                                                     float* __restrict__ partial) {
+                                                                     float* __restrict__ partial, int colmajor) {
   constexpr int TW = DW_TW, NX = (TW - 1) * ST + KS, TAPS = KS * KS;
   const int c4 = g.C >> 2, unit_lanes = 64 / cq_lanes, wb_n = (g.OW + TW - 1) / TW;
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -374,8 +374,18 @@ __global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float
     for (int j = 0; j < KS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cq < c4) {
       for (int u = u0 + ul; u < u1; u += unit_lanes) {
-        const int row = u / wb_n, ow0 = (u - row * wb_n) * TW;
-        const int n = row / g.OH, oh = row - n * g.OH;
+        // colmajor: consecutive units run DOWN a 4-column block of an image, so the image row wave r reads for unit oh + 1
+        // is the one wave r + 1 read for unit oh a moment ago (L1 hit) — row-major, the KS reads of an image row are a whole
+        // row of units apart and each comes from L2: (KS + 1) / 2 x the compulsory bytes on the L2 -> L1 path
+        int row, ow0, n, oh;
+        if (colmajor) {
+          const int per_img = g.OH * wb_n;
+          n = u / per_img; const int rem = u - n * per_img, wb = rem / g.OH;
+          oh = rem - wb * g.OH; ow0 = wb * TW; row = n * g.OH + oh;
+        } else {
+          row = u / wb_n; ow0 = (u - row * wb_n) * TW;
+          n = row / g.OH; oh = row - n * g.OH;
+        }
         float4 d[TW];
         const long dbase = ((long)row * g.OW + ow0) * c4 + cq;
 #pragma unroll
@@ -748,8 +758,21 @@ static int dw_wgrad_blocks(long npix, int& ppb) {
 // slabs of (row, column-block) units for the wave-per-kernel-row kernel: enough workgroups (slabs x channel groups) to
 // fill the chip even when a layer has few pixels (7x7x1152: 3584 units), at most 2048 partial slabs for dw_slab_sum
 static int dw_wave_slabs(long nunits, int c, int& cq_lanes, int& cgroups, int& upb) {
-  cq_lanes = 1; while (cq_lanes < c / 4 && cq_lanes < 64) cq_lanes <<= 1;
-  cgroups = cdiv(c / 4, cq_lanes);
+  // channel-quad lanes per wave: a power of two (the other lane bits walk units).  The smallest power of two >= C/4 leaves
+  // lanes idle when C/4 is not one (EfficientNet: C/4 = 24, 36, 168, 288 -> 75, 56, 87, 90 % of the lanes at work, and the
+  // kernel runs at the rate the L1 takes wave-wide requests): take the widest group of >= 8 lanes (one 128-byte line per
+  // pixel) that wastes the fewest lanes.  Measured per layer (profiles/r04_exp_dw_wgrad_lanes.txt): C = 96, 480, 672, 1152 gain
+  // 9 - 29 %; C = 144 (36 quads) loses 30 % in 8-lane groups and more in 4-lane groups, so a C/4 that fits one wave stays whole.
+  static const int pack = (int)env_long("EMBNET_DW_WGRAD_PACK", 1);
+  const int c4 = c / 4;
+  cq_lanes = 1; while (cq_lanes < c4 && cq_lanes < 64) cq_lanes <<= 1;
+  if (pack && !(c4 > 32 && c4 <= 64)) {                    // (33..64 quads: one masked 64-lane group is the fastest form measured)
+    auto use = [&](int l) { return (double)c4 / ((double)l * cdiv(c4, l)); };
+    int best = cq_lanes;
+    for (int l = cq_lanes >> 1; l >= 8; l >>= 1) if (use(l) > use(best) + 1e-9) best = l;
+    cq_lanes = best;
+  }
+  cgroups = cdiv(c4, cq_lanes);
   long slabs = (nunits + 15) / 16;
   const long cap = 2048 / cgroups > 0 ? 2048 / cgroups : 1;
   if (slabs > cap) slabs = cap;
@@ -779,12 +802,13 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
     int upb, cql, cgroups;
     const int blocks = dw_wave_slabs((long)n * oh * cdiv(ow, DW_TW), c, cql, cgroups, upb);
     const dim3 grid(blocks, cgroups);
+    static const int colmajor = (int)env_long("EMBNET_DW_WGRAD_COLMAJOR", 1);
     {
       EMBNET_TRACE("embnet::dwconv_wgrad4_wave_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream);
-      if (r == 3 && stride == 1) dwconv_wgrad4_wave_kernel<3, 1><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
-      else if (r == 3) dwconv_wgrad4_wave_kernel<3, 2><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
-      else if (stride == 1) dwconv_wgrad4_wave_kernel<5, 1><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
-      else dwconv_wgrad4_wave_kernel<5, 2><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace);
+      if (r == 3 && stride == 1) dwconv_wgrad4_wave_kernel<3, 1><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace, colmajor);
+      else if (r == 3) dwconv_wgrad4_wave_kernel<3, 2><<<grid, 192, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace, colmajor);
+      else if (stride == 1) dwconv_wgrad4_wave_kernel<5, 1><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace, colmajor);
+      else dwconv_wgrad4_wave_kernel<5, 2><<<grid, 320, 0, S(stream)>>>(x, dy, g, cql, upb, (float*)workspace, colmajor);
     }
     const long cnt = (long)r * s * c;
     { EMBNET_TRACE("embnet::dw_slab_sum_kernel", TRACE_BYTES, 4.0 * cnt * (blocks + 1), stream); dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, blocks, cnt, dw); }
