@@ -360,6 +360,9 @@ __global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float
                                                                      DwGeom g, int cq_lanes, int units_per_block,
                                                                      float* __restrict__ partial, int colmajor) {
   constexpr int TW = DW_TW, NX = (TW - 1) * ST + KS, TAPS = KS * KS;
+  // the TW dy quads of a unit are the same for the KS waves: each is fetched by ONE wave and handed over through LDS (two
+  // buffers, one barrier per trip) — 4 instead of 4*KS of the workgroup's (4 + NX)*KS wave-wide L1 requests per unit
+  __shared__ float4 dsh[2][TW][64];
   const int c4 = g.C >> 2, unit_lanes = 64 / cq_lanes, wb_n = (g.OW + TW - 1) / TW;
   const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cl = lane % cq_lanes, ul = lane / cq_lanes;
@@ -367,53 +370,62 @@ __global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float
   const int u0 = blockIdx.x * units_per_block, u1 = min(u0 + units_per_block, nunits);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* d4 = reinterpret_cast<const float4*>(dy);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   {                                                        // grid.y = channel-quad group: late layers have few pixels, many channels
     const int cq = blockIdx.y * cq_lanes + cl;
+    const bool cok = cq < c4;
     float4 acc[KS];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cq < c4) {
-      for (int u = u0 + ul; u < u1; u += unit_lanes) {
-        // colmajor: consecutive units run DOWN a 4-column block of an image, so the image row wave r reads for unit oh + 1
-        // is the one wave r + 1 read for unit oh a moment ago (L1 hit) — row-major, the KS reads of an image row are a whole
-        // row of units apart and each comes from L2: (KS + 1) / 2 x the compulsory bytes on the L2 -> L1 path
-        int row, ow0, n, oh;
-        if (colmajor) {
-          const int per_img = g.OH * wb_n;
-          n = u / per_img; const int rem = u - n * per_img, wb = rem / g.OH;
-          oh = rem - wb * g.OH; ow0 = wb * TW; row = n * g.OH + oh;
-        } else {
-          row = u / wb_n; ow0 = (u - row * wb_n) * TW;
-          n = row / g.OH; oh = row - n * g.OH;
+    for (int j = 0; j < KS; ++j) acc[j] = z4;
+    const int trips = (u1 - u0 + unit_lanes - 1) / unit_lanes;          // the same for every wave of the workgroup
+    for (int it = 0; it < trips; ++it) {
+      const int uu = u0 + it * unit_lanes + ul;
+      const bool live = cok && uu < u1;
+      const int u = min(uu, u1 - 1);
+      // colmajor: consecutive units run DOWN a 4-column block of an image, so the image row wave r reads for unit oh + 1
+      // is the one wave r + 1 read for unit oh a moment ago (L1 hit) — row-major, the KS reads of an image row are a whole
+      // row of units apart and each comes from L2: (KS + 1) / 2 x the compulsory bytes on the L2 -> L1 path
+      int row, ow0, n, oh;
+      if (colmajor) {
+        const int per_img = g.OH * wb_n;
+        n = u / per_img; const int rem = u - n * per_img, wb = rem / g.OH;
+        oh = rem - wb * g.OH; ow0 = wb * TW; row = n * g.OH + oh;
+      } else {
+        row = u / wb_n; ow0 = (u - row * wb_n) * TW;
+        n = row / g.OH; oh = row - n * g.OH;
+      }
+      const int iw0 = ow0 * ST - g.pad_l, ih = oh * ST + r - g.pad_t;
+      const bool rok = live && (unsigned)ih < (unsigned)g.H;
+      const long rbase = ((long)n * g.H + (rok ? ih : 0)) * g.W;
+      float4 xr[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int iw = iw0 + j;
+        const bool ok = rok && (unsigned)iw < (unsigned)g.W;
+        xr[j] = x4[ok ? (rbase + iw) * c4 + cq : 0];
+        if (!ok) xr[j] = z4;
+      }
+      const long dbase = ((long)row * g.OW + ow0) * c4 + cq;
+#pragma unroll
+      for (int q = 0; q < TW; ++q)
+        if (q % KS == r) {                                 // this wave's share of the unit's dy quads
+          const bool ok = live && ow0 + q < g.OW;
+          float4 v = d4[ok ? dbase + (long)q * c4 : 0];
+          if (!ok) v = z4;
+          dsh[it & 1][q][lane] = v;
         }
-        float4 d[TW];
-        const long dbase = ((long)row * g.OW + ow0) * c4 + cq;
+      __syncthreads();
+      float4 d[TW];
+#pragma unroll
+      for (int q = 0; q < TW; ++q) d[q] = dsh[it & 1][q][lane];
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
         for (int q = 0; q < TW; ++q) {
-          const bool ok = ow0 + q < g.OW;
-          d[q] = d4[ok ? dbase + (long)q * c4 : 0];
-          if (!ok) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 v = xr[q * ST + s_];
+          acc[s_].x = fmaf(v.x, d[q].x, acc[s_].x); acc[s_].y = fmaf(v.y, d[q].y, acc[s_].y);
+          acc[s_].z = fmaf(v.z, d[q].z, acc[s_].z); acc[s_].w = fmaf(v.w, d[q].w, acc[s_].w);
         }
-        const int iw0 = ow0 * ST - g.pad_l, ih = oh * ST + r - g.pad_t;
-        const bool rok = (unsigned)ih < (unsigned)g.H;
-        const long rbase = ((long)n * g.H + (rok ? ih : 0)) * g.W;
-        float4 xr[NX];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-          const int iw = iw0 + j;
-          const bool ok = rok && (unsigned)iw < (unsigned)g.W;
-          xr[j] = x4[ok ? (rbase + iw) * c4 + cq : 0];
-          if (!ok) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_)
-#pragma unroll
-          for (int q = 0; q < TW; ++q) {
-            const float4 v = xr[q * ST + s_];
-            acc[s_].x = fmaf(v.x, d[q].x, acc[s_].x); acc[s_].y = fmaf(v.y, d[q].y, acc[s_].y);
-            acc[s_].z = fmaf(v.z, d[q].z, acc[s_].z); acc[s_].w = fmaf(v.w, d[q].w, acc[s_].w);
-          }
-      }
     }
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(64 * KS) void dwconv_wgrad4_wave_kernel(const float
         a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
         a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
       }
-      if (ul == 0 && cq < c4)
+      if (ul == 0 && cok)
         reinterpret_cast<float4*>(partial)[((long)blockIdx.x * TAPS + r * KS + j) * c4 + cq] = a;
     }
   }
