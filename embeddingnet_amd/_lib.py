@@ -54,7 +54,7 @@ def lib():
         for name, (res, argtypes) in parse_header().items():
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, argtypes
-        if l.embnet_abi_version() != 14:
+        if l.embnet_abi_version() != 15:
             raise EmbnetError("libembnet_hip.so ABI version mismatch")
         _lib = l
     return _lib

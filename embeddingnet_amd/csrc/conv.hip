@@ -339,11 +339,30 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN],
 // thread.  A workgroup covers one band of `wtm` rows (the row band a wave owns in the main kernel) x 1024/wtm
 // columns of a tile, so that it can also emit that band's per-channel sum / sum of squares (stats != NULL)
 // in the same [2][cols][tile_m * bm/wtm + band] layout the main kernel's epilogue writes.
+// BatchNorm-backward sums riding on a data gradient.  The conv's INPUT was act(BN(x)): the BatchNormalization's backward needs
+// dbeta = sum dz and dgamma = sum dz * xhat over the pixels, dz = d(conv input) * act'(BN(x)) — a pass over two tensors
+// (bn_bwd_reduce4, 8 bytes per element).  The data-gradient epilogue holds d(conv input) in registers, so it reads x (4 bytes
+// per element) and emits the partial sums per row band in the forward statistics' layout [2][C][rows]; the BatchNormalization
+// backward then starts at its finalize kernel (embnet_bn_bwd_partials).  x == NULL: off.
+struct BnSums { const float* x; const float* scale; const float* shift; const float* mean; const float* rstd; int act; float* partial; int rows; };
+
+__device__ __forceinline__ void bn_sums_add(int act, float4 v, float4 xq, float4 sc, float4 sh, float4 mu, float4 rs,
+                                            float4& s1, float4& s2) {      // the arithmetic of bn_bwd_reduce4_kernel
+  float4 dz = v;
+  if (act) {
+    dz.x = act_grad(act, fmaf(xq.x, sc.x, sh.x), v.x); dz.y = act_grad(act, fmaf(xq.y, sc.y, sh.y), v.y);
+    dz.z = act_grad(act, fmaf(xq.z, sc.z, sh.z), v.z); dz.w = act_grad(act, fmaf(xq.w, sc.w, sh.w), v.w);
+  }
+  s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+  s2.x = fmaf(dz.x, (xq.x - mu.x) * rs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - mu.y) * rs.y, s2.y);
+  s2.z = fmaf(dz.z, (xq.z - mu.z) * rs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - mu.w) * rs.w, s2.w);
+}
+
 __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int parts, int bm, int bn, int wtm,
                                                          int n_full, int tiles_n, long m, int cols,
                                                          const float* __restrict__ bias, int relu,
                                                          const float* __restrict__ residual, float* __restrict__ out,
-                                                         float* __restrict__ stats, int stats_rows) {
+                                                         float* __restrict__ stats, int stats_rows, const BnSums bsum) {
   __shared__ float4 red[2][256];
   const int cpb = 1024 / wtm, qpb = cpb / 4;              // columns / column quads per workgroup
   const int blocks_per_tile = bm * bn / 1024, col_groups = bn / cpb;
@@ -367,9 +386,19 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
     if (residual) { const float4 q = *reinterpret_cast<const float4*>(residual + row * cols + col); a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
     *reinterpret_cast<float4*>(out + row * cols + col) = a;
   }
-  if (!stats) return;
-  red[0][threadIdx.x] = a;
-  red[1][threadIdx.x] = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+  if (bsum.x) {                                            // a data gradient's fix-up: the BatchNorm-backward sums of its tile rows
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (in)
+      bn_sums_add(bsum.act, a, *reinterpret_cast<const float4*>(bsum.x + row * cols + col),
+                  *reinterpret_cast<const float4*>(bsum.scale + col), *reinterpret_cast<const float4*>(bsum.shift + col),
+                  *reinterpret_cast<const float4*>(bsum.mean + col), *reinterpret_cast<const float4*>(bsum.rstd + col), s1, s2);
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    stats = bsum.partial; stats_rows = bsum.rows;
+  } else {
+    if (!stats) return;
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+  }
   __syncthreads();
   for (int s = wtm / 2; s >= 1; s >>= 1) {                // fixed tree over the band's rows
     if (rr < s) {
@@ -484,7 +513,7 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_fwd_kernel(Co
 template <class G, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; BnSums bn; };
 
 template <class G, bool VEC>
 __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(ConvDgradParams p) {
@@ -516,7 +545,9 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
     const int ecol = n0 + epi_col<G>();
     const bool cok = ecol < p.g.C;
     long base[G::TM][NJ];
-    float4 res[G::TM][NJ];
+    float4 res[G::TM][NJ];                                 // the other gradient (accumulate) or the BatchNorm input (bn): never both
+    const bool bnon = p.bn.x != nullptr;
+    const float* pre = bnon ? p.bn.x : p.add_src;
 #pragma unroll
     for (int im = 0; im < G::TM; ++im)
 #pragma unroll
@@ -524,17 +555,25 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
         uint32_t n, rem, hc, wc;
         cg.dHWc.divmod((uint32_t)min(m0 + epi_row<G>(im, j), M - 1), n, rem); cg.dWc.divmod(rem, hc, wc);
         base[im][j] = (((long)n * p.g.H + cg.hoff + st * (int)hc) * p.g.W + cg.woff + st * (int)wc) * p.g.C;
-        if (p.accumulate) res[im][j] = *reinterpret_cast<const float4*>(p.add_src + base[im][j] + (cok ? ecol : 0));
+        if (p.accumulate || bnon) res[im][j] = *reinterpret_cast<const float4*>(pre + base[im][j] + (cok ? ecol : 0));
       }
-    if (p.accumulate) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bsc = z4, bsh = z4, bmu = z4, brs = z4, s1 = z4, s2 = z4;
+    if (bnon && cok) {
+      bsc = *reinterpret_cast<const float4*>(p.bn.scale + ecol); bsh = *reinterpret_cast<const float4*>(p.bn.shift + ecol);
+      bmu = *reinterpret_cast<const float4*>(p.bn.mean + ecol); brs = *reinterpret_cast<const float4*>(p.bn.rstd + ecol);
+    }
+    if (p.accumulate || bnon) {
 #pragma unroll
       for (int im = 0; im < G::TM; ++im)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) settle(res[im][j]);
+      settle(bsc); settle(bsh); settle(bmu); settle(brs);
     }
     auto emit = [&](int im, int j, int col, float4 v) {
       if (p.accumulate) { const float4 o = res[im][j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *reinterpret_cast<float4*>(p.dx + base[im][j] + col) = v;
+      if (bnon) bn_sums_add(p.bn.act, v, res[im][j], bsc, bsh, bmu, brs, s1, s2);
     };
     if (m0 + G::BM <= M && n0 + G::BN <= p.g.C) {          // interior tile (wave-uniform): straight-line stores, no edge tests
       for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int, int c, float4 v) { emit(im, j, n0 + c, v); });
@@ -542,6 +581,19 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
       for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int r, int c, float4 v) {
         if (m0 + r < M && n0 + c < p.g.C) emit(im, j, n0 + c, v);
       });
+    }
+    if (bnon) {                                            // partial (tile_m * WAVES_M + wave_m) of [2][C][rows], as the forward statistics
+      constexpr int LPR = G::WTN / 4;
+      s1 = colquad_sum<LPR>(s1); s2 = colquad_sum<LPR>(s2);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int col = n0 + (wave % G::WAVES_N) * G::WTN + lane * 4;
+      if (lane < LPR && col < p.g.C) {
+        const long prow = (long)(m0 / G::BM) * G::WAVES_M + wave / G::WAVES_N, P = p.bn.rows;
+        float* d1 = p.bn.partial + (long)col * P + prow;
+        float* d2 = d1 + (long)p.g.C * P;
+        d1[0] = s1.x; d1[P] = s1.y; d1[2 * P] = s1.z; d1[3 * P] = s1.w;
+        d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
+      }
     }
     stamp(5);
     return;
@@ -762,7 +814,7 @@ void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int 
                        hipStream_t st) {
   EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (parts + 1 + (residual ? 1 : 0)), st);
   tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(ws, parts, bm, bn, wtm, n_full, tiles_n, m, cols, bias, relu,
-                                                           residual, out, stats, stats_rows);
+                                                           residual, out, stats, stats_rows, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
 }
 }  // namespace embnet
 
@@ -967,7 +1019,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
     EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (p.tail.parts + 1 + (residual ? 1 : 0)), st);
     tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
-                                                             cdiv(k, bn), M, k, bias, relu, residual, y, stats, p.stats_rows);
+                                                             cdiv(k, bn), M, k, bias, relu, residual, y, stats, p.stats_rows, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
   }
   return check_launch("conv2d_fwd");
 }
@@ -982,15 +1034,16 @@ extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int 
   return need;
 }
 
-extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
-                                       int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
-                                       int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
+                             int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                             int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
+                             void* stream, const BnSums bn) {
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dx) && aligned16(workspace), "conv2d_dgrad: output and workspace must be 16-byte aligned");
   EMBNET_CHECK_ARG(!(accumulate && dx_add), "conv2d_dgrad: accumulate (into dx) or dx_add (another tensor), not both");
   EMBNET_CHECK_ARG(aligned16(dx_add), "conv2d_dgrad: dx_add must be 16-byte aligned");
   ConvDgradParams p{dy, w, dx, {}, {}, {}, (accumulate != 0 || dx_add) ? 1 : 0, dx_add ? dx_add : dx};
+  p.bn = bn;
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_dgrad")) return rc;
   EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
   long max_m = 0;
@@ -1032,9 +1085,41 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
     const int rem = (int)(tiles - p.tail.n_full), bm = TILE_BM[tile], bn = TILE_BN[tile];
     EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (p.tail.parts + 1 + (p.accumulate ? 1 : 0)), st);
     tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(p.tail.ws, p.tail.parts, bm, bn, TILE_WTM[tile], p.tail.n_full,
-                                                             cdiv(c, bn), max_m, c, nullptr, 0, p.accumulate ? p.add_src : nullptr, dx, nullptr, 0);
+                                                             cdiv(c, bn), max_m, c, nullptr, 0, p.accumulate ? p.add_src : nullptr, dx, nullptr, 0, p.bn);
   }
   return check_launch("conv2d_dgrad");
+}
+
+extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
+                                       int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                       int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, accumulate, dx_add, workspace,
+                           workspace_bytes, stream, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
+}
+
+// rows of the [2][C][rows] partial sums embnet_conv2d_dgrad_bnsums_f32 writes for this geometry; 0: not available
+// (stride 1, C % 4 == 0 and K % 4 == 0 only: one class of rows = the input pixels in order, 16-byte epilogue)
+extern "C" int embnet_conv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int k, int stride) {
+  if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || stride != 1 || ((c | k) & 3)) return 0;
+  const long M = (long)n * h * wd;
+  const int tile = pick_tile(M, c, false, (long)r * s * k);
+  return cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
+}
+
+extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
+                                              int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                              const float* bn_x, const float* bn_scale, const float* bn_shift,
+                                              const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
+                                              int bn_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(bn_x && bn_scale && bn_shift && bn_mean && bn_rstd && bn_partial, "conv2d_dgrad_bnsums: null pointer");
+  EMBNET_CHECK_ARG(bn_rows > 0 && bn_rows == embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride),
+                   "conv2d_dgrad_bnsums: rows %d for this geometry (see embnet_conv2d_dgrad_bnsums_rows)", bn_rows);
+  EMBNET_CHECK_ARG(aligned16(bn_x) && aligned16(bn_scale) && aligned16(bn_shift) && aligned16(bn_mean) && aligned16(bn_rstd) &&
+                   aligned16(dy) && aligned16(w), "conv2d_dgrad_bnsums: operands must be 16-byte aligned");
+  EMBNET_CHECK_ARG(bn_act >= 0 && bn_act <= 2, "conv2d_dgrad_bnsums: activation code %d", bn_act);
+  return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, 0, nullptr, workspace, workspace_bytes,
+                           stream, BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows});
 }
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip

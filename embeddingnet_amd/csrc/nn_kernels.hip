@@ -396,10 +396,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
-                                                              float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                              float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                              int by_channel = 0) {
   const int col = blockIdx.x;
   double s, ss;
-  block_partial_sums(partial, blocks, c, col, s, ss);
+  block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
   if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
 }
 
@@ -1165,6 +1166,21 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
                                                                dbeta, dgamma, relu, training, dz, partial, drop); }
   colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias);
   return check_launch("bn_bwd_inrelu");
+}
+
+// BatchNorm backward whose sums were produced by the data gradient of the conv behind it (embnet_conv2d_dgrad_bnsums_f32):
+// finalize over the [2][c][rows] partials, then the apply pass of embnet_bn_bwd.  c % 4 == 0, training statistics.
+extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                      const float* save_rstd, const float* scale, const float* shift, int relu,
+                                      const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
+                                      float* dbeta, void* dx_planes, void* stream) {
+  EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && dx && dgamma && dbeta, "bn_bwd_partials: null pointer");
+  EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
+  EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
+  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1);
+  { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
+                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, (unsigned short*)dx_planes); }
+  return check_launch("bn_bwd_partials");
 }
 
 extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,

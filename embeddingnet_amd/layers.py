@@ -149,6 +149,15 @@ def _done(out, notify):
 # leaves (dz alias, dbias) in RELU_DONE under dz's address; the conv's backward finds its incoming gradient there and skips
 # its own relu_bwd_colsum pass.  A conv whose output has a second consumer never finds the entry (autograd hands it the SUM,
 # another tensor) and masks again — harmless, dz is already zero where the mask is.
+# BatchNorm-backward column sums from the data gradient of the conv behind the BatchNormalization (csrc/conv.hip BnSums):
+# BatchNormalization.forward tags its output with (x, stats, act); a stride-1 Conv2D on the gather kernels hands them to
+# embnet_conv2d_dgrad_bnsums_f32 and leaves the partial sums here under its dx's address; the BatchNormalization backward that
+# receives exactly that tensor starts at its finalize kernel.  (The entry keeps an alias of dx: autograd then never
+# accumulates a second consumer's gradient into it in place, so a hit means dy IS that data gradient.)
+FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
+BN_SUMS = {}
+_BN_FWD_STATS = {}
+
 # a Dropout directly behind a BatchNormalization rides on the BatchNormalization's kernels (backbones.Seq); 0: separate passes
 FUSE_DROPOUT_BN = [__import__("os").environ.get("EMBNET_FUSE_DROPOUT_BN", "1") == "1"]
 FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
@@ -253,8 +262,9 @@ def same_pad(n, k, s):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False,
-                planes=None):
-        """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward."""
+                planes=None, bn_src=None):
+        """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward.
+        bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums."""
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
@@ -284,6 +294,7 @@ class _Conv2dFn(torch.autograd.Function):
                 ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
                 in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
         ctx.patch = planes is not None
+        ctx.bn_src = bn_src
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
         ctx.bias_ref = bias                 # only its address / shape are used (gradient sink lookup)
@@ -349,9 +360,22 @@ class _Conv2dFn(torch.autograd.Function):
             else:
                 # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
                 dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-                check(lib.embnet_conv2d_dgrad_f32(
-                    ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
-                    dws.numel() * 4, stream()))
+                bn_src = getattr(ctx, "bn_src", None) if dskip is None else None
+                rows = lib.embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride) if bn_src is not None else 0
+                if rows > 0:
+                    bn_x, bn_stats, bn_act = bn_src
+                    partial = torch.empty((2, c, rows), device=x.device, dtype=torch.float32)
+                    sp = bn_stats.data_ptr()
+                    check(lib.embnet_conv2d_dgrad_bnsums_f32(
+                        ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(bn_x), sp + 8 * c, sp + 12 * c,
+                        sp, sp + 4 * c, int(bn_act), ptr(partial), rows, ptr(dws), dws.numel() * 4, stream()))
+                    if len(BN_SUMS) > 64:
+                        BN_SUMS.clear()
+                    BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
+                else:
+                    check(lib.embnet_conv2d_dgrad_f32(
+                        ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
+                        dws.numel() * 4, stream()))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
@@ -364,7 +388,7 @@ class _Conv2dFn(torch.autograd.Function):
             db = _done(db, db_note)
         if dskip is not None and dx is None and ctx.needs_input_grad[0]:
             dx = dskip
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -590,8 +614,12 @@ class Conv2D(nn.Module):
                 rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
             if rows > 0:
                 out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+        bn_src = getattr(x, "_bn_src", None)
+        if not (FUSE_BN_SUMS[0] and bn_src is not None and in_stats is None and self.stride == 1 and not with_skip
+                and torch.is_grad_enabled() and x.requires_grad and kernel is self.kernel):
+            bn_src = None
         out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
-                              planes)
+                              planes, bn_src)
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
@@ -742,6 +770,10 @@ class _BatchNormFn(torch.autograd.Function):
             ctx.dropout = (rate, seed, GRAPH_TICK)
             check(lib.embnet_affine_act_dropout(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
                                                 rate, seed, GRAPH_TICK, ptr(y), stream()))
+        if training and FUSE_BN_SUMS[0] and c % 4 == 0 and not dropout:
+            if len(_BN_FWD_STATS) > 64:
+                _BN_FWD_STATS.clear()
+            _BN_FWD_STATS[y.data_ptr()] = (x, stats, int(relu))
         ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
         ctx.in_relu_bias = in_relu_bias if (in_relu_bias is not None and not with_skip and c % 4 == 0) else None
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
@@ -774,6 +806,15 @@ class _BatchNormFn(torch.autograd.Function):
             DY_PLANES[dx.data_ptr()] = (planes, dx)
         drop = getattr(ctx, "dropout", None)
         inrelu = getattr(ctx, "in_relu_bias", None) is not None and planes is None and dskip is None
+        hit = BN_SUMS.pop(dy.data_ptr(), None) if BN_SUMS else None
+        if (hit is not None and hit[2] == x.data_ptr() and hit[3].shape == dy.shape and ctx.training and c % 4 == 0
+                and not inrelu and drop is None):
+            # dy is the data gradient of the conv behind this layer, which already produced the column sums
+            check(lib.embnet_bn_bwd_partials(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
+                                             int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes),
+                                             stream()))
+            dgamma, dbeta = finish()
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
         if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
             dyd = torch.empty_like(dy)
             check(lib.embnet_dropout(ptr(dy), dy.numel(), drop[0], drop[1], drop[2], ptr(dyd), stream()))
@@ -953,17 +994,26 @@ class BatchNormalization(nn.Module):
             y = self.forward(x)
             return y, _GapFn.apply(y)
         want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
+
+        def tag(y):          # (x, stats, act) for a conv behind this layer whose data gradient can emit the backward sums (BN_SUMS)
+            src = _BN_FWD_STATS.pop(y.data_ptr(), None)
+            if src is not None and torch.is_grad_enabled():
+                y._bn_src = src
+
         if planes_for is not None and not defer and planes_for.patch_capable(x.shape):
             out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), with_skip,
                                      True, want_dx_planes)
             y = out[0] if with_skip else out
             y._planes = _ACT_PLANES.pop(y.data_ptr())
+            tag(y)
             return out
         if with_skip and not defer:
-            return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), True,
-                                      False, want_dx_planes)
+            out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                     self.momentum, self.relu, self.training, _partials_of(x, self.training), True,
+                                     False, want_dx_planes)
+            tag(out[0])
+            return out
         if with_skip:
             return self.forward(x, defer=True), x
         if defer and x.shape[-1] % 4 == 0:
@@ -971,9 +1021,11 @@ class BatchNormalization(nn.Module):
                                           self.momentum, self.relu, self.training, _partials_of(x, self.training))
             return Deferred(raw, stats, self.relu)
         in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled()) else None
-        return _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                  self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
-                                  False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
+        y = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                               self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
+                               False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
+        tag(y)
+        return y
 
 
 class _InputBNConvFn(torch.autograd.Function):

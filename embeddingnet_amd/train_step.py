@@ -297,6 +297,8 @@ class TripletTrainer:
             L.SLAB_DEFER[0] = False
             L.flush_slab_reduces()              # (with a reducer: what its buckets have not flushed already)
         L.RELU_DONE.clear()
+        L.BN_SUMS.clear()                       # BatchNorm-backward sums nobody collected (the gradient had a second contribution)
+        L._BN_FWD_STATS.clear()
         L.DY_PLANES.clear()                     # gradient planes nobody collected (a consumer that fell back to the fp32 kernel)
         if self.reducer is not None:
             self.reducer.finish()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 14
+#define EMBNET_ABI_VERSION 15
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -183,6 +183,18 @@ size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, i
 int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
                             int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, const float* dx_add,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradient that also emits the BatchNorm-backward sums of the layer that produced this conv's input: the conv read
+ * a = act(bn_x*bn_scale + bn_shift) (a BatchNormalization with a fused activation, /root/reference/embedding_net/backbones.py:99-104:
+ * the zoo ResNets' pre-activation units), so  dz = dx * act'(..)  is that layer's output gradient; bn_partial [2][c][bn_rows]
+ * (bn_rows = embnet_conv2d_dgrad_bnsums_rows(...), 0 = geometry not supported: stride 1, c % 4 == 0, k % 4 == 0) receives the
+ * per-row-band sums of dz and dz * (bn_x - bn_mean) * bn_rstd — what embnet_bn_bwd's reduction pass would compute from two
+ * tensors — for embnet_bn_bwd_partials.  Everything else as embnet_conv2d_dgrad_f32 without accumulate / dx_add. */
+int embnet_conv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int k, int stride);
+int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
+                                   int k, int stride, int pad_t, int pad_l, int oh, int ow, const float* bn_x,
+                                   const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_rstd,
+                                   int bn_act, float* bn_partial, int bn_rows, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 /* dw[r,s,c,k]; split-K slabs live in `workspace` (>= embnet_conv2d_wgrad_workspace_bytes). */
 size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -274,6 +286,12 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                   float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm backward whose column sums came from the data gradient of the conv that consumed this layer's output
+ * (embnet_conv2d_dgrad_bnsums_f32 below): partials [2][c][rows] -> dbeta / dgamma (added in double), then the apply pass of
+ * embnet_bn_bwd.  Training statistics, c % 4 == 0. */
+int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                           const float* scale, const float* shift, int relu, const float* partials, int rows,
+                           const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* stream);
 /* BatchNorm backward for a BN whose input x is the output of a layer with a fused ReLU (conv -> ReLU -> BN, the small
  * backbones' block): dz = d(x) * [x > 0] (the gradient the producer's data / weight gradients consume, ReLU backward
  * included) and dbias[c] = column sums of dz (the producer's bias gradient), in the pass that computes d(x).  c % 4 == 0. */

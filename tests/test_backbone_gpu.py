@@ -161,23 +161,29 @@ def test_deferred_batchnorm_into_conv(dev, shape, k, stride, act):
     n, h, w, cin, cout = shape
     x = torch.randn((n, h, w, cin), device=dev) * 1.5 + 0.3
     res = {}
-    for defer in (False, True):
-        gen = torch.Generator().manual_seed(11)
-        bn = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
-        conv = L.Conv2D(cin, cout, k, strides=stride, padding=k // 2, use_bias=False, gen=gen).to(dev)
-        with torch.no_grad():
-            bn.gamma.copy_(torch.linspace(-1.0, 1.5, cin)); bn.beta.copy_(torch.linspace(0.4, -0.4, cin))
-        xt = x.clone().requires_grad_(True)
-        a = bn(xt, defer=defer)
-        assert isinstance(a, L.Deferred) == defer
-        y = conv(a)
-        y.backward(torch.cos(y.detach() * 3))
-        res[defer] = (y.detach(), xt.grad, conv.kernel.grad, bn.gamma.grad, bn.beta.grad, bn.moving_mean.clone())
-        if defer:                                   # a consumer that cannot fuse gets the materialised tensor
-            bn2 = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
+    # (the materialised path's BatchNorm-backward sums by the BatchNorm's own reduction pass, as the deferred path computes
+    # them: with layers.FUSE_BN_SUMS the conv's data gradient would produce them in another summation order)
+    fuse_bn_sums, L.FUSE_BN_SUMS[0] = L.FUSE_BN_SUMS[0], False
+    try:
+        for defer in (False, True):
+            gen = torch.Generator().manual_seed(11)
+            bn = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
+            conv = L.Conv2D(cin, cout, k, strides=stride, padding=k // 2, use_bias=False, gen=gen).to(dev)
             with torch.no_grad():
-                bn2.gamma.copy_(bn.gamma); bn2.beta.copy_(bn.beta)
-            assert torch.equal(bn(x, defer=True).materialize(), bn2(x))
+                bn.gamma.copy_(torch.linspace(-1.0, 1.5, cin)); bn.beta.copy_(torch.linspace(0.4, -0.4, cin))
+            xt = x.clone().requires_grad_(True)
+            a = bn(xt, defer=defer)
+            assert isinstance(a, L.Deferred) == defer
+            y = conv(a)
+            y.backward(torch.cos(y.detach() * 3))
+            res[defer] = (y.detach(), xt.grad, conv.kernel.grad, bn.gamma.grad, bn.beta.grad, bn.moving_mean.clone())
+            if defer:                                   # a consumer that cannot fuse gets the materialised tensor
+                bn2 = L.BatchNormalization(cin, epsilon=2e-5, activation=act).to(dev).train()
+                with torch.no_grad():
+                    bn2.gamma.copy_(bn.gamma); bn2.beta.copy_(bn.beta)
+                assert torch.equal(bn(x, defer=True).materialize(), bn2(x))
+    finally:
+        L.FUSE_BN_SUMS[0] = fuse_bn_sums
     for got, want, what in zip(res[True], res[False], ("y", "dx", "dW", "dgamma", "dbeta", "moving_mean")):
         assert torch.equal(got, want), what
 

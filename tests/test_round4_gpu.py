@@ -266,3 +266,82 @@ def test_dropout_behind_batchnorm_rides_on_its_kernels(dev, image, inrelu):
         for a, b in zip(sa, sb):
             assert torch.equal(a, b)
     assert not torch.equal(res[True][0][0], res[True][1][0])          # a new mask each step
+
+
+# ------------------------------------------------------------------------------------------------ BN backward sums from dgrad
+@pytest.mark.parametrize("shape,k,ks,with_skip", [((8, 14, 14, 64), 128, 1, False), ((4, 9, 11, 32), 64, 3, False),
+                                                  ((6, 7, 7, 256), 64, 1, True), ((3, 20, 20, 128), 256, 1, True)])
+def test_batchnorm_backward_sums_come_from_the_conv_data_gradient(dev, shape, k, ks, with_skip):
+    """BatchNormalization(+ReLU) -> stride-1 Conv2D on the gather kernels (the zoo ResNets' bn -> relu -> 1x1 conv,
+    reference backbones.py:99-104): the conv's data-gradient epilogue emits the BatchNorm-backward column sums
+    (embnet_conv2d_dgrad_bnsums_f32), the BatchNormalization backward starts at its finalize kernel
+    (embnet_bn_bwd_partials) and no bn_bwd_reduce kernel runs.  dx of the BN, dgamma, dbeta and the conv's gradients equal the
+    separate-pass chain within fp32 summation-order differences; with_skip: the BN's input also feeds a skip connection whose
+    gradient is folded into the BN backward apply (dx_add)."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_BN_SUMS[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(11)
+            c = shape[-1]
+            bn = L.BatchNormalization(c, relu=True).to(dev).train()
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            conv = L.Conv2D(c, k, ks, padding="same", use_bias=False, gen=gen).to(dev)
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            if with_skip:
+                a, skip = bn(xt, with_skip=True)
+                y = conv(a)
+                out = y.sum(dim=-1, keepdim=True) * 0.01 + skip          # a second path from the BN's input
+            else:
+                y = conv(bn(xt))
+                out = y
+            out.backward(torch.cos(out.detach() * 1.7))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(dx=xt.grad, dW=conv.kernel.grad, dgamma=bn.gamma.grad, dbeta=bn.beta.grad)
+        finally:
+            L.FUSE_BN_SUMS[0] = True
+            L.BN_SUMS.clear()
+    assert any("bn_bwd_reduce" in n for n in names[False])
+    assert not any("bn_bwd_reduce" in n for n in names[True]), names[True]
+    assert not L.BN_SUMS
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        scale = b.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (key, (a - b).abs().max().item(), scale)
+    assert torch.equal(res[True]["dW"], res[False]["dW"])
+
+
+def test_batchnorm_backward_sums_are_not_used_when_the_gradient_has_a_second_contribution(dev):
+    """Two convs read the same BatchNormalization output: autograd adds their data gradients, so neither conv's sums
+    describe the gradient the BatchNormalization receives — it must run its own reduction (and give the right answer)."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn((4, 10, 10, 32), device=dev)
+    res = {}
+    for fuse in (False, True):
+        L.FUSE_BN_SUMS[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(5)
+            bn = L.BatchNormalization(32, relu=True).to(dev).train()
+            c1 = L.Conv2D(32, 64, 1, use_bias=False, gen=gen).to(dev)
+            c2 = L.Conv2D(32, 64, 1, use_bias=False, gen=gen).to(dev)
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            a = bn(xt)
+            out = c1(a) + 0.5 * c2(a)
+            out.backward(torch.sin(out.detach()))
+            torch.cuda.synchronize()
+            names = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            assert any("bn_bwd_reduce" in n for n in names)
+            res[fuse] = (xt.grad.clone(), bn.gamma.grad.clone(), bn.beta.grad.clone())
+        finally:
+            L.FUSE_BN_SUMS[0] = True
+            L.BN_SUMS.clear()
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
