@@ -511,7 +511,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_fwd_kernel(ConvFwdParams p) { conv_fwd_body<G, VEC, false>(p); }
 // same, reading act(x*in_scale + in_shift) (InputTransform); its own symbol so the plain kernel keeps its code
 template <class G, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 
 struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; BnSums bn; };
 
@@ -697,7 +697,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
 template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256, (VA && VB) ? CONV_OCC<G> : 1) void conv_wgrad_kernel(ConvWgradParams p) { conv_wgrad_body<G, VA, VB, false>(p); }
 template <class G, bool VA, bool VB>
-__global__ __launch_bounds__(256) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
 
 // out[i] = sum_s slabs[s][i], fixed order.  A workgroup owns 32 float4 columns (512 contiguous bytes of
 // every slab) and spreads the slabs over 8 thread groups (slab s goes to group s % 8, each group keeping
