@@ -270,7 +270,10 @@ def test_dropout_behind_batchnorm_rides_on_its_kernels(dev, image, inrelu):
 
 # ------------------------------------------------------------------------------------------------ BN backward sums from dgrad
 @pytest.mark.parametrize("shape,k,ks,with_skip", [((8, 14, 14, 64), 128, 1, False), ((4, 9, 11, 32), 64, 3, False),
-                                                  ((6, 7, 7, 256), 64, 1, True), ((3, 20, 20, 128), 256, 1, True)])
+                                                  ((6, 7, 7, 256), 64, 1, True), ((3, 20, 20, 128), 256, 1, True),
+                                                  # C3's first bottleneck conv at its full size (256 images of one branch):
+                                                  # 6 272 whole tiles + K-split left-over tiles through the fix-up kernel
+                                                  ((256, 56, 56, 256), 64, 1, True), ((256, 14, 14, 256), 1024, 1, False)])
 def test_batchnorm_backward_sums_come_from_the_conv_data_gradient(dev, shape, k, ks, with_skip):
     """BatchNormalization(+ReLU) -> stride-1 Conv2D on the gather kernels (the zoo ResNets' bn -> relu -> 1x1 conv,
     reference backbones.py:99-104): the conv's data-gradient epilogue emits the BatchNorm-backward column sums
