@@ -49,9 +49,15 @@ __global__ __launch_bounds__(256) void mine_select_kernel(
   int result = -1;
   if (mode == EMBNET_MINE_HARDEST) {
     float best = -INFINITY; int bq = 0x7fffffff;
-    for (int q = lane; q < nneg; q += 64) {
-      const float v = loss_at(q);
-      if (v > best) { best = v; bq = q; }           // ascending q per lane: first max kept
+    // four loads in flight per lane (a wave with one dword load per trip is a chain of memory round trips: 256 trips x ~2 us
+    // at N = 16 384, 2.3 TB/s with every wave slot taken); the visiting order per lane is unchanged: q ascending
+    for (int q0 = lane; q0 < nneg; q0 += 4 * 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = q0 + 64 * u < nneg ? loss_at(q0 + 64 * u) : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v[u] > best) { best = v[u]; bq = q0 + 64 * u; }   // ascending q per lane: first max kept
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -65,32 +71,43 @@ __global__ __launch_bounds__(256) void mine_select_kernel(
   } else {
     const bool semi = mode == EMBNET_MINE_SEMIHARD;
     int total = 0;
-    for (int q0 = 0; q0 < nneg; q0 += 64) {
-      const int q = q0 + lane;
-      bool pred = false;
-      if (q < nneg) { const float v = loss_at(q); pred = v > 0.f && (!semi || v < margin); }
-      const unsigned long long m = __ballot(pred);
-      total += __popcll(m);
-      if (cand_mask && lane < 2 && q0 + 32 * lane < nneg)
-        cand_mask[(long)pair * mask_words + (q0 >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+    for (int qb = 0; qb < nneg; qb += 4 * 64) {            // four loads in flight per lane, ballots in column order
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int q = qb + 64 * u + lane; v[u] = q < nneg ? loss_at(q) : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q0 = qb + 64 * u;
+        if (q0 >= nneg) break;
+        const bool pred = q0 + lane < nneg && v[u] > 0.f && (!semi || v[u] < margin);
+        const unsigned long long m = __ballot(pred);
+        total += __popcll(m);
+        if (cand_mask && lane < 2 && q0 + 32 * lane < nneg)
+          cand_mask[(long)pair * mask_words + (q0 >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+      }
     }
     if (total > 0) {
       const uint32_t u = rng_u32(seed, (uint64_t)pair, 0);
       const int want = (int)(((uint64_t)u * (uint64_t)total) >> 32);   // uniform in [0,total)
       int cum = 0;
-      for (int q0 = 0; q0 < nneg; q0 += 64) {
-        const int q = q0 + lane;
-        bool pred = false;
-        if (q < nneg) { const float v = loss_at(q); pred = v > 0.f && (!semi || v < margin); }
-        const unsigned long long m = __ballot(pred);
-        const int cnt = __popcll(m);
-        if (want < cum + cnt) {
-          const int rank = __popcll(m & ((1ull << lane) - 1ull));
-          const unsigned long long hit = __ballot(pred && rank == want - cum);
-          result = q0 + __ffsll((long long)hit) - 1;
-          break;
+      for (int qb = 0; qb < nneg && result < 0; qb += 4 * 64) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = qb + 64 * u + lane; v[u] = q < nneg ? loss_at(q) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q0 = qb + 64 * u;
+          if (q0 >= nneg || result >= 0) break;
+          const bool pred = q0 + lane < nneg && v[u] > 0.f && (!semi || v[u] < margin);
+          const unsigned long long m = __ballot(pred);
+          const int cnt = __popcll(m);
+          if (want < cum + cnt) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned long long hit = __ballot(pred && rank == want - cum);
+            result = q0 + __ffsll((long long)hit) - 1;
+          }
+          cum += cnt;
         }
-        cum += cnt;
       }
     }
   }
@@ -148,10 +165,18 @@ __global__ __launch_bounds__(256) void batch_hard_kernel(const float* __restrict
   const int lo = (a / k) * k, hi = lo + k;
   const float* row = D + (long)a * n;
   float bp = -INFINITY, bn = INFINITY; int ip = 0x7fffffff, in_ = 0x7fffffff;
-  for (int c = lane; c < n; c += 64) {
-    const float v = row[c];
-    if (c >= lo && c < hi) { if (c != a && v > bp) { bp = v; ip = c; } }
-    else if (v < bn) { bn = v; in_ = c; }
+  for (int c0 = lane; c0 < n; c0 += 4 * 64) {              // four loads in flight per lane; columns visited in the same order
+    float vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vv[u] = c0 + 64 * u < n ? row[c0 + 64 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 64 * u;
+      if (c >= n) break;
+      const float v = vv[u];
+      if (c >= lo && c < hi) { if (c != a && v > bp) { bp = v; ip = c; } }
+      else if (v < bn) { bn = v; in_ = c; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
