@@ -114,6 +114,58 @@ __global__ __launch_bounds__(256) void mine_select_kernel(
   if (lane == 0) selected[pair] = result < 0 ? -1 : (result < lo ? result : result + k);
 }
 
+// `hardest`, one wave per ANCHOR row: the pairs (i, j > i) of an anchor scan the same row of D, so the row is read once and
+// every element is tested against the anchor's KP <= 7 positives (the per-pair kernel reads it once per positive: 1.5 x the
+// matrix for K = 4).  Same arithmetic, same visiting order per lane, same tie rule per pair: bit-identical selections.
+template <int KP>
+__global__ __launch_bounds__(256) void mine_hardest_anchor_kernel(const float* __restrict__ D, int n, int k, float margin,
+                                                                  int* __restrict__ selected, uint32_t* __restrict__ cand_mask,
+                                                                  int mask_words) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (a >= n) return;
+  const int c = a / k, ii = a - c * k, lo = c * k, nneg = n - k, npos = k - 1 - ii;
+  if (npos <= 0) return;                                   // the class's last row anchors no pair
+  const float* row = D + (long)a * n;
+  float dap[KP], best[KP]; int bq[KP];
+#pragma unroll
+  for (int j = 0; j < KP; ++j) { dap[j] = j < npos ? row[lo + ii + 1 + j] : 0.f; best[j] = -INFINITY; bq[j] = 0x7fffffff; }
+  for (int q0 = lane; q0 < nneg; q0 += 4 * 64) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int q = q0 + 64 * u; v[u] = q < nneg ? row[q < lo ? q : q + k] : INFINITY; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 64 * u;
+      if (q < nneg) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          const float l = __fadd_rn(__fsub_rn(dap[j], v[u]), margin);
+          if (l > best[j]) { best[j] = l; bq[j] = q; }     // ascending q per lane: first max kept
+        }
+      }
+    }
+  }
+  const int ppc = k * (k - 1) / 2, pair0 = c * ppc + ii * (2 * k - ii - 1) / 2;
+#pragma unroll
+  for (int j = 0; j < KP; ++j) {
+    if (j >= npos) break;
+    float b = best[j]; int q = bq[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(b, o, 64);
+      const int oq = __shfl_xor(q, o, 64);
+      if (ov > b || (ov == b && oq < q)) { b = ov; q = oq; }
+    }
+    const int result = (q != 0x7fffffff && b > 0.f) ? q : -1;
+    if (lane == 0) {
+      const int pair = pair0 + j;
+      selected[pair] = result < 0 ? -1 : (result < lo ? result : result + k);
+      if (cand_mask && result >= 0) atomicOr(&cand_mask[(long)pair * mask_words + (result >> 5)], 1u << (result & 31));
+    }
+  }
+}
+
 // Single workgroup: stable compaction of the active pairs into triplets[T][3], T -> *count.
 __global__ __launch_bounds__(1024) void mine_compact_kernel(const int* __restrict__ selected, int n, int p,
                                                             int k, int* __restrict__ triplets,
@@ -212,7 +264,15 @@ extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margi
     hipError_t e = hipMemsetAsync(cand_mask, 0, (size_t)npairs * mask_words * 4, s);
     if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "mine_triplets: memset: %s", hipGetErrorString(e));
   }
-  {
+  static const int by_anchor = (int)env_long("EMBNET_MINE_BY_ANCHOR", 1);
+  if (mode == EMBNET_MINE_HARDEST && by_anchor && k - 1 <= 7 && n >= 1024) {
+    // (below ~1 000 rows the launch is latency-sized either way and the per-pair kernel has 1.5 x the waves)
+    EMBNET_TRACE("embnet::mine_hardest_anchor_kernel", TRACE_BYTES, 4.0 * n * n, s);
+    const int grid = cdiv(n, 4);
+    if (k - 1 <= 1) mine_hardest_anchor_kernel<1><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
+    else if (k - 1 <= 3) mine_hardest_anchor_kernel<3><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
+    else mine_hardest_anchor_kernel<7><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
+  } else {
     EMBNET_TRACE("embnet::mine_select_kernel", TRACE_BYTES, 0.0, s);
     mine_select_kernel<<<cdiv(npairs, 4), 256, 0, s>>>(dist, n, p, k, margin, mode, seed, selected, cand_mask, mask_words);
   }

@@ -348,3 +348,50 @@ def test_batchnorm_backward_sums_are_not_used_when_the_gradient_has_a_second_con
             L.BN_SUMS.clear()
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ hardest mining by anchor
+@pytest.mark.parametrize("p,k,e,margin", [(512, 4, 64, 0.5), (300, 6, 32, 0.3), (700, 2, 16, 0.5), (130, 8, 32, 0.5), (4096, 4, 32, 0.5)])
+def test_hardest_mining_one_wave_per_anchor_matches_the_rule(dev, p, k, e, margin):
+    """`hardest` at N >= 1024 runs one wave per ANCHOR row (mine_hardest_anchor_kernel): every pair (i < j) of the class gets the
+    first arg-max of (D[i,j] - D[i,neg]) + margin over the out-of-class columns, kept iff > 0 — the reference's rule
+    (datagenerators.py:188-190, :235) in its float32 arithmetic, checked here against that rule written with torch on the same
+    matrix (duplicated rows force ties; a tight cluster gives inactive pairs), and the compaction keeps the pair order."""
+    from embeddingnet_amd import ops
+    n = p * k
+    g = torch.Generator(device=dev).manual_seed(p + k)
+    cent = torch.rand((p, e), device=dev, generator=g)
+    x = (cent.repeat_interleave(k, 0) + 0.35 * torch.rand((n, e), device=dev, generator=g)).abs()
+    x[5 * k + 1] = x[9 * k]                      # exact duplicates across classes: ties in the arg-max
+    x[7 * k] = x[11 * k + 1]
+    x[: 2 * k] = x[0] + 1e-4 * torch.rand((2 * k, e), device=dev, generator=g)   # two classes on top of each other
+    x[:, -1] = 0.0                                 # class 3 alone on the last axis: sqrt(2) from everybody, its pairs stay inactive
+    x[3 * k: 4 * k] = 1e-3 * torch.rand((k, e), device=dev, generator=g)
+    x[3 * k: 4 * k, -1] = 1.0
+    x = x / x.norm(dim=1, keepdim=True)
+    d = ops.pairwise_distances(x)
+    trip, count, sel = ops.mine_triplets(d, p, k, margin, "hardest")
+    torch.cuda.synchronize()
+    # the rule, pair by pair, in torch (float32, two roundings)
+    cls = torch.arange(n, device=dev) // k
+    want = torch.full((p * k * (k - 1) // 2,), -1, dtype=torch.int32, device=dev)
+    ppc = k * (k - 1) // 2
+    pair_of = [(i, j) for i in range(k) for j in range(i + 1, k)]
+    for q, (ii, jj) in enumerate(pair_of):
+        rows = torch.arange(p, device=dev) * k + ii
+        dap = d[rows, rows - ii + jj]
+        loss = (dap[:, None] - d[rows]) + torch.tensor(margin, device=dev)       # [p, n]
+        loss = torch.where(cls[None, :] == cls[rows][:, None], torch.full_like(loss, -float("inf")), loss)
+        best, idx = loss.max(dim=1)
+        # first maximal index (torch.max may return any tied index: take the smallest column holding the maximum)
+        first = torch.where(loss == best[:, None], torch.arange(n, device=dev)[None, :], torch.full_like(idx, n)[:, None]).min(dim=1).values
+        want[torch.arange(p, device=dev) * ppc + q] = torch.where(best > 0, first, torch.full_like(first, -1)).int()
+    assert torch.equal(sel, want)
+    live = want >= 0
+    assert int(count.item()) == int(live.sum().item()) and 0 < int(count.item()) < want.numel()
+    t = trip[: int(count.item())]
+    pairs = torch.nonzero(live).flatten()
+    cc, qq = pairs // ppc, pairs % ppc
+    ii = torch.tensor([a for a, _ in pair_of], device=dev)[qq]; jj = torch.tensor([b for _, b in pair_of], device=dev)[qq]
+    assert torch.equal(t[:, 0].long(), cc * k + ii) and torch.equal(t[:, 1].long(), cc * k + jj)
+    assert torch.equal(t[:, 2], want[live])
