@@ -166,6 +166,86 @@ __global__ __launch_bounds__(256) void mine_hardest_anchor_kernel(const float* _
   }
 }
 
+// The random rules (semihard: the reference's default; random_hard), one wave per ANCHOR row: two passes over the row — count the
+// candidates of each of the anchor's KP <= 7 pairs, then find every pair's want-th candidate — instead of two passes per pair.
+// Same predicates, same column order, same counter RNG (seed, pair): bit-identical selections and candidate masks.
+template <int KP>
+__global__ __launch_bounds__(256) void mine_random_anchor_kernel(const float* __restrict__ D, int n, int k, float margin, int semi,
+                                                                 uint64_t seed, int* __restrict__ selected,
+                                                                 uint32_t* __restrict__ cand_mask, int mask_words) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (a >= n) return;
+  const int c = a / k, ii = a - c * k, lo = c * k, nneg = n - k, npos = k - 1 - ii;
+  if (npos <= 0) return;
+  const float* row = D + (long)a * n;
+  const int ppc = k * (k - 1) / 2, pair0 = c * ppc + ii * (2 * k - ii - 1) / 2;
+  float dap[KP]; int total[KP];
+#pragma unroll
+  for (int j = 0; j < KP; ++j) { dap[j] = j < npos ? row[lo + ii + 1 + j] : 0.f; total[j] = 0; }
+  auto pred_of = [&](float v, int j, bool in) -> bool {
+    const float l = __fadd_rn(__fsub_rn(dap[j], v), margin);
+    return in && l > 0.f && (!semi || l < margin);
+  };
+  for (int qb = 0; qb < nneg; qb += 4 * 64) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int q = qb + 64 * u + lane; v[u] = q < nneg ? row[q < lo ? q : q + k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q0 = qb + 64 * u;
+      if (q0 >= nneg) break;
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        if (j >= npos) break;
+        const unsigned long long m = __ballot(pred_of(v[u], j, q0 + lane < nneg));
+        total[j] += __popcll(m);
+        if (cand_mask && lane < 2 && q0 + 32 * lane < nneg)
+          cand_mask[(long)(pair0 + j) * mask_words + (q0 >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+      }
+    }
+  }
+  int want[KP], cum[KP], result[KP], open = 0;
+#pragma unroll
+  for (int j = 0; j < KP; ++j) {
+    result[j] = -1; cum[j] = 0; want[j] = 0;
+    if (j < npos && total[j] > 0) {
+      const uint32_t u32 = rng_u32(seed, (uint64_t)(pair0 + j), 0);
+      want[j] = (int)(((uint64_t)u32 * (uint64_t)total[j]) >> 32);      // uniform in [0,total)
+      ++open;
+    }
+  }
+  for (int qb = 0; qb < nneg && open > 0; qb += 4 * 64) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int q = qb + 64 * u + lane; v[u] = q < nneg ? row[q < lo ? q : q + k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q0 = qb + 64 * u;
+      if (q0 >= nneg) break;
+#pragma unroll
+      for (int j = 0; j < KP; ++j) {
+        if (j >= npos || total[j] == 0 || result[j] >= 0) continue;
+        const bool pred = pred_of(v[u], j, q0 + lane < nneg);
+        const unsigned long long m = __ballot(pred);
+        const int cnt = __popcll(m);
+        if (want[j] < cum[j] + cnt) {
+          const int rank = __popcll(m & ((1ull << lane) - 1ull));
+          const unsigned long long hit = __ballot(pred && rank == want[j] - cum[j]);
+          result[j] = q0 + __ffsll((long long)hit) - 1;
+          --open;
+        }
+        cum[j] += cnt;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j)
+      if (j < npos) selected[pair0 + j] = result[j] < 0 ? -1 : (result[j] < lo ? result[j] : result[j] + k);
+  }
+}
+
 // Single workgroup: stable compaction of the active pairs into triplets[T][3], T -> *count.
 __global__ __launch_bounds__(1024) void mine_compact_kernel(const int* __restrict__ selected, int n, int p,
                                                             int k, int* __restrict__ triplets,
@@ -264,7 +344,7 @@ extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margi
     hipError_t e = hipMemsetAsync(cand_mask, 0, (size_t)npairs * mask_words * 4, s);
     if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "mine_triplets: memset: %s", hipGetErrorString(e));
   }
-  static const int by_anchor = (int)env_long("EMBNET_MINE_BY_ANCHOR", 1);
+  const int by_anchor = (int)env_long("EMBNET_MINE_BY_ANCHOR", 1);      // read per call: tests compare the two forms in one process
   if (mode == EMBNET_MINE_HARDEST && by_anchor && k - 1 <= 7 && n >= 1024) {
     // (below ~1 000 rows the launch is latency-sized either way and the per-pair kernel has 1.5 x the waves)
     EMBNET_TRACE("embnet::mine_hardest_anchor_kernel", TRACE_BYTES, 4.0 * n * n, s);
@@ -272,6 +352,12 @@ extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margi
     if (k - 1 <= 1) mine_hardest_anchor_kernel<1><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
     else if (k - 1 <= 3) mine_hardest_anchor_kernel<3><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
     else mine_hardest_anchor_kernel<7><<<grid, 256, 0, s>>>(dist, n, k, margin, selected, cand_mask, mask_words);
+  } else if (by_anchor && k - 1 <= 7 && n >= 1024) {
+    EMBNET_TRACE("embnet::mine_random_anchor_kernel", TRACE_BYTES, 8.0 * n * n, s);
+    const int grid = cdiv(n, 4), semi = mode == EMBNET_MINE_SEMIHARD ? 1 : 0;
+    if (k - 1 <= 1) mine_random_anchor_kernel<1><<<grid, 256, 0, s>>>(dist, n, k, margin, semi, seed, selected, cand_mask, mask_words);
+    else if (k - 1 <= 3) mine_random_anchor_kernel<3><<<grid, 256, 0, s>>>(dist, n, k, margin, semi, seed, selected, cand_mask, mask_words);
+    else mine_random_anchor_kernel<7><<<grid, 256, 0, s>>>(dist, n, k, margin, semi, seed, selected, cand_mask, mask_words);
   } else {
     EMBNET_TRACE("embnet::mine_select_kernel", TRACE_BYTES, 0.0, s);
     mine_select_kernel<<<cdiv(npairs, 4), 256, 0, s>>>(dist, n, p, k, margin, mode, seed, selected, cand_mask, mask_words);

@@ -395,3 +395,41 @@ def test_hardest_mining_one_wave_per_anchor_matches_the_rule(dev, p, k, e, margi
     ii = torch.tensor([a for a, _ in pair_of], device=dev)[qq]; jj = torch.tensor([b for _, b in pair_of], device=dev)[qq]
     assert torch.equal(t[:, 0].long(), cc * k + ii) and torch.equal(t[:, 1].long(), cc * k + jj)
     assert torch.equal(t[:, 2], want[live])
+
+
+@pytest.mark.parametrize("mode", ["semihard", "random_hard", "hardest"])
+@pytest.mark.parametrize("p,k,e", [(512, 4, 64), (300, 6, 32), (700, 2, 16), (130, 8, 32), (2048, 4, 32)])
+def test_mining_by_anchor_equals_mining_by_pair(dev, p, k, e, mode):
+    """From N = 1024 on the mining kernels run one wave per anchor row (the row is read once — twice for the random rules — for
+    all of the anchor's pairs) instead of one wave per pair: selections, candidate masks and the compacted triplet list are
+    bit-identical (same predicates, same column order, same counter RNG per pair)."""
+    import os
+    from embeddingnet_amd import ops
+    n = p * k
+    g = torch.Generator(device=dev).manual_seed(3 * p + k)
+    cent = torch.rand((p, e), device=dev, generator=g)
+    x = (cent.repeat_interleave(k, 0) + 0.3 * torch.rand((n, e), device=dev, generator=g)).abs()
+    x[5 * k + 1] = x[9 * k]
+    x[:, -1] = 0.0
+    x[3 * k: 4 * k] = 1e-3 * torch.rand((k, e), device=dev, generator=g)
+    x[3 * k: 4 * k, -1] = 1.0
+    x = x / x.norm(dim=1, keepdim=True)
+    d = ops.pairwise_distances(x)
+    out = {}
+    for by_anchor in ("0", "1"):
+        os.environ["EMBNET_MINE_BY_ANCHOR"] = by_anchor
+        try:
+            _lib.trace_reset(); _lib.trace_enable(True)
+            trip, count, sel, mask = ops.mine_triplets(d, p, k, 0.5, mode, seed=1234, with_candidates=True)
+            torch.cuda.synchronize()
+            names = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+        finally:
+            os.environ.pop("EMBNET_MINE_BY_ANCHOR", None)
+        assert any("anchor" in nm for nm in names) == (by_anchor == "1"), names
+        out[by_anchor] = (trip.clone(), count.clone(), sel.clone(), mask.clone())
+    cnt = int(out["0"][1].item())
+    assert 0 < cnt < out["0"][2].numel()
+    assert torch.equal(out["0"][1], out["1"][1]) and torch.equal(out["0"][2], out["1"][2])
+    assert torch.equal(out["0"][3], out["1"][3])
+    assert torch.equal(out["0"][0][:cnt], out["1"][0][:cnt])
