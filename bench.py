@@ -399,7 +399,12 @@ def main():
         log(f"  step mode: {'HIP graph replay' if getattr(trainer, '_graph', None) is not None else 'eager'}"
             + (f" (capture failed: {trainer._graph_error})" if getattr(trainer, "_graph_failed", False) else "")
             + (f"  probe: {trainer.graph_probe}" if getattr(trainer, "graph_probe", None) else ""))
-    log(f"  host enqueue {host_ms:.2f} ms/step, step {ms_per_step:.2f} ms ({'GPU' if host_ms < 0.9 * ms_per_step else 'host'}-bound)")
+    # the enqueue loop blocks once the HIP queue is full, so on a GPU-bound step its time approaches the step time; the host
+    # WORK per step is what the trainer's probe measured on an idle queue (graph_probe['host_ms'], triplet mode)
+    probe_host = (getattr(trainer, "graph_probe", None) or {}).get("host_ms") if args.mode != "siamese" else None
+    host_work = probe_host if probe_host is not None else host_ms
+    log(f"  enqueue loop {host_ms:.2f} ms/step" + (f", host work {probe_host:.2f} ms/step (probe, idle queue)" if probe_host is not None else "")
+        + f", step {ms_per_step:.2f} ms ({'GPU' if host_work < 0.9 * ms_per_step else 'host'}-bound)")
     roofline = None
     if trace:
         roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at), ms_per_step, args.config,
