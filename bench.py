@@ -401,7 +401,8 @@ def main():
             + (f"  probe: {trainer.graph_probe}" if getattr(trainer, "graph_probe", None) else ""))
     # the enqueue loop blocks once the HIP queue is full, so on a GPU-bound step its time approaches the step time; the host
     # WORK per step is what the trainer's probe measured on an idle queue (graph_probe['host_ms'], triplet mode)
-    probe_host = (getattr(trainer, "graph_probe", None) or {}).get("host_ms") if args.mode != "siamese" else None
+    replayed = args.mode != "siamese" and getattr(trainer, "_graph", None) is not None      # a replayed step has no per-kernel host work
+    probe_host = (getattr(trainer, "graph_probe", None) or {}).get("host_ms") if (args.mode != "siamese" and not replayed) else None
     host_work = probe_host if probe_host is not None else host_ms
     log(f"  enqueue loop {host_ms:.2f} ms/step" + (f", host work {probe_host:.2f} ms/step (probe, idle queue)" if probe_host is not None else "")
         + f", step {ms_per_step:.2f} ms ({'GPU' if host_work < 0.9 * ms_per_step else 'host'}-bound)")
