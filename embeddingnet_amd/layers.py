@@ -369,8 +369,8 @@ class _Conv2dFn(torch.autograd.Function):
                     check(lib.embnet_conv2d_dgrad_bnsums_f32(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(bn_x), sp + 8 * c, sp + 12 * c,
                         sp, sp + 4 * c, int(bn_act), ptr(partial), rows, ptr(dws), dws.numel() * 4, stream()))
-                    if len(BN_SUMS) > 64:
-                        BN_SUMS.clear()
+                    while len(BN_SUMS) >= 8:     # unclaimed entries (the gradient got a second contribution) pin a dx each: keep few
+                        BN_SUMS.pop(next(iter(BN_SUMS)))
                     BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
                 else:
                     check(lib.embnet_conv2d_dgrad_f32(
