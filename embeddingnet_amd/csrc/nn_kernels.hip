@@ -262,6 +262,82 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
   }
 }
 
+// BatchNorm backward of a layer whose output is also POOLED (squeeze-and-excite: layers._BNGapFn): the gradient is
+//   dy_total[n,p,c] = dy[n,p,c] + dpool[n,c] / hw
+// (embnet_gap_bwd's broadcast-add pass, 12 B per element on EfficientNet's 6C-wide tensors).  Here both BatchNorm passes form
+// it while they read dy — dpool[n, quad] is a 16-byte L1-resident load — with embnet_gap_bwd's two roundings (the two-launch chain's result to the
+// last bits), and the broadcast tensor is never written.
+struct DivU { uint32_t mul, shift; };                     // n / d for 0 <= n < 2^31 (conv_geom.h FastDiv)
+static DivU make_divu(uint32_t d) {
+  uint32_t sft = 0; while ((1ull << sft) < d) ++sft;
+  return DivU{(uint32_t)((((1ull << sft) - d) << 32) / d + 1), sft};
+}
+__device__ __forceinline__ uint32_t divu(uint32_t n, DivU f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+__device__ __forceinline__ float4 add_pool4(float4 dy, float4 g, float inv) {
+  return make_float4(__fadd_rn(__fmul_rn(g.x, inv), dy.x), __fadd_rn(__fmul_rn(g.y, inv), dy.y),
+                     __fadd_rn(__fmul_rn(g.z, inv), dy.z), __fadd_rn(__fmul_rn(g.w, inv), dy.w));
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_gap_kernel(const float* __restrict__ dy, const float* __restrict__ dpool,
+                                                                 DivU dhw, float inv_hw, const float* __restrict__ x, long m,
+                                                                 int c4, ColGeom g, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int relu,
+                                                                 float* __restrict__ partial) {
+  struct K4 { float4 sc, sh, mu, rs; };
+  col_reduce2_v4p(m, c4, g, partial, [&](int q) {
+    return K4{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q],
+              reinterpret_cast<const float4*>(mean)[q], reinterpret_cast<const float4*>(rstd)[q]};
+  }, [&](long r, int q, const K4& k, float4& a, float4& b) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
+    const float4 gp = reinterpret_cast<const float4*>(dpool)[(long)divu((uint32_t)r, dhw) * c4 + q];
+    float4 dz = add_pool4(reinterpret_cast<const float4*>(dy)[r * c4 + q], gp, inv_hw);
+    const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs;
+    if (relu) {
+      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
+      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
+    }
+    a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
+    b.x = fmaf(dz.x, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(dz.y, (xv.y - mu.y) * rs.y, b.y);
+    b.z = fmaf(dz.z, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(dz.w, (xv.w - mu.w) * rs.w, b.w);
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __restrict__ dy, const float* __restrict__ dpool,
+                                                                DivU dhwc4, float inv_hw, const float* __restrict__ x,
+                                                                long total4, int c4, float inv_m, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ dbeta,
+                                                                const float* __restrict__ dgamma, int relu, float* __restrict__ dx) {
+  const long stride = (long)gridDim.x * 256;
+  const bool fixed = stride % c4 == 0;                   // (as bn_bwd_apply4_kernel: the thread keeps its channel quad)
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sc = z4, sh = z4, mu = z4, rs = z4, db = z4, dg = z4;
+  auto consts = [&](int q) {
+    sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+    mu = reinterpret_cast<const float4*>(mean)[q]; rs = reinterpret_cast<const float4*>(rstd)[q];
+    db = reinterpret_cast<const float4*>(dbeta)[q]; dg = reinterpret_cast<const float4*>(dgamma)[q];
+  };
+  if (fixed) consts((int)(((long)blockIdx.x * 256 + threadIdx.x) % c4));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int q = (int)(i % c4);
+    if (!fixed) consts(q);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 gp = reinterpret_cast<const float4*>(dpool)[(long)divu((uint32_t)i, dhwc4) * c4 + q];
+    float4 dz = add_pool4(reinterpret_cast<const float4*>(dy)[i], gp, inv_hw);
+    if (relu) {
+      dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
+      dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
+    }
+    float4 o;
+    o.x = sc.x * (dz.x - db.x * inv_m - (xv.x - mu.x) * rs.x * dg.x * inv_m);
+    o.y = sc.y * (dz.y - db.y * inv_m - (xv.y - mu.y) * rs.y * dg.y * inv_m);
+    o.z = sc.z * (dz.z - db.z * inv_m - (xv.z - mu.z) * rs.z * dg.z * inv_m);
+    o.w = sc.w * (dz.w - db.w * inv_m - (xv.w - mu.w) * rs.w * dg.w * inv_m);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+}
+
 // BatchNorm backward apply for a BN whose INPUT is the output of a Conv2D / Dense with a fused ReLU (the small backbones'
 // conv -> ReLU -> BN blocks, /root/reference/embedding_net/backbones.py:44-68): the ReLU's backward and the bias gradient in
 // the same pass.  x >= 0 is the ReLU's output, so its mask is (x > 0):  dz = dx * [x > 0]  is what the producer's data /
@@ -1166,6 +1242,30 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
                                                                dbeta, dgamma, relu, training, dz, partial, drop); }
   colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias);
   return check_launch("bn_bwd_inrelu");
+}
+
+// BatchNorm backward on dy + dpool / hw (see bn_bwd_reduce4_gap_kernel): training statistics, c % 4 == 0, n * hw * c / 4 < 2^31
+extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, int n, int hw, const float* x, int c, const float* save_mean,
+                                 const float* save_rstd, const float* scale, const float* shift, int relu, float* dx,
+                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(dy && dpool && x && save_mean && save_rstd && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd_gap: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "bn_bwd_gap: n=%d hw=%d c=%d (c %% 4 == 0)", n, hw, c);
+  const long m = (long)n * hw;
+  EMBNET_CHECK_ARG(m * (c / 4) < 0x7FFFFFFFl, "bn_bwd_gap: tensor too large");
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "bn_bwd_gap: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  float* partial = (float*)workspace;
+  const ColGeom g4 = col_geom(m, c / 4);
+  const float inv_hw = 1.f / (float)hw;
+  { EMBNET_TRACE("embnet::bn_bwd_reduce4_gap_kernel", TRACE_BYTES, 8.0 * m * c, stream);
+    bn_bwd_reduce4_gap_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, dpool, make_divu((uint32_t)hw), inv_hw, x, m, c / 4, g4, save_mean, save_rstd,
+                                                                scale, shift, relu, partial); }
+  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
+  { EMBNET_TRACE("embnet::bn_bwd_apply4_gap_kernel", TRACE_BYTES, 12.0 * m * c, stream);
+    bn_bwd_apply4_gap_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, dpool, make_divu((uint32_t)((long)hw * (c / 4))), inv_hw, x,
+                                                                                    m * c / 4, c / 4, 1.f / (float)m, save_mean, save_rstd,
+                                                                                    scale, shift, dbeta, dgamma, relu, dx); }
+  return check_launch("bn_bwd_gap");
 }
 
 // BatchNorm backward whose sums were produced by the data gradient of the conv behind it (embnet_conv2d_dgrad_bnsums_f32):

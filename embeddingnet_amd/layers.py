@@ -155,6 +155,8 @@ def _done(out, notify):
 # receives exactly that tensor starts at its finalize kernel.  (The entry keeps an alias of dx: autograd then never
 # accumulates a second consumer's gradient into it in place, so a hit means dy IS that data gradient.)
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
+# the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
+FUSE_GAP_BN = [__import__("os").environ.get("EMBNET_FUSE_GAP_BN", "1") == "1"]
 BN_SUMS = {}
 _BN_FWD_STATS = {}
 
@@ -876,13 +878,20 @@ class _BNGapFn(torch.autograd.Function):
         n, c = x.shape[0], x.shape[-1]
         m = x.numel() // c
         dy = _c(dy)
+        dx = torch.empty_like(x)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+        if dg is not None and ctx.training and FUSE_GAP_BN[0] and m * (c // 4) < 2 ** 31 - 1:
+            # d(output) = dy + dg / hw formed inside the two BatchNorm-backward passes: the summed tensor is never written
+            check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(_c(dg)), n, m // n, ptr(x), c, stats.data_ptr(), stats.data_ptr() + 4 * c,
+                                        stats.data_ptr() + 8 * c, stats.data_ptr() + 12 * c, int(ctx.relu), ptr(dx), ptr(tg), ptr(tb),
+                                        ptr(ws), ws.numel() * 4, stream()))
+            dgamma, dbeta = finish()
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None
         if dg is not None:                                  # d(output) = dy + dg / hw, written once
             dz = torch.empty_like(dy)
             check(lib.embnet_gap_bwd(ptr(_c(dg)), n, m // n, c, ptr(dy), ptr(dz), stream()))
             dy = dz
-        dx = torch.empty_like(x)
-        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
-        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats.data_ptr() if ctx.training else None
         rstd = (stats.data_ptr() + 4 * c) if ctx.training else None
         check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 15
+#define EMBNET_ABI_VERSION 16
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -286,6 +286,13 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                   float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm backward of a layer whose output is also globally average-pooled (the squeeze-and-excite block of the EfficientNet
+ * MBConv, reference backbones.py:84-98): the output gradient is dy[n,p,c] + dpool[n,c] / hw; both passes form it on the fly with
+ * embnet_gap_bwd's arithmetic (the result of embnet_gap_bwd(dx_add = dy) followed by embnet_bn_bwd to the last bits), so the
+ * summed tensor is never written.  Training statistics, c % 4 == 0; workspace as embnet_bn_bwd. */
+int embnet_bn_bwd_gap(const float* dy, const float* dpool, int n, int hw, const float* x, int c, const float* save_mean,
+                      const float* save_rstd, const float* scale, const float* shift, int relu, float* dx, float* dgamma,
+                      float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* BatchNorm backward whose column sums came from the data gradient of the conv that consumed this layer's output
  * (embnet_conv2d_dgrad_bnsums_f32 below): partials [2][c][rows] -> dbeta / dgamma (added in double), then the apply pass of
  * embnet_bn_bwd.  Training statistics, c % 4 == 0. */

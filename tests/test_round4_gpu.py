@@ -433,3 +433,39 @@ def test_mining_by_anchor_equals_mining_by_pair(dev, p, k, e, mode):
     assert torch.equal(out["0"][1], out["1"][1]) and torch.equal(out["0"][2], out["1"][2])
     assert torch.equal(out["0"][3], out["1"][3])
     assert torch.equal(out["0"][0][:cnt], out["1"][0][:cnt])
+
+
+# ------------------------------------------------------------------------------------------------ pooled gradient in BN backward
+@pytest.mark.parametrize("shape,act", [((6, 14, 14, 96), "swish"), ((3, 7, 9, 240), "swish"), ((5, 28, 28, 32), "relu"),
+                                       ((256, 14, 14, 480), "swish")])
+def test_pooled_gradient_is_added_inside_the_batchnorm_backward(dev, shape, act):
+    """BatchNormalization(emit_gap=True) (the squeeze-and-excite input of an MBConv block, reference backbones.py:84-98): the
+    gradient of the pooled branch is added to dy inside the two BatchNorm-backward passes (embnet_bn_bwd_gap) instead of by
+    embnet_gap_bwd's pass — same summed gradient (embnet_gap_bwd's two roundings), dx / dgamma / dbeta equal to the last bits
+    (the compiler contracts the apply arithmetic differently in the two kernels), no gap_bwd kernel launched."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_GAP_BN[0] = fuse
+        try:
+            c = shape[-1]
+            bn = L.BatchNormalization(c, activation=act).to(dev).train()
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y, pooled = bn(xt, emit_gap=True)
+            gate = torch.sigmoid(pooled * 3.0)                                   # a stand-in for the squeeze-excite dense layers
+            out = y * gate.reshape(shape[0], 1, 1, c)
+            out.backward(torch.cos(out.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = (xt.grad.clone(), bn.gamma.grad.clone(), bn.beta.grad.clone())
+        finally:
+            L.FUSE_GAP_BN[0] = True
+    assert any("gap_bwd" in n for n in names[False]) and not any("gap_bwd" in n for n in names[True]), names[True]
+    assert any("bn_bwd_reduce4_gap" in n for n in names[True])
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1e-30)
