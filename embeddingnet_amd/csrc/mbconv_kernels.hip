@@ -622,6 +622,29 @@ __global__ __launch_bounds__(256) void chscale_bwd4_kernel(const float* __restri
   }
 }
 
+// ds only (the scaled tensor's own gradient dy * s is formed by its consumer: embnet_bn_bwd_gap's gate argument): 8 B per element
+__global__ __launch_bounds__(256) void chscale_dgate4_kernel(const float* __restrict__ x, const float* __restrict__ dy, int hw, int c4,
+                                                             float* __restrict__ ds) {
+  __shared__ float4 sh[256];
+  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cq = blockIdx.x * 16 + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq < c4) {
+    for (int p = pl; p < hw; p += 16) {                  // the accumulation order of chscale_bwd4_kernel
+      const long i = ((long)n * hw + p) * c4 + cq;
+      const float4 d = reinterpret_cast<const float4*>(dy)[i], xv = reinterpret_cast<const float4*>(x)[i];
+      acc.x = fmaf(d.x, xv.x, acc.x); acc.y = fmaf(d.y, xv.y, acc.y);
+      acc.z = fmaf(d.z, xv.z, acc.z); acc.w = fmaf(d.w, xv.w, acc.w);
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0 && cq < c4) {
+    for (int k = 1; k < 16; ++k) { const float4 o = sh[k * 16 + cl]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    reinterpret_cast<float4*>(ds)[(long)n * c4 + cq] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                           const float* __restrict__ dy, int hw, int c,
                                                           float* __restrict__ dx, float* __restrict__ ds) {
@@ -867,6 +890,12 @@ extern "C" int embnet_channel_scale_bwd(const float* x, const float* s, const fl
   if ((c & 3) == 0) { EMBNET_TRACE("embnet::chscale_bwd4_kernel", TRACE_BYTES, 12.0 * n * hw * c, stream); chscale_bwd4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, s, dy, hw, c / 4, dx, ds); }
   else { EMBNET_TRACE("embnet::chscale_bwd_kernel", TRACE_BYTES, 12.0 * n * hw * c, stream); chscale_bwd_kernel<<<dim3(cdiv(c, 256), n), 256, 0, S(stream)>>>(x, s, dy, hw, c, dx, ds); }
   return check_launch("channel_scale_bwd");
+}
+
+extern "C" int embnet_channel_scale_dgate(const float* x, const float* dy, int n, int hw, int c, float* ds, void* stream) {
+  EMBNET_CHECK_ARG(x && dy && ds && n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "channel_scale_dgate: bad argument (c %% 4 == 0)");
+  { EMBNET_TRACE("embnet::chscale_dgate4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream); chscale_dgate4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, dy, hw, c / 4, ds); }
+  return check_launch("channel_scale_dgate");
 }
 
 extern "C" int embnet_sample_dropout(const float* x, long total, long per_sample, float rate, uint64_t seed,

@@ -277,9 +277,16 @@ __device__ __forceinline__ float4 add_pool4(float4 dy, float4 g, float inv) {
   return make_float4(__fadd_rn(__fmul_rn(g.x, inv), dy.x), __fadd_rn(__fmul_rn(g.y, inv), dy.y),
                      __fadd_rn(__fmul_rn(g.z, inv), dy.z), __fadd_rn(__fmul_rn(g.w, inv), dy.w));
 }
+// ... and, with gate != NULL, dy is the gradient of the GATED tensor y * gate[n,c] (embnet_channel_scale_fwd): the scaling's
+// backward multiply (embnet_channel_scale_bwd's dx, one rounding) is applied here instead of being written and read back
+__device__ __forceinline__ float4 gate4(float4 dy, const float* __restrict__ gate, long idx) {
+  if (!gate) return dy;
+  const float4 s = reinterpret_cast<const float4*>(gate)[idx];
+  return make_float4(__fmul_rn(dy.x, s.x), __fmul_rn(dy.y, s.y), __fmul_rn(dy.z, s.z), __fmul_rn(dy.w, s.w));
+}
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_gap_kernel(const float* __restrict__ dy, const float* __restrict__ dpool,
-                                                                 DivU dhw, float inv_hw, const float* __restrict__ x, long m,
+                                                                 const float* __restrict__ gate, DivU dhw, float inv_hw, const float* __restrict__ x, long m,
                                                                  int c4, ColGeom g, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, int relu,
@@ -290,8 +297,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_gap_kernel(const float* __
               reinterpret_cast<const float4*>(mean)[q], reinterpret_cast<const float4*>(rstd)[q]};
   }, [&](long r, int q, const K4& k, float4& a, float4& b) {
     const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
-    const float4 gp = reinterpret_cast<const float4*>(dpool)[(long)divu((uint32_t)r, dhw) * c4 + q];
-    float4 dz = add_pool4(reinterpret_cast<const float4*>(dy)[r * c4 + q], gp, inv_hw);
+    const long nq = (long)divu((uint32_t)r, dhw) * c4 + q;
+    const float4 gp = reinterpret_cast<const float4*>(dpool)[nq];
+    float4 dz = add_pool4(gate4(reinterpret_cast<const float4*>(dy)[r * c4 + q], gate, nq), gp, inv_hw);
     const float4 sc = k.sc, sh = k.sh, mu = k.mu, rs = k.rs;
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_gap_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __restrict__ dy, const float* __restrict__ dpool,
-                                                                DivU dhwc4, float inv_hw, const float* __restrict__ x,
+                                                                const float* __restrict__ gate, DivU dhwc4, float inv_hw, const float* __restrict__ x,
                                                                 long total4, int c4, float inv_m, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ dbeta,
@@ -323,8 +331,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __r
     const int q = (int)(i % c4);
     if (!fixed) consts(q);
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    const float4 gp = reinterpret_cast<const float4*>(dpool)[(long)divu((uint32_t)i, dhwc4) * c4 + q];
-    float4 dz = add_pool4(reinterpret_cast<const float4*>(dy)[i], gp, inv_hw);
+    const long nq = (long)divu((uint32_t)i, dhwc4) * c4 + q;
+    const float4 gp = reinterpret_cast<const float4*>(dpool)[nq];
+    float4 dz = add_pool4(gate4(reinterpret_cast<const float4*>(dy)[i], gate, nq), gp, inv_hw);
     if (relu) {
       dz.x = act_grad(relu, fmaf(xv.x, sc.x, sh.x), dz.x); dz.y = act_grad(relu, fmaf(xv.y, sc.y, sh.y), dz.y);
       dz.z = act_grad(relu, fmaf(xv.z, sc.z, sh.z), dz.z); dz.w = act_grad(relu, fmaf(xv.w, sc.w, sh.w), dz.w);
@@ -1245,7 +1254,7 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
 }
 
 // BatchNorm backward on dy + dpool / hw (see bn_bwd_reduce4_gap_kernel): training statistics, c % 4 == 0, n * hw * c / 4 < 2^31
-extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, int n, int hw, const float* x, int c, const float* save_mean,
+extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, const float* gate, int n, int hw, const float* x, int c, const float* save_mean,
                                  const float* save_rstd, const float* scale, const float* shift, int relu, float* dx,
                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
   EMBNET_CHECK_ARG(dy && dpool && x && save_mean && save_rstd && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd_gap: null pointer");
@@ -1258,11 +1267,11 @@ extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, int n, int
   const ColGeom g4 = col_geom(m, c / 4);
   const float inv_hw = 1.f / (float)hw;
   { EMBNET_TRACE("embnet::bn_bwd_reduce4_gap_kernel", TRACE_BYTES, 8.0 * m * c, stream);
-    bn_bwd_reduce4_gap_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, dpool, make_divu((uint32_t)hw), inv_hw, x, m, c / 4, g4, save_mean, save_rstd,
+    bn_bwd_reduce4_gap_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, dpool, gate, make_divu((uint32_t)hw), inv_hw, x, m, c / 4, g4, save_mean, save_rstd,
                                                                 scale, shift, relu, partial); }
   bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
   { EMBNET_TRACE("embnet::bn_bwd_apply4_gap_kernel", TRACE_BYTES, 12.0 * m * c, stream);
-    bn_bwd_apply4_gap_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, dpool, make_divu((uint32_t)((long)hw * (c / 4))), inv_hw, x,
+    bn_bwd_apply4_gap_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, dpool, gate, make_divu((uint32_t)((long)hw * (c / 4))), inv_hw, x,
                                                                                     m * c / 4, c / 4, 1.f / (float)m, save_mean, save_rstd,
                                                                                     scale, shift, dbeta, dgamma, relu, dx); }
   return check_launch("bn_bwd_gap");

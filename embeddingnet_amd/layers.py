@@ -156,6 +156,9 @@ def _done(out, notify):
 # accumulates a second consumer's gradient into it in place, so a hit means dy IS that data gradient.)
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
+# the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
+FUSE_GATE_BN = [__import__("os").environ.get("EMBNET_FUSE_GATE_BN", "1") == "1"]
+GATE_PENDING = {}
 FUSE_GAP_BN = [__import__("os").environ.get("EMBNET_FUSE_GAP_BN", "1") == "1"]
 BN_SUMS = {}
 _BN_FWD_STATS = {}
@@ -851,11 +854,14 @@ class _BNGapFn(torch.autograd.Function):
     statistics as _BatchNormFn; the pooled gradient is broadcast into dy in one kernel before the usual BN backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, partials=None):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, partials=None, lazy_scale=False):
+        """lazy_scale: the caller promises that the first output's ONLY consumer is channel_scale(y, s, lazy=True); that
+        function then hands this layer the gradient of the gated tensor unscaled (GATE_PENDING) and backward applies s."""
         x = _c(x)
         lib = _lib.lib()
         n, c = x.shape[0], x.shape[-1]
         m = x.numel() // c
+        ctx.lazy_scale = bool(lazy_scale)
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
         if training:
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
@@ -881,13 +887,24 @@ class _BNGapFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
-        if dg is not None and ctx.training and FUSE_GAP_BN[0] and m * (c // 4) < 2 ** 31 - 1:
-            # d(output) = dy + dg / hw formed inside the two BatchNorm-backward passes: the summed tensor is never written
-            check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(_c(dg)), n, m // n, ptr(x), c, stats.data_ptr(), stats.data_ptr() + 4 * c,
+        gate = None
+        if getattr(ctx, "lazy_scale", False):
+            ent = GATE_PENDING.pop(dy.data_ptr(), None)
+            if ent is None or ent[1].shape != dy.shape:
+                raise _lib.EmbnetError("BatchNormalization(lazy_scale=True): the gradient of the gated tensor did not arrive "
+                                       "as channel_scale(lazy=True) left it — the BatchNormalization output has another consumer")
+            gate = ent[0]
+            if dg is None:
+                dg = torch.zeros((n, c), device=x.device, dtype=torch.float32)
+        if dg is not None and ctx.training and (FUSE_GAP_BN[0] or gate is not None) and m * (c // 4) < 2 ** 31 - 1:
+            # d(output) = dy (* gate) + dg / hw formed inside the two BatchNorm-backward passes: the summed tensor is never written
+            check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(_c(dg)), ptr(gate), n, m // n, ptr(x), c, stats.data_ptr(), stats.data_ptr() + 4 * c,
                                         stats.data_ptr() + 8 * c, stats.data_ptr() + 12 * c, int(ctx.relu), ptr(dx), ptr(tg), ptr(tb),
                                         ptr(ws), ws.numel() * 4, stream()))
             dgamma, dbeta = finish()
-            return dx, dgamma, dbeta, None, None, None, None, None, None, None
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        if gate is not None:                                # (not reached: lazy_scale is only granted in training mode)
+            raise _lib.EmbnetError("BatchNormalization(lazy_scale=True) needs training-mode statistics")
         if dg is not None:                                  # d(output) = dy + dg / hw, written once
             dz = torch.empty_like(dy)
             check(lib.embnet_gap_bwd(ptr(_c(dg)), n, m // n, c, ptr(dy), ptr(dz), stream()))
@@ -898,7 +915,7 @@ class _BNGapFn(torch.autograd.Function):
                                 int(ctx.relu), int(ctx.training), None, ptr(dx), ptr(tg), ptr(tb), None, ptr(ws),
                                 ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class Deferred:
@@ -986,7 +1003,7 @@ class BatchNormalization(nn.Module):
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
 
-    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None):
+    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None, lazy_scale=False):
         """dropout=<Dropout>: the Dropout layer that consumes the output, applied in this layer's passes when it is active
         (plain path only; the caller then skips the Dropout module).
         planes_for=<Conv2D>: the conv that consumes the output; when it can run the patch kernel on it
@@ -998,8 +1015,14 @@ class BatchNormalization(nn.Module):
         so that its gradient is added inside the BN backward kernel instead of by an autograd accumulation pass."""
         if emit_gap:
             if x.dim() == 4 and x.shape[-1] % 4 == 0:
-                return _BNGapFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
-                                      self.momentum, self.relu, self.training, _partials_of(x, self.training))
+                # lazy_scale (emit_gap only): see _BNGapFn.forward; granted when this layer can apply the gate in its backward
+                lazy = bool(lazy_scale and self.training and torch.is_grad_enabled() and FUSE_GATE_BN[0]
+                            and x.numel() // 4 < 2 ** 31 - 1)
+                y, g = _BNGapFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
+                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), lazy)
+                if lazy:
+                    y._lazy_scale_ok = True
+                return y, g
             y = self.forward(x)
             return y, _GapFn.apply(y)
         want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
@@ -1458,11 +1481,12 @@ class Swish(nn.Module):
 
 class _ChannelScaleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, s):
+    def forward(ctx, x, s, lazy=False):
         x, s = _c(x), _c(s)
         n, h, w, c = x.shape
         y = torch.empty_like(x)
         check(_lib.lib().embnet_channel_scale_fwd(ptr(x), ptr(s), n, h * w, c, ptr(y), stream()))
+        ctx.lazy = bool(lazy)
         ctx.save_for_backward(x, s)
         return y
 
@@ -1470,14 +1494,27 @@ class _ChannelScaleFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, s = ctx.saved_tensors
         n, h, w, c = x.shape
-        dx, ds = torch.empty_like(x), torch.empty_like(s)
-        check(_lib.lib().embnet_channel_scale_bwd(ptr(x), ptr(s), ptr(_c(dy)), n, h * w, c, ptr(dx), ptr(ds), stream()))
-        return dx, ds
+        dy = _c(dy)
+        ds = torch.empty_like(s)
+        if ctx.lazy:
+            # x's producer (a BatchNormalization that granted lazy_scale) multiplies by s inside its backward passes: only the
+            # gate's gradient is computed here and dy travels on UNSCALED, announced in GATE_PENDING (with an alias, so that
+            # autograd cannot add into it in place) — that layer raises if it receives anything else
+            check(_lib.lib().embnet_channel_scale_dgate(ptr(x), ptr(dy), n, h * w, c, ptr(ds), stream()))
+            while len(GATE_PENDING) >= 8:
+                GATE_PENDING.pop(next(iter(GATE_PENDING)))
+            GATE_PENDING[dy.data_ptr()] = (s, dy.detach())
+            return dy, ds, None
+        dx = torch.empty_like(x)
+        check(_lib.lib().embnet_channel_scale_bwd(ptr(x), ptr(s), ptr(dy), n, h * w, c, ptr(dx), ptr(ds), stream()))
+        return dx, ds, None
 
 
-def channel_scale(x, s):
-    """x[n,h,w,c] * s[n,c] (the squeeze-excite multiply)."""
-    return _ChannelScaleFn.apply(x, s.reshape(x.shape[0], x.shape[-1]))
+def channel_scale(x, s, lazy=False):
+    """x[n,h,w,c] * s[n,c] (the squeeze-excite multiply).  lazy=True: x is the output of BatchNormalization(emit_gap=True,
+    lazy_scale=True) and THIS is its only consumer — the multiply's backward is left to that layer (see _ChannelScaleFn)."""
+    lazy = bool(lazy and getattr(x, "_lazy_scale_ok", False) and x.shape[-1] % 4 == 0)
+    return _ChannelScaleFn.apply(x, s.reshape(x.shape[0], x.shape[-1]), lazy)
 
 
 class _SampleDropoutFn(torch.autograd.Function):

@@ -289,8 +289,10 @@ int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* s
 /* BatchNorm backward of a layer whose output is also globally average-pooled (the squeeze-and-excite block of the EfficientNet
  * MBConv, reference backbones.py:84-98): the output gradient is dy[n,p,c] + dpool[n,c] / hw; both passes form it on the fly with
  * embnet_gap_bwd's arithmetic (the result of embnet_gap_bwd(dx_add = dy) followed by embnet_bn_bwd to the last bits), so the
- * summed tensor is never written.  Training statistics, c % 4 == 0; workspace as embnet_bn_bwd. */
-int embnet_bn_bwd_gap(const float* dy, const float* dpool, int n, int hw, const float* x, int c, const float* save_mean,
+ * summed tensor is never written.  gate (NULL or [n,c]): dy is the gradient of the GATED tensor y * gate (embnet_channel_scale_fwd)
+ * and the scaling's backward multiply is applied here too — its caller then only needs embnet_channel_scale_dgate.
+ * Training statistics, c % 4 == 0; workspace as embnet_bn_bwd. */
+int embnet_bn_bwd_gap(const float* dy, const float* dpool, const float* gate, int n, int hw, const float* x, int c, const float* save_mean,
                       const float* save_rstd, const float* scale, const float* shift, int relu, float* dx, float* dgamma,
                       float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* BatchNorm backward whose column sums came from the data gradient of the conv that consumed this layer's output
@@ -398,6 +400,8 @@ int embnet_activation_fwd(const float* x, long total, int kind, float* y, void* 
 int embnet_activation_bwd(const float* x, const float* dy, long total, int kind, float* dx, void* stream);
 /* squeeze-excite multiply: y[n,p,c] = x[n,p,c]*s[n,c]; bwd gives dx and ds[n,c]. */
 int embnet_channel_scale_fwd(const float* x, const float* s, int n, int hw, int c, float* y, void* stream);
+/* ds[n,c] = sum_p dy * x only (embnet_channel_scale_bwd without dx: see embnet_bn_bwd_gap's gate).  c % 4 == 0. */
+int embnet_channel_scale_dgate(const float* x, const float* dy, int n, int hw, int c, float* ds, void* stream);
 int embnet_channel_scale_bwd(const float* x, const float* s, const float* dy, int n, int hw, int c, float* dx,
                              float* ds, void* stream);
 /* drop-connect: Dropout with noise_shape (None,1,1,1): one keep/drop decision per sample, inverted scaling. */

@@ -469,3 +469,54 @@ def test_pooled_gradient_is_added_inside_the_batchnorm_backward(dev, shape, act)
     assert any("bn_bwd_reduce4_gap" in n for n in names[True])
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(6, 14, 14, 96), (3, 7, 9, 240), (128, 14, 14, 480)])
+def test_gate_multiply_backward_rides_on_the_batchnorm_backward(dev, shape):
+    """The squeeze-and-excite chain of an MBConv block (reference backbones.py:84-98): y, pooled = BN(x); s = gate(pooled);
+    out = y * s.  With lazy_scale the scaling's backward only computes the gate's gradient (embnet_channel_scale_dgate) and
+    the BatchNorm backward applies dy * s itself (embnet_bn_bwd_gap's gate): no chscale_bwd / gap_bwd kernel, the same
+    gradients to the last bits."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    n, c = shape[0], shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_GATE_BN[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(2)
+            bn = L.BatchNormalization(c, activation="swish").to(dev).train()
+            se = L.Dense(c, c, gen=gen).to(dev)
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y, pooled = bn(xt, emit_gap=True, lazy_scale=True)
+            s = L.sigmoid(se(pooled))
+            out = L.channel_scale(y, s, lazy=True)
+            out.backward(torch.cos(out.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = (xt.grad.clone(), bn.gamma.grad.clone(), bn.beta.grad.clone(), se.kernel.grad.clone(), se.bias.grad.clone())
+        finally:
+            L.FUSE_GATE_BN[0] = True
+            L.GATE_PENDING.clear()
+    assert any("chscale_bwd" in nm for nm in names[False])
+    assert not any("chscale_bwd" in nm or "gap_bwd" in nm for nm in names[True]), names[True]
+    assert any("chscale_dgate4" in nm for nm in names[True]) and not L.GATE_PENDING
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1e-30)
+
+
+def test_lazy_gate_with_a_second_consumer_fails_loudly(dev):
+    """lazy_scale is a promise that the BatchNormalization output feeds the scaling only; a second consumer makes autograd
+    add another gradient to the unscaled one — the BatchNormalization backward must refuse instead of returning a wrong dx."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn((4, 6, 6, 32), device=dev, requires_grad=True)
+    bn = L.BatchNormalization(32, activation="swish").to(dev).train()
+    y, pooled = bn(x, emit_gap=True, lazy_scale=True)
+    out = L.channel_scale(y, torch.sigmoid(pooled), lazy=True) + 0.5 * y          # the forbidden second use of y
+    with pytest.raises(_lib.EmbnetError, match="another consumer"):
+        out.sum().backward()
+    L.GATE_PENDING.clear()
