@@ -190,9 +190,22 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         # rocprofv3 prints a plain kernel with its argument list ("embnet::bn_bwd_apply4_kernel(float const*, ...)"), the
         # library's trace names it without; template instantiations carry the same text in both
         key = name if name in prof.get("kernels", {}) else next((k for k in prof.get("kernels", {}) if k.startswith(name + "(")), None)
+        src = f"profiles/{tfile} [{workload}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
+        if key is None and prof.get("detail"):
+            # a trace label that stands for several template instantiations ("embnet::dwconv_row4_kernel" = every
+            # dwconv_row4x2_kernel<KS, ST, FLIP, TW> the step launches): launch-weighted mean over the instantiations
+            stem = name.split("::")[-1].split("<")[0].replace("_kernel", "")
+            inst = {k: v for k, v in prof["detail"].items()
+                    if k.split("(")[0].split("<")[0].split("::")[-1].startswith(stem) and v.get("launches")}
+            if inst:
+                n_l = sum(v["launches"] for v in inst.values())
+                roof["traffic"] = round(sum(prof["kernels"][k] * v["launches"] for k, v in inst.items()) / n_l)
+                roof["traffic_source"] = src + f", launch-weighted over {len(inst)} instantiations of {stem}*"
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["traffic_algorithmic"], 1), 2)
+                break
         if key is not None:
             roof["traffic"] = prof["kernels"][key]
-            roof["traffic_source"] = f"profiles/{tfile} [{workload}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command)"
+            roof["traffic_source"] = src
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["traffic_algorithmic"], 1), 2)
             break
     return roof, by
