@@ -347,6 +347,72 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __r
   }
 }
 
+// Squeeze-and-excite backward, first pass.  The block's tensor a = act(BN(x)) is gated: out = a * s[n,c], and pooled: s = f(mean_p a).
+// With dg = d(out) this ONE pass over (dg, x) produces, per image and channel,
+//   T0 = sum_p dg * a                (the gate's gradient: embnet_channel_scale_dgate's result, a recomputed from x)
+//   S1 = sum_p a' dg   S2 = sum_p a'   S3 = sum_p a' dg xhat   S4 = sum_p a' xhat       (a' = act'(BN(x)), xhat = (x - mean) rstd)
+// from which the BatchNorm-backward sums follow without a second pass over the tensors, because the layer's output gradient
+// dz = a' (dg s[n,c] + dpool[n,c] / hw) is linear in the two per-(n,c) factors:
+//   dbeta[c] = sum_n (s S1 + dpool/hw S2),   dgamma[c] = sum_n (s S3 + dpool/hw S4)      (se_bn_finalize_kernel, in double).
+// Replaces embnet_channel_scale_dgate + bn_bwd_reduce4_gap (8 + 8 B per element) by one 8-byte pass.  out: [n][5][c].
+__global__ __launch_bounds__(256) void se_bn_sums4_kernel(const float* __restrict__ dg, const float* __restrict__ x, int hw, int c4,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                          float* __restrict__ out) {
+  __shared__ float4 sh[5][256];
+  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cq = blockIdx.x * 16 + cl;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 t0 = z4, s1 = z4, s2 = z4, s3 = z4, s4 = z4;
+  if (cq < c4) {
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sf = reinterpret_cast<const float4*>(shift)[cq];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
+    for (int p = pl; p < hw; p += 16) {                  // (the accumulation order of chscale_bwd4_kernel / chscale_dgate4_kernel)
+      const long i = ((long)n * hw + p) * c4 + cq;
+      const float4 d = reinterpret_cast<const float4*>(dg)[i], xv = reinterpret_cast<const float4*>(x)[i];
+      auto one = [&](float dgv, float xq, float scq, float sfq, float muq, float rsq, float& T0, float& S1, float& S2, float& S3, float& S4) {
+        const float z = fmaf(xq, scq, sfq);
+        float av, ad;                                      // act(z) and act'(z); swish from ONE sigmoid (exp + rcp are quarter rate)
+        if (act == 2) { const float sg = __frcp_rn(1.f + __expf(-z)); av = z * sg; ad = sg * fmaf(z, 1.f - sg, 1.f); }
+        else if (act == 1) { av = fmaxf(z, 0.f); ad = z > 0.f ? 1.f : 0.f; }
+        else { av = z; ad = 1.f; }
+        T0 = fmaf(dgv, av, T0);
+        const float xh = (xq - muq) * rsq, adg = ad * dgv;
+        S1 += adg; S2 += ad; S3 = fmaf(adg, xh, S3); S4 = fmaf(ad, xh, S4);
+      };
+      one(d.x, xv.x, sc.x, sf.x, mu.x, rs.x, t0.x, s1.x, s2.x, s3.x, s4.x);
+      one(d.y, xv.y, sc.y, sf.y, mu.y, rs.y, t0.y, s1.y, s2.y, s3.y, s4.y);
+      one(d.z, xv.z, sc.z, sf.z, mu.z, rs.z, t0.z, s1.z, s2.z, s3.z, s4.z);
+      one(d.w, xv.w, sc.w, sf.w, mu.w, rs.w, t0.w, s1.w, s2.w, s3.w, s4.w);
+    }
+  }
+  sh[0][threadIdx.x] = t0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2; sh[3][threadIdx.x] = s3; sh[4][threadIdx.x] = s4;
+  __syncthreads();
+  if (pl < 5 && cq < c4) {                                 // pixel lane q < 5 adds quantity q over the 16 pixel lanes, in lane order
+    float4 a = sh[pl][cl];
+    for (int k = 1; k < 16; ++k) { const float4 o = sh[pl][k * 16 + cl]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+    reinterpret_cast<float4*>(out)[((long)n * 5 + pl) * c4 + cq] = a;
+  }
+}
+
+// dbeta / dgamma from the per-(n,c) sums (see se_bn_sums4_kernel): one WAVE per channel, lanes stride the images, the lane
+// partials are added by a fixed butterfly in double (a serial loop over 256 images per thread was a 250 us latency chain)
+__global__ __launch_bounds__(256) void se_bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gate,
+                                                             const float* __restrict__ dpool, int n, int c, float inv_hw,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= c) return;
+  double b = 0.0, g = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const float* sp = sums + (long)i * 5 * c + col;
+    const double s = (double)gate[(long)i * c + col], pq = (double)__fmul_rn(dpool[(long)i * c + col], inv_hw);
+    b += s * (double)sp[c] + pq * (double)sp[2 * c];
+    g += s * (double)sp[3 * c] + pq * (double)sp[4 * c];
+  }
+  b = wave_sum(b); g = wave_sum(g);
+  if (lane == 0) { dbeta[col] = (float)b; dgamma[col] = (float)g; }
+}
+
 // BatchNorm backward apply for a BN whose INPUT is the output of a Conv2D / Dense with a fused ReLU (the small backbones'
 // conv -> ReLU -> BN blocks, /root/reference/embedding_net/backbones.py:44-68): the ReLU's backward and the bias gradient in
 // the same pass.  x >= 0 is the ReLU's output, so its mask is (x > 0):  dz = dx * [x > 0]  is what the producer's data /
@@ -1275,6 +1341,33 @@ extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, const floa
                                                                                     m * c / 4, c / 4, 1.f / (float)m, save_mean, save_rstd,
                                                                                     scale, shift, dbeta, dgamma, relu, dx); }
   return check_launch("bn_bwd_gap");
+}
+
+// squeeze-and-excite backward, pass 1 (se_bn_sums4_kernel): sums [n][5][c]; row 0 of every image = the gate's gradient
+extern "C" int embnet_se_bn_sums(const float* dg, const float* x, int n, int hw, int c, const float* save_mean, const float* save_rstd,
+                                 const float* scale, const float* shift, int act, float* sums, void* stream) {
+  EMBNET_CHECK_ARG(dg && x && save_mean && save_rstd && scale && shift && sums, "se_bn_sums: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0 && act >= 0 && act <= 2, "se_bn_sums: n=%d hw=%d c=%d act=%d (c %% 4 == 0)", n, hw, c, act);
+  EMBNET_TRACE("embnet::se_bn_sums4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream);
+  se_bn_sums4_kernel<<<dim3((c / 4 + 15) / 16, n), 256, 0, S(stream)>>>(dg, x, hw, c / 4, save_mean, save_rstd, scale, shift, act, sums);
+  return check_launch("se_bn_sums");
+}
+
+// BatchNorm backward on dy * gate + dpool / hw with the column sums taken from embnet_se_bn_sums (no reduction pass)
+extern "C" int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const float* gate, const float* sums, int n, int hw,
+                                      const float* x, int c, const float* save_mean, const float* save_rstd, const float* scale,
+                                      const float* shift, int relu, float* dx, float* dgamma, float* dbeta, void* stream) {
+  EMBNET_CHECK_ARG(dy && dpool && gate && sums && x && save_mean && save_rstd && scale && shift && dx && dgamma && dbeta, "bn_bwd_gap_sums: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "bn_bwd_gap_sums: n=%d hw=%d c=%d (c %% 4 == 0)", n, hw, c);
+  const long m = (long)n * hw;
+  EMBNET_CHECK_ARG(m * (c / 4) < 0x7FFFFFFFl, "bn_bwd_gap_sums: tensor too large");
+  const float inv_hw = 1.f / (float)hw;
+  se_bn_finalize_kernel<<<(c + 3) / 4, 256, 0, S(stream)>>>(sums, gate, dpool, n, c, inv_hw, dbeta, dgamma);
+  { EMBNET_TRACE("embnet::bn_bwd_apply4_gap_kernel", TRACE_BYTES, 12.0 * m * c, stream);
+    bn_bwd_apply4_gap_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, dpool, gate, make_divu((uint32_t)((long)hw * (c / 4))), inv_hw, x,
+                                                                                    m * c / 4, c / 4, 1.f / (float)m, save_mean, save_rstd,
+                                                                                    scale, shift, dbeta, dgamma, relu, dx); }
+  return check_launch("bn_bwd_gap_sums");
 }
 
 // BatchNorm backward whose sums were produced by the data gradient of the conv behind it (embnet_conv2d_dgrad_bnsums_f32):

@@ -157,6 +157,7 @@ def _done(out, notify):
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
 # the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
+SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
 FUSE_GATE_BN = [__import__("os").environ.get("EMBNET_FUSE_GATE_BN", "1") == "1"]
 GATE_PENDING = {}
 FUSE_GAP_BN = [__import__("os").environ.get("EMBNET_FUSE_GAP_BN", "1") == "1"]
@@ -875,6 +876,8 @@ class _BNGapFn(torch.autograd.Function):
         ctx.relu, ctx.training, ctx.has_gamma = act, training, gamma is not None
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
         ctx.save_for_backward(x, stats)
+        if lazy_scale:                                      # for channel_scale(lazy=True): this layer's input, statistics, activation
+            _BN_FWD_STATS[y.data_ptr()] = (x, stats, int(act))
         return y, g
 
     @staticmethod
@@ -896,6 +899,13 @@ class _BNGapFn(torch.autograd.Function):
             gate = ent[0]
             if dg is None:
                 dg = torch.zeros((n, c), device=x.device, dtype=torch.float32)
+            if ent[2] is not None and ctx.training and m * (c // 4) < 2 ** 31 - 1:
+                # channel_scale's backward already summed everything this layer's dbeta / dgamma need (embnet_se_bn_sums)
+                check(lib.embnet_bn_bwd_gap_sums(ptr(dy), ptr(_c(dg)), ptr(gate), ptr(ent[2]), n, m // n, ptr(x), c, stats.data_ptr(),
+                                                 stats.data_ptr() + 4 * c, stats.data_ptr() + 8 * c, stats.data_ptr() + 12 * c,
+                                                 int(ctx.relu), ptr(dx), ptr(tg), ptr(tb), stream()))
+                dgamma, dbeta = finish()
+                return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
         if dg is not None and ctx.training and (FUSE_GAP_BN[0] or gate is not None) and m * (c // 4) < 2 ** 31 - 1:
             # d(output) = dy (* gate) + dg / hw formed inside the two BatchNorm-backward passes: the summed tensor is never written
             check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(_c(dg)), ptr(gate), n, m // n, ptr(x), c, stats.data_ptr(), stats.data_ptr() + 4 * c,
@@ -1021,7 +1031,7 @@ class BatchNormalization(nn.Module):
                 y, g = _BNGapFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                       self.momentum, self.relu, self.training, _partials_of(x, self.training), lazy)
                 if lazy:
-                    y._lazy_scale_ok = True
+                    y._lazy_scale_ok = _BN_FWD_STATS.pop(y.data_ptr())
                 return y, g
             y = self.forward(x)
             return y, _GapFn.apply(y)
@@ -1481,12 +1491,13 @@ class Swish(nn.Module):
 
 class _ChannelScaleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, s, lazy=False):
+    def forward(ctx, x, s, lazy=None):
+        """lazy = (bn_x, bn_stats, bn_act) of the BatchNormalization that produced x and granted lazy_scale, or None."""
         x, s = _c(x), _c(s)
         n, h, w, c = x.shape
         y = torch.empty_like(x)
         check(_lib.lib().embnet_channel_scale_fwd(ptr(x), ptr(s), n, h * w, c, ptr(y), stream()))
-        ctx.lazy = bool(lazy)
+        ctx.lazy = lazy
         ctx.save_for_backward(x, s)
         return y
 
@@ -1496,14 +1507,25 @@ class _ChannelScaleFn(torch.autograd.Function):
         n, h, w, c = x.shape
         dy = _c(dy)
         ds = torch.empty_like(s)
-        if ctx.lazy:
+        if ctx.lazy is not None:
             # x's producer (a BatchNormalization that granted lazy_scale) multiplies by s inside its backward passes: only the
             # gate's gradient is computed here and dy travels on UNSCALED, announced in GATE_PENDING (with an alias, so that
             # autograd cannot add into it in place) — that layer raises if it receives anything else
-            check(_lib.lib().embnet_channel_scale_dgate(ptr(x), ptr(dy), n, h * w, c, ptr(ds), stream()))
+            sums = None
+            if SE_BN_SUMS[0]:
+                # ... and the same pass over (dy, the BatchNormalization's input) leaves the per-(image, channel) sums from which
+                # that layer's dbeta / dgamma follow: it then skips its reduction pass (embnet_se_bn_sums)
+                bn_x, bn_stats, bn_act = ctx.lazy
+                sums = torch.empty((n, 5, c), device=x.device, dtype=torch.float32)
+                sp = bn_stats.data_ptr()
+                check(_lib.lib().embnet_se_bn_sums(ptr(dy), ptr(bn_x), n, h * w, c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, int(bn_act),
+                                                   ptr(sums), stream()))
+                ds = sums[:, 0, :]
+            else:
+                check(_lib.lib().embnet_channel_scale_dgate(ptr(x), ptr(dy), n, h * w, c, ptr(ds), stream()))
             while len(GATE_PENDING) >= 8:
                 GATE_PENDING.pop(next(iter(GATE_PENDING)))
-            GATE_PENDING[dy.data_ptr()] = (s, dy.detach())
+            GATE_PENDING[dy.data_ptr()] = (s, dy.detach(), sums)
             return dy, ds, None
         dx = torch.empty_like(x)
         check(_lib.lib().embnet_channel_scale_bwd(ptr(x), ptr(s), ptr(dy), n, h * w, c, ptr(dx), ptr(ds), stream()))
@@ -1513,8 +1535,8 @@ class _ChannelScaleFn(torch.autograd.Function):
 def channel_scale(x, s, lazy=False):
     """x[n,h,w,c] * s[n,c] (the squeeze-excite multiply).  lazy=True: x is the output of BatchNormalization(emit_gap=True,
     lazy_scale=True) and THIS is its only consumer — the multiply's backward is left to that layer (see _ChannelScaleFn)."""
-    lazy = bool(lazy and getattr(x, "_lazy_scale_ok", False) and x.shape[-1] % 4 == 0)
-    return _ChannelScaleFn.apply(x, s.reshape(x.shape[0], x.shape[-1]), lazy)
+    src = getattr(x, "_lazy_scale_ok", None) if (lazy and x.shape[-1] % 4 == 0) else None
+    return _ChannelScaleFn.apply(x, s.reshape(x.shape[0], x.shape[-1]), src)
 
 
 class _SampleDropoutFn(torch.autograd.Function):

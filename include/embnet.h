@@ -295,6 +295,16 @@ int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* s
 int embnet_bn_bwd_gap(const float* dy, const float* dpool, const float* gate, int n, int hw, const float* x, int c, const float* save_mean,
                       const float* save_rstd, const float* scale, const float* shift, int relu, float* dx, float* dgamma,
                       float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* Squeeze-and-excite backward without a BatchNorm reduction pass.  embnet_se_bn_sums: ONE pass over dg = d(gated tensor) and the
+ * BatchNormalization's input x gives sums[n][5][c]: row 0 = the gate's gradient sum_p dg * act(BN(x)) (what
+ * embnet_channel_scale_dgate computes from the stored activation), rows 1..4 = sum_p of a' dg, a', a' dg xhat, a' xhat
+ * (a' = act'(BN(x))).  embnet_bn_bwd_gap_sums: dbeta / dgamma from those rows, the gate and the pooled gradient (the layer's
+ * output gradient is a' (dg gate + dpool / hw), linear in the two per-(n,c) factors), then embnet_bn_bwd_gap's apply pass. */
+int embnet_se_bn_sums(const float* dg, const float* x, int n, int hw, int c, const float* save_mean, const float* save_rstd,
+                      const float* scale, const float* shift, int act, float* sums, void* stream);
+int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const float* gate, const float* sums, int n, int hw, const float* x,
+                           int c, const float* save_mean, const float* save_rstd, const float* scale, const float* shift, int relu,
+                           float* dx, float* dgamma, float* dbeta, void* stream);
 /* BatchNorm backward whose column sums came from the data gradient of the conv that consumed this layer's output
  * (embnet_conv2d_dgrad_bnsums_f32 below): partials [2][c][rows] -> dbeta / dgamma (added in double), then the apply pass of
  * embnet_bn_bwd.  Training statistics, c % 4 == 0. */

@@ -483,6 +483,7 @@ def test_gate_multiply_backward_rides_on_the_batchnorm_backward(dev, shape):
     res, names = {}, {}
     for fuse in (False, True):
         L.FUSE_GATE_BN[0] = fuse
+        L.SE_BN_SUMS[0] = False                      # (the reduction pass stays: this test is about the gate multiply alone)
         try:
             gen = torch.Generator().manual_seed(2)
             bn = L.BatchNormalization(c, activation="swish").to(dev).train()
@@ -501,6 +502,7 @@ def test_gate_multiply_backward_rides_on_the_batchnorm_backward(dev, shape):
             res[fuse] = (xt.grad.clone(), bn.gamma.grad.clone(), bn.beta.grad.clone(), se.kernel.grad.clone(), se.bias.grad.clone())
         finally:
             L.FUSE_GATE_BN[0] = True
+            L.SE_BN_SUMS[0] = True
             L.GATE_PENDING.clear()
     assert any("chscale_bwd" in nm for nm in names[False])
     assert not any("chscale_bwd" in nm or "gap_bwd" in nm for nm in names[True]), names[True]
@@ -520,3 +522,42 @@ def test_lazy_gate_with_a_second_consumer_fails_loudly(dev):
     with pytest.raises(_lib.EmbnetError, match="another consumer"):
         out.sum().backward()
     L.GATE_PENDING.clear()
+
+
+@pytest.mark.parametrize("shape,act", [((6, 14, 14, 96), "swish"), ((3, 7, 9, 240), "swish"), ((64, 28, 28, 144), "swish"),
+                                       ((5, 10, 10, 32), "relu")])
+def test_squeeze_excite_backward_needs_no_batchnorm_reduction_pass(dev, shape, act):
+    """embnet_se_bn_sums: the pass that sums the gate's gradient also leaves, per image and channel, the four sums from which
+    the BatchNormalization's dbeta / dgamma follow (the output gradient a' (dg s + dpool / hw) is linear in the two per-(n,c)
+    factors) — no bn_bwd_reduce kernel runs, and every gradient equals the pass-by-pass chain within fp32 re-association."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    n, c = shape[0], shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.SE_BN_SUMS[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(2)
+            bn = L.BatchNormalization(c, activation=act).to(dev).train()
+            se = L.Dense(c, c, gen=gen).to(dev)
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y, pooled = bn(xt, emit_gap=True, lazy_scale=True)
+            out = L.channel_scale(y, L.sigmoid(se(pooled)), lazy=True)
+            out.backward(torch.cos(out.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(dx=xt.grad.clone(), dgamma=bn.gamma.grad.clone(), dbeta=bn.beta.grad.clone(), dW=se.kernel.grad.clone(),
+                             db=se.bias.grad.clone())
+        finally:
+            L.SE_BN_SUMS[0] = True
+            L.GATE_PENDING.clear()
+    assert any("bn_bwd_reduce4_gap" in nm for nm in names[False]) and any("chscale_dgate4" in nm for nm in names[False])
+    assert not any("bn_bwd_reduce" in nm or "chscale" in nm.replace("chscale_fwd", "") for nm in names[True]), names[True]
+    assert any("se_bn_sums4" in nm for nm in names[True])
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
