@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void affine_act_gap4_kernel(const float* __res
     auto one = [&](const float4 v, int p) {
       float4 o = make_float4(fmaf(v.x, sc.x, sf.x), fmaf(v.y, sc.y, sf.y), fmaf(v.z, sc.z, sf.z), fmaf(v.w, sc.w, sf.w));
       if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
-      yi[(long)p * c4] = o;
+      if (y) yi[(long)p * c4] = o;                        // y == NULL: pooled means only (the tensor is formed later, gated)
       acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
     };
     int p = pl;
@@ -1486,11 +1486,46 @@ extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, vo
 
 extern "C" int embnet_affine_act_gap(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act,
                                      float* y, float* gap, void* stream) {
-  EMBNET_CHECK_ARG(x && scale && shift && y && gap && n > 0 && hw > 0 && c > 0, "affine_act_gap: bad argument");
+  EMBNET_CHECK_ARG(x && scale && shift && gap && n > 0 && hw > 0 && c > 0, "affine_act_gap: bad argument");
   EMBNET_CHECK_ARG((c & 3) == 0, "affine_act_gap: channel count %d not a multiple of 4", c);
-  EMBNET_TRACE("embnet::affine_act_gap4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream);
+  EMBNET_TRACE("embnet::affine_act_gap4_kernel", TRACE_BYTES, (y ? 8.0 : 4.0) * n * hw * c, stream);
   affine_act_gap4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, scale, shift, act, y, gap);
   return check_launch("affine_act_gap");
+}
+
+// y[n,p,c] = act(x*scale + shift) * gate[n,c]: the BatchNormalization apply and the squeeze-and-excite multiply in one pass over
+// x (embnet_affine_act_gap(y = NULL) has produced the pooled means the gate was computed from): the activated tensor itself is
+// never written.  The arithmetic of embnet_affine_act followed by embnet_channel_scale_fwd (one extra rounding each).
+__global__ __launch_bounds__(256) void affine_act_scale4_kernel(const float* __restrict__ x, long total4, int c4, DivU dhwc4,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int act, const float* __restrict__ gate, float* __restrict__ y) {
+  const long stride = (long)gridDim.x * 256;
+  const bool fixed = stride % c4 == 0;
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+  if (fixed) {
+    const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+    sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int q = (int)(i % c4);
+    if (!fixed) { sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q]; }
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 g = reinterpret_cast<const float4*>(gate)[(long)divu((uint32_t)i, dhwc4) * c4 + q];
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
+    reinterpret_cast<float4*>(y)[i] = make_float4(__fmul_rn(o.x, g.x), __fmul_rn(o.y, g.y), __fmul_rn(o.z, g.z), __fmul_rn(o.w, g.w));
+  }
+}
+
+extern "C" int embnet_affine_act_scale(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act,
+                                       const float* gate, float* y, void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && gate && y && n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "affine_act_scale: bad argument (c %% 4 == 0)");
+  const long total4 = (long)n * hw * (c / 4);
+  EMBNET_CHECK_ARG(total4 < 0x7FFFFFFFl, "affine_act_scale: tensor too large");
+  EMBNET_TRACE("embnet::affine_act_scale4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream);
+  affine_act_scale4_kernel<<<ew_blocks_c4(total4, c / 4), 256, 0, S(stream)>>>(x, total4, c / 4, make_divu((uint32_t)((long)hw * (c / 4))), scale, shift,
+                                                                               act, gate, y);
+  return check_launch("affine_act_scale");
 }
 
 extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream) {

@@ -82,10 +82,9 @@ class MBConv(nn.Module):
             x = self.expand_bn(x)
         # BN + swish and the squeeze-and-excite pooling of its output in one pass; in backward the pooled gradient is
         # broadcast into the scaling's gradient by one kernel (no accumulation pass)
-        # lazy_scale: x has one consumer, the scaling — its backward multiply (dy * s) is applied inside the BatchNorm backward too
-        x, g = self.bn(self.dwconv(x), emit_gap=True, lazy_scale=True)
-        s = L.sigmoid(self.se_expand(L.swish(self.se_reduce(g))))
-        x = L.channel_scale(x, s, lazy=True)
+        # BN + swish, the squeeze-and-excite pooling of its output and the gating in two passes over the depthwise output (the
+        # activated tensor is never written); in backward two more (layers.BatchNormalization.se_gate)
+        x = self.bn.se_gate(self.dwconv(x), lambda g: L.sigmoid(self.se_expand(L.swish(self.se_reduce(g)))))
         x = self.project_bn(self.project_conv(x, emit_stats=self.training))
         if self.skip:
             if self.drop is not None:

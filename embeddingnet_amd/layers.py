@@ -157,6 +157,8 @@ def _done(out, notify):
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
 # the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
+SE_TWO_STAGE = [__import__("os").environ.get("EMBNET_SE_TWO_STAGE", "1") == "1"]  # ... and the activated tensor is never written (se_gate)
+POOL_PENDING = {}
 SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
 FUSE_GATE_BN = [__import__("os").environ.get("EMBNET_FUSE_GATE_BN", "1") == "1"]
 GATE_PENDING = {}
@@ -928,6 +930,80 @@ class _BNGapFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class _BNPoolFn(torch.autograd.Function):
+    """Stage 1 of BatchNormalization.se_gate: statistics + the per-image channel means of act(BN(x)) — the activated tensor is
+    NOT written (embnet_affine_act_gap with y = NULL).  Its backward runs after _BNScaleFn's (the gate depends on this output)
+    and computes the whole layer's dx / dgamma / dbeta from what that left in POOL_PENDING (embnet_bn_bwd_gap_sums)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, partials, token):
+        x = _c(x)
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
+        g = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        check(lib.embnet_affine_act_gap(ptr(x), n, m // n, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(act),
+                                        None, ptr(g), stream()))
+        ctx.relu, ctx.has_gamma, ctx.token = act, gamma is not None, token
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        ctx.save_for_backward(x, stats)
+        _BN_FWD_STATS[g.data_ptr()] = (x, stats, int(act))
+        return g
+
+    @staticmethod
+    def backward(ctx, dpool):
+        x, stats = ctx.saved_tensors
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        ent = POOL_PENDING.pop(ctx.token, None)
+        if ent is None:
+            raise _lib.EmbnetError("BatchNormalization.se_gate: the gated tensor's gradient has not been computed before the pooled "
+                                   "branch's — the gate must be a function of the pooled means, and the gated tensor must be used")
+        dg, gate, sums = ent
+        dx = torch.empty_like(x)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
+        sp = stats.data_ptr()
+        check(lib.embnet_bn_bwd_gap_sums(ptr(dg), ptr(_c(dpool)), ptr(gate), ptr(sums), n, m // n, ptr(x), c, sp, sp + 4 * c, sp + 8 * c,
+                                         sp + 12 * c, int(ctx.relu), ptr(dx), ptr(tg), ptr(tb), stream()))
+        dgamma, dbeta = finish()
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class _BNScaleFn(torch.autograd.Function):
+    """Stage 2 of BatchNormalization.se_gate: out = act(BN(x)) * s[n,c] in one pass over x (embnet_affine_act_scale).  Backward:
+    one pass over (d out, x) gives the gate's gradient and the per-(image, channel) sums of embnet_se_bn_sums; the gradient
+    with respect to x is produced by _BNPoolFn.backward once the pooled branch's gradient is known."""
+
+    @staticmethod
+    def forward(ctx, x, s, stats, act, token):
+        n, c = x.shape[0], x.shape[-1]
+        hw = x.numel() // (n * c)
+        s = _c(s)
+        y = torch.empty_like(x)
+        sp = stats.data_ptr()
+        check(_lib.lib().embnet_affine_act_scale(ptr(x), n, hw, c, sp + 8 * c, sp + 12 * c, int(act), ptr(s), ptr(y), stream()))
+        ctx.act, ctx.token = int(act), token
+        ctx.save_for_backward(x, s, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dg):
+        x, s, stats = ctx.saved_tensors
+        n, c = x.shape[0], x.shape[-1]
+        hw = x.numel() // (n * c)
+        dg = _c(dg)
+        sums = torch.empty((n, 5, c), device=x.device, dtype=torch.float32)
+        sp = stats.data_ptr()
+        check(_lib.lib().embnet_se_bn_sums(ptr(dg), ptr(x), n, hw, c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, ctx.act, ptr(sums), stream()))
+        while len(POOL_PENDING) >= 8:
+            POOL_PENDING.pop(next(iter(POOL_PENDING)))
+        POOL_PENDING[ctx.token] = (dg, s, sums)
+        return None, sums[:, 0, :], None, None, None
+
+
 class Deferred:
     """A BatchNormalization(+activation) output that has not been written.  `raw` is the BN's input (as an
     autograd alias whose gradient is the gradient of the BN OUTPUT), `stats` [4,C] = mean, rstd, scale, shift,
@@ -1013,6 +1089,14 @@ class BatchNormalization(nn.Module):
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
 
+    def se_gate(self, x, gate_fn):
+        """act(BN(x)) * gate_fn(mean over the pixels of act(BN(x))): the squeeze-and-excite gating of an MBConv block
+        (reference backbones.py:84-98) with THIS layer's output as its only input.  gate_fn maps the pooled means [n,c] to the
+        gate [n,c] and must depend on them.  In training the activated tensor is never written: one pass over x for the
+        pooled means (4 B per element), one for the gated output (8 B), and in backward one for the gate's gradient and the
+        BatchNorm sums (8 B), one for dx (12 B)."""
+        return _se_gate(self, x, gate_fn)
+
     def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None, lazy_scale=False):
         """dropout=<Dropout>: the Dropout layer that consumes the output, applied in this layer's passes when it is active
         (plain path only; the caller then skips the Dropout module).
@@ -1068,6 +1152,21 @@ class BatchNormalization(nn.Module):
                                False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
         tag(y)
         return y
+
+
+def _se_gate(bn, x, gate_fn):
+    """BatchNormalization.se_gate (below)."""
+    c = x.shape[-1]
+    if (SE_TWO_STAGE[0] and SE_BN_SUMS[0] and FUSE_GATE_BN[0] and bn.training and torch.is_grad_enabled() and x.dim() == 4
+            and c % 4 == 0 and x.numel() // 4 < 2 ** 31 - 1 and x.requires_grad):
+        token = object()
+        pooled = _BNPoolFn.apply(x, bn.gamma, bn.beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum, bn.relu,
+                                 _partials_of(x, True), token)
+        bn_x, stats, act = _BN_FWD_STATS.pop(pooled.data_ptr())
+        s = gate_fn(pooled)
+        return _BNScaleFn.apply(bn_x, s.reshape(x.shape[0], c), stats, act, token)
+    y, g = bn(x, emit_gap=True, lazy_scale=True)
+    return channel_scale(y, gate_fn(g), lazy=True)
 
 
 class _InputBNConvFn(torch.autograd.Function):

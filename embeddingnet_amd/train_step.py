@@ -300,6 +300,7 @@ class TripletTrainer:
         L.BN_SUMS.clear()                       # BatchNorm-backward sums nobody collected (the gradient had a second contribution)
         L._BN_FWD_STATS.clear()
         L.GATE_PENDING.clear()
+        L.POOL_PENDING.clear()
         L.DY_PLANES.clear()                     # gradient planes nobody collected (a consumer that fell back to the fp32 kernel)
         if self.reducer is not None:
             self.reducer.finish()

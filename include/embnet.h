@@ -351,6 +351,10 @@ int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const floa
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 /* act(x*scale + shift) -> y AND its per-image channel means -> gap[n,c], one pass (the BatchNormalization + swish in front
  * of a squeeze-and-excite block, whose pooling reads what the BN writes); scale/shift from embnet_bn_train_fwd(y = NULL). */
+/* y = act(x*scale + shift) * gate[n,c] in one pass (the BatchNormalization apply and the squeeze-and-excite multiply; the pooled
+ * means the gate was computed from come from embnet_affine_act_gap with y = NULL, so the activated tensor is never written). */
+int embnet_affine_act_scale(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act,
+                            const float* gate, float* y, void* stream);
 int embnet_affine_act_gap(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act, float* y,
                           float* gap, void* stream);
 int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream);

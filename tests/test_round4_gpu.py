@@ -561,3 +561,42 @@ def test_squeeze_excite_backward_needs_no_batchnorm_reduction_pass(dev, shape, a
     for key in res[True]:
         a, b = res[True][key], res[False][key]
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,act", [((6, 14, 14, 96), "swish"), ((3, 7, 9, 240), "swish"), ((64, 28, 28, 144), "swish"),
+                                       ((5, 10, 10, 32), "relu")])
+def test_se_gate_never_writes_the_activated_tensor(dev, shape, act):
+    """BatchNormalization.se_gate: the pooled means from one pass over the BatchNormalization's input (no output written), the
+    gated output act(BN(x)) * s from a second — no chscale / affine_act_gap-with-output / bn_bwd_reduce kernels — with the same
+    output and gradients as the layer-by-layer chain (output to the last bit of the product, gradients within 2e-5)."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    n, c = shape[0], shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.SE_TWO_STAGE[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(2)
+            bn = L.BatchNormalization(c, activation=act).to(dev).train()
+            se = L.Dense(c, c, gen=gen).to(dev)
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            out = bn.se_gate(xt, lambda g: L.sigmoid(se(g)))
+            out.backward(torch.cos(out.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(out=out.detach().clone(), dx=xt.grad.clone(), dgamma=bn.gamma.grad.clone(), dbeta=bn.beta.grad.clone(),
+                             dW=se.kernel.grad.clone(), db=se.bias.grad.clone(), mm=bn.moving_mean.clone())
+        finally:
+            L.SE_TWO_STAGE[0] = True
+            L.GATE_PENDING.clear(); L.POOL_PENDING.clear()
+    assert any("chscale_fwd" in nm for nm in names[False])
+    assert not any("chscale" in nm or "bn_bwd_reduce" in nm for nm in names[True]), names[True]
+    assert any("affine_act_scale4" in nm for nm in names[True]) and not L.POOL_PENDING
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        tol = 2e-7 if key in ("out", "mm") else 2e-5
+        assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
