@@ -1528,6 +1528,62 @@ extern "C" int embnet_affine_act_scale(const float* x, int n, int hw, int c, con
   return check_launch("affine_act_scale");
 }
 
+// y = drop_n(x*scale + shift) + skip: the BatchNormalization apply, the per-sample drop-connect (efficientnet's FixedDropout with
+// noise_shape (None,1,1,1): embnet_sample_dropout's mask, rng_u32(seed, n, 2)) and the residual Add of an MBConv block in one
+// pass (28 -> 12 bytes per element); drop_factor_kernel leaves factor[n,c] = 1/(1-rate) or 0 for the backward (embnet_bn_bwd_gap's gate).
+// The three layers' arithmetic, rounding for rounding.  rate == 0: no drop (factor 1).
+__global__ __launch_bounds__(256) void affine_drop_add4_kernel(const float* __restrict__ x, long total4, int c4, DivU dhwc4,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               float rate, uint64_t seed, const uint64_t* __restrict__ seed_add,
+                                                               const float* __restrict__ skip, float* __restrict__ y) {
+  if (seed_add) seed += *seed_add;
+  const float keep_scale = 1.f / (1.f - rate);
+  const uint32_t thr = (uint32_t)((double)rate * 4294967296.0);
+  const long stride = (long)gridDim.x * 256;
+  const bool fixed = stride % c4 == 0;
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+  if (fixed) {
+    const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+    sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int q = (int)(i % c4);
+    if (!fixed) { sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q]; }
+    const uint32_t nimg = divu((uint32_t)i, dhwc4);
+    const bool keep = rate <= 0.f || rng_u32(seed, (uint64_t)nimg, 2) >= thr;
+    const float4 v = reinterpret_cast<const float4*>(x)[i], k = reinterpret_cast<const float4*>(skip)[i];
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (rate > 0.f) {
+      o.x = keep ? __fmul_rn(o.x, keep_scale) : 0.f; o.y = keep ? __fmul_rn(o.y, keep_scale) : 0.f;
+      o.z = keep ? __fmul_rn(o.z, keep_scale) : 0.f; o.w = keep ? __fmul_rn(o.w, keep_scale) : 0.f;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(__fadd_rn(o.x, k.x), __fadd_rn(o.y, k.y), __fadd_rn(o.z, k.z), __fadd_rn(o.w, k.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void drop_factor_kernel(int n, int c, float rate, uint64_t seed, const uint64_t* __restrict__ seed_add,
+                                                          float* __restrict__ factor) {
+  if (seed_add) seed += *seed_add;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * c) return;
+  const uint32_t thr = (uint32_t)((double)rate * 4294967296.0);
+  factor[i] = (rate <= 0.f || rng_u32(seed, (uint64_t)(i / c), 2) >= thr) ? 1.f / (1.f - rate) : 0.f;
+}
+
+extern "C" int embnet_affine_drop_add(const float* x, int n, int hw, int c, const float* scale, const float* shift, float rate,
+                                      uint64_t seed, const uint64_t* seed_add_dev, const float* skip, float* y, float* factor,
+                                      void* stream) {
+  EMBNET_CHECK_ARG(x && scale && shift && skip && y && factor && n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "affine_drop_add: bad argument (c %% 4 == 0)");
+  EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "affine_drop_add: rate %f outside [0,1)", rate);
+  const long total4 = (long)n * hw * (c / 4);
+  EMBNET_CHECK_ARG(total4 < 0x7FFFFFFFl, "affine_drop_add: tensor too large");
+  drop_factor_kernel<<<(n * c + 255) / 256, 256, 0, S(stream)>>>(n, c, rate, seed, seed_add_dev, factor);
+  EMBNET_TRACE("embnet::affine_drop_add4_kernel", TRACE_BYTES, 12.0 * n * hw * c, stream);
+  affine_drop_add4_kernel<<<ew_blocks_c4(total4, c / 4), 256, 0, S(stream)>>>(x, total4, c / 4, make_divu((uint32_t)((long)hw * (c / 4))), scale, shift,
+                                                                              rate, seed, seed_add_dev, skip, y);
+  return check_launch("affine_drop_add");
+}
+
 extern "C" int embnet_gap_bwd(const float* dy, int n, int hw, int c, const float* dx_add, float* dx, void* stream) {
   EMBNET_CHECK_ARG(dy && dx && n > 0 && hw > 0 && c > 0, "gap_bwd: bad argument");
   EMBNET_CHECK_ARG(!dx_add || (c & 3) == 0, "gap_bwd: dx_add needs c %% 4 == 0 (got %d)", c);

@@ -85,12 +85,10 @@ class MBConv(nn.Module):
         # BN + swish, the squeeze-and-excite pooling of its output and the gating in two passes over the depthwise output (the
         # activated tensor is never written); in backward two more (layers.BatchNormalization.se_gate)
         x = self.bn.se_gate(self.dwconv(x), lambda g: L.sigmoid(self.se_expand(L.swish(self.se_reduce(g)))))
-        x = self.project_bn(self.project_conv(x, emit_stats=self.training))
-        if self.skip:
-            if self.drop is not None:
-                x = self.drop(x)
-            x = L.add(x, inp)
-        return x
+        x = self.project_conv(x, emit_stats=self.training)
+        if self.skip:                # BN apply + drop-connect + Add in one pass (layers.BatchNormalization.drop_add)
+            return self.project_bn.drop_add(x, inp, self.drop)
+        return self.project_bn(x)
 
 
 class EfficientNet(nn.Module):

@@ -157,6 +157,8 @@ def _done(out, notify):
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
 # the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
+# BatchNorm apply + DropConnect + Add of an MBConv tail as one pass, the drop factor applied inside the BatchNorm backward
+FUSE_DROP_ADD = [__import__("os").environ.get("EMBNET_FUSE_DROP_ADD", "1") == "1"]
 SE_TWO_STAGE = [__import__("os").environ.get("EMBNET_SE_TWO_STAGE", "1") == "1"]  # ... and the activated tensor is never written (se_gate)
 POOL_PENDING = {}
 SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
@@ -1004,6 +1006,45 @@ class _BNScaleFn(torch.autograd.Function):
         return None, sums[:, 0, :], None, None, None
 
 
+class _BNDropAddFn(torch.autograd.Function):
+    """BatchNormalization (no activation) -> DropConnect (per-sample) -> Add(skip): the tail of an MBConv block with an identity
+    shortcut, as one forward pass (embnet_affine_drop_add) and a BatchNorm backward that applies the drop factor while it reads
+    the output gradient (embnet_bn_bwd_gap with gate = factor, dpool = 0); the skip's gradient IS the output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, partials, skip, rate, seed):
+        x, skip = _c(x), _c(skip)
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, 0, None, stats, moving_mean, moving_var, partials)
+        y = torch.empty_like(x)
+        factor = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        check(lib.embnet_affine_drop_add(ptr(x), n, m // n, c, stats.data_ptr() + 8 * c, stats.data_ptr() + 12 * c, float(rate), seed,
+                                         GRAPH_TICK, ptr(skip), ptr(y), ptr(factor), stream()))
+        ctx.has_gamma, ctx.gamma_ref, ctx.beta_ref = gamma is not None, gamma, beta
+        ctx.save_for_backward(x, stats, factor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, factor = ctx.saved_tensors
+        lib = _lib.lib()
+        n, c = x.shape[0], x.shape[-1]
+        m = x.numel() // c
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
+        ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
+        zero = torch.zeros((n, c), device=x.device, dtype=torch.float32)
+        sp = stats.data_ptr()
+        check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(zero), ptr(factor), n, m // n, ptr(x), c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, 0,
+                                    ptr(dx), ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, stream()))
+        dgamma, dbeta = finish()
+        return dx, dgamma, dbeta, None, None, None, None, None, dy, None, None
+
+
 class Deferred:
     """A BatchNormalization(+activation) output that has not been written.  `raw` is the BN's input (as an
     autograd alias whose gradient is the gradient of the BN OUTPUT), `stats` [4,C] = mean, rstd, scale, shift,
@@ -1088,6 +1129,24 @@ class BatchNormalization(nn.Module):
 
     def train(self, mode=True):
         return super().train(mode and not self.frozen)
+
+    def drop_add(self, x, skip, drop=None):
+        """Add(skip, DropConnect(BN(x))): the tail of an MBConv block with an identity shortcut (reference backbones.py:84-98;
+        drop: a layers.DropConnect or None).  In training, for a linear BatchNormalization on 4-multiple channels, one forward
+        pass and no drop-connect / Add passes in backward (_BNDropAddFn); otherwise the three layers one after the other."""
+        c = x.shape[-1]
+        if (FUSE_DROP_ADD[0] and self.training and self.relu == 0 and torch.is_grad_enabled() and x.dim() == 4 and c % 4 == 0
+                and x.numel() // 4 < 2 ** 31 - 1 and skip.shape == x.shape):
+            rate, seed = 0.0, 0
+            if drop is not None and drop.training and drop.enabled and drop.rate > 0:
+                drop._step += 1
+                rate, seed = drop.rate, (drop.seed << 32) + drop._step
+            return _BNDropAddFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps, self.momentum,
+                                      _partials_of(x, True), skip, rate, seed)
+        y = self(x)
+        if drop is not None:
+            y = drop(y)
+        return add(y, skip)
 
     def se_gate(self, x, gate_fn):
         """act(BN(x)) * gate_fn(mean over the pixels of act(BN(x))): the squeeze-and-excite gating of an MBConv block

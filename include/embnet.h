@@ -351,6 +351,11 @@ int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const floa
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 /* act(x*scale + shift) -> y AND its per-image channel means -> gap[n,c], one pass (the BatchNormalization + swish in front
  * of a squeeze-and-excite block, whose pooling reads what the BN writes); scale/shift from embnet_bn_train_fwd(y = NULL). */
+/* y = drop_n(x*scale + shift) + skip: the BatchNormalization apply, the per-sample drop-connect (embnet_sample_dropout's mask) and the
+ * residual Add of an MBConv block (reference backbones.py:84-98) in one pass; factor [n,c] receives 1/(1-rate) or 0 per sample —
+ * the gate of embnet_bn_bwd_gap for the backward (dpool = zeros).  rate = 0: a plain BatchNorm apply + Add. */
+int embnet_affine_drop_add(const float* x, int n, int hw, int c, const float* scale, const float* shift, float rate, uint64_t seed,
+                           const uint64_t* seed_add_dev, const float* skip, float* y, float* factor, void* stream);
 /* y = act(x*scale + shift) * gate[n,c] in one pass (the BatchNormalization apply and the squeeze-and-excite multiply; the pooled
  * means the gate was computed from come from embnet_affine_act_gap with y = NULL, so the activated tensor is never written). */
 int embnet_affine_act_scale(const float* x, int n, int hw, int c, const float* scale, const float* shift, int act,

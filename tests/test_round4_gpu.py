@@ -600,3 +600,46 @@ def test_se_gate_never_writes_the_activated_tensor(dev, shape, act):
         a, b = res[True][key], res[False][key]
         tol = 2e-7 if key in ("out", "mm") else 2e-5
         assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,rate", [((8, 14, 14, 80), 0.25), ((5, 7, 9, 192), 0.1), ((6, 28, 28, 40), 0.0), ((64, 14, 14, 112), 0.3)])
+def test_batchnorm_dropconnect_add_in_one_pass(dev, shape, rate):
+    """The tail of an MBConv block with an identity shortcut (reference backbones.py:84-98): project BatchNormalization ->
+    DropConnect (whole samples) -> Add(block input).  BatchNormalization.drop_add does the three in one forward pass
+    (bit-identical output: the same mask, the same roundings) and its backward applies the drop factor inside the BatchNorm
+    backward — no sample_dropout / add / bn_bwd_reduce4-without-gate kernels; gradients to the last bits; the mask changes per step."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    skip0 = torch.randn(shape, device=dev)
+    c = shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_DROP_ADD[0] = fuse
+        try:
+            bn = L.BatchNormalization(c).to(dev).train()
+            drop = L.DropConnect(rate, seed=9).train() if rate > 0 else None
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            outs = []
+            _lib.trace_reset(); _lib.trace_enable(True)
+            for step in range(2):
+                xt = x.clone().requires_grad_(True); sk = skip0.clone().requires_grad_(True)
+                bn.gamma.grad = bn.beta.grad = None
+                out = bn.drop_add(xt, sk, drop)
+                out.backward(torch.cos(out.detach() * 2.0 + step))
+                outs.append((out.detach().clone(), xt.grad.clone(), sk.grad.clone(), bn.gamma.grad.clone(), bn.beta.grad.clone()))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = outs
+        finally:
+            L.FUSE_DROP_ADD[0] = True
+    assert not any("sample_dropout" in nm or nm.endswith("add_kernel") for nm in names[True]), names[True]
+    assert any("affine_drop_add4" in nm for nm in names[True])
+    for sa, sb in zip(res[True], res[False]):
+        assert torch.equal(sa[0], sb[0]) and torch.equal(sa[2], sb[2])           # output and the skip's gradient: bit-identical
+        for a, b in zip(sa[1:], sb[1:]):
+            assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1e-30)
+    if rate > 0:
+        dropped = [(o[0] == skip0).flatten(1).all(dim=1) for o in res[True]]     # a dropped sample's output is the skip itself
+        assert int(dropped[0].sum()) + int(dropped[1].sum()) > 0 or shape[0] < 6
