@@ -225,14 +225,20 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
 // against (3*10 + 9) per 8 for 3x3.  A real loop over the input rows (one row's loads in flight; unrolled, hipcc hoists
 // every row's loads: 330-490 VGPRs), so the kernel row of an (input row, output row) pair is a run-time, wave-uniform
 // index and the weights are loaded where they are used (L1 hits), as in the one-row kernel.
-template <int KS, int ST, bool FLIP, int TW>
+// STATS (forward only): the workgroup also writes the per-channel sum and sum of squares of the outputs it produced as row
+// blockIdx.x of stats[2][C][gridDim.x] — the statistics partials of the BatchNormalization that follows (the layout the conv
+// epilogues write, embnet_bn_train_fwd's `partials`), so that layer does not read the tensor for them.  Threads i, i + c4, ..
+// of a workgroup hold the same channel quad; quads a workgroup does not touch (C/4 > 256) stay as the caller zeroed them.
+template <int KS, int ST, bool FLIP, int TW, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            DwGeom g, float* __restrict__ y) {
+                                                            DwGeom g, float* __restrict__ y, float* __restrict__ stats = nullptr) {
   constexpr int NX = (TW - 1) * ST + KS, TH = 2, NR = (TH - 1) * ST + KS;
   const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW, hb_n = (g.OH + TH - 1) / TH;
   const long total = (long)g.N * hb_n * wb_n * c4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i0 < total;
+  if (!STATS && !live) return;
+  const long i = STATS ? (live ? i0 : total - 1) : i0;
   const int cq = (int)(i % c4);
   long t = i / c4;
   const int ow0 = (int)(t % wb_n) * TW; t /= wb_n;
@@ -276,13 +282,40 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
       }
     }
   }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
   for (int a = 0; a < TH; ++a) {
-    if (oh0 + a >= g.OH) break;
+    if (oh0 + a >= g.OH || (STATS && !live)) break;
     float4* yo = reinterpret_cast<float4*>(y) + (((long)n * g.OH + oh0 + a) * g.OW + ow0) * c4 + cq;
 #pragma unroll
     for (int q = 0; q < TW; ++q)
-      if (ow0 + q < g.OW) yo[(long)q * c4] = acc[a][q];
+      if (ow0 + q < g.OW) {
+        const float4 v = acc[a][q];
+        yo[(long)q * c4] = v;
+        if (STATS) {
+          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+          s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        }
+      }
+  }
+  if (STATS) {
+    __shared__ float4 red[2][256];
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {                          // threads t, t + c4, .. of the workgroup share a channel quad, added in order
+      float4 a1 = red[0][threadIdx.x], a2 = red[1][threadIdx.x];
+      for (int u = threadIdx.x + c4; u < 256; u += c4) {
+        const float4 o1 = red[0][u], o2 = red[1][u];
+        a1.x += o1.x; a1.y += o1.y; a1.z += o1.z; a1.w += o1.w;
+        a2.x += o2.x; a2.y += o2.y; a2.z += o2.z; a2.w += o2.w;
+      }
+      const int col = 4 * (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+      const long P = gridDim.x;
+      float* d1 = stats + (long)col * P + blockIdx.x;
+      float* d2 = d1 + (long)g.C * P;
+      d1[0] = a1.x; d1[P] = a1.y; d1[2 * P] = a1.z; d1[3 * P] = a1.w;
+      d2[0] = a2.x; d2[P] = a2.y; d2[2 * P] = a2.z; d2[3 * P] = a2.w;
+    }
   }
 }
 
@@ -708,16 +741,28 @@ static int make_dw(DwGeom& g, int n, int h, int w, int c, int r, int s, int stri
   return 0;
 }
 
-template <int KS, int ST, bool FLIP>
-static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st) {
+static bool dw_wide(const DwGeom& g) {
   static const int forced = (int)env_long("EMBNET_DW_TW", 0);            // 4 / 8: A/B
   // eight columns per thread unless that wastes more than an eighth of a row the four-column blocks tile exactly
-  const bool wide = forced ? forced == 8 : (g.OW >= 7 && cdiv(g.OW, 8) * 8 <= cdiv(g.OW, 4) * 4 + g.OW / 8);
-  static const int rows2 = (int)env_long("EMBNET_DW_ROWS2", 1);          // 0: one output row per thread (A/B)
-  if (rows2 && g.OH >= 2) {                                               // two output rows per thread
-    const long units = (long)g.N * cdiv(g.OH, 2) * (g.C / 4);
-    if (wide) dwconv_row4x2_kernel<KS, ST, FLIP, 8><<<cdiv(units * cdiv(g.OW, 8), 256), 256, 0, st>>>(x, w, g, y);
-    else dwconv_row4x2_kernel<KS, ST, FLIP, 4><<<cdiv(units * cdiv(g.OW, 4), 256), 256, 0, st>>>(x, w, g, y);
+  return forced ? forced == 8 : (g.OW >= 7 && cdiv(g.OW, 8) * 8 <= cdiv(g.OW, 4) * 4 + g.OW / 8);
+}
+static bool dw_rows2(const DwGeom& g) { static const int rows2 = (int)env_long("EMBNET_DW_ROWS2", 1); return rows2 && g.OH >= 2; }
+static long dw_rows2_grid(const DwGeom& g) {
+  return cdiv((long)g.N * cdiv(g.OH, 2) * (g.C / 4) * cdiv(g.OW, dw_wide(g) ? 8 : 4), 256);
+}
+
+template <int KS, int ST, bool FLIP>
+static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st, float* stats = nullptr) {
+  const bool wide = dw_wide(g);
+  if (dw_rows2(g)) {                                                      // two output rows per thread
+    const long grid = dw_rows2_grid(g);
+    if (stats && !FLIP) {
+      if (wide) dwconv_row4x2_kernel<KS, ST, false, 8, true><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      else dwconv_row4x2_kernel<KS, ST, false, 4, true><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      return;
+    }
+    if (wide) dwconv_row4x2_kernel<KS, ST, FLIP, 8><<<grid, 256, 0, st>>>(x, w, g, y);
+    else dwconv_row4x2_kernel<KS, ST, FLIP, 4><<<grid, 256, 0, st>>>(x, w, g, y);
     return;
   }
   if (wide) dwconv_row4_kernel<KS, ST, FLIP, 8><<<cdiv((long)g.N * g.OH * cdiv(g.OW, 8) * (g.C / 4), 256), 256, 0, st>>>(x, w, g, y);
@@ -727,19 +772,34 @@ static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, floa
 // EMBNET_DW_ROWS=0 falls back to the per-pixel kernels (A/B)
 static bool dw_rows() { static const bool on = env_long("EMBNET_DW_ROWS", 1) != 0; return on; }
 
-extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
-                                       int s, int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+static bool dw_fwd_rows_path(int c, int r, int s, int stride) {
+  return (c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows();
+}
+
+// rows P of the statistics partials [2][c][P] embnet_dwconv2d_fwd_stats_f32 writes for this geometry (0: not available — the
+// two-rows-per-thread kernels only); when c / 4 > 256 the caller zeroes the buffer first (a workgroup covers 256 channel quads)
+extern "C" int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int stride, int oh, int ow) {
+  if (n <= 0 || c <= 0 || oh <= 0 || ow <= 0 || !dw_fwd_rows_path(c, r, s, stride)) return 0;
+  DwGeom g{n, 0, 0, c, r, s, stride, 0, 0, oh, ow};
+  if (!dw_rows2(g)) return 0;
+  const long grid = dw_rows2_grid(g);
+  return grid < 0x7FFFFFFF ? (int)grid : 0;
+}
+
+static int dwconv2d_fwd_impl(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
+                             int s, int stride, int pad_t, int pad_l, int oh, int ow, float* stats, void* stream) {
   EMBNET_CHECK_ARG(x && w && y, "dwconv2d_fwd: null pointer");
   DwGeom g;
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_fwd")) return rc;
   const long total = (long)n * oh * ow * c;
   const int grid4 = cdiv(total / 4, 256);
-  if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
+  EMBNET_CHECK_ARG(!stats || embnet_dwconv2d_fwd_stats_rows(n, c, r, s, stride, oh, ow) > 0, "dwconv2d_fwd_stats: statistics are not available for this geometry");
+  if (dw_fwd_rows_path(c, r, s, stride)) {
     EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream);
-    if (r == 3 && stride == 1) launch_dw_rows<3, 1, false>(x, w, g, y, S(stream));
-    else if (r == 3) launch_dw_rows<3, 2, false>(x, w, g, y, S(stream));
-    else if (stride == 1) launch_dw_rows<5, 1, false>(x, w, g, y, S(stream));
-    else launch_dw_rows<5, 2, false>(x, w, g, y, S(stream));
+    if (r == 3 && stride == 1) launch_dw_rows<3, 1, false>(x, w, g, y, S(stream), stats);
+    else if (r == 3) launch_dw_rows<3, 2, false>(x, w, g, y, S(stream), stats);
+    else if (stride == 1) launch_dw_rows<5, 1, false>(x, w, g, y, S(stream), stats);
+    else launch_dw_rows<5, 2, false>(x, w, g, y, S(stream), stats);
     return check_launch("dwconv2d_fwd");
   }
   if ((c & 3) == 0 && r == s && r == 3) { EMBNET_TRACE("embnet::dwconv_fwd4_sq_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd4_sq_kernel<3><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
@@ -747,6 +807,18 @@ extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y,
   else if ((c & 3) == 0) { EMBNET_TRACE("embnet::dwconv_fwd_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd_kernel<4><<<grid4, 256, 0, S(stream)>>>(x, w, g, y); }
   else { EMBNET_TRACE("embnet::dwconv_fwd_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream); dwconv_fwd_kernel<1><<<cdiv(total, 256), 256, 0, S(stream)>>>(x, w, g, y); }
   return check_launch("dwconv2d_fwd");
+}
+
+extern "C" int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
+                                       int s, int stride, int pad_t, int pad_l, int oh, int ow, void* stream) {
+  return dwconv2d_fwd_impl(x, w, y, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, nullptr, stream);
+}
+
+// ... with the statistics partials of the BatchNormalization that follows (see dwconv_row4x2_kernel STATS)
+extern "C" int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
+                                             int s, int stride, int pad_t, int pad_l, int oh, int ow, float* stats, void* stream) {
+  EMBNET_CHECK_ARG(stats, "dwconv2d_fwd_stats: null pointer");
+  return dwconv2d_fwd_impl(x, w, y, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, stats, stream);
 }
 
 extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,

@@ -159,6 +159,7 @@ FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
 # BatchNorm apply + DropConnect + Add of an MBConv tail as one pass, the drop factor applied inside the BatchNorm backward
 FUSE_DROP_ADD = [__import__("os").environ.get("EMBNET_FUSE_DROP_ADD", "1") == "1"]
+DW_EMIT_STATS = [__import__("os").environ.get("EMBNET_DW_EMIT_STATS", "1") == "1"]     # depthwise forward emits the next BN's statistics
 SE_TWO_STAGE = [__import__("os").environ.get("EMBNET_SE_TWO_STAGE", "1") == "1"]  # ... and the activated tensor is never written (se_gate)
 POOL_PENDING = {}
 SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
@@ -1558,14 +1559,20 @@ class Dropout(nn.Module):
 # ----------------------------------------------------------------------------- MBConv pieces
 class _DepthwiseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, geom):
+    def forward(ctx, x, w, geom, out_stats=None):
+        """out_stats [2,C,P] (P = embnet_dwconv2d_fwd_stats_rows): the kernel also writes the per-channel sums of y, the
+        statistics partials of the BatchNormalization that follows (DepthwiseConv2D(emit_stats=True))."""
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s = w.shape[0], w.shape[1]
         stride, pt, pl, oh, ow = geom
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
-        check(_lib.lib().embnet_dwconv2d_fwd_f32(ptr(x), ptr(w), ptr(y), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
-                                                 stream()))
+        if out_stats is not None:
+            check(_lib.lib().embnet_dwconv2d_fwd_stats_f32(ptr(x), ptr(w), ptr(y), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                           ptr(out_stats), stream()))
+        else:
+            check(_lib.lib().embnet_dwconv2d_fwd_f32(ptr(x), ptr(w), ptr(y), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                     stream()))
         ctx.geom = geom
         ctx.save_for_backward(x, w)
         return y
@@ -1589,7 +1596,7 @@ class _DepthwiseFn(torch.autograd.Function):
             check(lib.embnet_dwconv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s,
                                                 stride, pt, pl, oh, ow, stream()))
             dw = _done(dw, note)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 def conv_normal_(t, gen):
@@ -1609,11 +1616,22 @@ class DepthwiseConv2D(nn.Module):
         # fan_out of a depthwise kernel in Keras' VarianceScaling: k*k*depth_multiplier(=1)... uses shape[-1]*rf
         self.depthwise_kernel = nn.Parameter(conv_normal_(w, gen))
 
-    def forward(self, x):
+    def forward(self, x, emit_stats=False):
+        """emit_stats: a training-mode BatchNormalization reads this output next — the kernel also produces its per-channel
+        sums (attached to the result as `_bn_partials`, as Conv2D does), so that layer skips its statistics pass."""
         h, w = x.shape[1], x.shape[2]
         oh, pt = same_pad(h, self.k, self.stride)
         ow, pl = same_pad(w, self.k, self.stride)
-        return _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow))
+        out_stats = None
+        if emit_stats and DW_EMIT_STATS[0]:
+            n, c = x.shape[0], x.shape[-1]
+            rows = _lib.lib().embnet_dwconv2d_fwd_stats_rows(n, c, self.k, self.k, self.stride, oh, ow)
+            if rows > 0:               # (a workgroup covers 256 channel quads: wider layers start from zeros)
+                out_stats = (torch.zeros if c // 4 > 256 else torch.empty)((2, c, rows), device=x.device, dtype=torch.float32)
+        y = _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow), out_stats)
+        if out_stats is not None:
+            y._bn_partials = out_stats
+        return y
 
 
 class _ActFn(torch.autograd.Function):

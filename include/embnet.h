@@ -408,6 +408,13 @@ int embnet_bn_bwd_inrelu_dropout(const float* dy, const float* x, long m, int c,
 /* DepthwiseConv2D: x[n,h,w,c], w[r,s,c] (Keras depthwise_kernel [r,s,c,1]), y[n,oh,ow,c]; padding as conv2d. */
 int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s,
                             int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
+/* DepthwiseConv2D forward that also writes the statistics partials [2][c][P] (sum, sum of squares of y per channel, one row per
+ * workgroup; P = embnet_dwconv2d_fwd_stats_rows(...), 0 = not available for the geometry) of the BatchNormalization that follows
+ * (embnet_bn_train_fwd's `partials`): that layer then does not read y for its statistics.  When c / 4 > 256 the caller zeroes
+ * `stats` first. */
+int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int stride, int oh, int ow);
+int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s, int stride,
+                                  int pad_t, int pad_l, int oh, int ow, float* stats, void* stream);
 int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
                               int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
 size_t embnet_dwconv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int oh, int ow);

@@ -643,3 +643,39 @@ def test_batchnorm_dropconnect_add_in_one_pass(dev, shape, rate):
     if rate > 0:
         dropped = [(o[0] == skip0).flatten(1).all(dim=1) for o in res[True]]     # a dropped sample's output is the skip itself
         assert int(dropped[0].sum()) + int(dropped[1].sum()) > 0 or shape[0] < 6
+
+
+@pytest.mark.parametrize("shape,k,stride", [((6, 14, 14, 96), 3, 1), ((3, 15, 17, 240), 5, 2), ((5, 28, 28, 32), 5, 1),
+                                            ((4, 7, 7, 1152), 3, 1), ((32, 56, 56, 144), 3, 2)])
+def test_depthwise_forward_emits_the_batchnorm_statistics(dev, shape, k, stride):
+    """DepthwiseConv2D(emit_stats=True) -> BatchNormalization (an MBConv block's dwconv -> bn, reference backbones.py:84-98): the
+    depthwise kernel writes the per-channel sums of its output as the BatchNormalization's statistics partials (also for
+    C / 4 > 256, where a workgroup covers part of the channels), no bn_stats kernel runs, and the layer's output, moving
+    statistics and every gradient equal the separate-pass chain within fp32 summation order."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    c = shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.DW_EMIT_STATS[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(4)
+            dw = L.DepthwiseConv2D(c, k, strides=stride, gen=gen).to(dev)
+            bn = L.BatchNormalization(c, activation="swish").to(dev).train()
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y = bn(dw(xt, emit_stats=True))
+            y.backward(torch.cos(y.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(y=y.detach().clone(), dx=xt.grad.clone(), dw=dw.depthwise_kernel.grad.clone(), dgamma=bn.gamma.grad.clone(),
+                             dbeta=bn.beta.grad.clone(), mm=bn.moving_mean.clone(), mv=bn.moving_variance.clone())
+        finally:
+            L.DW_EMIT_STATS[0] = True
+    assert any("bn_stats" in nm for nm in names[False]) and not any("bn_stats" in nm for nm in names[True]), names[True]
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
