@@ -229,9 +229,14 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
 // blockIdx.x of stats[2][C][gridDim.x] — the statistics partials of the BatchNormalization that follows (the layout the conv
 // epilogues write, embnet_bn_train_fwd's `partials`), so that layer does not read the tensor for them.  Threads i, i + c4, ..
 // of a workgroup hold the same channel quad; quads a workgroup does not touch (C/4 > 256) stay as the caller zeroed them.
-template <int KS, int ST, bool FLIP, int TW, bool STATS = false>
+// STATS = 2 (stride-1 data gradient, FLIP): y is the gradient of the depthwise layer's INPUT a = act(BN(e)); the workgroup writes
+// the BatchNorm-backward sums of that layer instead — sum dz and sum dz * ehat with dz = y * act'(BN(e)) — reading e once per
+// output (conv.hip's BnSums for the depthwise data gradient): the BatchNormalization backward skips its reduction pass.
+struct DwBn { const float* e; const float* scale; const float* shift; const float* mean; const float* rstd; int act; };
+template <int KS, int ST, bool FLIP, int TW, int STATS = 0>
 __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            DwGeom g, float* __restrict__ y, float* __restrict__ stats = nullptr) {
+                                                            DwGeom g, float* __restrict__ y, float* __restrict__ stats = nullptr,
+                                                            const DwBn bn = DwBn{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   constexpr int NX = (TW - 1) * ST + KS, TH = 2, NR = (TH - 1) * ST + KS;
   const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW, hb_n = (g.OH + TH - 1) / TH;
   const long total = (long)g.N * hb_n * wb_n * c4;
@@ -283,18 +288,40 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
     }
   }
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  float4 bsc = s1, bsh = s1, bmu = s1, brs = s1;
+  if (STATS == 2) {
+    bsc = reinterpret_cast<const float4*>(bn.scale)[cq]; bsh = reinterpret_cast<const float4*>(bn.shift)[cq];
+    bmu = reinterpret_cast<const float4*>(bn.mean)[cq]; brs = reinterpret_cast<const float4*>(bn.rstd)[cq];
+  }
 #pragma unroll
   for (int a = 0; a < TH; ++a) {
     if (oh0 + a >= g.OH || (STATS && !live)) break;
-    float4* yo = reinterpret_cast<float4*>(y) + (((long)n * g.OH + oh0 + a) * g.OW + ow0) * c4 + cq;
+    const long o0 = (((long)n * g.OH + oh0 + a) * g.OW + ow0) * c4 + cq;
+    float4* yo = reinterpret_cast<float4*>(y) + o0;
+    float4 ev[TW];
+    if (STATS == 2) {
+#pragma unroll
+      for (int q = 0; q < TW; ++q) ev[q] = reinterpret_cast<const float4*>(bn.e)[o0 + (long)(ow0 + q < g.OW ? q : 0) * c4];
+    }
 #pragma unroll
     for (int q = 0; q < TW; ++q)
       if (ow0 + q < g.OW) {
         const float4 v = acc[a][q];
         yo[(long)q * c4] = v;
-        if (STATS) {
+        if (STATS == 1) {
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        }
+        if (STATS == 2) {                                 // the arithmetic of bn_bwd_reduce4_kernel
+          const float4 xq = ev[q];
+          float4 dz = v;
+          if (bn.act) {
+            dz.x = act_grad(bn.act, fmaf(xq.x, bsc.x, bsh.x), v.x); dz.y = act_grad(bn.act, fmaf(xq.y, bsc.y, bsh.y), v.y);
+            dz.z = act_grad(bn.act, fmaf(xq.z, bsc.z, bsh.z), v.z); dz.w = act_grad(bn.act, fmaf(xq.w, bsc.w, bsh.w), v.w);
+          }
+          s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+          s2.x = fmaf(dz.x, (xq.x - bmu.x) * brs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - bmu.y) * brs.y, s2.y);
+          s2.z = fmaf(dz.z, (xq.z - bmu.z) * brs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - bmu.w) * brs.w, s2.w);
         }
       }
   }
@@ -752,13 +779,19 @@ static long dw_rows2_grid(const DwGeom& g) {
 }
 
 template <int KS, int ST, bool FLIP>
-static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st, float* stats = nullptr) {
+static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st, float* stats = nullptr,
+                           const DwBn* bn = nullptr) {
   const bool wide = dw_wide(g);
   if (dw_rows2(g)) {                                                      // two output rows per thread
     const long grid = dw_rows2_grid(g);
     if (stats && !FLIP) {
-      if (wide) dwconv_row4x2_kernel<KS, ST, false, 8, true><<<grid, 256, 0, st>>>(x, w, g, y, stats);
-      else dwconv_row4x2_kernel<KS, ST, false, 4, true><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      if (wide) dwconv_row4x2_kernel<KS, ST, false, 8, 1><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      else dwconv_row4x2_kernel<KS, ST, false, 4, 1><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      return;
+    }
+    if (stats && FLIP && ST == 1 && bn) {                                // data gradient + BatchNorm-backward sums
+      if (wide) dwconv_row4x2_kernel<KS, 1, true, 8, 2><<<grid, 256, 0, st>>>(x, w, g, y, stats, *bn);
+      else dwconv_row4x2_kernel<KS, 1, true, 4, 2><<<grid, 256, 0, st>>>(x, w, g, y, stats, *bn);
       return;
     }
     if (wide) dwconv_row4x2_kernel<KS, ST, FLIP, 8><<<grid, 256, 0, st>>>(x, w, g, y);
@@ -819,6 +852,37 @@ extern "C" int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, flo
                                              int s, int stride, int pad_t, int pad_l, int oh, int ow, float* stats, void* stream) {
   EMBNET_CHECK_ARG(stats, "dwconv2d_fwd_stats: null pointer");
   return dwconv2d_fwd_impl(x, w, y, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, stats, stream);
+}
+
+// rows P of the [2][c][P] BatchNorm-backward partial sums embnet_dwconv2d_dgrad_bnsums_f32 writes (0: not available — stride-1
+// layers on the two-rows-per-thread kernel only); when c / 4 > 256 the caller zeroes the buffer first
+extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int stride) {
+  if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || stride != 1 || !dw_fwd_rows_path(c, r, s, stride)) return 0;
+  DwGeom gf{n, 0, 0, c, r, s, 1, 0, 0, h, wd};
+  if (!dw_rows2(gf)) return 0;
+  const long grid = dw_rows2_grid(gf);
+  return grid < 0x7FFFFFFF ? (int)grid : 0;
+}
+
+// Stride-1 depthwise data gradient that also emits the BatchNorm-backward sums of the layer in front of the depthwise conv (its
+// input was act(BN(bn_x)); MBConv: expand_bn -> dwconv): see dwconv_row4x2_kernel STATS = 2 and embnet_conv2d_dgrad_bnsums_f32.
+extern "C" int embnet_dwconv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
+                                                int s, int stride, int pad_t, int pad_l, int oh, int ow, const float* bn_x,
+                                                const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                                const float* bn_rstd, int bn_act, float* bn_partial, int bn_rows, void* stream) {
+  EMBNET_CHECK_ARG(dy && w && dx && bn_x && bn_scale && bn_shift && bn_mean && bn_rstd && bn_partial, "dwconv2d_dgrad_bnsums: null pointer");
+  EMBNET_CHECK_ARG(bn_act >= 0 && bn_act <= 2, "dwconv2d_dgrad_bnsums: activation code %d", bn_act);
+  EMBNET_CHECK_ARG(bn_rows > 0 && bn_rows == embnet_dwconv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, stride),
+                   "dwconv2d_dgrad_bnsums: rows %d for this geometry (see embnet_dwconv2d_dgrad_bnsums_rows)", bn_rows);
+  DwGeom g;
+  if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_dgrad_bnsums")) return rc;
+  const long total = (long)n * h * wd * c;
+  EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
+  const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
+  const DwBn bn{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act};
+  if (r == 3) launch_dw_rows<3, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
+  else launch_dw_rows<5, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
+  return check_launch("dwconv2d_dgrad_bnsums");
 }
 
 extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,

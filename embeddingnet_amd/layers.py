@@ -160,6 +160,7 @@ FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
 # BatchNorm apply + DropConnect + Add of an MBConv tail as one pass, the drop factor applied inside the BatchNorm backward
 FUSE_DROP_ADD = [__import__("os").environ.get("EMBNET_FUSE_DROP_ADD", "1") == "1"]
 DW_EMIT_STATS = [__import__("os").environ.get("EMBNET_DW_EMIT_STATS", "1") == "1"]     # depthwise forward emits the next BN's statistics
+DW_BN_SUMS = [__import__("os").environ.get("EMBNET_DW_BN_SUMS", "1") == "1"]   # ... and its stride-1 data gradient the previous BN's backward sums
 SE_TWO_STAGE = [__import__("os").environ.get("EMBNET_SE_TWO_STAGE", "1") == "1"]  # ... and the activated tensor is never written (se_gate)
 POOL_PENDING = {}
 SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
@@ -1559,9 +1560,11 @@ class Dropout(nn.Module):
 # ----------------------------------------------------------------------------- MBConv pieces
 class _DepthwiseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, geom, out_stats=None):
+    def forward(ctx, x, w, geom, out_stats=None, bn_src=None):
         """out_stats [2,C,P] (P = embnet_dwconv2d_fwd_stats_rows): the kernel also writes the per-channel sums of y, the
-        statistics partials of the BatchNormalization that follows (DepthwiseConv2D(emit_stats=True))."""
+        statistics partials of the BatchNormalization that follows (DepthwiseConv2D(emit_stats=True)).
+        bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the stride-1 data gradient also emits that layer's
+        backward sums (BN_SUMS, as _Conv2dFn)."""
         x, w = _c(x), _c(w)
         n, h, wd, c = x.shape
         r, s = w.shape[0], w.shape[1]
@@ -1573,7 +1576,7 @@ class _DepthwiseFn(torch.autograd.Function):
         else:
             check(_lib.lib().embnet_dwconv2d_fwd_f32(ptr(x), ptr(w), ptr(y), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
                                                      stream()))
-        ctx.geom = geom
+        ctx.geom, ctx.bn_src = geom, bn_src
         ctx.save_for_backward(x, w)
         return y
 
@@ -1588,15 +1591,28 @@ class _DepthwiseFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.embnet_dwconv2d_dgrad_f32(ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
-                                                stream()))
+            bn_src = getattr(ctx, "bn_src", None)
+            rows = lib.embnet_dwconv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, stride) if bn_src is not None else 0
+            if rows > 0:
+                bn_x, bn_stats, bn_act = bn_src
+                partial = (torch.zeros if c // 4 > 256 else torch.empty)((2, c, rows), device=x.device, dtype=torch.float32)
+                sp = bn_stats.data_ptr()
+                check(lib.embnet_dwconv2d_dgrad_bnsums_f32(ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                           ptr(bn_x), sp + 8 * c, sp + 12 * c, sp, sp + 4 * c, int(bn_act),
+                                                           ptr(partial), rows, stream()))
+                while len(BN_SUMS) >= 8:
+                    BN_SUMS.pop(next(iter(BN_SUMS)))
+                BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
+            else:
+                check(lib.embnet_dwconv2d_dgrad_f32(ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, stride, pt, pl, oh, ow,
+                                                    stream()))
         if ctx.needs_input_grad[1]:
             dw, note = _sink(w)
             ws = workspace(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, r, s, oh, ow), x.device)
             check(lib.embnet_dwconv2d_wgrad_f32(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s,
                                                 stride, pt, pl, oh, ow, stream()))
             dw = _done(dw, note)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def conv_normal_(t, gen):
@@ -1628,7 +1644,11 @@ class DepthwiseConv2D(nn.Module):
             rows = _lib.lib().embnet_dwconv2d_fwd_stats_rows(n, c, self.k, self.k, self.stride, oh, ow)
             if rows > 0:               # (a workgroup covers 256 channel quads: wider layers start from zeros)
                 out_stats = (torch.zeros if c // 4 > 256 else torch.empty)((2, c, rows), device=x.device, dtype=torch.float32)
-        y = _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow), out_stats)
+        bn_src = getattr(x, "_bn_src", None)
+        if not (DW_BN_SUMS[0] and FUSE_BN_SUMS[0] and bn_src is not None and self.stride == 1 and torch.is_grad_enabled()
+                and x.requires_grad and x.shape[-1] % 4 == 0):
+            bn_src = None
+        y = _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow), out_stats, bn_src)
         if out_stats is not None:
             y._bn_partials = out_stats
         return y

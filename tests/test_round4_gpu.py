@@ -679,3 +679,39 @@ def test_depthwise_forward_emits_the_batchnorm_statistics(dev, shape, k, stride)
     for key in res[True]:
         a, b = res[True][key], res[False][key]
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape,k", [((6, 14, 14, 96), 3), ((3, 15, 17, 240), 5), ((4, 7, 7, 1152), 3), ((32, 28, 28, 144), 5)])
+def test_depthwise_data_gradient_emits_the_batchnorm_backward_sums(dev, shape, k):
+    """BatchNormalization(swish) -> stride-1 DepthwiseConv2D (an MBConv block's expand_bn -> dwconv, reference backbones.py:84-98):
+    the depthwise data gradient emits the BatchNorm-backward sums (embnet_dwconv2d_dgrad_bnsums_f32), the BatchNormalization
+    backward starts at its finalize kernel — no bn_bwd_reduce kernel — and everything equals the separate-pass chain within fp32
+    summation order (the depthwise gradients themselves bit for bit)."""
+    from embeddingnet_amd import layers as L
+    x = torch.randn(shape, device=dev)
+    c = shape[-1]
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.DW_BN_SUMS[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(4)
+            bn = L.BatchNormalization(c, activation="swish").to(dev).train()
+            dw = L.DepthwiseConv2D(c, k, strides=1, gen=gen).to(dev)
+            with torch.no_grad():
+                bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y = dw(bn(xt))
+            y.backward(torch.cos(y.detach() * 2.0))
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(dx=xt.grad.clone(), dw=dw.depthwise_kernel.grad.clone(), dgamma=bn.gamma.grad.clone(), dbeta=bn.beta.grad.clone())
+        finally:
+            L.DW_BN_SUMS[0] = True
+            L.BN_SUMS.clear()
+    assert any("bn_bwd_reduce" in nm for nm in names[False]) and not any("bn_bwd_reduce" in nm for nm in names[True]), names[True]
+    assert torch.equal(res[True]["dw"], res[False]["dw"]) and not L.BN_SUMS
+    for key in res[True]:
+        a, b = res[True][key], res[False][key]
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
