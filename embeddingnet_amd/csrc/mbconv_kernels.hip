@@ -225,6 +225,40 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
 // against (3*10 + 9) per 8 for 3x3.  A real loop over the input rows (one row's loads in flight; unrolled, hipcc hoists
 // every row's loads: 330-490 VGPRs), so the kernel row of an (input row, output row) pair is a run-time, wave-uniform
 // index and the weights are loaded where they are used (L1 hits), as in the one-row kernel.
+// Row blockIdx.x of stats[2][C][gridDim.x] from the per-thread float4 sums of a workgroup whose thread t handles channel quad
+// (256 * blockIdx.x + t) % c4: threads t, t + c4, .. share a quad and are added in order (every thread of the workgroup calls this)
+__device__ __forceinline__ void dw_block_sums(float4 s1, float4 s2, int c4, int C, float* __restrict__ stats) {
+  __shared__ float4 red[2][256];
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if ((int)threadIdx.x < c4) {
+    float4 a1 = red[0][threadIdx.x], a2 = red[1][threadIdx.x];
+    for (int u = threadIdx.x + c4; u < 256; u += c4) {
+      const float4 o1 = red[0][u], o2 = red[1][u];
+      a1.x += o1.x; a1.y += o1.y; a1.z += o1.z; a1.w += o1.w;
+      a2.x += o2.x; a2.y += o2.y; a2.z += o2.z; a2.w += o2.w;
+    }
+    const int col = 4 * (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
+    const long P = gridDim.x;
+    float* d1 = stats + (long)col * P + blockIdx.x;
+    float* d2 = d1 + (long)C * P;
+    d1[0] = a1.x; d1[P] = a1.y; d1[2 * P] = a1.z; d1[3 * P] = a1.w;
+    d2[0] = a2.x; d2[P] = a2.y; d2[2 * P] = a2.z; d2[3 * P] = a2.w;
+  }
+}
+struct DwBn { const float* e; const float* scale; const float* shift; const float* mean; const float* rstd; int act; };
+__device__ __forceinline__ void dw_bn_sums_add(const DwBn& bn, float4 v, float4 xq, float4 sc, float4 sh, float4 mu, float4 rs,
+                                               float4& s1, float4& s2) {          // the arithmetic of bn_bwd_reduce4_kernel
+  float4 dz = v;
+  if (bn.act) {
+    dz.x = act_grad(bn.act, fmaf(xq.x, sc.x, sh.x), v.x); dz.y = act_grad(bn.act, fmaf(xq.y, sc.y, sh.y), v.y);
+    dz.z = act_grad(bn.act, fmaf(xq.z, sc.z, sh.z), v.z); dz.w = act_grad(bn.act, fmaf(xq.w, sc.w, sh.w), v.w);
+  }
+  s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+  s2.x = fmaf(dz.x, (xq.x - mu.x) * rs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - mu.y) * rs.y, s2.y);
+  s2.z = fmaf(dz.z, (xq.z - mu.z) * rs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - mu.w) * rs.w, s2.w);
+}
+
 // STATS (forward only): the workgroup also writes the per-channel sum and sum of squares of the outputs it produced as row
 // blockIdx.x of stats[2][C][gridDim.x] — the statistics partials of the BatchNormalization that follows (the layout the conv
 // epilogues write, embnet_bn_train_fwd's `partials`), so that layer does not read the tensor for them.  Threads i, i + c4, ..
@@ -232,7 +266,6 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
 // STATS = 2 (stride-1 data gradient, FLIP): y is the gradient of the depthwise layer's INPUT a = act(BN(e)); the workgroup writes
 // the BatchNorm-backward sums of that layer instead — sum dz and sum dz * ehat with dz = y * act'(BN(e)) — reading e once per
 // output (conv.hip's BnSums for the depthwise data gradient): the BatchNormalization backward skips its reduction pass.
-struct DwBn { const float* e; const float* scale; const float* shift; const float* mean; const float* rstd; int act; };
 template <int KS, int ST, bool FLIP, int TW, int STATS = 0>
 __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             DwGeom g, float* __restrict__ y, float* __restrict__ stats = nullptr,
@@ -312,52 +345,28 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
-        if (STATS == 2) {                                 // the arithmetic of bn_bwd_reduce4_kernel
-          const float4 xq = ev[q];
-          float4 dz = v;
-          if (bn.act) {
-            dz.x = act_grad(bn.act, fmaf(xq.x, bsc.x, bsh.x), v.x); dz.y = act_grad(bn.act, fmaf(xq.y, bsc.y, bsh.y), v.y);
-            dz.z = act_grad(bn.act, fmaf(xq.z, bsc.z, bsh.z), v.z); dz.w = act_grad(bn.act, fmaf(xq.w, bsc.w, bsh.w), v.w);
-          }
-          s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
-          s2.x = fmaf(dz.x, (xq.x - bmu.x) * brs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - bmu.y) * brs.y, s2.y);
-          s2.z = fmaf(dz.z, (xq.z - bmu.z) * brs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - bmu.w) * brs.w, s2.w);
-        }
+        if (STATS == 2) dw_bn_sums_add(bn, v, ev[q], bsc, bsh, bmu, brs, s1, s2);
       }
   }
-  if (STATS) {
-    __shared__ float4 red[2][256];
-    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
-    __syncthreads();
-    if ((int)threadIdx.x < c4) {                          // threads t, t + c4, .. of the workgroup share a channel quad, added in order
-      float4 a1 = red[0][threadIdx.x], a2 = red[1][threadIdx.x];
-      for (int u = threadIdx.x + c4; u < 256; u += c4) {
-        const float4 o1 = red[0][u], o2 = red[1][u];
-        a1.x += o1.x; a1.y += o1.y; a1.z += o1.z; a1.w += o1.w;
-        a2.x += o2.x; a2.y += o2.y; a2.z += o2.z; a2.w += o2.w;
-      }
-      const int col = 4 * (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
-      const long P = gridDim.x;
-      float* d1 = stats + (long)col * P + blockIdx.x;
-      float* d2 = d1 + (long)g.C * P;
-      d1[0] = a1.x; d1[P] = a1.y; d1[2 * P] = a1.z; d1[3 * P] = a1.w;
-      d2[0] = a2.x; d2[P] = a2.y; d2[2 * P] = a2.z; d2[3 * P] = a2.w;
-    }
-  }
+  if (STATS) dw_block_sums(s1, s2, c4, g.C, stats);
 }
 
 // Stride-2 data gradient: dx[ih,iw] = sum over (r,s) with (ih+pt-r) and (iw+pl-s) even of dy[(ih+pt-r)/2, (iw+pl-s)/2] * w[r,s].
 // Block of 4 dx columns starting at a multiple of 4, so which taps are live in each column only depends on the column's
 // offset t and the parity PLP of pad_l: s = s0(t) + 2b with s0 = (t + PLP) & 1, and the dy column is
 // base + e(t) - b, e(t) = (t + PLP - s0) / 2, base = w0/2 + (pad_l - PLP)/2.  All register indices are static.
-template <int KS, int PLP>
+// STATS = 2: also the BatchNorm-backward sums of the layer in front of the depthwise conv (dwconv_row4x2_kernel STATS = 2).
+template <int KS, int PLP, int STATS = 0>
 __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                   DwGeom g, float* __restrict__ dx) {
+                                                                   DwGeom g, float* __restrict__ dx, float* __restrict__ stats = nullptr,
+                                                                   const DwBn bn = DwBn{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   constexpr int TW = DW_TW, OFF = (KS - 1) / 2, MAXE = PLP ? 2 : 1, NX = MAXE + OFF + 1;
   const int c4 = g.C >> 2, wb_n = (g.W + TW - 1) / TW;
   const long total = (long)g.N * g.H * wb_n * c4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i0 < total;
+  if (!STATS && !live) return;
+  const long i = STATS ? (live ? i0 : total - 1) : i0;
   const int cq = (int)(i % c4);
   long t = i / c4;
   const int w0 = (int)(t % wb_n) * TW; t /= wb_n;
@@ -401,10 +410,29 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
       }
     }
   }
-  float4* xo = reinterpret_cast<float4*>(dx) + (((long)n * g.H + ih) * g.W + w0) * c4 + cq;
+  const long o0 = (((long)n * g.H + ih) * g.W + w0) * c4 + cq;
+  float4* xo = reinterpret_cast<float4*>(dx) + o0;
+  if (!STATS) {
 #pragma unroll
-  for (int q = 0; q < TW; ++q)
-    if (w0 + q < g.W) xo[(long)q * c4] = acc[q];
+    for (int q = 0; q < TW; ++q)
+      if (w0 + q < g.W) xo[(long)q * c4] = acc[q];
+    return;
+  }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (live) {
+    const float4 bsc = reinterpret_cast<const float4*>(bn.scale)[cq], bsh = reinterpret_cast<const float4*>(bn.shift)[cq];
+    const float4 bmu = reinterpret_cast<const float4*>(bn.mean)[cq], brs = reinterpret_cast<const float4*>(bn.rstd)[cq];
+    float4 ev[TW];
+#pragma unroll
+    for (int q = 0; q < TW; ++q) ev[q] = reinterpret_cast<const float4*>(bn.e)[o0 + (long)(w0 + q < g.W ? q : 0) * c4];
+#pragma unroll
+    for (int q = 0; q < TW; ++q)
+      if (w0 + q < g.W) {
+        xo[(long)q * c4] = acc[q];
+        dw_bn_sums_add(bn, acc[q], ev[q], bsc, bsh, bmu, brs, s1, s2);
+      }
+  }
+  dw_block_sums(s1, s2, c4, g.C, stats);
 }
 
 // Weight gradient, same column blocking, one WAVE per kernel row (workgroup = KS waves): wave r accumulates dw[r, 0..KS)
@@ -857,7 +885,11 @@ extern "C" int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, flo
 // rows P of the [2][c][P] BatchNorm-backward partial sums embnet_dwconv2d_dgrad_bnsums_f32 writes (0: not available — stride-1
 // layers on the two-rows-per-thread kernel only); when c / 4 > 256 the caller zeroes the buffer first
 extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int stride) {
-  if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || stride != 1 || !dw_fwd_rows_path(c, r, s, stride)) return 0;
+  if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || (stride != 1 && stride != 2) || !dw_fwd_rows_path(c, r, s, stride)) return 0;
+  if (stride == 2) {                                     // dwconv_dgrad4_s2_row_kernel: one thread per (row, 4-column block, quad)
+    const long grid = cdiv((long)n * h * cdiv(wd, DW_TW) * (c / 4), 256);
+    return grid < 0x7FFFFFFF ? (int)grid : 0;
+  }
   DwGeom gf{n, 0, 0, c, r, s, 1, 0, 0, h, wd};
   if (!dw_rows2(gf)) return 0;
   const long grid = dw_rows2_grid(gf);
@@ -877,9 +909,21 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_f32(const float* dy, const float* w,
   DwGeom g;
   if (int rc = make_dw(g, n, h, wd, c, r, s, stride, pad_t, pad_l, oh, ow, "dwconv2d_dgrad_bnsums")) return rc;
   const long total = (long)n * h * wd * c;
+  const DwBn bn{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act};
+  if (stride == 2) {
+    EMBNET_TRACE("embnet::dwconv_dgrad4_s2_row_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
+    const int gridr = bn_rows;
+    if (r == 3) {
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<3, 1, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      else dwconv_dgrad4_s2_row_kernel<3, 0, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+    } else {
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<5, 1, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      else dwconv_dgrad4_s2_row_kernel<5, 0, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+    }
+    return check_launch("dwconv2d_dgrad_bnsums");
+  }
   EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
   const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
-  const DwBn bn{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act};
   if (r == 3) launch_dw_rows<3, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
   else launch_dw_rows<5, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
   return check_launch("dwconv2d_dgrad_bnsums");

@@ -1645,7 +1645,7 @@ class DepthwiseConv2D(nn.Module):
             if rows > 0:               # (a workgroup covers 256 channel quads: wider layers start from zeros)
                 out_stats = (torch.zeros if c // 4 > 256 else torch.empty)((2, c, rows), device=x.device, dtype=torch.float32)
         bn_src = getattr(x, "_bn_src", None)
-        if not (DW_BN_SUMS[0] and FUSE_BN_SUMS[0] and bn_src is not None and self.stride == 1 and torch.is_grad_enabled()
+        if not (DW_BN_SUMS[0] and FUSE_BN_SUMS[0] and bn_src is not None and self.stride in (1, 2) and torch.is_grad_enabled()
                 and x.requires_grad and x.shape[-1] % 4 == 0):
             bn_src = None
         y = _DepthwiseFn.apply(x, self.depthwise_kernel, (self.stride, pt, pl, oh, ow), out_stats, bn_src)

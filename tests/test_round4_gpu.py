@@ -681,9 +681,11 @@ def test_depthwise_forward_emits_the_batchnorm_statistics(dev, shape, k, stride)
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
 
 
-@pytest.mark.parametrize("shape,k", [((6, 14, 14, 96), 3), ((3, 15, 17, 240), 5), ((4, 7, 7, 1152), 3), ((32, 28, 28, 144), 5)])
-def test_depthwise_data_gradient_emits_the_batchnorm_backward_sums(dev, shape, k):
-    """BatchNormalization(swish) -> stride-1 DepthwiseConv2D (an MBConv block's expand_bn -> dwconv, reference backbones.py:84-98):
+@pytest.mark.parametrize("shape,k,stride", [((6, 14, 14, 96), 3, 1), ((3, 15, 17, 240), 5, 1), ((4, 7, 7, 1152), 3, 1),
+                                            ((32, 28, 28, 144), 5, 1), ((6, 14, 14, 96), 3, 2), ((3, 15, 17, 240), 5, 2),
+                                            ((2, 9, 9, 1152), 5, 2), ((16, 56, 56, 144), 5, 2), ((5, 12, 13, 32), 3, 2)])
+def test_depthwise_data_gradient_emits_the_batchnorm_backward_sums(dev, shape, k, stride):
+    """BatchNormalization(swish) -> DepthwiseConv2D (stride 1 or 2) (an MBConv block's expand_bn -> dwconv, reference backbones.py:84-98):
     the depthwise data gradient emits the BatchNorm-backward sums (embnet_dwconv2d_dgrad_bnsums_f32), the BatchNormalization
     backward starts at its finalize kernel — no bn_bwd_reduce kernel — and everything equals the separate-pass chain within fp32
     summation order (the depthwise gradients themselves bit for bit)."""
@@ -696,7 +698,7 @@ def test_depthwise_data_gradient_emits_the_batchnorm_backward_sums(dev, shape, k
         try:
             gen = torch.Generator().manual_seed(4)
             bn = L.BatchNormalization(c, activation="swish").to(dev).train()
-            dw = L.DepthwiseConv2D(c, k, strides=1, gen=gen).to(dev)
+            dw = L.DepthwiseConv2D(c, k, strides=stride, gen=gen).to(dev)
             with torch.no_grad():
                 bn.gamma.copy_(torch.linspace(0.5, 1.5, c)); bn.beta.copy_(torch.linspace(-0.3, 0.3, c))
             xt = x.clone().requires_grad_(True)
