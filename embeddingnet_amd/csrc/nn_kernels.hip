@@ -686,6 +686,41 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
   reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// conv -> ReLU -> MaxPool (the `simple` backbone, reference backbones.py:21-31): the pool's backward, the ReLU mask of the
+// conv in front of it and that conv's bias gradient in one pass over the conv output.  Unfused the pooled gradient is
+// scattered into a full-size tensor (4 B/elem written) that relu_bwd_colsum reads back beside y (12 B/elem): 16 + 5/s^2
+// bytes per element of y; here 8 + 5/s^2.  y is the conv's ReLU output (= the pool's input); windows whose maximum is 0
+// carry no gradient either way (the mask zeroes them), every other value is the same sum in the same window order.
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_colsum4_kernel(
+    const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ y, long m, int h, int w,
+    DivU dw, DivU dh, int c4, int k, int stride, int pad, int oh, int ow, ColGeom g, float* __restrict__ dz,
+    float* __restrict__ partial) {
+  col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
+    const uint32_t t = divu((uint32_t)r, dw);
+    const int iw = (int)((uint32_t)r - t * (uint32_t)w);
+    const uint32_t img = divu(t, dh);
+    const int ih = (int)(t - img * (uint32_t)h);
+    const float4 yv = reinterpret_cast<const float4*>(y)[r * c4 + q];
+    float gr[4] = {0.f, 0.f, 0.f, 0.f};
+    const int y_hi = min((ih + pad) / stride, oh - 1), x_hi = min((iw + pad) / stride, ow - 1);
+    for (int y_o = y_hi; y_o >= 0 && y_o * stride - pad + k > ih; --y_o)
+      for (int x_o = x_hi; x_o >= 0 && x_o * stride - pad + k > iw; --x_o) {
+        const uint32_t tap = (uint32_t)((ih - (y_o * stride - pad)) * k + (iw - (x_o * stride - pad)));
+        const long o = (((long)img * oh + y_o) * ow + x_o) * c4 + q;
+        const uint32_t am = reinterpret_cast<const uint32_t*>(argmax)[o];
+        const float4 d = reinterpret_cast<const float4*>(dy)[o];
+        gr[0] += (am & 0xff) == tap ? d.x : 0.f;
+        gr[1] += ((am >> 8) & 0xff) == tap ? d.y : 0.f;
+        gr[2] += ((am >> 16) & 0xff) == tap ? d.z : 0.f;
+        gr[3] += (am >> 24) == tap ? d.w : 0.f;
+      }
+    const float4 v = make_float4(yv.x > 0.f ? gr[0] : 0.f, yv.y > 0.f ? gr[1] : 0.f, yv.z > 0.f ? gr[2] : 0.f,
+                                 yv.w > 0.f ? gr[3] : 0.f);
+    reinterpret_cast<float4*>(dz)[r * c4 + q] = v;
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  });
+}
+
 // ---------------------------------------------------------------- BN-apply + activation + max-pool, fused
 // The zoo ResNet stem is bn0 -> relu -> ZeroPadding2D(1) -> MaxPool(3,2) on the largest activation of the
 // net (112x112x64 per image).  Unfused that is: BN apply (read x, write a), pool (read a, write y), and
@@ -1428,6 +1463,27 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
   else
     { EMBNET_TRACE("embnet::maxpool_bwd_kernel", TRACE_BYTES, 4.0 * total + 5.0 * n * oh * ow * c, stream); maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, n, h, w, c, k, stride, pad, oh, ow, dx); }
   return check_launch("maxpool_bwd");
+}
+
+extern "C" int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w,
+                                              int c, int k, int stride, int pad, int oh, int ow, float* dz, float* dbias,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(dy && argmax && y && dz && dbias && workspace, "maxpool_relu_bwd_colsum: null pointer");
+  EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0 && pad >= 0,
+                   "maxpool_relu_bwd_colsum: bad geometry");
+  EMBNET_CHECK_ARG((c & 3) == 0, "maxpool_relu_bwd_colsum: channel count %d not a multiple of 4 (use maxpool_bwd + relu_bwd_colsum)", c);
+  EMBNET_CHECK_ARG((oh - 1) * stride + k <= h + 2 * pad && (ow - 1) * stride + k <= w + 2 * pad,
+                   "maxpool_relu_bwd_colsum: window leaves the padded image");
+  const long m = (long)n * h * w;
+  EMBNET_CHECK_ARG(m < (1l << 31), "maxpool_relu_bwd_colsum: %ld pixels (limit 2^31 - 1)", m);
+  if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
+    return fail(EMBNET_EWORKSPACE, "maxpool_relu_bwd_colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
+  const ColGeom g4 = col_geom(m, c / 4);
+  { EMBNET_TRACE("embnet::maxpool_relu_bwd_colsum4_kernel", TRACE_BYTES, 8.0 * m * c + 5.0 * n * oh * ow * c, stream);
+    maxpool_relu_bwd_colsum4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, y, m, h, w, make_divu((uint32_t)w), make_divu((uint32_t)h),
+                                                                       c / 4, k, stride, pad, oh, ow, g4, dz, (float*)workspace); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbias);
+  return check_launch("maxpool_relu_bwd_colsum");
 }
 
 extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,

@@ -173,6 +173,8 @@ _BN_FWD_STATS = {}
 # a Dropout directly behind a BatchNormalization rides on the BatchNormalization's kernels (backbones.Seq); 0: separate passes
 FUSE_DROPOUT_BN = [__import__("os").environ.get("EMBNET_FUSE_DROPOUT_BN", "1") == "1"]
 FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
+# conv -> ReLU -> MaxPool (the 'simple' backbone): the same hand-over from MaxPool2D's backward (embnet_maxpool_relu_bwd_colsum)
+FUSE_RELU_POOL = [_os.environ.get("EMBNET_FUSE_RELU_POOL", "1") != "0"]
 RELU_DONE = {}
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
 DY_PLANES = {}
@@ -637,7 +639,8 @@ class Conv2D(nn.Module):
             y._bn_partials = out_stats
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
-        if self.relu and self.bias is not None and FUSE_RELU_BN[0] and self.kernel.shape[3] % 4 == 0 and residual is None:
+        if (self.relu and self.bias is not None and (FUSE_RELU_BN[0] or FUSE_RELU_POOL[0]) and self.kernel.shape[3] % 4 == 0
+                and residual is None):
             y._relu_conv = (self.bias,)        # see RELU_DONE
         return (y, out[1]) if with_skip else y
 
@@ -1207,7 +1210,7 @@ class BatchNormalization(nn.Module):
             raw, stats = _BNDeferFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                           self.momentum, self.relu, self.training, _partials_of(x, self.training))
             return Deferred(raw, stats, self.relu)
-        in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled()) else None
+        in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled() and FUSE_RELU_BN[0]) else None
         y = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
                                False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
@@ -1351,7 +1354,9 @@ def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
 # ----------------------------------------------------------------------------- pooling
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, stride, pad):
+    def forward(ctx, x, k, stride, pad, relu_bias=None):
+        """relu_bias: the bias of the Conv2D (fused ReLU) whose output x is, when that conv's ReLU backward and bias gradient
+        are to ride on this layer's backward (FUSE_RELU_POOL) — x is then kept for backward (the conv keeps it anyway)."""
         x = _c(x)
         n, h, w, c = x.shape
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -1361,17 +1366,34 @@ class _MaxPoolFn(torch.autograd.Function):
         arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
         check(_lib.lib().embnet_maxpool_fwd(ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(y), ptr(arg), stream()))
         ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow)
-        ctx.save_for_backward(arg)
+        ctx.relu_bias = relu_bias
+        if relu_bias is not None:
+            ctx.save_for_backward(arg, x)
+        else:
+            ctx.save_for_backward(arg)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (arg,) = ctx.saved_tensors
+        arg = ctx.saved_tensors[0]
         n, h, w, c, k, stride, pad, oh, ow = ctx.cfg
         dy = _c(dy)
         dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32)
-        check(_lib.lib().embnet_maxpool_bwd(ptr(dy), ptr(arg), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), stream()))
-        return dx, None, None, None
+        lib = _lib.lib()
+        if ctx.relu_bias is not None:
+            # x is the ReLU output of the conv in front: the mask and the bias gradient ride on this pass and the conv's
+            # backward finds its incoming gradient in RELU_DONE (as behind a BatchNormalization)
+            x = ctx.saved_tensors[1]
+            db, db_note = _sink(ctx.relu_bias)
+            ws = workspace(lib.embnet_bn_workspace_bytes(n * h * w, c), dy.device)
+            check(lib.embnet_maxpool_relu_bwd_colsum(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), ptr(db),
+                                                     ptr(ws), ws.numel() * 4, stream()))
+            if len(RELU_DONE) > 64:
+                RELU_DONE.clear()
+            RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
+            return dx, None, None, None, None
+        check(lib.embnet_maxpool_bwd(ptr(dy), ptr(arg), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), stream()))
+        return dx, None, None, None, None
 
 
 class MaxPool2D(nn.Module):
@@ -1382,6 +1404,9 @@ class MaxPool2D(nn.Module):
         self.k, self.s, self.p = pool_size, strides or pool_size, zero_pad
 
     def forward(self, x):
+        rc = getattr(x, "_relu_conv", None) if (FUSE_RELU_POOL[0] and torch.is_grad_enabled() and x.requires_grad) else None
+        if rc is not None and x.shape[3] % 4 == 0 and x.shape[0] * x.shape[1] * x.shape[2] < 2 ** 31:
+            return _MaxPoolFn.apply(x, self.k, self.s, self.p, rc[0])
         return _MaxPoolFn.apply(x, self.k, self.s, self.p)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 16
+#define EMBNET_ABI_VERSION 17
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -331,6 +331,14 @@ int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int st
                        float* y, uint8_t* argmax, void* stream);
 int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
                        int pad, int oh, int ow, float* dx, void* stream);
+/* embnet_maxpool_bwd followed by embnet_relu_bwd_colsum in one pass, for the conv -> ReLU -> MaxPool blocks of the
+ * 'simple' backbone (reference backbones.py:21-31): y is the pool's input (the Conv2D's ReLU output); dz[n,h,w,c] is the
+ * gradient w.r.t. the Conv2D's pre-activation, dbias[c] its column sums.  The scattered full-size gradient never exists
+ * (8 + 5/stride^2 bytes per element of y instead of 16 + 5/stride^2).  dz equals the two-call result bit for bit; dbias is
+ * the same sum in another fp32 order.  c % 4 == 0, n*h*w < 2^31; workspace >= embnet_bn_workspace_bytes(n*h*w, c). */
+int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w, int c,
+                                   int k, int stride, int pad, int oh, int ow, float* dz, float* dbias, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* BatchNorm-apply + activation + ZeroPadding2D(pad) + MaxPool(k,stride) in one pass (the zoo ResNet stem
  * bn0 -> relu -> pad -> pool, reference backbones.py:99-104 via image-classifiers).  scale/shift come from

@@ -717,3 +717,68 @@ def test_depthwise_data_gradient_emits_the_batchnorm_backward_sums(dev, shape, k
     for key in res[True]:
         a, b = res[True][key], res[False][key]
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-30), (key, (a - b).abs().max().item(), b.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ conv -> ReLU -> MaxPool blocks
+@pytest.mark.parametrize("shape,k,cout,pool", [((4, 21, 21, 16), 4, 64, (2, 2, 0)), ((3, 18, 15, 32), 3, 128, (2, 2, 0)),
+                                               ((2, 17, 17, 8), 3, 32, (3, 2, 1)), ((32, 105, 105, 3), 10, 64, (2, 2, 0))])
+def test_relu_backward_fused_into_maxpool_backward(dev, shape, k, cout, pool):
+    """conv(+bias, ReLU) -> MaxPool2D (the 'simple' backbone's blocks, reference backbones.py:21-31; the last case is its first
+    block at full size): with the ReLU's backward and the bias gradient folded into the pool's backward
+    (embnet_maxpool_relu_bwd_colsum) the pooled output, dx and dW equal the unfused chain bit for bit (the masked gradient is the
+    same number, element by element), the bias gradient within fp32 summation order — and no relu_bwd_colsum / maxpool_bwd4
+    kernel is launched."""
+    from embeddingnet_amd import layers as L
+    x = torch.rand(shape, device=dev) - 0.3
+    res, names = {}, {}
+    for fuse in (False, True):
+        L.FUSE_RELU_POOL[0] = fuse
+        try:
+            gen = torch.Generator().manual_seed(5)
+            conv = L.Conv2D(shape[-1], cout, k, activation="relu", gen=gen).to(dev)
+            with torch.no_grad():
+                conv.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+            mp = L.MaxPool2D(pool[0], pool[1], zero_pad=pool[2])
+            xt = x.clone().requires_grad_(True)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y = mp(conv(xt))
+            y.backward(torch.sin(y.detach() * 3) + 0.1)
+            torch.cuda.synchronize()
+            names[fuse] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            res[fuse] = dict(y=y.detach(), dx=xt.grad, dW=conv.kernel.grad, db=conv.bias.grad)
+        finally:
+            L.FUSE_RELU_POOL[0] = True
+            L.RELU_DONE.clear()
+    assert any("relu_bwd_colsum" in n for n in names[False]) and any("maxpool_bwd4" in n for n in names[False])
+    assert not any("relu_bwd_colsum_kernel" in n or "maxpool_bwd4" in n for n in names[True]), names[True]
+    assert any("maxpool_relu_bwd_colsum4" in n for n in names[True])
+    for key in ("y", "dx", "dW"):
+        assert torch.equal(res[True][key], res[False][key]), key
+    a, b = res[True]["db"], res[False]["db"]
+    assert (a - b).abs().max().item() <= 2e-6 * (b.abs().max().item() + 1e-30)
+    assert b.abs().max().item() > 0
+
+
+def test_fused_maxpool_backward_is_not_used_when_the_conv_output_has_a_second_consumer(dev):
+    """The conv's output read by the pool AND by another layer: autograd hands the conv the sum of both gradients (another
+    tensor), the hand-over entry is not found and the conv masks and sums itself — gradients equal the unfused run."""
+    from embeddingnet_amd import layers as L
+    x = torch.rand((2, 12, 12, 8), device=dev) - 0.3
+    res = {}
+    for fuse in (False, True):
+        L.FUSE_RELU_POOL[0] = fuse
+        try:
+            conv = L.Conv2D(8, 16, 3, activation="relu", gen=torch.Generator().manual_seed(2)).to(dev)
+            with torch.no_grad():
+                conv.bias.fill_(0.05)
+            xt = x.clone().requires_grad_(True)
+            a = conv(xt)
+            y = L.MaxPool2D()(a)
+            (y.sum() * 2 + (a * a).sum()).backward()
+            res[fuse] = (xt.grad, conv.kernel.grad, conv.bias.grad)
+        finally:
+            L.FUSE_RELU_POOL[0] = True
+            L.RELU_DONE.clear()
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
