@@ -347,6 +347,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __r
   }
 }
 
+// Per-(image, channel) sums over the pixels of an NHWC tensor (the squeeze-and-excite reductions): a workgroup = one image x
+// `cls` channel quads (cls = 2^cls_log2 <= 16 consecutive threads -> up to 256 contiguous bytes per pixel), the other
+// blockDim.x / cls thread groups stride the pixels.  256 threads on the small maps; 1024 where (channel blocks x images)
+// alone would leave the chip with one 4-wave workgroup per CU (112^2 x 32: 256 workgroups for 411 MB — 1.2 TB/s with 256
+// threads, half of them idle at c4 = 8).  Q sums per thread: pixel lanes of a wave by xor butterfly, then the <= 16 per-wave
+// sums through LDS in wave order; thread q * cls + cl receives sum q of channel lane cl.
+struct PixGeom { int cls_log2, xblocks, threads; };
+static PixGeom pix_geom(int n, int hw, int c4) {
+  PixGeom g;
+  g.cls_log2 = 4;
+  while (g.cls_log2 > 0 && (1 << (g.cls_log2 - 1)) >= c4) --g.cls_log2;
+  g.xblocks = (c4 + (1 << g.cls_log2) - 1) >> g.cls_log2;
+  static const long wide = env_long("EMBNET_PIX_WIDE", 1);               // A/B knob: 0 = 256 threads everywhere
+  g.threads = (wide && (long)g.xblocks * n < 2048 && hw >= 256) ? 1024 : 256;
+  return g;
+}
+template <int Q, class F>
+__device__ __forceinline__ void pixel_lane_sums(float4 (&v)[Q], int cls, F store) {
+  __shared__ float4 sh[Q][16][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, cl = threadIdx.x & (cls - 1);
+  for (int o = cls; o < 64; o <<= 1) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      v[q].x += __shfl_xor(v[q].x, o, 64); v[q].y += __shfl_xor(v[q].y, o, 64);
+      v[q].z += __shfl_xor(v[q].z, o, 64); v[q].w += __shfl_xor(v[q].w, o, 64);
+    }
+  }
+  if (lane < cls) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) sh[q][wave][cl] = v[q];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < Q * cls) {
+    const int q = threadIdx.x / cls;
+    float4 a = sh[q][0][cl];
+    for (int w = 1; w < nw; ++w) { const float4 o = sh[q][w][cl]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+    store(q, a);
+  }
+}
+
 // Squeeze-and-excite backward, first pass.  The block's tensor a = act(BN(x)) is gated: out = a * s[n,c], and pooled: s = f(mean_p a).
 // With dg = d(out) this ONE pass over (dg, x) produces, per image and channel,
 //   T0 = sum_p dg * a                (the gate's gradient: embnet_channel_scale_dgate's result, a recomputed from x)
@@ -355,44 +395,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_gap_kernel(const float* __r
 // dz = a' (dg s[n,c] + dpool[n,c] / hw) is linear in the two per-(n,c) factors:
 //   dbeta[c] = sum_n (s S1 + dpool/hw S2),   dgamma[c] = sum_n (s S3 + dpool/hw S4)      (se_bn_finalize_kernel, in double).
 // Replaces embnet_channel_scale_dgate + bn_bwd_reduce4_gap (8 + 8 B per element) by one 8-byte pass.  out: [n][5][c].
-__global__ __launch_bounds__(256) void se_bn_sums4_kernel(const float* __restrict__ dg, const float* __restrict__ x, int hw, int c4,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                          float* __restrict__ out) {
-  __shared__ float4 sh[5][256];
-  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int cq = blockIdx.x * 16 + cl;
+__global__ __launch_bounds__(1024) void se_bn_sums4_kernel(const float* __restrict__ dg, const float* __restrict__ x, int hw, int c4,
+                                                           int cls_log2, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                           float* __restrict__ out) {
+  const int cls = 1 << cls_log2, n = blockIdx.y, cl = threadIdx.x & (cls - 1), pl = threadIdx.x >> cls_log2;
+  const int npl = blockDim.x >> cls_log2;
+  const int cq = blockIdx.x * cls + cl;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 t0 = z4, s1 = z4, s2 = z4, s3 = z4, s4 = z4;
+  float4 v[5] = {z4, z4, z4, z4, z4};                      // T0, S1 .. S4
   if (cq < c4) {
     const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sf = reinterpret_cast<const float4*>(shift)[cq];
     const float4 mu = reinterpret_cast<const float4*>(mean)[cq], rs = reinterpret_cast<const float4*>(rstd)[cq];
-    for (int p = pl; p < hw; p += 16) {                  // (the accumulation order of chscale_bwd4_kernel / chscale_dgate4_kernel)
-      const long i = ((long)n * hw + p) * c4 + cq;
-      const float4 d = reinterpret_cast<const float4*>(dg)[i], xv = reinterpret_cast<const float4*>(x)[i];
-      auto one = [&](float dgv, float xq, float scq, float sfq, float muq, float rsq, float& T0, float& S1, float& S2, float& S3, float& S4) {
-        const float z = fmaf(xq, scq, sfq);
-        float av, ad;                                      // act(z) and act'(z); swish from ONE sigmoid (exp + rcp are quarter rate)
-        if (act == 2) { const float sg = __frcp_rn(1.f + __expf(-z)); av = z * sg; ad = sg * fmaf(z, 1.f - sg, 1.f); }
-        else if (act == 1) { av = fmaxf(z, 0.f); ad = z > 0.f ? 1.f : 0.f; }
-        else { av = z; ad = 1.f; }
-        T0 = fmaf(dgv, av, T0);
-        const float xh = (xq - muq) * rsq, adg = ad * dgv;
-        S1 += adg; S2 += ad; S3 = fmaf(adg, xh, S3); S4 = fmaf(ad, xh, S4);
-      };
-      one(d.x, xv.x, sc.x, sf.x, mu.x, rs.x, t0.x, s1.x, s2.x, s3.x, s4.x);
-      one(d.y, xv.y, sc.y, sf.y, mu.y, rs.y, t0.y, s1.y, s2.y, s3.y, s4.y);
-      one(d.z, xv.z, sc.z, sf.z, mu.z, rs.z, t0.z, s1.z, s2.z, s3.z, s4.z);
-      one(d.w, xv.w, sc.w, sf.w, mu.w, rs.w, t0.w, s1.w, s2.w, s3.w, s4.w);
+    const float4* dgi = reinterpret_cast<const float4*>(dg) + (long)n * hw * c4 + cq;
+    const float4* xi = reinterpret_cast<const float4*>(x) + (long)n * hw * c4 + cq;
+    auto one = [&](float dgv, float xq, float scq, float sfq, float muq, float rsq, float& T0, float& S1, float& S2, float& S3, float& S4) {
+      const float z = fmaf(xq, scq, sfq);
+      float av, ad;                                        // act(z) and act'(z); swish from ONE sigmoid (exp + rcp are quarter rate)
+      if (act == 2) { const float sg = __frcp_rn(1.f + __expf(-z)); av = z * sg; ad = sg * fmaf(z, 1.f - sg, 1.f); }
+      else if (act == 1) { av = fmaxf(z, 0.f); ad = z > 0.f ? 1.f : 0.f; }
+      else { av = z; ad = 1.f; }
+      T0 = fmaf(dgv, av, T0);
+      const float xh = (xq - muq) * rsq, adg = ad * dgv;
+      S1 += adg; S2 += ad; S3 = fmaf(adg, xh, S3); S4 = fmaf(ad, xh, S4);
+    };
+    auto quad = [&](const float4 d, const float4 xv) {
+      one(d.x, xv.x, sc.x, sf.x, mu.x, rs.x, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x);
+      one(d.y, xv.y, sc.y, sf.y, mu.y, rs.y, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y);
+      one(d.z, xv.z, sc.z, sf.z, mu.z, rs.z, v[0].z, v[1].z, v[2].z, v[3].z, v[4].z);
+      one(d.w, xv.w, sc.w, sf.w, mu.w, rs.w, v[0].w, v[1].w, v[2].w, v[3].w, v[4].w);
+    };
+    int p = pl;
+    for (; p + npl < hw; p += 2 * npl) {                   // two pixels per trip: four 16-byte loads in flight per lane
+      const float4 d0 = dgi[(long)p * c4], x0 = xi[(long)p * c4], d1 = dgi[(long)(p + npl) * c4], x1 = xi[(long)(p + npl) * c4];
+      quad(d0, x0); quad(d1, x1);
     }
+    if (p < hw) quad(dgi[(long)p * c4], xi[(long)p * c4]);
   }
-  sh[0][threadIdx.x] = t0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2; sh[3][threadIdx.x] = s3; sh[4][threadIdx.x] = s4;
-  __syncthreads();
-  if (pl < 5 && cq < c4) {                                 // pixel lane q < 5 adds quantity q over the 16 pixel lanes, in lane order
-    float4 a = sh[pl][cl];
-    for (int k = 1; k < 16; ++k) { const float4 o = sh[pl][k * 16 + cl]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
-    reinterpret_cast<float4*>(out)[((long)n * 5 + pl) * c4 + cq] = a;
-  }
+  pixel_lane_sums<5>(v, cls, [&](int q, const float4 a) {
+    if (cq < c4) reinterpret_cast<float4*>(out)[((long)n * 5 + q) * c4 + cq] = a;
+  });
 }
 
 // dbeta / dgamma from the per-(n,c) sums (see se_bn_sums4_kernel): one WAVE per channel, lanes stride the images, the lane
@@ -894,13 +936,13 @@ __global__ __launch_bounds__(256) void gap_fwd4_kernel(const float* __restrict__
 // and its per-image channel means come out of the same read (squeeze-and-excite pools the tensor it then scales).
 // Same decomposition as gap_fwd4_kernel (16 channel quads x 16 pixel lanes per workgroup, grid = (c4/16, n)); four
 // pixels per trip so four loads are in flight per lane.
-__global__ __launch_bounds__(256) void affine_act_gap4_kernel(const float* __restrict__ x, int hw, int c4,
-                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              int act, float* __restrict__ y, float* __restrict__ gap) {
-  __shared__ float4 sh[256];
-  const int n = blockIdx.y, cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int cq = blockIdx.x * 16 + cl;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+__global__ __launch_bounds__(1024) void affine_act_gap4_kernel(const float* __restrict__ x, int hw, int c4, int cls_log2,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int act, float* __restrict__ y, float* __restrict__ gap) {
+  const int cls = 1 << cls_log2, n = blockIdx.y, cl = threadIdx.x & (cls - 1), pl = threadIdx.x >> cls_log2;
+  const int npl = blockDim.x >> cls_log2;
+  const int cq = blockIdx.x * cls + cl;
+  float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
   if (cq < c4) {
     const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sf = reinterpret_cast<const float4*>(shift)[cq];
     const float4* xi = reinterpret_cast<const float4*>(x) + (long)n * hw * c4 + cq;
@@ -909,22 +951,19 @@ __global__ __launch_bounds__(256) void affine_act_gap4_kernel(const float* __res
       float4 o = make_float4(fmaf(v.x, sc.x, sf.x), fmaf(v.y, sc.y, sf.y), fmaf(v.z, sc.z, sf.z), fmaf(v.w, sc.w, sf.w));
       if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
       if (y) yi[(long)p * c4] = o;                        // y == NULL: pooled means only (the tensor is formed later, gated)
-      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      acc[0].x += o.x; acc[0].y += o.y; acc[0].z += o.z; acc[0].w += o.w;
     };
     int p = pl;
-    for (; p + 48 < hw; p += 64) {
-      const float4 v0 = xi[(long)p * c4], v1 = xi[(long)(p + 16) * c4], v2 = xi[(long)(p + 32) * c4], v3 = xi[(long)(p + 48) * c4];
-      one(v0, p); one(v1, p + 16); one(v2, p + 32); one(v3, p + 48);
+    for (; p + 3 * npl < hw; p += 4 * npl) {
+      const float4 v0 = xi[(long)p * c4], v1 = xi[(long)(p + npl) * c4], v2 = xi[(long)(p + 2 * npl) * c4], v3 = xi[(long)(p + 3 * npl) * c4];
+      one(v0, p); one(v1, p + npl); one(v2, p + 2 * npl); one(v3, p + 3 * npl);
     }
-    for (; p < hw; p += 16) one(xi[(long)p * c4], p);
+    for (; p < hw; p += npl) one(xi[(long)p * c4], p);
   }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  if (pl == 0 && cq < c4) {
-    for (int k = 1; k < 16; ++k) { const float4 o = sh[k * 16 + cl]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-    const float inv = 1.f / (float)hw;
-    reinterpret_cast<float4*>(gap)[(long)n * c4 + cq] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-  }
+  const float inv = 1.f / (float)hw;
+  pixel_lane_sums<1>(acc, cls, [&](int, const float4 a) {
+    if (cq < c4) reinterpret_cast<float4*>(gap)[(long)n * c4 + cq] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  });
 }
 
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, int n, int hw, int c,
@@ -1384,7 +1423,8 @@ extern "C" int embnet_se_bn_sums(const float* dg, const float* x, int n, int hw,
   EMBNET_CHECK_ARG(dg && x && save_mean && save_rstd && scale && shift && sums, "se_bn_sums: null pointer");
   EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0 && act >= 0 && act <= 2, "se_bn_sums: n=%d hw=%d c=%d act=%d (c %% 4 == 0)", n, hw, c, act);
   EMBNET_TRACE("embnet::se_bn_sums4_kernel", TRACE_BYTES, 8.0 * n * hw * c, stream);
-  se_bn_sums4_kernel<<<dim3((c / 4 + 15) / 16, n), 256, 0, S(stream)>>>(dg, x, hw, c / 4, save_mean, save_rstd, scale, shift, act, sums);
+  const PixGeom g = pix_geom(n, hw, c / 4);
+  se_bn_sums4_kernel<<<dim3(g.xblocks, n), g.threads, 0, S(stream)>>>(dg, x, hw, c / 4, g.cls_log2, save_mean, save_rstd, scale, shift, act, sums);
   return check_launch("se_bn_sums");
 }
 
@@ -1545,7 +1585,8 @@ extern "C" int embnet_affine_act_gap(const float* x, int n, int hw, int c, const
   EMBNET_CHECK_ARG(x && scale && shift && gap && n > 0 && hw > 0 && c > 0, "affine_act_gap: bad argument");
   EMBNET_CHECK_ARG((c & 3) == 0, "affine_act_gap: channel count %d not a multiple of 4", c);
   EMBNET_TRACE("embnet::affine_act_gap4_kernel", TRACE_BYTES, (y ? 8.0 : 4.0) * n * hw * c, stream);
-  affine_act_gap4_kernel<<<dim3(cdiv(c / 4, 16), n), 256, 0, S(stream)>>>(x, hw, c / 4, scale, shift, act, y, gap);
+  const PixGeom g = pix_geom(n, hw, c / 4);
+  affine_act_gap4_kernel<<<dim3(g.xblocks, n), g.threads, 0, S(stream)>>>(x, hw, c / 4, g.cls_log2, scale, shift, act, y, gap);
   return check_launch("affine_act_gap");
 }
 
