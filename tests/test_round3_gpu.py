@@ -364,7 +364,8 @@ def test_dp_two_graph_step_equals_eager_over_gloo(tmp_path, backbone):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
 
 
-def test_dp_gradients_are_written_in_place(dev):
+@pytest.mark.parametrize("backbone,image", [("resnet18", 64), ("simple", 105)])
+def test_dp_gradients_are_written_in_place(dev, backbone, image):
     """With the reducer's gradient sinks armed (TripletTrainer + KerasOptimizer) a data-parallel step produces the same
     flat gradient as plain autograd, and autograd launches NO accumulation (`add`) kernel for the parameters: every
     weight-gradient / BatchNorm / bias kernel wrote its slot of the flat buffer itself."""
@@ -373,10 +374,10 @@ def test_dp_gradients_are_written_in_place(dev):
     from embeddingnet_amd.optimizers import KerasOptimizer
     from embeddingnet_amd.parallel import GradReducer
     from embeddingnet_amd.train_step import TripletTrainer
-    x = torch.rand((12, 64, 64, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    x = torch.rand((12, image, image, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
     flats = []
-    for direct in (False, True):
-        base, _ = B.get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None, seed=2, device=dev)
+    for direct in (False, True):        # ('simple': the bias gradients come from the MaxPool backward, embnet_maxpool_relu_bwd_colsum)
+        base, _ = B.get_backbone((image, image, 3), encodings_len=32, backbone_name=backbone, backbone_weights=None, seed=2, device=dev)
         params = [p for p in base.parameters() if p.requires_grad]
         opt = KerasOptimizer(params, "sgd", 0.0)
         red = GradReducer(params)
