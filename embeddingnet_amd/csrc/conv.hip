@@ -816,6 +816,11 @@ void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int 
   tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(ws, parts, bm, bn, wtm, n_full, tiles_n, m, cols, bias, relu,
                                                            residual, out, stats, stats_rows, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
 }
+// host helper for conv_wgrad_planes.hip: the fixed-order sum of split-K slabs into the gradient
+void launch_slab_reduce(const float* slabs, int splits, long n, float* out, hipStream_t st) {
+  EMBNET_TRACE("embnet::slab_reduce_kernel", TRACE_BYTES, 4.0 * n * (splits + 1), st);
+  slab_reduce_kernel<<<(n & 3) ? cdiv(n, 256) : cdiv(n / 4, 32), 256, 0, st>>>(slabs, splits, n, out);
+}
 }  // namespace embnet
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

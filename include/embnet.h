@@ -255,6 +255,20 @@ int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* c
  * front of a patch convolution writes the convolution's operand in its final form. */
 int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
                              void* planes, void* stream);
+/* Weight gradient of a 3x3, stride-1, pad-1 ('same') convolution FROM THE PLANES (csrc/conv_wgrad_planes.hip):
+ * dw[3,3,c,k] = sum over pixels of x[n,h,wd,c] (shifted by the tap) * dy[n,h,wd,k], both operands as planes (layout above).
+ * Every operand byte is fetched once per (64 channels x 64 filters) tile and all nine taps are accumulated from one window
+ * of positions in LDS; split over pixel ranges into fp32 slabs [splits][9*c*k] in `workspace` and summed in fixed order
+ * (bitwise reproducible).  reduce = 0 leaves the slabs for embnet_slab_reduce_multi (descriptor: workspace, dw, 9*c*k,
+ * embnet_conv2d_wgrad_planes_splits).  Same six-term products as embnet_conv2d_wgrad_f32; the order of the pixel sum
+ * differs, so results agree within fp32 rounding, not bitwise.  supported: 1 for r = s = 3, stride 1, pad 1, oh = h,
+ * ow = wd <= 62, c % 64 == 0, k % 64 == 0. */
+int embnet_conv2d_wgrad_planes_supported(int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                                         int oh, int ow);
+int embnet_conv2d_wgrad_planes_splits(int n, int h, int wd, int c, int k);
+size_t embnet_conv2d_wgrad_planes_workspace_bytes(int n, int h, int wd, int c, int k);
+int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw, void* workspace,
+                                   size_t workspace_bytes, int n, int h, int wd, int c, int k, int reduce, void* stream);
 
 /* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out].
  * workspace (optional, may be NULL/0): >= embnet_dense_fwd_workspace_bytes lets a forward with few output tiles and a long
