@@ -166,9 +166,11 @@ class ResidualUnit(nn.Module):
         if self.post:                                    # projection shortcut: conv1 and sc read the same tensor
             y1, sc = L.conv_pair(self.bn1(x, defer=d, planes_for=self.conv1), self.conv1, self.sc, emit_stats=st)
         else:                                            # identity shortcut: its gradient joins dx inside bn1's backward
-            a, sc = self.bn1(x, defer=d, with_skip=True, planes_for=self.conv1)
+            # (sole: conv1 is a's only reader -> a may exist as planes only)
+            a, sc = self.bn1(x, defer=d, with_skip=True, planes_for=self.conv1, sole=self.kind == "basic")
             y1 = self.conv1(a, emit_stats=st)
-        y = self.bn2(y1, defer=d, planes_for=self.conv2)
+        # bn2 is y1's only reader and (basic units) conv2 its output's: both tensors may live as planes only (layers.PLANES_ONLY)
+        y = self.bn2(y1, defer=d, planes_for=self.conv2, sole=self.kind == "basic", owns_input=True)
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
         return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d), residual=sc, emit_stats=st)

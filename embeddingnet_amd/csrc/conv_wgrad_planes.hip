@@ -39,10 +39,12 @@ namespace wgp {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-// buffer_load_dwordx4 ... lds: lane l's 16 bytes at (rsrc base + soff + voff) -> LDS byte lds + 16 l  (M0 = LDS base)
+// buffer_load_dwordx4 ... lds: lane l's 16 bytes at (rsrc base + soff + voff) -> LDS byte lds + 16 l  (M0 = LDS base).
+// (M0 is a reserved register to the compiler — it cannot be named as a clobber; nothing else in this kernel uses it: gfx950's
+// ds_read / ds_write take no M0, and there is no movrel, GWS or message instruction here.)
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds, unsigned voff, unsigned soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+               :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 constexpr int XR = 256;                      // x ring: positions

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       const float4 a = reinterpret_cast<const float4*>(dx_add)[i];
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
-    reinterpret_cast<float4*>(dx)[i] = o;
+    if (dx) reinterpret_cast<float4*>(dx)[i] = o;        // (NULL: planes only — every consumer of dx reads the planes)
     if (dx_planes) {                                     // the same values as bf16 pieces, chunk-major: dy operand of the
       const long pix = i / c4; const int q = (int)(i - pix * c4);      // patch data gradient of the convolution in front
       const Split4 s = split4(o);
@@ -1335,7 +1335,8 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
                              const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                              const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
                              size_t workspace_bytes, void* stream) {
-  EMBNET_CHECK_ARG(dy && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  EMBNET_CHECK_ARG(dy && x && scale && shift && (dx || dx_planes) && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  EMBNET_CHECK_ARG(dx || ((c & 3) == 0 && !bn_scalar()), "bn_bwd: dx = NULL (planes only) needs the four-channel kernels");
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd: dx_planes needs c %% 16 == 0");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_bwd: m=%ld c=%d", m, c);
@@ -1451,7 +1452,7 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
                                       const float* save_rstd, const float* scale, const float* shift, int relu,
                                       const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
                                       float* dbeta, void* dx_planes, void* stream) {
-  EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && dx && dgamma && dbeta, "bn_bwd_partials: null pointer");
+  EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && (dx || dx_planes) && dgamma && dbeta, "bn_bwd_partials: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
   bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1);

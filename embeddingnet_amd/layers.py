@@ -40,12 +40,18 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+_WS_RETIRED = []
+
+
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (kernels on one stream run in order, so reuse is safe)."""
+    """Grow-only scratch buffer per device (kernels on one stream run in order, so reuse is safe).  A buffer that is outgrown
+    is kept alive, never returned to the allocator: a captured HIP graph replays launches that hold its address."""
     n = max((int(nbytes) + 3) // 4, 256)
     key = (device.index, _lib.stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < n:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
         _WS[key] = buf
     return buf
@@ -63,8 +69,33 @@ _SLAB_PENDING = []          # (slab buffer, dw, elements, splits)
 _SLAB_BUFS = {}             # kernel storage address -> slab buffer (scratch: any stale content is overwritten before use)
 
 
-def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0):
-    """dw[r,s,c,k] = weight gradient of a convolution (embnet_conv2d_wgrad_f32), its slab sum deferred when SLAB_DEFER."""
+WGRAD_PLANES = [_os.environ.get("EMBNET_WGRAD_PLANES", "1") != "0"]   # [False]: every weight gradient on the gather loop (A/B)
+_SLAB_RETIRED = []          # replaced slab buffers: a captured graph may still write into them, so they are never freed
+
+
+def _slab_buffer(w, need, device):
+    """The split-K slab buffer of kernel `w` (scratch, any stale content is overwritten before use).  A buffer that has to grow
+    is RETIRED, not freed: a captured HIP graph replays launches that hold its address."""
+    buf = _SLAB_BUFS.get(w.data_ptr())
+    if buf is None or buf.numel() < need or buf.device != device:
+        if buf is not None:
+            _SLAB_RETIRED.append(buf)
+        buf = _SLAB_BUFS[w.data_ptr()] = torch.empty(need, dtype=torch.float32, device=device)
+    return buf
+
+
+def wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow):
+    return WGRAD_PLANES[0] and bool(_lib.lib().embnet_conv2d_wgrad_planes_supported(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow))
+
+
+def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0,
+               x_planes=None, dz_planes=None):
+    """dw[r,s,c,k] = weight gradient of a convolution, its slab sum deferred when SLAB_DEFER.  With the planes of BOTH operands
+    (x_planes: kept by the forward patch conv, dz_planes: left by the BatchNormalization behind the conv) and a geometry
+    embnet_conv2d_wgrad_planes_supported accepts, the planes kernel computes it (csrc/conv_wgrad_planes.hip) and the fp32
+    tensors are not read; otherwise embnet_conv2d_wgrad_f32."""
+    planes = x_planes is not None and dz_planes is not None and in_scale is None and \
+        wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow)
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
     # (only for a leaf kernel: the gradient of a derived one — the channel-padded kernel of an image conv — is consumed by the
     # next backward node at once)
@@ -73,21 +104,28 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
         if any(e[4] is w for e in _SLAB_PENDING):               # the same kernel a second time in one backward (shared layer):
             flush_slab_reduces()                                # finish the first gradient, compute this one in place
             splits = 1
+        elif planes:
+            splits = lib.embnet_conv2d_wgrad_planes_splits(n, h, wd, c, k)
         else:
             splits = lib.embnet_conv2d_wgrad_splits(n, c, r, s, k, oh, ow)
         if splits > 1:
-            need = lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4
-            buf = _SLAB_BUFS.get(w.data_ptr())
-            if buf is None or buf.numel() < need or buf.device != x.device:
-                if len(_SLAB_BUFS) > 512:
-                    _SLAB_BUFS.clear()
-                buf = _SLAB_BUFS[w.data_ptr()] = torch.empty(need, dtype=torch.float32, device=x.device)
-            check(lib.embnet_conv2d_wgrad_slabs_f32(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
-                                                    stride, pt, pl, oh, ow, in_scale, in_shift, in_act, stream()))
+            if planes:
+                buf = _slab_buffer(w, lib.embnet_conv2d_wgrad_planes_workspace_bytes(n, h, wd, c, k) // 4, x.device)
+                check(lib.embnet_conv2d_wgrad_planes_f32(ptr(x_planes), ptr(dz_planes), ptr(dw), ptr(buf), buf.numel() * 4,
+                                                         n, h, wd, c, k, 0, stream()))
+            else:
+                buf = _slab_buffer(w, lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4, x.device)
+                check(lib.embnet_conv2d_wgrad_slabs_f32(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
+                                                        stride, pt, pl, oh, ow, in_scale, in_shift, in_act, stream()))
             # (an alias of dw, not dw itself: autograd adopts a returned gradient as .grad only while nobody else holds that
             # tensor object — a second reference would make it clone the still-unreduced buffer)
             _SLAB_PENDING.append((buf, dw.detach(), r * s * c * k, splits, w))
             return
+    if planes:
+        ws = workspace(lib.embnet_conv2d_wgrad_planes_workspace_bytes(n, h, wd, c, k), x.device)
+        check(lib.embnet_conv2d_wgrad_planes_f32(ptr(x_planes), ptr(dz_planes), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, k,
+                                                 1, stream()))
+        return
     ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
     check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl,
                                       oh, ow, in_scale, in_shift, in_act, stream()))
@@ -242,6 +280,19 @@ def refresh_weight_planes(module):
         e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
 
 
+PLANES_ONLY = [_os.environ.get("EMBNET_PLANES_ONLY", "1") != "0"]     # [False]: every planes tensor keeps its fp32 copy (A/B)
+
+
+def _placeholder(shape, device):
+    """A tensor of `shape` WITHOUT its fp32 storage (one element, all strides 0): stands in autograd's graph for a tensor that
+    exists only as planes.  It is not contiguous, so _lib.ptr() refuses it: a kernel that would read its values fails loudly."""
+    return torch.empty_strided(tuple(shape), (0,) * len(shape), device=device, dtype=torch.float32)
+
+
+def _is_placeholder(t):
+    return t.dim() == 4 and t.numel() > 1 and t.stride() == (0, 0, 0, 0)
+
+
 def _take_dy_planes(dy):
     e = DY_PLANES.pop(dy.data_ptr(), None)
     return e[0] if (e is not None and e[1].shape == dy.shape) else None
@@ -279,7 +330,9 @@ class _Conv2dFn(torch.autograd.Function):
                 planes=None, bn_src=None):
         """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward.
         bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums."""
-        x, w = _c(x), _c(w)
+        w = _c(w)
+        if not (planes is not None and _is_placeholder(x)):       # (a planes-only input has no fp32 values to read)
+            x = _c(x)
         n, h, wd, c = x.shape
         r, s, c2, k = w.shape
         if c2 != c:
@@ -308,6 +361,7 @@ class _Conv2dFn(torch.autograd.Function):
                 ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
                 in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
         ctx.patch = planes is not None
+        ctx.x_planes = planes                # kept for the weight gradient (conv_wgrad)
         ctx.bn_src = bn_src
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
@@ -325,7 +379,9 @@ class _Conv2dFn(torch.autograd.Function):
         n, h, wd, c = x.shape
         r, s, _, k = w.shape
         stride, pt, pl, oh, ow = ctx.geom
-        dy = _c(dy)
+        dy_only_planes = _is_placeholder(dy)     # the BatchNormalization behind this conv wrote its dx as planes ONLY
+        if not dy_only_planes:
+            dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
         dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -348,12 +404,23 @@ class _Conv2dFn(torch.autograd.Function):
                 check(lib.embnet_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dz), stream()))
         else:
             dz = dy
-        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         in_scale = (in_stats.data_ptr() + 8 * in_stats.shape[1]) if in_stats is not None else None
         in_shift = (in_stats.data_ptr() + 12 * in_stats.shape[1]) if in_stats is not None else None
 
+        # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
+        dy_planes = _take_dy_planes(dy) if (ctx.patch and not ctx.relu) else None
+        if dy_only_planes and dy_planes is None:
+            raise _lib.EmbnetError("conv2d backward: the gradient exists only as planes and they are gone (DY_PLANES)")
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_dw and dy_planes is None and _is_placeholder(x):
+            # the input exists only as planes and nobody left planes of the gradient (its producer was not the BatchNormalization
+            # the forward saw): split it here, one extra pass
+            dy_planes = torch.empty(3 * dz.numel(), device=dz.device, dtype=torch.int16)
+            check(lib.embnet_planes_from_f32(ptr(dz), dz.numel() // k, k, ptr(dy_planes), stream()))
+
         def run_wgrad():
-            conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act)
+            conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
+                       getattr(ctx, "x_planes", None), dy_planes)
 
         dw_note = None
         if need_dw:
@@ -365,10 +432,8 @@ class _Conv2dFn(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 run_wgrad()
-        # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
-        dy_planes = _take_dy_planes(dy) if (ctx.patch and not ctx.relu) else None
         if need_dx:
-            dx = torch.empty_like(x)
+            dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
             if dy_planes is not None and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
                 _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dskip)
             else:
@@ -437,6 +502,7 @@ class _ConvPairFn(torch.autograd.Function):
                     int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
             ys.append(y)
         ctx.patch = planes is not None
+        ctx.x_planes = planes
         ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
         ctx.save_for_backward(x, w1, w2, in_stats)
         return ys[0], ys[1]
@@ -455,10 +521,13 @@ class _ConvPairFn(torch.autograd.Function):
             if dy is None:
                 dws.append(None)
                 continue
-            dy = _c(dy)
+            if not _is_placeholder(dy):
+                dy = _c(dy)
             r, s, _, k = w.shape
             stride, pt, pl, oh, ow = geom
             dy_planes = _take_dy_planes(dy) if (ctx.patch and w is w1) else None
+            if _is_placeholder(dy) and dy_planes is None:
+                raise _lib.EmbnetError("conv_pair backward: the gradient exists only as planes and they are gone (DY_PLANES)")
             if dx is not None:
                 if dy_planes is not None and first and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
                     _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, None)
@@ -471,7 +540,8 @@ class _ConvPairFn(torch.autograd.Function):
             dw = None
             if need_dw:
                 dw, note = _sink(w)
-                conv_wgrad(lib, x, dy, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act)
+                conv_wgrad(lib, x, dy, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
+                           getattr(ctx, "x_planes", None) if w is w1 else None, dy_planes)
                 dw = _done(dw, note)
             dws.append(dw)
         if dx is not None and first:
@@ -508,6 +578,8 @@ def conv_pair(x, conv1, conv2, emit_stats=False):
         y1._bn_partials = out_stats
     if planes is not None:
         y1._wants_dy_planes = True
+        if conv1.planes_only_gradient(x.shape, g1):
+            y1._dy_planes_only = True
     return y1, y2
 
 
@@ -639,10 +711,33 @@ class Conv2D(nn.Module):
             y._bn_partials = out_stats
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
+            # ... and ONLY as planes when this conv takes both of its gradients from them and the BatchNormalization is told
+            # that nobody else reads its dx (BatchNormalization.forward(owns_input=True))
+            if self.planes_only_gradient(x.shape, geom) and kernel is self.kernel and not with_skip:
+                y._dy_planes_only = True
         if (self.relu and self.bias is not None and (FUSE_RELU_BN[0] or FUSE_RELU_POOL[0]) and self.kernel.shape[3] % 4 == 0
                 and residual is None):
             y._relu_conv = (self.bias,)        # see RELU_DONE
         return (y, out[1]) if with_skip else y
+
+    def planes_only_input(self, x_shape):
+        """True when no pass of this conv reads an fp32 copy of its input: forward on the patch kernel, weight gradient on the
+        planes kernel (the data gradient never reads the input)."""
+        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.patch_capable(x_shape)):
+            return False
+        n, h, w, c = x_shape
+        stride, pt, pl, oh, ow = self.geometry(h, w)
+        return wgrad_planes_ok(n, h, w, c, 3, 3, self.kernel.shape[3], stride, pt, pl, oh, ow)
+
+    def planes_only_gradient(self, x_shape, geom=None):
+        """True when this conv's backward reads NO fp32 copy of its output gradient: data gradient on the patch kernel, weight
+        gradient on the planes kernel, no bias gradient, no fused ReLU."""
+        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.bias is None and not self.relu and self.patch_capable(x_shape)):
+            return False
+        n, h, w, c = x_shape
+        stride, pt, pl, oh, ow = geom if geom is not None else self.geometry(h, w)
+        k = self.kernel.shape[3]
+        return wgrad_planes_ok(n, h, w, c, 3, 3, k, stride, pt, pl, oh, ow) and patch_ok(n, oh, ow, k, 3, 3, c, 1, h, w)
 
     def patch_capable(self, x_shape):
         """True when this conv on an input of that shape runs the patch kernel (csrc/conv_patch.hip): 3x3, stride 1,
@@ -756,17 +851,22 @@ def _bn_grad_targets(ctx, c, device, gamma_idx=1, beta_idx=2):
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
-                with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None, dropout=None):
+                with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None, dropout=None,
+                planes_only=False, dx_planes_only=False):
         """dropout=(rate, seed): a Dropout layer directly behind this one rides on its passes (embnet_affine_act_dropout,
         embnet_bn_bwd_inrelu_dropout; the mask and arithmetic of embnet_dropout).
         emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
         address; BatchNormalization.forward hangs them on the tensor).  emit_dx_planes: backward writes dx also as planes
-        into DY_PLANES (the producer of x is a patch conv, whose data gradient reads them)."""
+        into DY_PLANES (the producer of x is a patch conv, whose data gradient reads them).
+        planes_only (with emit_planes): the fp32 output is NOT written — the returned tensor is a placeholder (_placeholder)
+        whose only consumer, the caller promises, is a conv that reads the planes in all three of its passes.
+        dx_planes_only (with emit_dx_planes): likewise for dx in backward — its only reader is the conv in front."""
         x = _c(x)
         lib = _lib.lib()
         c = x.shape[-1]
         m = x.numel() // c
-        y = torch.empty_like(x)
+        planes_only = bool(planes_only and emit_planes and not dropout)
+        y = _placeholder(x.shape, x.device) if planes_only else torch.empty_like(x)
         stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
         yk = None if (emit_planes or dropout) else y                         # planes / dropout: statistics first, then one pass
         if training:
@@ -777,7 +877,7 @@ class _BatchNormFn(torch.autograd.Function):
         if emit_planes:
             planes = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
             check(lib.embnet_affine_act_planes(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
-                                               ptr(y), ptr(planes), stream()))
+                                               None if planes_only else ptr(y), ptr(planes), stream()))
             _ACT_PLANES[y.data_ptr()] = planes
         ctx.dropout = None
         if dropout:
@@ -790,6 +890,7 @@ class _BatchNormFn(torch.autograd.Function):
                 _BN_FWD_STATS.clear()
             _BN_FWD_STATS[y.data_ptr()] = (x, stats, int(relu))
         ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
+        ctx.dx_planes_only = bool(dx_planes_only) and ctx.emit_dx_planes and not with_skip
         ctx.in_relu_bias = in_relu_bias if (in_relu_bias is not None and not with_skip and c % 4 == 0) else None
         ctx.relu, ctx.training, ctx.has_gamma = relu, training, gamma is not None
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
@@ -808,7 +909,9 @@ class _BatchNormFn(torch.autograd.Function):
         m = x.numel() // c
         dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
-        dx = torch.empty_like(x)
+        only = getattr(ctx, "dx_planes_only", False) and dskip is None
+        dx = _placeholder(x.shape, x.device) if only else torch.empty_like(x)
+        dxp = None if only else ptr(dx)
         tg, tb, finish = _bn_grad_targets(ctx, c, x.device)
         ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
         mean = stats.data_ptr() if ctx.training else None
@@ -826,10 +929,10 @@ class _BatchNormFn(torch.autograd.Function):
                 and not inrelu and drop is None):
             # dy is the data gradient of the conv behind this layer, which already produced the column sums
             check(lib.embnet_bn_bwd_partials(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
-                                             int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes),
+                                             int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
                                              stream()))
             dgamma, dbeta = finish()
-            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+            return (dx, dgamma, dbeta) + (None,) * 14
         if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
             dyd = torch.empty_like(dy)
             check(lib.embnet_dropout(ptr(dy), dy.numel(), drop[0], drop[1], drop[2], ptr(dyd), stream()))
@@ -852,10 +955,10 @@ class _BatchNormFn(torch.autograd.Function):
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
         else:
             check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                    int(ctx.relu), int(ctx.training), ptr(dskip), ptr(dx), ptr(tg), ptr(tb), ptr(planes), ptr(ws),
+                                    int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
                                     ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+        return (dx, dgamma, dbeta) + (None,) * 14
 
 
 class _BNGapFn(torch.autograd.Function):
@@ -1161,8 +1264,13 @@ class BatchNormalization(nn.Module):
         BatchNorm sums (8 B), one for dx (12 B)."""
         return _se_gate(self, x, gate_fn)
 
-    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None, lazy_scale=False):
-        """dropout=<Dropout>: the Dropout layer that consumes the output, applied in this layer's passes when it is active
+    def forward(self, x, defer=False, with_skip=False, emit_gap=False, planes_for=None, dropout=None, lazy_scale=False,
+                sole=False, owns_input=False):
+        """sole=True (with planes_for): the caller promises that `planes_for` is the ONLY consumer of the output; when that conv
+        reads planes in all three passes (Conv2D.planes_only_gradient) the fp32 output is never written (a placeholder is returned).
+        owns_input=True: the caller promises that this layer is the ONLY consumer of x; when x's producer takes its gradients
+        from planes alone (`x._dy_planes_only`) backward writes dx as planes only.
+        dropout=<Dropout>: the Dropout layer that consumes the output, applied in this layer's passes when it is active
         (plain path only; the caller then skips the Dropout module).
         planes_for=<Conv2D>: the conv that consumes the output; when it can run the patch kernel on it
         (Conv2D.patch_capable) the output is also written as bf16 planes (`y._planes`) in the same pass.
@@ -1184,6 +1292,8 @@ class BatchNormalization(nn.Module):
             y = self.forward(x)
             return y, _GapFn.apply(y)
         want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
+        dx_only = bool(want_dx_planes and owns_input and PLANES_ONLY[0] and getattr(x, "_dy_planes_only", False)
+                       and x.shape[-1] % 16 == 0)
 
         def tag(y):          # (x, stats, act) for a conv behind this layer whose data gradient can emit the backward sums (BN_SUMS)
             src = _BN_FWD_STATS.pop(y.data_ptr(), None)
@@ -1191,9 +1301,10 @@ class BatchNormalization(nn.Module):
                 y._bn_src = src
 
         if planes_for is not None and not defer and planes_for.patch_capable(x.shape):
+            y_only = bool(sole and PLANES_ONLY[0] and planes_for.planes_only_input(x.shape))
             out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), with_skip,
-                                     True, want_dx_planes)
+                                     True, want_dx_planes, None, None, y_only, dx_only)
             y = out[0] if with_skip else out
             y._planes = _ACT_PLANES.pop(y.data_ptr())
             tag(y)
@@ -1213,7 +1324,8 @@ class BatchNormalization(nn.Module):
         in_relu_bias = getattr(x, "_relu_conv", None) if (self.training and torch.is_grad_enabled() and FUSE_RELU_BN[0]) else None
         y = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
-                               False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None)
+                               False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None,
+                               False, dx_only and in_relu_bias is None and dropout is None)
         tag(y)
         return y
 

@@ -332,7 +332,10 @@ int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const f
                          const float* scale, const float* shift, int relu, int training, float* dz, float* dgamma,
                          float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 /* dx_planes (NULL, or 3*m*c bf16, c % 16 == 0): dx ALSO as the pre-split planes embnet_conv2d_patch_f32 takes (below) —
- * the gradient of the convolution output in front of this BatchNormalization, i.e. that convolution's data-gradient operand. */
+ * the gradient of the convolution output in front of this BatchNormalization, i.e. that convolution's data-gradient operand.
+ * With dx_planes given, dx may be NULL (embnet_bn_bwd, embnet_bn_bwd_partials; c % 4 == 0): the fp32 tensor is not written —
+ * for a convolution that takes both its data gradient (embnet_conv2d_patch_f32) and its weight gradient
+ * (embnet_conv2d_wgrad_planes_f32) from the planes. */
 
 /* y = act(x*scale[c] + shift[c]) on x[m,c]: the apply half of BatchNormalization on its own (scale/shift from
  * bn_train_fwd / bn_infer_fwd with y = NULL), for a deferred BN output whose consumer cannot fuse it. */
