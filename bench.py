@@ -35,23 +35,10 @@ sys.path.insert(0, ROOT)
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start one child per GPU BEFORE anything here touches the GPU (a
-    process that has initialised HIP must never re-execute itself), relay rank 0's JSON line, return the worst exit code."""
-    import socket
-    import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    kids = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                     stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = kids[0].communicate()
-    rcs = [k.wait() for k in kids]
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    return next((rc for rc in rcs if rc), 0)
+    process that has initialised HIP must never re-execute itself) and watch them (embeddingnet_amd/launch.py): the first
+    rank that fails ends the world at once with its exit code; rank 0 prints the JSON line to the inherited stdout."""
+    from embeddingnet_amd import launch
+    return launch.spawn(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout_s=3600)
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
@@ -59,6 +46,16 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
                if a == "--gpus" or a.startswith("--gpus=")), 1)
     if _n > 1:
         sys.exit(spawn_ranks(_n))
+
+if __name__ == "__main__":
+    # before anything touches the GPU: this rank's threads onto the cores of its GPU's NUMA node (no numactl / taskset hop)
+    from embeddingnet_amd import launch as _launch
+    _PIN = _launch.pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0"))) if int(os.environ.get("WORLD_SIZE", "1")) > 1 \
+        else "affinity unchanged (one rank)"
+    if os.environ.get("EMBNET_TEST_FAIL_RANK") == os.environ.get("RANK", "0") and "WORLD_SIZE" in os.environ:
+        sys.exit(3)                      # test hook: this rank dies in start-up (tests/test_host_cpu.py)
+else:
+    _PIN = "affinity unchanged (imported)"
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -402,12 +399,25 @@ def main():
         t = torch.tensor([1.0 if dead else 0.0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dead = t.item() > 0.5
+    # per-rank record for rank 0's log: device, core affinity, step mode, how the gradient mean is taken
+    mine = {"rank": rank, "device": f"{torch.cuda.get_device_name(dev)} [{dev.index}]", "affinity": _PIN,
+            "step_mode": ("siamese eager" if args.mode == "siamese" else
+                          ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),
+            "gradient_mean": reducer.mean_mode if reducer is not None else None, "host_enqueue_ms": round(host_ms, 3)}
+    ranks_info = [mine]
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     if dead and not args.allow_dead:
         raise SystemExit(f"bench: the timed region ran on a dead problem ({live}): loss 0 / fallback triplet means all-zero "
                          "gradients; no throughput is reported for it (raise --pool, or --allow-dead for an A/B)")
     if rank != 0:
         return
 
+    if world > 1:
+        for r in ranks_info:
+            log(f"  rank {r['rank']}: {r['device']}, {r['affinity']}, step {r['step_mode']}, gradient mean: {r['gradient_mean']}, "
+                f"host enqueue {r['host_enqueue_ms']} ms/step")
     if args.mode != "siamese":
         log(f"  step mode: {'HIP graph replay' if getattr(trainer, '_graph', None) is not None else 'eager'}"
             + (f" (capture failed: {trainer._graph_error})" if getattr(trainer, "_graph_failed", False) else "")
@@ -450,6 +460,7 @@ def main():
                    "step_mode": ("siamese eager" if args.mode == "siamese" else
                                  ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),
                    "mining": getattr(args, "mining", None) if args.mode != "siamese" else None,
+                   "ranks": ranks_info if world > 1 else None,
                    "sustained": sustained,
                    "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
                    "sustained_over_timed": round(sustained["ms_per_step"] / ms_per_step, 4) if sustained else None},

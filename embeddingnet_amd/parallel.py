@@ -36,7 +36,17 @@ def init_distributed(backend=None, timeout_s=None):
         if timeout_s:
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except Exception as e:          # noqa: BLE001 — whatever the store raises when the port is taken
+            # a self-spawned world (embeddingnet_amd/launch.py) picked its port by bind-and-close: if somebody took it before
+            # rank 0 bound it, say so with the exit code the parent restarts the world for
+            if os.environ.get("EMBNET_SPAWNED") == "1" and any(t in str(e).lower() for t in ("address already in use", "eaddrinuse")):
+                import sys
+                from .launch import EXIT_PORT_IN_USE
+                print(f"[rank {rank}] rendezvous port {os.environ.get('MASTER_PORT')} is in use: {e}", file=sys.stderr, flush=True)
+                sys.exit(EXIT_PORT_IN_USE)
+            raise
     return rank, world, local
 
 
@@ -140,14 +150,20 @@ class GradReducer:
         self._fired = set()                                 # parameters already counted in this step
         # default: SUM + one in-place scale of the flat buffer (works on every backend); on RCCL the mean is taken inside
         # the collective (ReduceOp.AVG is NCCL/RCCL-only), checked once against sum-and-scale on the first real exchange
+        # EMBNET_DP_AVG=1 opts into the in-collective mean; the default stays SUM + scale (one ~15 us pass over the flat buffer)
+        # until a multi-GPU run has validated AVG on this RCCL (N > 1 has never run on hardware).  Constructing a
+        # reducer with EMBNET_DP_AVG=1 at world size > 1 issues three small collectives (the self-check below): every rank must
+        # construct its reducer at the same point.
         self._avg = dist.ReduceOp.SUM
-        self._avg_checked = False
-        if self._reduce and dist.get_backend(process_group) == "nccl" and os.environ.get("EMBNET_DP_AVG", "1") == "1":
-            self._avg = dist.ReduceOp.AVG                   # RCCL averages inside the collective: no scaling pass over the buffer
-            if self.world > 1 and not self._avg_matches_sum_and_scale(dev):
+        self.mean_mode = "sum + scale"
+        if self._reduce and dist.get_backend(process_group) == "nccl" and os.environ.get("EMBNET_DP_AVG", "0") == "1":
+            if self.world == 1 or self._avg_matches_sum_and_scale(dev):
+                self._avg = dist.ReduceOp.AVG               # RCCL averages inside the collective: no scaling pass over the buffer
+                self.mean_mode = "ReduceOp.AVG" + (" (self-check passed)" if self.world > 1 else "")
+            else:
                 import warnings
-                warnings.warn("GradReducer: ReduceOp.AVG disagrees with sum-and-scale on this RCCL; using SUM + scale")
-                self._avg = dist.ReduceOp.SUM
+                warnings.warn("GradReducer: ReduceOp.AVG unavailable or disagreeing with sum-and-scale on this RCCL; using SUM + scale")
+                self.mean_mode = "sum + scale (ReduceOp.AVG failed its self-check)"
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _avg_matches_sum_and_scale(self, dev):
@@ -160,11 +176,14 @@ class GradReducer:
         ok = True
         try:
             dist.all_reduce(a, op=dist.ReduceOp.AVG, group=self.group)
-        except Exception:                   # a build without AVG raises on every rank alike (argument check, no communication)
+        except Exception:                   # a build without AVG raises in the argument check, before any communication
             ok = False
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-        self._avg_checked = True
-        return ok and bool(torch.allclose(a, b / self.world, rtol=1e-6, atol=1e-6))
+        ok = ok and bool(torch.allclose(a, b / self.world, rtol=1e-6, atol=1e-6))
+        # the verdict is itself agreed on (MIN over ranks): no rank may average in the collective while another sums and scales
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0.5)
 
     @staticmethod
     def _pad(n, quantum=4):

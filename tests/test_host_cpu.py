@@ -418,11 +418,11 @@ def test_lr_schedule_overrides_plateau_as_in_the_reference(monkeypatch):
 
 
 def test_apply_gpu_ids(monkeypatch):
-    """GENERAL.gpu_ids (reference train.py:121-133): visible devices + one process per listed GPU under torch.distributed.run."""
-    import subprocess as sp
+    """GENERAL.gpu_ids (reference train.py:121-133): visible devices + one watched process per listed GPU (launch.spawn)."""
     import tools.train as T
+    from embeddingnet_amd import launch
     calls = []
-    monkeypatch.setattr(sp, "call", lambda cmd: calls.append(cmd) or 0)
+    monkeypatch.setattr(launch, "spawn", lambda n, argv, **kw: calls.append((n, argv)) or 0)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
     monkeypatch.setattr(sys, "argv", ["tools/train.py", "cfg.yml", "--max_epochs", "1"])
@@ -435,15 +435,116 @@ def test_apply_gpu_ids(monkeypatch):
     with pytest.raises(SystemExit) as e:
         T.apply_gpu_ids("0, 3,5")
     assert e.value.code == 0 and os.environ["HIP_VISIBLE_DEVICES"] == "0,3,5"
-    cmd = calls[0]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=3" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert cmd[-3:] == ["cfg.yml", "--max_epochs", "1"] and cmd[-4].endswith("tools/train.py")
+    n, argv = calls[0]
+    assert n == 3 and argv[0] == sys.executable and argv[1].endswith("tools/train.py") and argv[-3:] == ["cfg.yml", "--max_epochs", "1"]
     # under a launcher the world is the launcher's: nothing is re-spawned
     calls.clear()
     monkeypatch.setenv("WORLD_SIZE", "2")
     T.apply_gpu_ids("0,1,2")
     assert not calls
+
+
+_RANK_SCRIPT = """
+import os, sys, time
+rank = int(os.environ["RANK"])
+assert os.environ["WORLD_SIZE"] == sys.argv[1] and os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[2]
+if mode == "ok":
+    print("line from rank", rank, flush=True)
+elif mode == "fail1":                       # rank 1 dies at once; the others would wait "in a collective" for a minute
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(60)
+elif mode == "hang":
+    time.sleep(60)
+elif mode == "port":                        # the first world loses the race for its port, the second runs
+    marker = sys.argv[3]
+    if not os.path.exists(marker):
+        if rank == 0:
+            open(marker, "w").write(os.environ["MASTER_PORT"])
+            sys.exit(98)
+        time.sleep(60)
+    print("second world on port", os.environ["MASTER_PORT"], "first was", open(marker).read(), flush=True)
+"""
+
+
+def test_launch_spawn_watches_every_rank(tmp_path):
+    """embeddingnet_amd/launch.py: all ranks succeed -> 0 and rank 0's stdout comes through; one rank dies -> the others are
+    terminated and ITS code is returned within seconds (not after the sleepers' minute); a parent-side time limit; a lost
+    race for the rendezvous port (exit code 98) restarts the world on a new port."""
+    import time
+    from embeddingnet_amd import launch
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    run = lambda n, *a, **kw: launch.spawn(n, [sys.executable, str(script), str(n)] + list(a), log=lambda *m: None, **kw)
+    out = subprocess.run([sys.executable, "-c",
+                          f"import sys; sys.path.insert(0, {ROOT!r}); from embeddingnet_amd import launch; "
+                          f"sys.exit(launch.spawn(3, [sys.executable, {str(script)!r}, '3', 'ok']))"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "line from rank 0"      # the other ranks' stdout is not relayed
+    t0 = time.time()
+    assert run(4, "fail1") == 7
+    assert time.time() - t0 < 20
+    t0 = time.time()
+    assert run(2, "hang", timeout_s=1.5) == launch.EXIT_TIMEOUT
+    assert time.time() - t0 < 20
+    marker = tmp_path / "first_port"
+    assert run(2, "port", str(marker)) == 0 and marker.exists()
+    assert run(2, "port", str(tmp_path / "never"), retries=0) == launch.EXIT_PORT_IN_USE
+
+
+def test_pin_to_gpu_numa_reads_the_topology(tmp_path, monkeypatch):
+    """launch.gpu_cpu_sets / pin_to_gpu_numa on a fake sysfs tree: KFD GPU nodes in node order -> DRM render minor ->
+    local_cpulist; CPU nodes skipped; a device without NUMA information (numa_node -1) and HIP_VISIBLE_DEVICES remapping."""
+    from embeddingnet_amd import launch
+    kfd, drm = tmp_path / "kfd", tmp_path / "drm"
+    have = sorted(os.sched_getaffinity(0))
+    lists = [f"{have[0]}", f"{have[-1]}", ""]
+    spec = [(0, 0, None), (1, 0, None),                          # two CPU nodes
+            (2, 304, (128, 0, lists[0])), (3, 304, (129, 1, lists[1])), (4, 304, (130, -1, lists[2]))]
+    for node, simd, gpu in spec:
+        d = kfd / str(node)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if gpu else 64}\nsimd_count {simd}\ndrm_render_minor {gpu[0] if gpu else 0}\n")
+        if gpu:
+            dev = drm / f"renderD{gpu[0]}" / "device"
+            dev.mkdir(parents=True)
+            (dev / "numa_node").write_text(f"{gpu[1]}\n")
+            (dev / "local_cpulist").write_text(gpu[2] + "\n")
+    sets = launch.gpu_cpu_sets(str(kfd), str(drm))
+    assert sets == [{have[0]}, {have[-1]}, None]
+    assert launch._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    before = os.sched_getaffinity(0)
+    try:
+        assert "no NUMA information" in launch.pin_to_gpu_numa(2, sets) and os.sched_getaffinity(0) == before
+        msg = launch.pin_to_gpu_numa(1, sets)
+        assert "pinned to 1 cores local to device 1" in msg and os.sched_getaffinity(0) == {have[-1]}
+        os.sched_setaffinity(0, before)
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")          # local rank 1 is physical device 0
+        launch.pin_to_gpu_numa(1, sets)
+        assert os.sched_getaffinity(0) == {have[0]}
+        os.sched_setaffinity(0, before)
+        monkeypatch.setenv("EMBNET_PIN", "0")
+        assert "EMBNET_PIN=0" in launch.pin_to_gpu_numa(0, sets) and os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_bench_rank_that_dies_in_startup_ends_the_world_at_once():
+    """`python bench.py --gpus 2` where rank 1 exits during start-up (EMBNET_TEST_FAIL_RANK): rank 0 is waiting in the
+    rendezvous for it; the parent must return rank 1's code within seconds, not at the distributed timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(EMBNET_TEST_FAIL_RANK="1", EMBNET_DIST_BACKEND="gloo")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert time.time() - t0 < 90                                 # (the first `import torch` of a fresh container takes a while)
+    assert "rank 1 exited with code 3" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 def test_optimizer_state_roundtrip(tmp_path):

@@ -110,6 +110,22 @@ def test_bench_starts_its_own_ranks():
     assert len(d["config"]["host_enqueue_ms_per_step_by_rank"]) == 2 and d["config"]["loss_min_timed"] > 0
 
 
+def test_bench_world_of_eight_on_one_gpu():
+    """The N = 8 control flow on hardware that has one GPU: eight ranks over gloo share it, tiny shapes (simple2 64x64, two
+    classes per rank).  What has then run at world size 8: the rendezvous, the model broadcast, the first-backward bucket order
+    agreement, the collective capture decision (TripletTrainer._agree), eight bucketed gradient all-reduces per step, the MAX
+    of the elapsed times, the liveness MAX, the per-rank record in rank 0's line.  (RCCL itself: the driver's scaling run.)"""
+    out, d = _bench("--gpus", "8", "--config", "c1", "--k-classes", "2", "--pool", "8", "--steps", "6", "--warmup", "4",
+                    "--mining", "hardest", "--allow-dead",       # (8 images per rank: a step without a violating triplet is possible)
+                    env={"EMBNET_DIST_BACKEND": "gloo"})
+    assert out.returncode == 0 and d is not None, out.stderr[-3000:]
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * 2 * 4 and d["config"]["parallelism"] == "dp8"
+    ranks = d["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and len({r["step_mode"] for r in ranks}) == 1
+    assert all(r["gradient_mean"] == "sum + scale" for r in ranks) and d["config"]["loss_first_timed"] > 0
+    assert out.stderr.count("gradient mean:") == 8
+
+
 # ------------------------------------------------------------------------------------------------ DP with odd-sized slots
 def test_dp_efficientnet_gradients_in_place(dev):
     """EfficientNet-B0 has parameters whose size is not a multiple of 4 (squeeze-excite reduce biases of 6 / 10 elements):

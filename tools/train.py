@@ -113,11 +113,10 @@ def apply_gpu_ids(gpu_ids):
     os.environ.setdefault('HIP_VISIBLE_DEVICES', ','.join(ids))
     print(f'Using gpu ids: {",".join(ids)}')
     if len(ids) > 1:
-        import subprocess
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={len(ids)}',
-               '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 1000),
-               os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        # one process per listed GPU, started and WATCHED by embeddingnet_amd/launch.py: a rank that dies ends the world at
+        # once with its exit code instead of leaving the others in a collective until the process-group timeout
+        from embeddingnet_amd import launch
+        sys.exit(launch.spawn(len(ids), [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
 
 def main():
@@ -126,6 +125,9 @@ def main():
     p_train, p_model, p_loader, p_gen = cfg['train'], cfg['model'], cfg['dataloader'], cfg['generator']
     apply_gpu_ids(cfg['general'].get('gpu_ids'))
     paths = create_save_folders(cfg['general'])
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:        # before the first GPU call: stay on the cores next to this rank's GPU
+        from embeddingnet_amd import launch
+        print(f"[rank {os.environ.get('RANK', '0')}] {launch.pin_to_gpu_numa(int(os.environ.get('LOCAL_RANK', '0')))}", flush=True)
     rank, world, local = init_distributed()
     dev = torch.device('cuda', local % max(torch.cuda.device_count(), 1))    # (ranks > GPUs only in the gloo debug mode)
     torch.cuda.set_device(dev)
