@@ -166,13 +166,48 @@ class TripletsDataGenerator(ENDataGenerator):
         self.mode = negatives_selection_mode
         self._calls = 0
 
-    def sample_batch(self):
-        """reference :202-205,211-218: P classes without replacement, K images per class WITH replacement,
-        stacked class-contiguous.  Returns float32 [P*K,H,W,3]."""
+    def sample_plan(self):
+        """reference :202-205: WHICH images make the next batch — P classes without replacement, K image indices per class WITH
+        replacement — drawn from the global np.random stream in the reference's order.  -> (class names, [K indices] per class)."""
         selected = np.random.choice(self.n_classes, size=self.k_classes, replace=False)
         classes = [self.class_names[c] for c in selected]
         idxs = [np.random.choice(self.n_samples[cl], size=self.k_samples, replace=True) for cl in classes]
+        return classes, idxs
+
+    def load_plan_u8(self, plan, out=None):
+        """The planned batch as DECODED uint8 [P*K,H,W,3] (BGR, resized; augmentations applied), class-contiguous — what the
+        input pipeline's worker threads run (embeddingnet_amd/input_pipeline.py); file-backed datasets only."""
+        classes, idxs = plan
+        h, w = self.input_shape[0], self.input_shape[1]
+        if out is None:
+            out = np.empty((self.k_classes * self.k_samples, h, w, 3), np.uint8)
+        row = 0
+        for cl, ix in zip(classes, idxs):
+            src = self.class_files_paths[cl]
+            if isinstance(src, np.ndarray):
+                raise TypeError("load_plan_u8: in-memory float datasets are not uint8 images")
+            for i in ix:
+                img = get_image(src[int(i)], self.input_shape)
+                if self.augmentations is not None:
+                    img = self.augmentations(image=img)['image']
+                out[row] = img
+                row += 1
+        return out
+
+    def load_plan(self, plan):
+        """The planned batch as the reference delivers it: float32 [P*K,H,W,3] in [0,1] (reference :211-218)."""
+        classes, idxs = plan
         return np.vstack([self._get_images_set(cl, ix, with_aug=self.augmentations) for cl, ix in zip(classes, idxs)])
+
+    def sample_batch(self):
+        """reference :202-205,211-218: P classes without replacement, K images per class WITH replacement,
+        stacked class-contiguous.  Returns float32 [P*K,H,W,3]."""
+        return self.load_plan(self.sample_plan())
+
+    def feeder(self, device, depth=10, workers=None, log=None):
+        """The batches of sample_batch() as device tensors, produced ahead of the step (input_pipeline.Feeder)."""
+        from .input_pipeline import Feeder
+        return Feeder(self, device, depth=depth, workers=workers, log=log)
 
     def get_batch_triplets_mining(self):
         """reference :201-258 with the embedding / distance / mining work on the GPU."""

@@ -270,6 +270,14 @@ size_t embnet_conv2d_wgrad_planes_workspace_bytes(int n, int h, int wd, int c, i
 int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw, void* workspace,
                                    size_t workspace_bytes, int n, int h, int wd, int c, int k, int reduce, void* stream);
 
+/* Input pipeline, last step (datagenerators.py:145-156: cv2 decode -> resize -> `/ 255.` on the host, per batch): uint8
+ * images [n_src, pixels, c_in] (BGR as decoded) -> float32 batch dst[n, pixels, c_out]:
+ *   dst[i][p][j] = j < c_in ? src[index ? index[i] : i][p][j] / denom : 0      (float32 division: the reference's values bit for bit)
+ * index (NULL = the first n images in order) gathers a batch out of a dataset that is resident in HBM as uint8; c_out > c_in
+ * pads channels with zeros (the 4-channel image the stem convolution gathers 16 bytes at a time).  n <= 65535. */
+int embnet_u8_to_f32(const void* src, const int32_t* index, int n, long pixels, int c_in, int c_out, float denom, float* dst,
+                     void* stream);
+
 /* Dense (backbones.py:35,72,75,114,116; models.py:44): x[m,in], w[in,out], y[m,out].
  * workspace (optional, may be NULL/0): >= embnet_dense_fwd_workspace_bytes lets a forward with few output tiles and a long
  * reduction (simple2's Flatten -> Dense(512): 12 800 x 512 at batch 32) cut K over workgroups (partial slabs + fixed-order

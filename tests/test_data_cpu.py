@@ -119,3 +119,69 @@ def test_triplet_sampler_is_class_contiguous_with_replacement(tree):
     assert (cls == cls[:, :1]).all() and len(set(cls[:, 0])) == 3          # contiguous blocks, distinct classes
     with pytest.raises(KeyError):
         TripletsDataGenerator(None, dl.train_data, dl.class_names, negatives_selection_mode="nope")
+
+
+def _gen(tree, k_classes=3, k_samples=4, shape=(16, 16, 3)):
+    from embeddingnet_amd.datagenerators import ENDataLoader, TripletsDataGenerator
+    dl = ENDataLoader(str(tree), validate=False)
+    return TripletsDataGenerator(embedding_model=None, class_files_paths=dl.train_data, class_names=dl.class_names,
+                                 input_shape=list(shape), k_classes=k_classes, k_samples=k_samples, margin=0.5,
+                                 negatives_selection_mode="semihard")
+
+
+def test_sample_plan_draws_the_reference_stream_and_loads_the_same_batch(tree):
+    """sample_batch() = load_plan(sample_plan()): the plan consumes the global np.random stream exactly as the reference's
+    sampler does (datagenerators.py:202-205: one choice() of the classes, then one choice() per class), and the uint8 form
+    the input pipeline moves (load_plan_u8) divided by 255 in float32 IS the float batch."""
+    gen = _gen(tree)
+    np.random.seed(5)
+    want_cls = np.random.choice(gen.n_classes, size=3, replace=False)
+    want_idx = [np.random.choice(gen.n_samples[gen.class_names[c]], size=4, replace=True) for c in want_cls]
+    after = np.random.randint(1 << 30)
+    np.random.seed(5)
+    classes, idxs = gen.sample_plan()
+    assert classes == [gen.class_names[c] for c in want_cls] and all(np.array_equal(a, b) for a, b in zip(idxs, want_idx))
+    assert np.random.randint(1 << 30) == after                             # nothing else was drawn
+    np.random.seed(5)
+    batch = gen.sample_batch()
+    u8 = gen.load_plan_u8((classes, idxs))
+    assert u8.dtype == np.uint8 and u8.shape == (12, 16, 16, 3)
+    assert np.array_equal(u8.astype(np.float32) / np.float32(255.), batch)
+
+
+def test_prefetcher_delivers_the_planned_batches_in_order(tree):
+    """BatchPrefetcher's host side: plans are drawn on the consumer's thread (so the np.random stream is the sequential one),
+    worker threads decode `depth` batches ahead, batches come out in plan order and equal the sequential sample_batch() run."""
+    from embeddingnet_amd.input_pipeline import BatchPrefetcher
+    gen = _gen(tree)
+    np.random.seed(11)
+    want = [gen.sample_batch() for _ in range(9)]
+    np.random.seed(11)
+    pf = BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (12, 16, 16, 3), "cpu", depth=4, workers=3)
+    try:
+        for w in want[: 9 - 4]:                                            # (the prefetcher has drawn `depth` plans ahead)
+            got = pf.next_u8().numpy().astype(np.float32) / np.float32(255.)
+            assert np.array_equal(got, w)
+        with pytest.raises(Exception):
+            pf.next()                                                      # device tensors need the device: no CPU conversion
+    finally:
+        pf.close()
+
+
+def test_prefetcher_surfaces_a_worker_error(tree):
+    from embeddingnet_amd.input_pipeline import BatchPrefetcher
+    gen = _gen(tree)
+    calls = []
+
+    def load(plan, out):
+        calls.append(1)
+        if len(calls) == 3:
+            raise FileNotFoundError("gone.jpg")
+        return gen.load_plan_u8(plan, out)
+    pf = BatchPrefetcher(gen.sample_plan, load, (12, 16, 16, 3), "cpu", depth=2, workers=1)
+    try:
+        pf.next_u8(); pf.next_u8()
+        with pytest.raises(FileNotFoundError):
+            pf.next_u8()
+    finally:
+        pf.close()

@@ -193,7 +193,12 @@ def main():
     history = {'loss': [], 'val_loss': []}
     n_epochs = min(p_train['n_epochs'], args.max_epochs or p_train['n_epochs'])
 
+    # triplet mode: batches are planned on this thread and decoded / uploaded ahead of the step (input_pipeline.Feeder: the
+    # role of Keras' fit_generator enqueuer, reference train.py:172-177)
+    feeder = None if siamese else train_gen.feeder(dev, log=(print if rank == 0 else None))
+    import time
     for epoch in range(n_epochs):
+        t_epoch, n_images = time.perf_counter(), 0
         # LearningRateScheduler.on_epoch_begin (reference train.py:80-81): sets the rate outright, which discards the
         # previous epoch's ReduceLROnPlateau reduction (see Plateau) unless TRAIN.plateau_persistent is set
         lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size'])
@@ -215,10 +220,14 @@ def main():
                 opt.step()
                 losses.append(loss.detach())
             else:
-                losses.append(trainer.step(torch.from_numpy(train_gen.sample_batch()).to(dev)))
+                xb = feeder.next()
+                n_images += xb.shape[0]
+                losses.append(trainer.step(xb))
         epoch_loss = all_reduce_mean(float(torch.stack(losses).mean().item()))     # mean over ranks (logging + monitor)
         history['loss'].append(epoch_loss)
         msg = f'Epoch {epoch + 1}/{n_epochs} - lr {lr:.3g} - loss {epoch_loss:.4f}'
+        if n_images:                                  # (the .item() above waited for the epoch's last step)
+            msg += f' - {n_images * world / (time.perf_counter() - t_epoch):.0f} images/s'
         value = epoch_loss
         if val_gen is not None:
             trainable.eval()
