@@ -125,13 +125,30 @@ extern "C" int embnet_debug_set_stamps_pairwise(void* buf) {      // diagnostic 
 }
 #endif
 
+// Tile and K-split choice.  A launch should put >= ~512 workgroups on the 256 CUs (two resident per CU cover each other's
+// prologue and epilogue): 128x128 tiles from 384 tiles on (N >= ~2 500); below that 64x64 tiles, and where even those are
+// fewer than 512 the reduction is cut over workgroups (partial Gram slabs + pairwise_finish_kernel) — round 4 ran N = 1 024 as
+// 64 tiles of 128x128 on a quarter of the chip (0.13-0.17 of the fp32 MFMA peak, profiles/r04_gemm_sweep.json; now 0.29-0.52).
+static bool pairwise_big_tiles(int n) {
+  static const long gl_min = env_long("EMBNET_PAIRWISE_GL_MIN_TILES", 384);
+  return (long)cdiv(n, 128) * cdiv(n, 128) >= gl_min;
+}
 static void pairwise_plan(int n, int e, int& splits, int& kt_per_split) {
   const int kt_total = cdiv(e, BK);
   splits = 1; kt_per_split = kt_total;
+  if (pairwise_big_tiles(n)) return;
   const long tiles = (long)cdiv(n, 64) * cdiv(n, 64);
-  if (n >= 512 || kt_total < 32) return;
-  long want = 256 / tiles;
-  if (want > kt_total / 8) want = kt_total / 8;
+  // measured (tools/exp/run_r05_gemm_mid.sh, profiles/r05_gemm_mid_sweep.txt): the split pays where the tiles alone leave CUs
+  // idle (N = 512: 64 tiles) or the reduction is long (E >= 2 048: a second workgroup per CU hides the first one's latencies);
+  // at N = 1 024, E <= 512 the 256 tiles already occupy every CU and the slab pass only adds its ~6 us (17.5 vs 11.7 us)
+  static const long target = env_long("EMBNET_PAIRWISE_SPLIT_TARGET", 0);
+  static const long min_kt = env_long("EMBNET_PAIRWISE_MIN_KT", 4);
+  long want = (target > 0 ? target : (kt_total >= 64 ? 512 : 256)) / tiles;
+  if (n < 512) {                                     // the batch sizes of a training step: as tuned in round 3
+    if (kt_total < 32) return;
+    want = 256 / tiles; if (want > kt_total / 8) want = kt_total / 8;
+  }
+  else if (want > kt_total / min_kt) want = kt_total / min_kt;
   if (want < 2) return;
   kt_per_split = cdiv(kt_total, want);
   splits = cdiv(kt_total, kt_per_split);
@@ -175,7 +192,7 @@ extern "C" int embnet_pairwise_dist_f32(const float* x, int n, int e, float* dis
     return check_launch("pairwise_dist");
   }
   EMBNET_TRACE_FLOP("embnet::pairwise_kernel", 2.0 * n * n * e, 4.0 * ((double)n * e + (double)n * n), s);
-  if (n >= 1024) {
+  if (pairwise_big_tiles(n)) {
     const int grid = cdiv(n, 128) * cdiv(n, 128);
     if (vec) pairwise_kernel<GL, true><<<grid, 256, 0, s>>>(p); else pairwise_kernel<GL, false><<<grid, 256, 0, s>>>(p);
   } else {
@@ -275,8 +292,16 @@ extern "C" int embnet_cross_dist_f32(const float* q, int nq, const float* x, int
   CrossParams p{q, x, qn, xn, dist, nq, n, e, squared};
   const bool vec = (e & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   using GS = Geom<64, 64, 2, 2>;
-  const int grid = cdiv(nq, 64) * cdiv(n, 64);
-  if (vec) cross_dist_kernel<GS, true><<<grid, 256, 0, s>>>(p); else cross_dist_kernel<GS, false><<<grid, 256, 0, s>>>(p);
+  using GL = Geom<128, 128, 2, 2>;
+  EMBNET_TRACE_FLOP("embnet::cross_dist_kernel", 2.0 * nq * n * e, 4.0 * ((double)nq * e + (double)n * e + (double)nq * n), s);
+  static const long gl_min = env_long("EMBNET_PAIRWISE_GL_MIN_TILES", 384);
+  if ((long)cdiv(nq, 128) * cdiv(n, 128) >= gl_min) {           // queries x gallery large enough to fill the chip with 128x128 tiles
+    const int grid = cdiv(nq, 128) * cdiv(n, 128);
+    if (vec) cross_dist_kernel<GL, true><<<grid, 256, 0, s>>>(p); else cross_dist_kernel<GL, false><<<grid, 256, 0, s>>>(p);
+  } else {
+    const int grid = cdiv(nq, 64) * cdiv(n, 64);
+    if (vec) cross_dist_kernel<GS, true><<<grid, 256, 0, s>>>(p); else cross_dist_kernel<GS, false><<<grid, 256, 0, s>>>(p);
+  }
   return check_launch("cross_dist");
 }
 

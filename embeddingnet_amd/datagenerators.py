@@ -178,7 +178,7 @@ class TripletsDataGenerator(ENDataGenerator):
         """The planned batch as DECODED uint8 [P*K,H,W,3] (BGR, resized; augmentations applied), class-contiguous — what the
         input pipeline's worker threads run (embeddingnet_amd/input_pipeline.py); file-backed datasets only."""
         classes, idxs = plan
-        h, w = self.input_shape[0], self.input_shape[1]
+        h, w = self.input_shape[1], self.input_shape[0]     # get_image resizes to (input_shape[0], input_shape[1]) = (width, height)
         if out is None:
             out = np.empty((self.k_classes * self.k_samples, h, w, 3), np.uint8)
         row = 0

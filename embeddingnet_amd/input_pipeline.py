@@ -62,7 +62,10 @@ class DeviceImageStore:
 
     def __init__(self, class_files_paths, class_names, input_shape, device, workers=None, chunk=512, log=None):
         self.device = torch.device(device)
-        self.shape = (int(input_shape[0]), int(input_shape[1]), 3)
+        # (rows, columns) of a decoded image: get_image resizes to (input_shape[0], input_shape[1]) = (width, height), the
+        # reference's cv2.resize call (utils.py:13-21) — the same thing for the square shapes every shipped config uses
+        self.input_shape = [int(input_shape[0]), int(input_shape[1]), 3]
+        self.shape = (int(input_shape[1]), int(input_shape[0]), 3)
         self.first, files = {}, []
         for cl in class_names:
             self.first[cl] = len(files)
@@ -83,7 +86,7 @@ class DeviceImageStore:
                 view = host.numpy()
 
                 def one(i, path=None):
-                    view[i] = decode_u8(part[i], self.shape)
+                    view[i] = decode_u8(part[i], self.input_shape)
                 list(pool.map(one, range(len(part))))
                 self.data[lo:lo + len(part)].copy_(host, non_blocking=False)
         self.decode_seconds = time.perf_counter() - t0
@@ -211,7 +214,7 @@ class Feeder:
             else:
                 self.kind = "prefetch"
                 b = gen.k_classes * gen.k_samples
-                self.prefetch = BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (b, gen.input_shape[0], gen.input_shape[1], 3),
+                self.prefetch = BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (b, gen.input_shape[1], gen.input_shape[0], 3),
                                                 device, depth, workers)
         if log:
             log(f"input pipeline: {self.kind}")

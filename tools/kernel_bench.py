@@ -44,7 +44,7 @@ def gemm_sweep(args):
             x = torch.rand((n, e), device=dev, generator=g)
             x = x / x.norm(dim=1, keepdim=True)
             lib = _lib.lib()
-            ws = torch.empty(max(n, 256), device=dev)
+            ws = torch.empty(max(lib.embnet_pairwise_workspace_bytes(n, e) // 4 + 4, 256), device=dev)     # (room for the K-split slabs)
             d = torch.empty((n, n), device=dev)
             fn = lambda: check(lib.embnet_pairwise_dist_f32(ptr(x), n, e, ptr(d), 0, ptr(ws), ws.numel() * 4, stream()))
             t = timeit(fn, iters=args.iters)
@@ -52,6 +52,21 @@ def gemm_sweep(args):
             rows.append(dict(N=n, E=e, us=round(t * 1e6, 1), tflops=round(tf, 2), frac=round(tf / PEAK, 4)))
             print(f"pairwise N={n:6d} E={e:5d}  {t * 1e6:10.1f} us  {tf:7.2f} TFLOP/s  {tf / PEAK:6.1%} of fp32 MFMA peak",
                   flush=True)
+    # the kNN evaluation's cross-distance (reference models.py:128-142 through sklearn's brute-force kneighbors): queries x gallery
+    for (nq, n) in ((1024, 16384), (1024, 4096)):
+        for e in args.e:
+            if e > 1024:
+                continue
+            g = torch.Generator(device=dev).manual_seed(8)
+            q, x = torch.rand((nq, e), device=dev, generator=g), torch.rand((n, e), device=dev, generator=g)
+            lib = _lib.lib()
+            ws = torch.empty(lib.embnet_cross_dist_workspace_bytes(nq, n) // 4 + 4, device=dev)
+            d = torch.empty((nq, n), device=dev)
+            fn = lambda: check(lib.embnet_cross_dist_f32(ptr(q), nq, ptr(x), n, e, ptr(d), 0, ptr(ws), ws.numel() * 4, stream()))
+            t = timeit(fn, iters=args.iters)
+            tf = 2.0 * nq * n * e / t / 1e12
+            rows.append(dict(kind="cross", Q=nq, N=n, E=e, us=round(t * 1e6, 1), tflops=round(tf, 2), frac=round(tf / PEAK, 4)))
+            print(f"cross    Q={nq:5d} N={n:6d} E={e:5d}  {t * 1e6:10.1f} us  {tf:7.2f} TFLOP/s  {tf / PEAK:6.1%} of fp32 MFMA peak", flush=True)
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 
