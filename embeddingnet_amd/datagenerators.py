@@ -19,16 +19,7 @@ import torch
 from . import ops
 
 
-def get_image(img_path, input_shape=None):
-    """reference utils.py:13-21 (cv2.imread + resize) on PIL: uint8 HxWx3, BGR channel order."""
-    from PIL import Image
-    if not os.path.exists(img_path):
-        print('image is not exist ' + img_path)
-        return None
-    img = Image.open(img_path).convert("RGB")
-    if input_shape:
-        img = img.resize((input_shape[0], input_shape[1]), Image.BILINEAR)
-    return np.asarray(img)[:, :, ::-1]
+from ._decode_worker import get_image      # noqa: E402,F401  (torch-free module: the decode worker processes import it)
 
 
 class ENDataLoader():
@@ -173,6 +164,11 @@ class TripletsDataGenerator(ENDataGenerator):
         classes = [self.class_names[c] for c in selected]
         idxs = [np.random.choice(self.n_samples[cl], size=self.k_samples, replace=True) for cl in classes]
         return classes, idxs
+
+    def plan_paths(self, plan):
+        """The planned batch's image files in row order (class-contiguous) — what the decode worker processes are handed."""
+        classes, idxs = plan
+        return [self.class_files_paths[cl][int(i)] for cl, ix in zip(classes, idxs) for i in ix]
 
     def load_plan_u8(self, plan, out=None):
         """The planned batch as DECODED uint8 [P*K,H,W,3] (BGR, resized; augmentations applied), class-contiguous — what the

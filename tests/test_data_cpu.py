@@ -185,3 +185,30 @@ def test_prefetcher_surfaces_a_worker_error(tree):
             pf.next_u8()
     finally:
         pf.close()
+
+
+def test_prefetcher_with_decode_worker_processes(tree):
+    """The same batches when worker PROCESSES (python -m embeddingnet_amd._decode_worker: no torch) decode into the shared
+    staging array; a missing file surfaces as an error on the consumer's thread; the staging file is removed on close."""
+    from embeddingnet_amd.input_pipeline import BatchPrefetcher
+    gen = _gen(tree)
+    np.random.seed(13)
+    want = [gen.sample_batch() for _ in range(7)]
+    np.random.seed(13)
+    pf = BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (12, 16, 16, 3), "cpu", depth=3, workers=2, paths_fn=gen.plan_paths,
+                         input_shape=gen.input_shape, rows_per_task=5)
+    path = pf.procs.path
+    try:
+        assert os.path.exists(path)
+        for w in want[:4]:
+            assert np.array_equal(pf.next_u8().numpy().astype(np.float32) / np.float32(255.), w)
+    finally:
+        pf.close()
+    assert not os.path.exists(path)
+    bad = BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (12, 16, 16, 3), "cpu", depth=2, workers=2,
+                          paths_fn=lambda plan: ["/nonexistent/x.jpg"] * 12, input_shape=gen.input_shape)
+    try:
+        with pytest.raises(RuntimeError, match="FileNotFoundError"):
+            bad.next_u8()
+    finally:
+        bad.close()

@@ -64,7 +64,7 @@ def test_u8_to_f32_is_the_reference_division(dev, n, h, w, pad):
     assert rc != 0 and b"u8_to_f32" in _lib.lib().embnet_last_error()
 
 
-@pytest.mark.parametrize("kind", ["store", "prefetch"])
+@pytest.mark.parametrize("kind", ["store", "prefetch", "prefetch-threads"])
 def test_feeder_equals_sample_batch(dev, tree, kind, monkeypatch):
     """The HBM-resident store and the prefetcher deliver, batch after batch, exactly the tensor the sequential
     sample_batch() -> torch.from_numpy -> .to(device) path delivered (same np.random stream, same float32 values)."""
@@ -73,10 +73,13 @@ def test_feeder_equals_sample_batch(dev, tree, kind, monkeypatch):
     np.random.seed(3)
     want = [gen.sample_batch() for _ in range(14)]
     monkeypatch.setenv("EMBNET_IMAGE_STORE", "1" if kind == "store" else "0")
+    monkeypatch.setenv("EMBNET_DECODE_PROCESSES", "0" if kind == "prefetch-threads" else "1")
+    kind = kind.split("-")[0]
     np.random.seed(3)
     feeder = gen.feeder(dev, depth=4, workers=3)
-    assert feeder.kind == kind
+    assert feeder.kind.startswith(kind)
     try:
+        assert kind == "store" or ("processes" in feeder.kind) == (os.environ["EMBNET_DECODE_PROCESSES"] == "1")
         for w in want[: 14 - (4 if kind == "prefetch" else 0) - 1]:
             got = feeder.next()
             assert got.dtype == torch.float32 and got.is_cuda and np.array_equal(got.cpu().numpy(), w)

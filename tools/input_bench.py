@@ -5,7 +5,8 @@ Writes a JPEG tree (`--classes` x `--per-class` files at the config's resolution
 the fused triplet step of a bench config (c1: simple2 64x64 8x4; c2: ResNet18 224x224 32x4) fed four ways:
   resident     one batch already in HBM, stepped on repeatedly (what bench.py times, minus its batch cycling)
   sequential   the round-4 path: sample_batch() (PIL decode + /255 on the training thread) -> from_numpy -> blocking copy
-  prefetch     input_pipeline.BatchPrefetcher: worker threads decode `depth` batches ahead into pinned uint8, side-stream copy
+  prefetch     input_pipeline.BatchPrefetcher: worker PROCESSES decode `depth` batches ahead into a shared, page-locked uint8
+               staging array, side-stream copy (prefetch_threads: the same with a thread pool — GIL-bound)
   store        input_pipeline.DeviceImageStore: dataset decoded once, uint8 resident in HBM, one gather+convert kernel per batch
 Prints one JSON object (images/s each, the host core count, decode rate, store build time)."""
 import argparse
@@ -104,6 +105,11 @@ def main():
     out["sequential_images_per_s"], out["sequential_ms_per_step"] = timed(lambda: torch.from_numpy(gen.sample_batch()).to(dev),
                                                                           steps=seq_steps, warm=2)
     pf = IP.BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (n,) + shape, dev, depth=args.depth, workers=workers)
+    out["prefetch_threads_images_per_s"], out["prefetch_threads_ms_per_step"] = timed(pf.next, steps=max(10, seq_steps))
+    pf.close()
+    pf = IP.BatchPrefetcher(gen.sample_plan, gen.load_plan_u8, (n,) + shape, dev, depth=args.depth, workers=workers,
+                            paths_fn=gen.plan_paths, input_shape=list(shape))
+    out["prefetch_staging_pinned"] = bool(getattr(pf, "pinned", False))
     out["prefetch_images_per_s"], out["prefetch_ms_per_step"] = timed(pf.next)
     pf.close()
     msgs = []
