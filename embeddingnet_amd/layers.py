@@ -63,9 +63,149 @@ def workspace(nbytes, device):
 # queued, and flush_slab_reduces() adds ALL queued gradients up in one launch (embnet_slab_reduce_multi; same summation
 # order, bit-identical) — before the optimizer, or before a gradient bucket's all-reduce.  Nothing else may read a queued
 # dw before the flush; outside the trainer the flag is off and every wgrad finishes in place.
+# ---- step context ------------------------------------------------------------------------------------------------------
+# Fused kernels hand side-products from one autograd node to another (a BatchNorm backward's masked gradient to the conv in
+# front of it, a data gradient's column sums to the BatchNorm behind it, planes of a gradient to the patch conv, split-K slabs
+# to the one launch that sums them ...).  Every such hand-over lives in a StepContext — not in module globals — and the names
+# this module has always used (BN_SUMS, RELU_DONE, GATE_PENDING, POOL_PENDING, DY_PLANES, _BN_FWD_STATS, _ACT_PLANES,
+# _SLAB_PENDING) are views of the CURRENT context:
+#   * TripletTrainer owns one context per trainer and runs every step inside it (train_step.py); two models trained or
+#     evaluated in one process therefore never see each other's entries;
+#   * bare autograd use (SiameseNet's loop, user scripts) runs in the default context;
+#   * whatever a backward pass leaves unclaimed (a gradient that got a second contribution never meets its entry) is dropped
+#     when THAT backward ends — the first entry made during a backward queues an end-of-backward callback on the autograd
+#     engine — and counted in `context.unclaimed`, so entries neither pile up nor pin activation-sized tensors.
+class StepContext:
+    DICTS = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "bn_fwd_stats", "act_planes")
+    BACKWARD = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes")      # made and consumed inside one backward
+
+    def __init__(self, name="default"):
+        self.name = name
+        for n in self.DICTS:
+            setattr(self, n, {})
+        self.slab_pending = []
+        self.unclaimed = {}                 # dict name -> entries dropped at the end of a backward, over the context's life
+        self._armed = -1
+
+    def leftovers(self):
+        return {n: len(getattr(self, n)) for n in self.DICTS if getattr(self, n)}
+
+    def end_of_backward(self):
+        self._armed = -1
+        for n in self.BACKWARD:
+            d = getattr(self, n)
+            if d:
+                self.unclaimed[n] = self.unclaimed.get(n, 0) + len(d)
+                d.clear()
+
+    def clear(self):
+        for n in self.DICTS:
+            getattr(self, n).clear()
+        self.slab_pending.clear()
+
+
+_CONTEXTS = [StepContext("default")]
+
+
+def current_context():
+    return _CONTEXTS[-1]
+
+
+class step_context:
+    """`with step_context(ctx):` — the fused hand-overs of everything run inside go through `ctx`."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        _CONTEXTS.append(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _CONTEXTS.pop()
+        return False
+
+
+def _arm_cleanup(ctx):
+    """Inside a backward pass: make sure ctx.end_of_backward runs when this pass ends."""
+    try:
+        tid = torch._C._current_graph_task_id()
+    except AttributeError:
+        return
+    if tid != -1 and ctx._armed != tid:
+        ctx._armed = tid
+        torch.autograd.Variable._execution_engine.queue_callback(ctx.end_of_backward)
+
+
+class _CtxDict:
+    """A module-level name that reads and writes the CURRENT context's dict of that name."""
+
+    def __init__(self, name):
+        self._n = name
+
+    def _d(self):
+        return getattr(_CONTEXTS[-1], self._n)
+
+    def __setitem__(self, k, v):
+        ctx = _CONTEXTS[-1]
+        if self._n in StepContext.BACKWARD:
+            _arm_cleanup(ctx)
+        getattr(ctx, self._n)[k] = v
+
+    def __getitem__(self, k):
+        return self._d()[k]
+
+    def __contains__(self, k):
+        return k in self._d()
+
+    def __len__(self):
+        return len(self._d())
+
+    def __iter__(self):
+        return iter(self._d())
+
+    def __bool__(self):
+        return bool(self._d())
+
+    def pop(self, *a):
+        return self._d().pop(*a)
+
+    def get(self, *a):
+        return self._d().get(*a)
+
+    def clear(self):
+        self._d().clear()
+
+    def items(self):
+        return self._d().items()
+
+
+class _CtxList:
+    def __init__(self, name):
+        self._n = name
+
+    def _l(self):
+        return getattr(_CONTEXTS[-1], self._n)
+
+    def append(self, v):
+        self._l().append(v)
+
+    def clear(self):
+        self._l().clear()
+
+    def __iter__(self):
+        return iter(self._l())
+
+    def __len__(self):
+        return len(self._l())
+
+    def __bool__(self):
+        return bool(self._l())
+
+
 SLAB_DEFER = [False]
 SLAB_DEFER_ENABLED = [_os.environ.get("EMBNET_SLAB_DEFER", "1") != "0"]      # [False]: per-layer slab sums everywhere (A/B)
-_SLAB_PENDING = []          # (slab buffer, dw, elements, splits)
+_SLAB_PENDING = _CtxList("slab_pending")          # (slab buffer, dw, elements, splits, kernel) of the current context
 _SLAB_BUFS = {}             # kernel storage address -> slab buffer (scratch: any stale content is overwritten before use)
 
 
@@ -200,23 +340,23 @@ FUSE_DROP_ADD = [__import__("os").environ.get("EMBNET_FUSE_DROP_ADD", "1") == "1
 DW_EMIT_STATS = [__import__("os").environ.get("EMBNET_DW_EMIT_STATS", "1") == "1"]     # depthwise forward emits the next BN's statistics
 DW_BN_SUMS = [__import__("os").environ.get("EMBNET_DW_BN_SUMS", "1") == "1"]   # ... and its stride-1 data gradient the previous BN's backward sums
 SE_TWO_STAGE = [__import__("os").environ.get("EMBNET_SE_TWO_STAGE", "1") == "1"]  # ... and the activated tensor is never written (se_gate)
-POOL_PENDING = {}
+POOL_PENDING = _CtxDict("pool_pending")
 SE_BN_SUMS = [__import__("os").environ.get("EMBNET_SE_BN_SUMS", "1") == "1"]      # ... and its reduction pass rides on the gate's gradient pass
 FUSE_GATE_BN = [__import__("os").environ.get("EMBNET_FUSE_GATE_BN", "1") == "1"]
-GATE_PENDING = {}
+GATE_PENDING = _CtxDict("gate_pending")
 FUSE_GAP_BN = [__import__("os").environ.get("EMBNET_FUSE_GAP_BN", "1") == "1"]
-BN_SUMS = {}
-_BN_FWD_STATS = {}
+BN_SUMS = _CtxDict("bn_sums")
+_BN_FWD_STATS = _CtxDict("bn_fwd_stats")
 
 # a Dropout directly behind a BatchNormalization rides on the BatchNormalization's kernels (backbones.Seq); 0: separate passes
 FUSE_DROPOUT_BN = [__import__("os").environ.get("EMBNET_FUSE_DROPOUT_BN", "1") == "1"]
 FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
 # conv -> ReLU -> MaxPool (the 'simple' backbone): the same hand-over from MaxPool2D's backward (embnet_maxpool_relu_bwd_colsum)
 FUSE_RELU_POOL = [_os.environ.get("EMBNET_FUSE_RELU_POOL", "1") != "0"]
-RELU_DONE = {}
+RELU_DONE = _CtxDict("relu_done")
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
-DY_PLANES = {}
-_ACT_PLANES = {}
+DY_PLANES = _CtxDict("dy_planes")
+_ACT_PLANES = _CtxDict("act_planes")
 WEIGHT_EPOCH = [0]
 
 

@@ -45,6 +45,7 @@ class TripletTrainer:
         self.model, self.opt = base_model, optimizer
         self.p, self.k, self.margin, self.mode = int(k_classes), int(k_samples), float(margin), negatives_selection_mode
         self.seed, self.step_no, self.reducer = int(seed), 0, reducer
+        self.ctx = L.StepContext(f"TripletTrainer@{id(self):x}")       # this trainer's fused hand-overs (layers.StepContext)
         # one launch for distance matrix + mining + hinge + mean when the batch fits the fused kernel (N <= 512)
         self.fused_loss = os.environ.get("EMBNET_FUSED_LOSS", "1") == "1"
         if self.mode not in tuple(ops.MINING_MODES) + ("batch_hard",):
@@ -275,6 +276,12 @@ class TripletTrainer:
                 self.opt.coef_dev = saved
 
     def _eager_step(self, images, count_step=False, with_update=True):
+        """One step inside THIS trainer's step context (layers.StepContext): the fused hand-overs of its forward and backward
+        never meet those of another model stepped or evaluated in the same process."""
+        with L.step_context(self.ctx):
+            return self._eager_step_body(images, count_step, with_update)
+
+    def _eager_step_body(self, images, count_step=False, with_update=True):
         self.model.train()
         if count_step:
             self.step_no += 1
@@ -296,12 +303,10 @@ class TripletTrainer:
         finally:
             L.SLAB_DEFER[0] = False
             L.flush_slab_reduces()              # (with a reducer: what its buckets have not flushed already)
-        L.RELU_DONE.clear()
-        L.BN_SUMS.clear()                       # BatchNorm-backward sums nobody collected (the gradient had a second contribution)
+        # what the backward left unclaimed (BatchNorm-backward sums whose gradient got a second contribution, gradient planes of a
+        # consumer that fell back to the fp32 kernel) was dropped and counted when the backward ended (StepContext.end_of_backward)
+        self.ctx.end_of_backward()
         L._BN_FWD_STATS.clear()
-        L.GATE_PENDING.clear()
-        L.POOL_PENDING.clear()
-        L.DY_PLANES.clear()                     # gradient planes nobody collected (a consumer that fell back to the fp32 kernel)
         if self.reducer is not None:
             self.reducer.finish()
         if with_update:

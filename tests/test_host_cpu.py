@@ -27,7 +27,10 @@ def test_library_exports_every_declared_symbol():
     assert bound.embnet_pairwise_workspace_bytes(128, 256) == 512          # row norms only: short reduction, no K split
     # the reference's default encodings_len = 4096 at a 128-row batch: 4 tiles x 128 K tiles -> K split, partial Gram slabs
     assert bound.embnet_pairwise_workspace_bytes(128, 4096) == 512 + 16 * 128 * 128 * 4
-    assert bound.embnet_pairwise_workspace_bytes(1024, 4096) == 4096          # enough tiles: unsplit
+    # N = 1 024: 256 tiles of 64x64 occupy every CU -> unsplit at E <= 1 024; a long reduction gets a second workgroup per CU
+    assert bound.embnet_pairwise_workspace_bytes(1024, 512) == 4096
+    assert bound.embnet_pairwise_workspace_bytes(1024, 4096) == 4096 + 2 * 1024 * 1024 * 4
+    assert bound.embnet_pairwise_workspace_bytes(4096, 4096) == 4 * 4096     # 1 024 tiles of 128x128: unsplit
     # simple2's Flatten -> Dense(512) at batch 32: 8 output tiles, 400 K tiles -> split; ResNet heads: not
     assert bound.embnet_dense_fwd_workspace_bytes(32, 12800, 512) == 58 * 32 * 512 * 4
     assert bound.embnet_dense_fwd_workspace_bytes(128, 512, 128) == 0

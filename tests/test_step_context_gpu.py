@@ -1,0 +1,108 @@
+"""The fused hand-overs live in a step context (layers.StepContext), not in module globals:
+two models alive in one process, a forward that is never followed by a backward, and plain autograd loops all leave the
+training step's results bit for bit what an isolated run produces, and nothing piles up."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _trainer(dev, name, shape, seed, p=4, k=3):
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+    base, _ = B.get_backbone(shape, encodings_len=32, backbone_name=name, backbone_weights=None, seed=seed, device=dev)
+    for m in base.modules():
+        if hasattr(m, "enabled"):
+            m.enabled = False
+    opt = KerasOptimizer([q for q in base.parameters() if q.requires_grad], "adam", 1e-3)
+    return base, TripletTrainer(base, opt, p, k, margin=0.5, negatives_selection_mode="hardest", seed=1)
+
+
+def _batches(dev, shape, n, count, seed):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    return [torch.rand((n,) + shape, device=dev, generator=gen) for _ in range(count)]
+
+
+def _weights(model):
+    return [q.detach().clone() for q in model.parameters()]
+
+
+@pytest.mark.parametrize("name,shape", [("resnet18", (64, 64, 3)), ("efficientnet-b0", (64, 64, 3)), ("simple2", (64, 64, 3))])
+def test_two_models_interleaved_equal_the_isolated_runs(dev, name, shape):
+    """A training model and a second model (validation forwards in inference mode, AND a second trainer stepping between the
+    first one's steps) in one process: the first trainer's losses and final weights are bit for bit those of a run on its own."""
+    from embeddingnet_amd import layers as L
+    xs = _batches(dev, shape, 12, 4, seed=3)
+    base, tr = _trainer(dev, name, shape, seed=2)
+    alone = [tr.step(x).item() for x in xs]
+    w_alone = _weights(base)
+    del base, tr
+    base, tr = _trainer(dev, name, shape, seed=2)
+    other, tr_other = _trainer(dev, name, shape, seed=9)
+    ys = _batches(dev, shape, 12, 4, seed=8)
+    mixed = []
+    for x, y in zip(xs, ys):
+        other.eval()
+        with torch.no_grad():
+            other(y)                                   # a validation forward of another model
+        tr_other.step(y)                               # ... and a training step of it
+        mixed.append(tr.step(x).item())
+        assert tr.ctx is not tr_other.ctx and not tr.ctx.leftovers() and not tr_other.ctx.leftovers()
+    assert mixed == alone
+    for a, b in zip(w_alone, _weights(base)):
+        assert torch.equal(a, b)
+    assert not L.current_context().leftovers() and L.current_context().name == "default"
+
+
+def test_forward_without_backward_then_a_training_step(dev):
+    """A training-mode forward whose graph is dropped (no backward), then a training step: same loss and weights as the step
+    alone; the orphaned forward leaves nothing in any context."""
+    from embeddingnet_amd import layers as L
+    shape = (64, 64, 3)
+    xs = _batches(dev, shape, 12, 3, seed=4)
+    base, tr = _trainer(dev, "resnet18", shape, seed=5)
+    alone = [tr.step(x).item() for x in xs]
+    w_alone = _weights(base)
+    del base, tr
+    base, tr = _trainer(dev, "resnet18", shape, seed=5)
+    got = []
+    for x in xs:
+        mm = [m.moving_mean.clone() for m in base.modules() if hasattr(m, "moving_mean")]
+        base.train()
+        orphan = base(xs[0] * 0.5)                     # builds an autograd graph (and would update BN moving statistics) ...
+        del orphan
+        for m, keep in zip([m for m in base.modules() if hasattr(m, "moving_mean")], mm):
+            m.moving_mean.copy_(keep)                  # ... which this test puts back: only the hand-over state is under test
+        assert not L.current_context().leftovers()
+        got.append(tr.step(x).item())
+    # (moving variances were touched by the orphan forwards too, but they do not enter a training step's arithmetic)
+    assert got == alone
+    for (n1, a), b in zip([(n, q) for n, q in base.named_parameters()], w_alone):
+        assert torch.equal(a.detach(), b), n1
+
+
+def test_plain_autograd_backward_drops_what_it_left_unclaimed(dev):
+    """Bare autograd use (no trainer): a BatchNormalization output with two consumers — the conv behind it emits backward sums
+    that the BatchNormalization never meets (its gradient is the SUM of two contributions) — the unclaimed entry is dropped
+    when the backward ends (counted in the default context), not left pinning its tensors."""
+    from embeddingnet_amd import layers as L
+    ctx = L.current_context()
+    ctx.unclaimed.clear()
+    c = 64
+    bn = L.BatchNormalization(c, relu=True).to(dev).train()
+    conv = L.Conv2D(c, c, 1, use_bias=False, gen=torch.Generator().manual_seed(1)).to(dev)
+    x = torch.randn(4, 9, 9, c, device=dev, requires_grad=True)
+    for _ in range(3):
+        a = bn(x)
+        y = conv(a) + a * 0.5                          # second consumer of the BatchNormalization's output
+        y.sum().backward()
+        assert not ctx.leftovers()
+    assert ctx.unclaimed.get("bn_sums", 0) == 3, ctx.unclaimed

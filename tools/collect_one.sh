@@ -2,7 +2,7 @@
 # Refresh ONE config's committed measurements (gpurun -- 'bash tools/collect_one.sh rNN c1s'): its FETCH_SIZE / WRITE_SIZE
 # passes merged into profiles/rNN_pmc_traffic.json, then its bench line + kernel table -> gpurun_out/<tag>/.
 set -u
-tag=${1:-r04}; c=${2:-c1s}
+tag=${1:-r05}; c=${2:-c1s}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd "$root"

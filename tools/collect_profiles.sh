@@ -3,7 +3,7 @@
 # kernel-trace summary of the headline command, the PMC passes for HBM traffic (separate passes, no tracing domains beside
 # --kernel-trace) and for shader clock / MFMA utilisation -> gpurun_out/<tag>/.  Copy what should be judged into profiles/.
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd "$root"
