@@ -169,11 +169,12 @@ class ResidualUnit(nn.Module):
             # (sole: conv1 is a's only reader -> a may exist as planes only)
             a, sc = self.bn1(x, defer=d, with_skip=True, planes_for=self.conv1, sole=self.kind == "basic")
             y1 = self.conv1(a, emit_stats=st)
-        # bn2 is y1's only reader and (basic units) conv2 its output's: both tensors may live as planes only (layers.PLANES_ONLY)
-        y = self.bn2(y1, defer=d, planes_for=self.conv2, sole=self.kind == "basic", owns_input=True)
+        # bn2 is y1's only reader and conv2 its output's: both tensors may live as planes only (layers.PLANES_ONLY)
+        y = self.bn2(y1, defer=d, planes_for=self.conv2, sole=True, owns_input=True)
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
-        return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d), residual=sc, emit_stats=st)
+        # bottleneck: bn3 is conv2's only reader (owns_input: its dx may be planes only when conv2 is a stride-1 patch conv)
+        return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d, owns_input=True), residual=sc, emit_stats=st)
 
 
 class ResNet(nn.Module):

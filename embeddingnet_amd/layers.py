@@ -424,13 +424,17 @@ PLANES_ONLY = [_os.environ.get("EMBNET_PLANES_ONLY", "1") != "0"]     # [False]:
 
 
 def _placeholder(shape, device):
-    """A tensor of `shape` WITHOUT its fp32 storage (one element, all strides 0): stands in autograd's graph for a tensor that
-    exists only as planes.  It is not contiguous, so _lib.ptr() refuses it: a kernel that would read its values fails loudly."""
-    return torch.empty_strided(tuple(shape), (0,) * len(shape), device=device, dtype=torch.float32)
+    """A tensor of `shape` WITHOUT its fp32 storage: stands in autograd's graph for a tensor that exists only as planes.  All
+    strides are 0 over a three-float storage at offset 1 — a signature no ordinary tensor has (the gradient of `.sum()` is also
+    an all-zero-stride view, of ONE float at offset 0: that one is a real tensor and must be read) — and it is not
+    contiguous, so _lib.ptr() refuses it: a kernel that would read its values fails loudly."""
+    base = torch.empty(3, device=device, dtype=torch.float32)
+    return base.as_strided(tuple(shape), (0,) * len(shape), 1)
 
 
 def _is_placeholder(t):
-    return t.dim() == 4 and t.numel() > 1 and t.stride() == (0, 0, 0, 0)
+    return (t.dim() == 4 and t.numel() > 1 and t.stride() == (0, 0, 0, 0) and t.storage_offset() == 1
+            and t.untyped_storage().nbytes() == 12)
 
 
 def _take_dy_planes(dy):
