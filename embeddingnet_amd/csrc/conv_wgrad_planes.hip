@@ -64,6 +64,7 @@ struct Params {
   unsigned x_plane_bytes, dy_plane_bytes, x_chunk_bytes, dy_chunk_bytes;
   int tiles_k, tiles, splits, stages_total, stages_per_split, HB;
   long slab_elems;
+  int knobs;                   // experiments (EMBNET_WGP_KNOBS): bit 0 = s_setprio 1 for waves 4-7, bit 1 = for the x loaders (0-3)
 };
 
 __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) {
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  if (((p.knobs & 1) && wave >= 4) || ((p.knobs & 2) && wave < 4)) __builtin_amdgcn_s_setprio(1);
 
   for (int u = 0; u < HB + D; ++u) issue(u);
   for (int j = 0; j < nst; ++j) {
@@ -257,6 +259,8 @@ extern "C" int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* 
   p.x_chunk_bytes = p.dy_chunk_bytes = (unsigned)((size_t)n * h * wd * 32);
   p.tiles_k = pl.tiles_k; p.tiles = pl.tiles; p.splits = pl.splits; p.stages_total = pl.stages_total;
   p.stages_per_split = pl.stages_per_split; p.HB = pl.HB; p.slab_elems = 9l * c * k;
+  static const int knobs = (int)env_long("EMBNET_WGP_KNOBS", 0);
+  p.knobs = knobs;
   hipStream_t st = (hipStream_t)stream;
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
