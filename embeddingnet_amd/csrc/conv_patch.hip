@@ -403,8 +403,10 @@ static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int
   pl.tps = pl.bn == 64 ? 3 : 1;
   pl.nbs = pl.bn == 64 ? 3 : 6;
   pl.LR = patch_rows(n, oh, ow, r, s);
+  static const int tps3 = (int)env_long("EMBNET_PATCH_TPS3", 0);       // experiment: three taps per barrier at BN = 128 too (two 36 KB slots)
+  if (pl.bn == 128 && tps3 && 2 * (size_t)3 * pl.LR * 32 + (size_t)2 * 3 * 3 * 128 * 32 <= 160 * 1024) { pl.tps = 3; pl.nbs = 2; }
   pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
-  if (pl.bn == 128 && pl.lds > 160 * 1024) {             // a long patch (small maps: many image seams per tile): shorter weight ring
+  if (pl.bn == 128 && pl.tps == 1 && pl.lds > 160 * 1024) {             // a long patch (small maps: many image seams per tile): shorter weight ring
     pl.nbs = 4;
     pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
   }
@@ -483,12 +485,14 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
   p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   {
-    EMBNET_TRACE_FLOP(pl.bn == 128 ? (pl.nbs == 6 ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6>(embnet::patch::PatchParams)"
+    EMBNET_TRACE_FLOP(pl.bn == 128 && pl.tps == 3 ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 3, 2>(embnet::patch::PatchParams)" :
+                      pl.bn == 128 ? (pl.nbs == 6 ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6>(embnet::patch::PatchParams)"
                                                   : "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 4>(embnet::patch::PatchParams)")
                                    : "void embnet::patch::conv_patch_kernel<64, 3, 3, 3, 3>(embnet::patch::PatchParams)",
                       2.0 * M * k * r * s * c,
                       6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
-    if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
+    if (pl.bn == 128 && pl.tps == 3) launch_patch<128, 3, 2>(p, pl.lds, st);
+    else if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
     else launch_patch<64, 3, 3>(p, pl.lds, st);
   }
   if (p.n_pieces > 0)
