@@ -883,7 +883,8 @@ extern "C" int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, flo
 }
 
 // rows P of the [2][c][P] BatchNorm-backward partial sums embnet_dwconv2d_dgrad_bnsums_f32 writes (0: not available — stride-1
-// layers on the two-rows-per-thread kernel only); when c / 4 > 256 the caller zeroes the buffer first
+// layers on the two-rows-per-thread kernel and stride-2 layers on dwconv_dgrad4_s2_row_kernel only); when c / 4 > 256 the caller
+// zeroes the buffer first
 extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int stride) {
   if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || (stride != 1 && stride != 2) || !dw_fwd_rows_path(c, r, s, stride)) return 0;
   if (stride == 2) {                                     // dwconv_dgrad4_s2_row_kernel: one thread per (row, 4-column block, quad)
