@@ -225,6 +225,13 @@ int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
 const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int r, int s, int k, int oh, int ow);
 
+/* 1x1 convolutions with a thin reduction (csrc/conv_thin.hip): embnet_conv2d_fwd_f32 with r = s = 1, pad 0, c <= 40 (EfficientNet's
+ * expand convs) and embnet_conv2d_dgrad_f32 with r = s = 1, stride 1, k <= 40 (its project convs' data gradient) run as an HBM
+ * stream — exact fp32 FMA chains over the reduction, the dense output written as one contiguous stream, statistics rows as
+ * embnet_conv2d_fwd_stats_rows reports — instead of an implicit GEMM with a one-tile K loop.  1 when (reduction, output
+ * columns) takes that path (EMBNET_CONV_THIN=0 turns it off). */
+int embnet_conv1x1_thin_supported(int red, int ncols);
+
 /* ---- stride-1 3x3 convolution on pre-split operands ("patch" kernel, csrc/conv_patch.hip) --------------------------------
  * The zoo ResNets' 3x3 stride-1 layers (backbones.py:99-104), forward and data gradient, 1.1-1.25x faster than the kernels
  * above: every fp32 operand value is split into its three bf16 pieces ONCE, by the kernel that produces the tensor, and the
