@@ -855,6 +855,11 @@ static int pick_tile(long m, int ncols, bool strided_dgrad = false, long kdepth 
   // In the training step (bench.py, EMBNET_BENCH_DETAIL, per layer): 14x14x256 -> 256 195 us vs 221 forward and
   // 198 vs 235 data gradient, 28x28x128 s2 -> 256 105 vs 117; 128-wide layers are neutral, and the stride classes of
   // a strided data gradient (unequal K per class) lose with the big tile (162 vs 114 us) -> they keep the old rule.
+  // short reductions (EfficientNet's 1x1 convs at 14x14 / 7x7: 3-6 K tiles): the loop is a few gather round trips whatever the
+  // tile; EMBNET_CONV_SHORTK = 1 / 3 picks 128x64 / 64x64 tiles for them (more workgroups per CU to hide the trips) — experiment
+  static const int shortk = (int)env_long("EMBNET_CONV_SHORTK", 0);
+  static const long shortk_max = env_long("EMBNET_CONV_SHORTK_MAX", 8);
+  if (shortk && kdepth > 0 && kdepth <= shortk_max * BK && !strided_dgrad && ncols >= 64) return shortk;
   static const long t128_min = env_long("EMBNET_CONV_T128_MIN", 384);
   const long t128 = cdiv(m, 128) * cdiv(ncols, 128);
   if ((ncols >= 256 && !strided_dgrad && t128 >= t128_min) || (ncols >= 128 && t128 >= 4 * 768)) return 0;
