@@ -1144,7 +1144,11 @@ extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, f
 }
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
-static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split) {
+static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt_per_split, bool one_by_one = false) {
+  if (one_by_one && thin_wgrad_applies(rows, k)) {      // conv_thin.hip: a 1x1 conv with a thin side is a stream, not a GEMM
+    tile = -1; splits = thin_wgrad_splits(kg, rows, k); kt_per_split = 0;
+    return;
+  }
   // few gradient rows (1x1 convs on 16..64 channels, EfficientNet): 64-row tiles, whatever the width
   tile = (rows <= 64 && k > 32) ? 3 : (k <= 32 ? 2 : (k <= 64 ? 1 : 0));
   // 128-row tiles waste the last half tile of a 576-row (3x3x64) gradient; 192-row tiles fit it exactly
@@ -1181,7 +1185,7 @@ static void wgrad_plan(int rows, int k, long kg, int& tile, int& splits, int& kt
 extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0) return 0;
   int tile, splits, ktps;
-  wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, splits, ktps);
+  wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, splits, ktps, r == 1 && s == 1);
   return splits > 1 ? (size_t)splits * r * s * c * k * sizeof(float) : 0;
 }
 
@@ -1214,12 +1218,27 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
   if (int rc = make_geom(p.g, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, "conv2d_wgrad")) return rc;
   int tile;
   const int rows = r * s * c;
-  wgrad_plan(rows, k, (long)n * oh * ow, tile, p.splits, p.kt_per_split);
+  wgrad_plan(rows, k, (long)n * oh * ow, tile, p.splits, p.kt_per_split, r == 1 && s == 1);
   const size_t need = embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow);
   if (need > workspace_bytes || (need && !workspace))
     return fail(EMBNET_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   if (p.splits > 1) p.out = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  if (tile < 0) {
+    // thin 1x1 weight gradient (the split count every caller planned with is this path's): one slab per workgroup + the slab sum
+    EMBNET_CHECK_ARG(pad_t == 0 && pad_l == 0 && !in_scale && aligned16(x) && aligned16(dy),
+                     "conv2d_wgrad: a 1x1 conv with a thin side takes pad 0, no fused input transform and 16-byte aligned operands "
+                     "(EMBNET_CONV_THIN_WGRAD=0 restores the implicit-GEMM kernel)");
+    if (do_main)
+      if (int rc = launch_thin_wgrad(x, dy, p.splits > 1 ? (float*)workspace : dw, (long)n * oh * ow, c, k, stride, n, h, wd, oh, ow, st))
+        return rc;
+    if (p.splits > 1 && do_reduce) {
+      const long cnt = (long)rows * k;
+      EMBNET_TRACE("embnet::slab_reduce_kernel", TRACE_BYTES, 4.0 * cnt * (p.splits + 1), st);
+      slab_reduce_kernel<<<(cnt & 3) ? cdiv(cnt, 256) : cdiv(cnt / 4, 32), 256, 0, st>>>((const float*)workspace, p.splits, cnt, dw);
+    }
+    return check_launch("conv2d_wgrad");
+  }
   const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
   p.fair_from = fair_from(grid.x, tile, true);
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
@@ -1282,7 +1301,7 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
 extern "C" int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0) return 0;
   int tile, splits, ktps;
-  wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, splits, ktps);
+  wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, splits, ktps, r == 1 && s == 1);
   return splits;
 }
 
@@ -1346,8 +1365,9 @@ extern "C" const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd,
              geoms[pick_tile(max_m, c, oh < h, (long)r * s * k)], tk);
   } else if (kind == 2) {
     int tile, sp, kt;
-    wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt);
-    if (((c | k) & 3) == 0 && wgrad_k32() && tile != 1)
+    wgrad_plan(r * s * c, k, (long)n * oh * ow, tile, sp, kt, r == 1 && s == 1);
+    if (tile < 0) snprintf(buf, sizeof buf, "embnet::thinw::thin_wgrad_kernel");
+    else if (((c | k) & 3) == 0 && wgrad_k32() && tile != 1)
       snprintf(buf, sizeof buf, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", geoms[tile]);
     else
       snprintf(buf, sizeof buf, "void embnet::conv_wgrad_kernel<embnet::Geom<%s>, %s, %s>(embnet::ConvWgradParams)",

@@ -44,6 +44,11 @@ int thin_gemm_stats_rows(long m, int ncols);
 int launch_thin_gemm(const float* in, const float* w, int w_transposed, long m, int red, int ncols, float* out, float* stats,
                      const float* bias, int relu, int stride, int n, int h, int wd, int oh, int ow, hipStream_t st);
 
+bool thin_wgrad_applies(int c, int k);
+int thin_wgrad_splits(long m, int c, int k);
+int launch_thin_wgrad(const float* x, const float* dy, float* slabs, long m, int c, int k, int stride, int n, int h, int wd, int oh,
+                      int ow, hipStream_t st);
+
 inline int make_geom(ConvGeom& g, int n, int h, int w, int c, int r, int s, int k, int stride, int pad_t,
                      int pad_l, int oh, int ow, const char* who) {
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && r > 0 && s > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0,

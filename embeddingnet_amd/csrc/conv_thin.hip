@@ -60,25 +60,29 @@ __global__ __launch_bounds__(256, 3) void thin_gemm_kernel(const Params p) {
   float4 s1 = z4, s2 = z4;
   const long first = (long)blockIdx.x * p.groups * GP;
   float4 pre[4];
+  // (branch-free: every slot loads from a clamped, valid address and is zeroed afterwards — a load under a branch makes hipcc
+  // wait for it on the spot, which turned the prefetch into one memory round trip per slot)
   auto fetch = [&](int g) {                                      // group g's tile -> registers (zeros past the end)
     const long base = first + (long)g * GP;
+    long addr[4]; bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + u * 256;
-      pre[u] = z4;
-      if (i < T4 && g < p.groups) {
-        uint32_t pl, r4; p.dR4.divmod((uint32_t)i, pl, r4);      // pixel of the tile, channel quad
-        long pix = base + pl;
-        if (pix < p.m) {
-          if (p.st != 1) {
-            uint32_t n, rem, oh, ow;
-            p.dOHW.divmod((uint32_t)pix, n, rem); p.dOW.divmod(rem, oh, ow);
-            pix = ((long)n * p.H + (long)oh * p.st) * p.W + (long)ow * p.st;
-          }
-          pre[u] = in4[pix * R4 + r4];
-        }
+      uint32_t pl, r4; p.dR4.divmod((uint32_t)(i < T4 ? i : 0), pl, r4);      // pixel of the tile, channel quad
+      long pix = base + pl;
+      ok[u] = i < T4 && g < p.groups && pix < p.m;
+      if (!ok[u]) pix = 0;
+      if (p.st != 1) {
+        uint32_t n, rem, oh, ow;
+        p.dOHW.divmod((uint32_t)pix, n, rem); p.dOW.divmod(rem, oh, ow);
+        pix = ((long)n * p.H + (long)oh * p.st) * p.W + (long)ow * p.st;
       }
+      addr[u] = pix * R4 + r4;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pre[u] = in4[addr[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (!ok[u]) pre[u] = z4;
   };
   fetch(0);
   for (int g = 0; g < p.groups; ++g) {
@@ -150,6 +154,123 @@ __global__ __launch_bounds__(256, 3) void thin_gemm_kernel(const Params p) {
 
 }  // namespace thin
 
+// ---- weight gradient of the same layers: T[r][n] = sum_m A[m][r] * Bw[m][n], A the THIN operand (x of an expand conv, dy of a
+// project conv), Bw the wide one — a reduction over pixels whose inputs are streams and whose output is tiny.  conv.hip's split-K
+// kernel moves it at 2.9-4.2 TB/s (one 32-pixel K tile in flight per workgroup).  Here a workgroup walks tiles of TPIX pixels
+// (both operands, up to 32 KB, fetched with coalesced 16-byte loads one tile AHEAD: registers -> LDS behind a barrier pair);
+// thread (pixel slot, row group, column quad) keeps RQ x 4 rows x one float4 of T in registers and adds its slot's pixels (x
+// as LDS broadcasts); the slots' sums meet in LDS in slot order; one fp32 slab per workgroup, summed in fixed order by
+// conv.hip's slab_reduce (bitwise reproducible).  Exact fp32 FMA chains over the pixels of a slot.
+namespace thinw {
+
+constexpr int PRE = 8;                       // float4s a thread prefetches: tiles of up to 256 * 8 float4 = 32 KB
+
+struct Params {
+  const float* a; const float* b; float* slabs;
+  long m; int R, NQ, RG, TP, TPIX, tiles_per_block, transposed;
+  // the conv INPUT (x) may be strided against the output pixels that index dy: a_is_x says which operand x is
+  int a_is_x, st, H, W; FastDiv dOHW, dOW, dR4, dNQ;
+};
+
+template <int RQ>
+__global__ __launch_bounds__(256, RQ <= 1 ? 3 : 2) void thin_wgrad_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, R = p.R, R4 = R >> 2, NQ = p.NQ, N = 4 * NQ;
+  const int TA4 = p.TPIX * R4, T4 = TA4 + p.TPIX * NQ;
+  float4* const as4 = reinterpret_cast<float4*>(lds);
+  float4* const bs4 = as4 + TA4;
+  const float4* a4g = reinterpret_cast<const float4*>(p.a);
+  const float4* b4g = reinterpret_cast<const float4*>(p.b);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int q = tid % NQ, t2 = tid / NQ, rg = t2 % p.RG, ps = t2 / p.RG;
+  const bool active = ps < p.TP;
+  const long first = (long)blockIdx.x * p.tiles_per_block * p.TPIX;
+  float4 pre[PRE];
+  auto fetch = [&](int t) {                                      // branch-free, as thin_gemm_kernel's
+    const long base = first + (long)t * p.TPIX;
+    const float4* src[PRE]; bool ok[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const int i = tid + u * 256;
+      const bool is_a = i < TA4;
+      uint32_t pl, qd;
+      if (is_a) p.dR4.divmod((uint32_t)i, pl, qd); else p.dNQ.divmod((uint32_t)(i < T4 ? i - TA4 : 0), pl, qd);
+      long pix = base + pl;
+      ok[u] = i < T4 && t < p.tiles_per_block && pix < p.m;
+      if (!ok[u]) pix = 0;
+      if (p.st != 1 && (is_a == (p.a_is_x != 0))) {              // this operand is the strided conv input
+        uint32_t n, rem, oh, ow;
+        p.dOHW.divmod((uint32_t)pix, n, rem); p.dOW.divmod(rem, oh, ow);
+        pix = ((long)n * p.H + (long)oh * p.st) * p.W + (long)ow * p.st;
+      }
+      src[u] = is_a ? a4g + (pix * R4 + qd) : b4g + (pix * NQ + qd);
+    }
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) pre[u] = *src[u];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) if (!ok[u]) pre[u] = z4;
+  };
+  float4 acc[4 * RQ];
+#pragma unroll
+  for (int i = 0; i < 4 * RQ; ++i) acc[i] = z4;
+  fetch(0);
+  for (int t = 0; t < p.tiles_per_block; ++t) {
+    if (first + (long)t * p.TPIX >= p.m) break;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) { const int i = tid + u * 256; if (i < T4) as4[i] = pre[u]; }
+    __syncthreads();
+    fetch(t + 1);
+    if (active) {
+      for (int pl = ps; pl < p.TPIX; pl += p.TP) {
+        const float4 bq = bs4[pl * NQ + q];
+#pragma unroll
+        for (int r4 = 0; r4 < RQ; ++r4) {
+          const float4 av = as4[pl * R4 + rg * RQ + r4];
+          acc[4 * r4 + 0].x = fmaf(av.x, bq.x, acc[4 * r4 + 0].x); acc[4 * r4 + 0].y = fmaf(av.x, bq.y, acc[4 * r4 + 0].y);
+          acc[4 * r4 + 0].z = fmaf(av.x, bq.z, acc[4 * r4 + 0].z); acc[4 * r4 + 0].w = fmaf(av.x, bq.w, acc[4 * r4 + 0].w);
+          acc[4 * r4 + 1].x = fmaf(av.y, bq.x, acc[4 * r4 + 1].x); acc[4 * r4 + 1].y = fmaf(av.y, bq.y, acc[4 * r4 + 1].y);
+          acc[4 * r4 + 1].z = fmaf(av.y, bq.z, acc[4 * r4 + 1].z); acc[4 * r4 + 1].w = fmaf(av.y, bq.w, acc[4 * r4 + 1].w);
+          acc[4 * r4 + 2].x = fmaf(av.z, bq.x, acc[4 * r4 + 2].x); acc[4 * r4 + 2].y = fmaf(av.z, bq.y, acc[4 * r4 + 2].y);
+          acc[4 * r4 + 2].z = fmaf(av.z, bq.z, acc[4 * r4 + 2].z); acc[4 * r4 + 2].w = fmaf(av.z, bq.w, acc[4 * r4 + 2].w);
+          acc[4 * r4 + 3].x = fmaf(av.w, bq.x, acc[4 * r4 + 3].x); acc[4 * r4 + 3].y = fmaf(av.w, bq.y, acc[4 * r4 + 3].y);
+          acc[4 * r4 + 3].z = fmaf(av.w, bq.z, acc[4 * r4 + 3].z); acc[4 * r4 + 3].w = fmaf(av.w, bq.w, acc[4 * r4 + 3].w);
+        }
+      }
+    }
+  }
+  // the pixel slots' sums meet in LDS, slot TP-1 first, slot 0 adds them up in that order and writes the workgroup's slab
+  float4* sc = reinterpret_cast<float4*>(lds);                   // [RG * 4 RQ rows][NQ]
+  const int row0 = rg * 4 * RQ;
+  for (int s = p.TP - 1; s >= 1; --s) {
+    __syncthreads();
+    if (active && ps == s) {
+#pragma unroll
+      for (int i = 0; i < 4 * RQ; ++i) sc[(row0 + i) * NQ + q] = acc[i];
+    }
+    __syncthreads();
+    if (active && ps == 0) {
+#pragma unroll
+      for (int i = 0; i < 4 * RQ; ++i) {
+        const float4 v = sc[(row0 + i) * NQ + q];
+        acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+      }
+    }
+  }
+  if (active && ps == 0) {
+    float* slab = p.slabs + (long)blockIdx.x * R * N;
+#pragma unroll
+    for (int i = 0; i < 4 * RQ; ++i) {
+      const int r = row0 + i;
+      if (!p.transposed) *reinterpret_cast<float4*>(slab + (long)r * N + 4 * q) = acc[i];
+      else { slab[(long)(4 * q + 0) * R + r] = acc[i].x; slab[(long)(4 * q + 1) * R + r] = acc[i].y;
+             slab[(long)(4 * q + 2) * R + r] = acc[i].z; slab[(long)(4 * q + 3) * R + r] = acc[i].w; }
+    }
+  }
+}
+
+}  // namespace thinw
+
 // ---- host side (used by conv.hip's forward / data-gradient entry points) ---------------------------------------------------
 static bool thin_enabled() { static const bool v = env_long("EMBNET_CONV_THIN", 1) != 0; return v; }
 
@@ -187,6 +308,72 @@ int launch_thin_gemm(const float* in, const float* w, int w_transposed, long m, 
   EMBNET_TRACE("embnet::thin::thin_gemm_kernel", TRACE_BYTES, 4.0 * ((double)m * red + (double)m * ncols + (double)red * ncols), st);
   thin::thin_gemm_kernel<<<blocks, 256, lds, st>>>(p);
   return check_launch("thin_gemm");
+}
+
+
+// weight gradient dW[c][k] of a 1x1 conv with min(c, k) thin: shape-only decision (embnet_conv2d_wgrad_splits must know it)
+static bool thinw_groups(int thin, int& rg, int& rq) {
+  switch (thin) {
+    case 4: case 8: case 12: case 16: case 20: rg = 1; rq = thin / 4; return true;
+    case 24: case 32: case 40: rg = 2; rq = thin / 8; return true;
+    default: return false;
+  }
+}
+bool thin_wgrad_applies(int c, int k) {
+  static const bool on = env_long("EMBNET_CONV_THIN_WGRAD", 1) != 0;
+  const int thin_dim = c < k ? c : k, wide = c < k ? k : c;
+  int rg, rq;
+  if (!on || !thin_enabled() || !thinw_groups(thin_dim, rg, rq) || (wide & 3) || wide < 8 || wide > 1024) return false;
+  if ((long)thin_dim * wide > thin::MAX_B_FLOATS) return false;
+  const int nq = wide / 4;
+  if (nq * rg > 256) return false;
+  return (256 * thinw::PRE) / (thin_dim / 4 + nq) >= 8;          // at least 8 pixels per tile
+}
+static void thinw_plan(long m, int thin_dim, int wide, int& tpix, int& tiles_per_block, int& blocks) {
+  tpix = (256 * thinw::PRE) / (thin_dim / 4 + wide / 4);
+  if (tpix > 128) tpix = 128;
+  tpix &= ~3;
+  const long tiles = (m + tpix - 1) / tpix;
+  // whole rounds of resident workgroups: three per CU with 4 accumulator rows (<= 168 registers), two beyond
+  static const long forced = env_long("EMBNET_THIN_WGRAD_BLOCKS", 0);
+  int rg, rq; thinw_groups(thin_dim, rg, rq);
+  const long target = forced > 0 ? forced : (rq <= 1 ? 768 : 512);
+  long per = (tiles + target - 1) / target;
+  if (per < 4) per = 4;                                           // a workgroup's slab and its fill are worth at least four tiles
+  tiles_per_block = (int)per;
+  blocks = (int)((tiles + per - 1) / per);
+}
+int thin_wgrad_splits(long m, int c, int k) {
+  int tpix, per, blocks; thinw_plan(m, c < k ? c : k, c < k ? k : c, tpix, per, blocks); return blocks;
+}
+
+// slabs [blocks][c*k] in dW's layout [c][k]; returns the launch status.  x [*, c] (strided by `stride` against dy's pixels), dy [m, k]
+int launch_thin_wgrad(const float* x, const float* dy, float* slabs, long m, int c, int k, int stride, int n, int h, int wd, int oh,
+                      int ow, hipStream_t st) {
+  thinw::Params p{};
+  const bool x_thin = c < k;
+  const int thin_dim = x_thin ? c : k, wide = x_thin ? k : c;
+  int rq; thinw_groups(thin_dim, p.RG, rq);
+  p.a = x_thin ? x : dy; p.b = x_thin ? dy : x; p.slabs = slabs; p.m = m; p.R = thin_dim; p.NQ = wide / 4;
+  p.TP = 256 / (p.NQ * p.RG);
+  int blocks; thinw_plan(m, thin_dim, wide, p.TPIX, p.tiles_per_block, blocks);
+  if (p.TP > p.TPIX) p.TP = p.TPIX;
+  p.transposed = x_thin ? 0 : 1;                                  // T is [thin][wide]; dW is [c][k]
+  p.a_is_x = x_thin ? 1 : 0; p.st = stride; p.H = h; p.W = wd;
+  p.dOHW = FastDiv::make((uint32_t)(oh * ow)); p.dOW = FastDiv::make((uint32_t)ow);
+  p.dR4 = FastDiv::make((uint32_t)(thin_dim / 4)); p.dNQ = FastDiv::make((uint32_t)p.NQ);
+  size_t lds = (size_t)p.TPIX * (thin_dim + wide) * sizeof(float);
+  const size_t red = (size_t)thin_dim * wide * sizeof(float);
+  if (lds < red) lds = red;
+  EMBNET_TRACE("embnet::thinw::thin_wgrad_kernel", TRACE_BYTES, 4.0 * ((double)m * (c + k) + (double)c * k * blocks), st);
+  switch (rq) {
+    case 1: thinw::thin_wgrad_kernel<1><<<blocks, 256, lds, st>>>(p); break;
+    case 2: thinw::thin_wgrad_kernel<2><<<blocks, 256, lds, st>>>(p); break;
+    case 3: thinw::thin_wgrad_kernel<3><<<blocks, 256, lds, st>>>(p); break;
+    case 4: thinw::thin_wgrad_kernel<4><<<blocks, 256, lds, st>>>(p); break;
+    default: thinw::thin_wgrad_kernel<5><<<blocks, 256, lds, st>>>(p); break;
+  }
+  return check_launch("thin_wgrad");
 }
 
 }  // namespace embnet

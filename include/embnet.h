@@ -228,8 +228,10 @@ const char* embnet_conv2d_kernel_name(int kind, int n, int h, int wd, int c, int
 /* 1x1 convolutions with a thin reduction (csrc/conv_thin.hip): embnet_conv2d_fwd_f32 with r = s = 1, pad 0, c <= 40 (EfficientNet's
  * expand convs) and embnet_conv2d_dgrad_f32 with r = s = 1, stride 1, k <= 40 (its project convs' data gradient) run as an HBM
  * stream — exact fp32 FMA chains over the reduction, the dense output written as one contiguous stream, statistics rows as
- * embnet_conv2d_fwd_stats_rows reports — instead of an implicit GEMM with a one-tile K loop.  1 when (reduction, output
- * columns) takes that path (EMBNET_CONV_THIN=0 turns it off). */
+ * embnet_conv2d_fwd_stats_rows reports — instead of an implicit GEMM with a one-tile K loop; embnet_conv2d_wgrad_f32 with
+ * r = s = 1, pad 0 and min(c, k) in {4, 8, ..., 20, 24, 32, 40} likewise (one slab per workgroup; embnet_conv2d_wgrad_splits /
+ * _workspace_bytes report this path's counts).  1 when (reduction, output columns) takes the forward / data-gradient path
+ * (EMBNET_CONV_THIN=0 turns all of it off, EMBNET_CONV_THIN_WGRAD=0 the weight gradient). */
 int embnet_conv1x1_thin_supported(int red, int ncols);
 
 /* ---- stride-1 3x3 convolution on pre-split operands ("patch" kernel, csrc/conv_patch.hip) --------------------------------

@@ -123,3 +123,31 @@ def test_thin_conv_with_bias_relu_and_stride(dev):
     close(xt.grad, xr.grad, 2e-5, "dx")
     close(conv.kernel.grad, P["c/kernel"].grad, 2e-5, "dW")
     close(conv.bias.grad, P["c/bias"].grad, 2e-5, "dbias")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,stride", [(6, 17, 15, 16, 96, 1), (4, 9, 11, 144, 24, 1), (5, 7, 7, 40, 240, 1), (3, 12, 10, 32, 16, 1),
+                                                   (130, 14, 14, 24, 144, 1), (2, 13, 9, 12, 40, 2), (2, 6, 6, 20, 8, 1)])
+def test_thin_weight_gradient_vs_oracle(dev, n, h, w, cin, cout, stride):
+    """dW of a 1x1 conv with a thin side (thin_wgrad_kernel): x thin (expand), dy thin (project: the transposed slab), a strided
+    case, many workgroups (130 images) and few; the trace names the kernel; two launches give bit-identical gradients."""
+    from embeddingnet_amd import layers as L
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    conv = L.Conv2D(cin, cout, 1, strides=stride, use_bias=False, gen=torch.Generator().manual_seed(4)).to(dev)
+    xt = g(x, dev).requires_grad_(True)
+    y = conv(xt)
+    dy = rs.randn(*y.shape).astype(np.float32)
+    _, names = _names(lambda: y.backward(g(dy, dev)))
+    assert any("thin_wgrad" in nm for nm in names) and not any("conv_wgrad_kernel" in nm for nm in names), names
+    P = {"c/kernel": conv.kernel.detach().cpu().double().requires_grad_(True)}
+    ctx = OB.Ctx(P, training=True)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr = OB.conv2d(ctx, "c", xr, cout, 1, stride=stride, bias=False)
+    yr.backward(torch.tensor(dy, dtype=torch.float64))
+    close(conv.kernel.grad, P["c/kernel"].grad, 2e-5, "dW (thin kernel)")
+    close(xt.grad, xr.grad, 2e-5, "dx")
+    first = conv.kernel.grad.clone()
+    conv.kernel.grad = None
+    xt.grad = None
+    conv(xt).backward(g(dy, dev))
+    assert torch.equal(conv.kernel.grad, first)
