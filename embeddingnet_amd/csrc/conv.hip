@@ -1005,9 +1005,9 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   hipStream_t st = (hipStream_t)stream;
   if (r == 1 && s == 1 && thin_gemm_applies(c, k)) {
     // thin reduction: an HBM stream, not a matrix problem (conv_thin.hip); the statistics' row count follows this path
-    const bool can = pad_t == 0 && pad_l == 0 && !residual && !in_scale && aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(stats);
-    if (can) return launch_thin_gemm(x, w, 0, M, c, k, y, stats, bias, relu, stride, n, h, wd, oh, ow, st);
-    EMBNET_CHECK_ARG(!stats, "conv2d_fwd: epilogue statistics of a thin 1x1 conv go with pad 0, no residual and no input transform");
+    const bool can = pad_t == 0 && pad_l == 0 && !in_scale && aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(stats);
+    if (can) return launch_thin_gemm(x, w, 0, M, c, k, y, stats, bias, relu, residual, stride, n, h, wd, oh, ow, st);
+    EMBNET_CHECK_ARG(!stats, "conv2d_fwd: epilogue statistics of a thin 1x1 conv go with pad 0 and no input transform");
   }
   const int tile = pick_tile(M, k, false, (long)r * s * c);
   const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
@@ -1065,7 +1065,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int n, 
   if (r == 1 && s == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && !accumulate && !dx_add && !bn.partial && aligned16(dy) &&
       aligned16(w) && thin_gemm_applies(k, c))
     // dx[m, c] = dy[m, k] * W[c, k]^T with a thin k: an HBM stream whose output is wide (conv_thin.hip)
-    return launch_thin_gemm(dy, w, 1, (long)n * h * wd, k, c, dx, nullptr, nullptr, 0, 1, n, h, wd, h, wd, (hipStream_t)stream);
+    return launch_thin_gemm(dy, w, 1, (long)n * h * wd, k, c, dx, nullptr, nullptr, 0, nullptr, 1, n, h, wd, h, wd, (hipStream_t)stream);
   EMBNET_CHECK_ARG(stride * stride <= MAX_CLASSES, "conv2d_dgrad: stride %d > 3 unsupported", stride);
   long max_m = 0;
   for (int ph = 0; ph < stride; ++ph)

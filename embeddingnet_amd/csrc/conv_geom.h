@@ -42,7 +42,7 @@ void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int 
 bool thin_gemm_applies(int red, int ncols);
 int thin_gemm_stats_rows(long m, int ncols);
 int launch_thin_gemm(const float* in, const float* w, int w_transposed, long m, int red, int ncols, float* out, float* stats,
-                     const float* bias, int relu, int stride, int n, int h, int wd, int oh, int ow, hipStream_t st);
+                     const float* bias, int relu, const float* residual, int stride, int n, int h, int wd, int oh, int ow, hipStream_t st);
 
 bool thin_wgrad_applies(int c, int k);
 int thin_wgrad_splits(long m, int c, int k);

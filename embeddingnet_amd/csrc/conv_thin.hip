@@ -30,7 +30,7 @@ constexpr int MAX_B_FLOATS = 12288;          // 48 KB of LDS for B
 constexpr int MAX_TILE4 = 1024;              // float4s of one input tile (TP * PIX pixels x R / 4): at most 4 per thread
 
 struct Params {
-  const float* in; const float* w; float* out; float* stats; const float* bias; int relu;
+  const float* in; const float* w; float* out; float* stats; const float* bias; int relu; const float* residual;
   long m; int R, NQ, TP, groups, wt;         // wt: 0 = w is [R][N], 1 = w is [N][R] (data gradient: B = W^T)
   int stats_P;
   // strided 1x1 forward: output pixel (n, oh, ow) reads input pixel (n, oh*st, ow*st); st == 1: same index
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256, 3) void thin_gemm_kernel(const Params p) {
     for (int j = 0; j < PIX; ++j) {
       const long po = base + ps + (long)j * p.TP;
       if (active && po < p.m) {
+        if (p.residual) {                                        // the Add behind the conv (the statistics are of the sum)
+          const float4 rv = reinterpret_cast<const float4*>(p.residual)[po * p.NQ + q];
+          acc[j].x += rv.x; acc[j].y += rv.y; acc[j].z += rv.z; acc[j].w += rv.w;
+        }
         out4[po * p.NQ + q] = acc[j];
         s1.x += acc[j].x; s1.y += acc[j].y; s1.z += acc[j].z; s1.w += acc[j].w;
         s2.x = fmaf(acc[j].x, acc[j].x, s2.x); s2.y = fmaf(acc[j].y, acc[j].y, s2.y);
@@ -294,10 +298,10 @@ static void thin_plan(long m, int ncols, int& tp, int& groups, int& blocks) {
 int thin_gemm_stats_rows(long m, int ncols) { int tp, g, b; thin_plan(m, ncols, tp, g, b); return b; }
 
 int launch_thin_gemm(const float* in, const float* w, int w_transposed, long m, int red, int ncols, float* out, float* stats,
-                     const float* bias, int relu, int stride, int n, int h, int wd, int oh, int ow, hipStream_t st) {
+                     const float* bias, int relu, const float* residual, int stride, int n, int h, int wd, int oh, int ow, hipStream_t st) {
   thin::Params p{};
   p.in = in; p.w = w; p.out = out; p.stats = stats; p.m = m; p.R = red; p.NQ = ncols / 4; p.wt = w_transposed;
-  p.bias = bias; p.relu = relu;
+  p.bias = bias; p.relu = relu; p.residual = residual;
   int blocks; thin_plan(m, ncols, p.TP, p.groups, blocks);
   p.stats_P = blocks;
   p.st = stride; p.H = h; p.W = wd; p.OH = oh; p.OW = ow;
