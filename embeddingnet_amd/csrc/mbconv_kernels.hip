@@ -9,7 +9,7 @@
 
 namespace embnet {
 
-struct DwGeom { int N, H, W, C, R, S, stride, pad_t, pad_l, OH, OW; };
+struct DwGeom { int N, H, W, C, R, S, stride, pad_t, pad_l, OH, OW; int img_major; };   // img_major: dwconv_row4x2_kernel's thread order
 
 // y[n,oh,ow,c] = sum_{r,s} x[n, oh*st+r-pt, ow*st+s-pl, c] * w[r,s,c]      bytes: 4*(in + out)
 template <int V>   // V = 4: float4 over channels (C % 4 == 0), V = 1: scalar
@@ -277,11 +277,24 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
   const bool live = i0 < total;
   if (!STATS && !live) return;
   const long i = STATS ? (live ? i0 : total - 1) : i0;
-  const int cq = (int)(i % c4);
-  long t = i / c4;
-  const int ow0 = (int)(t % wb_n) * TW; t /= wb_n;
-  const int oh0 = (int)(t % hb_n) * TH;
-  const int n = (int)(t / hb_n);
+  int cq, ow0, oh0, n;
+  if (!STATS && g.img_major) {
+    // small maps: consecutive threads = 8 channel quads x every (row pair, column block) of ONE image, so the rows a unit shares
+    // with its neighbours are fetched by the same CU close in time (L1 hits) instead of by workgroups on other CUs: the kernels
+    // wait on memory (SQ_WAIT_ANY 50-67 % of the wave cycles) with every quad requested (KS + ST) / 2 x 1.5 times from L2
+    const int units = hb_n * wb_n, cgs = c4 >> 3;
+    long t = i >> 3;
+    const int unit = (int)(t % units); t /= units;
+    cq = (int)(t % cgs) * 8 + (int)(i & 7);
+    n = (int)(t / cgs);
+    ow0 = (unit % wb_n) * TW; oh0 = (unit / wb_n) * TH;
+  } else {
+    cq = (int)(i % c4);
+    long t = i / c4;
+    ow0 = (int)(t % wb_n) * TW; t /= wb_n;
+    oh0 = (int)(t % hb_n) * TH;
+    n = (int)(t / hb_n);
+  }
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* w4 = reinterpret_cast<const float4*>(w);
   float4 acc[TH][TW];
@@ -807,8 +820,11 @@ static long dw_rows2_grid(const DwGeom& g) {
 }
 
 template <int KS, int ST, bool FLIP>
-static void launch_dw_rows(const float* x, const float* w, const DwGeom& g, float* y, hipStream_t st, float* stats = nullptr,
+static void launch_dw_rows(const float* x, const float* w, const DwGeom& g_in, float* y, hipStream_t st, float* stats = nullptr,
                            const DwBn* bn = nullptr) {
+  DwGeom g = g_in;
+  static const long img_max = env_long("EMBNET_DW_IMG_MAX", 0);         // experiment: image-major thread order for maps up to this many pixels
+  g.img_major = (!stats && img_max > 0 && (long)g.OH * g.OW <= img_max && ((g.C / 4) & 7) == 0) ? 1 : 0;
   const bool wide = dw_wide(g);
   if (dw_rows2(g)) {                                                      // two output rows per thread
     const long grid = dw_rows2_grid(g);
