@@ -264,6 +264,8 @@ def main():
         if stop:
             print('EarlyStopping')
             break
+    if feeder is not None:
+        feeder.close()                                # decode worker processes, staging file in /dev/shm
     if rank == 0:
         np.savez(os.path.join(paths['plots'], 'history.npz'), **{k: np.asarray(v) for k, v in history.items()})
     dump = os.environ.get('EMBNET_DUMP_FINAL_WEIGHTS')     # diagnostics: EVERY rank's final weights -> <prefix><rank>.npz
