@@ -64,9 +64,10 @@ struct Params {
   unsigned x_plane_bytes, dy_plane_bytes, x_chunk_bytes, dy_chunk_bytes;
   int tiles_k, tiles, splits, stages_total, stages_per_split, HB;
   long slab_elems;
-  int knobs;                   // experiments (EMBNET_WGP_KNOBS): bit 0 = s_setprio 1 for waves 4-7, bit 1 = for the x loaders (0-3)
+  int knobs;                   // experiments (EMBNET_WGP_KNOBS): bit 0 = s_setprio 1 for waves 4-7, bit 1 = for the x loaders (0-3), bit 2 = stagger
 };
 
+template <bool STAG>
 __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -134,11 +135,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   if (((p.knobs & 1) && wave >= 4) || ((p.knobs & 2) && wave < 4)) __builtin_amdgcn_s_setprio(1);
 
+  // STAG: waves 4-7 run HALF A STAGE behind waves 0-3 (the partner waves of a SIMD then alternate between the barrier / DMA-issue
+  // / fragment-read phase and the MFMA phase instead of meeting in both: microarchitecture guide, 'Two waves per SIMD', item 9).
+  // A stage becomes two ticks with a barrier each; the early waves' stage start is the late waves' stage middle.  The x loaders
+  // (early) issue at their stage MIDDLE (the block they overwrite is read by the late waves until then), the dy loaders (late) at
+  // their stage START; each group waits for its own requests in front of the barrier that starts the OTHER group's stage.
+  const bool late = STAG && wave >= 4;
   for (int u = 0; u < HB + D; ++u) issue(u);
+  if (late) {                                                    // tick 0 belongs to the early waves' first half stage
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   for (int j = 0; j < nst; ++j) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");      // unit j + HB has landed (this wave's part)
+    if (!late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");   // unit j + HB has landed (this wave's part)
     __builtin_amdgcn_s_barrier();                                            // ... everybody's; stage j - 1 is done everywhere
-    issue(j + HB + D);
+    if (!STAG || late) issue(j + HB + D);
     const unsigned char* bs = ba + (j & (NS - 1)) * DY_SLOT;
     bf16x8 b[3];
 #pragma unroll
@@ -166,6 +177,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+      if (STAG && t == 5) {                                      // the stage's middle = the other group's stage start
+        if (late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!late) issue(j + HB + D);
+      }
       if (t + 1 < 9) load_a(t + 1, a[(t + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);          // the next tap's reads go out BEFORE this tap's MFMAs
 #pragma unroll
@@ -174,6 +190,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
       __builtin_amdgcn_sched_barrier(0);          // one tap's fragments ahead, not all nine (registers)
     }
   }
+  if (STAG && !late) __builtin_amdgcn_s_barrier();               // the late waves' last half stage
 
   // ---- the two halves meet in LDS; half 0 stores --------------------------------------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // no DMA (the run-ahead requests past the end) lands after this
@@ -263,13 +280,18 @@ extern "C" int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* 
   p.knobs = knobs;
   hipStream_t st = (hipStream_t)stream;
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
   const int grid = (pl.tiles * pl.splits + 7) / 8 * 8;
   {
     const double m = (double)n * h * wd;
     EMBNET_TRACE_FLOP("embnet::wgp::conv_wgrad_planes_kernel(embnet::wgp::Params)", 2.0 * m * k * 9.0 * c,
                       6.0 * m * (c + k) + 4.0 * 9.0 * c * k * pl.splits, st);
-    conv_wgrad_planes_kernel<<<grid, 512, LDS_BYTES, st>>>(p);
+    if (knobs & 4) conv_wgrad_planes_kernel<true><<<grid, 512, LDS_BYTES, st>>>(p);
+    else conv_wgrad_planes_kernel<false><<<grid, 512, LDS_BYTES, st>>>(p);
   }
   if (pl.splits > 1 && reduce) launch_slab_reduce((const float*)workspace, pl.splits, 9l * c * k, dw, st);
   return check_launch("conv2d_wgrad_planes");
