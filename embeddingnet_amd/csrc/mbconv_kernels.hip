@@ -4,12 +4,10 @@
 // per-sample drop-connect, |a-b|.  NHWC fp32.  The 1x1 expand/project convolutions and the SE
 // dense layers run on the MFMA engine (conv.hip / dense.hip); nothing here is GEMM-shaped:
 // a depthwise tap is one multiply per loaded element, so these are priced in bytes.
-#include "common.h"
+#include "dw_geom.h"
 #include "../../include/embnet.h"
 
 namespace embnet {
-
-struct DwGeom { int N, H, W, C, R, S, stride, pad_t, pad_l, OH, OW; int img_major; };   // img_major: dwconv_row4x2_kernel's thread order
 
 // y[n,oh,ow,c] = sum_{r,s} x[n, oh*st+r-pt, ow*st+s-pl, c] * w[r,s,c]      bytes: 4*(in + out)
 template <int V>   // V = 4: float4 over channels (C % 4 == 0), V = 1: scalar
@@ -246,19 +244,6 @@ __device__ __forceinline__ void dw_block_sums(float4 s1, float4 s2, int c4, int 
     d2[0] = a2.x; d2[P] = a2.y; d2[2 * P] = a2.z; d2[3 * P] = a2.w;
   }
 }
-struct DwBn { const float* e; const float* scale; const float* shift; const float* mean; const float* rstd; int act; };
-__device__ __forceinline__ void dw_bn_sums_add(const DwBn& bn, float4 v, float4 xq, float4 sc, float4 sh, float4 mu, float4 rs,
-                                               float4& s1, float4& s2) {          // the arithmetic of bn_bwd_reduce4_kernel
-  float4 dz = v;
-  if (bn.act) {
-    dz.x = act_grad(bn.act, fmaf(xq.x, sc.x, sh.x), v.x); dz.y = act_grad(bn.act, fmaf(xq.y, sc.y, sh.y), v.y);
-    dz.z = act_grad(bn.act, fmaf(xq.z, sc.z, sh.z), v.z); dz.w = act_grad(bn.act, fmaf(xq.w, sc.w, sh.w), v.w);
-  }
-  s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
-  s2.x = fmaf(dz.x, (xq.x - mu.x) * rs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - mu.y) * rs.y, s2.y);
-  s2.z = fmaf(dz.z, (xq.z - mu.z) * rs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - mu.w) * rs.w, s2.w);
-}
-
 // STATS (forward only): the workgroup also writes the per-channel sum and sum of squares of the outputs it produced as row
 // blockIdx.x of stats[2][C][gridDim.x] — the statistics partials of the BatchNormalization that follows (the layout the conv
 // epilogues write, embnet_bn_train_fwd's `partials`), so that layer does not read the tensor for them.  Threads i, i + c4, ..
@@ -823,6 +808,10 @@ template <int KS, int ST, bool FLIP>
 static void launch_dw_rows(const float* x, const float* w, const DwGeom& g_in, float* y, hipStream_t st, float* stats = nullptr,
                            const DwBn* bn = nullptr) {
   DwGeom g = g_in;
+  if (ST == 1 && dwt::tile_applies(g, !stats ? 0 : (FLIP ? 2 : 1)) && (!stats || !FLIP || bn)) {   // small maps: LDS-tile kernel (dwconv_tile.hip)
+    dwt::launch_tile(x, w, g, FLIP, y, stats, bn, st);
+    return;
+  }
   static const long img_max = env_long("EMBNET_DW_IMG_MAX", 0);         // experiment: image-major thread order for maps up to this many pixels
   g.img_major = (!stats && img_max > 0 && (long)g.OH * g.OW <= img_max && ((g.C / 4) & 7) == 0) ? 1 : 0;
   const bool wide = dw_wide(g);
@@ -858,6 +847,10 @@ static bool dw_fwd_rows_path(int c, int r, int s, int stride) {
 extern "C" int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int stride, int oh, int ow) {
   if (n <= 0 || c <= 0 || oh <= 0 || ow <= 0 || !dw_fwd_rows_path(c, r, s, stride)) return 0;
   DwGeom g{n, 0, 0, c, r, s, stride, 0, 0, oh, ow};
+  if (stride == 1) {                                       // same-size layers on small maps: the LDS-tile kernel's rows
+    const DwGeom gs{n, oh, ow, c, r, s, 1, (r - 1) / 2, (s - 1) / 2, oh, ow};
+    if (dwt::tile_applies(gs, 1)) return dwt::tile_stats_rows(gs, 1);
+  }
   if (!dw_rows2(g)) return 0;
   const long grid = dw_rows2_grid(g);
   return grid < 0x7FFFFFFF ? (int)grid : 0;
@@ -871,8 +864,13 @@ static int dwconv2d_fwd_impl(const float* x, const float* w, float* y, int n, in
   const long total = (long)n * oh * ow * c;
   const int grid4 = cdiv(total / 4, 256);
   EMBNET_CHECK_ARG(!stats || embnet_dwconv2d_fwd_stats_rows(n, c, r, s, stride, oh, ow) > 0, "dwconv2d_fwd_stats: statistics are not available for this geometry");
+  if (stats && stride == 1) {                              // the rows function assumed a same-size layer
+    const DwGeom gs{n, oh, ow, c, r, s, 1, (r - 1) / 2, (s - 1) / 2, oh, ow};
+    EMBNET_CHECK_ARG(dwt::tile_applies(gs, 1) == dwt::tile_applies(g, 1) && (!dwt::tile_applies(g, 1) || dwt::tile_stats_rows(gs, 1) == dwt::tile_stats_rows(g, 1)),
+                     "dwconv2d_fwd_stats: statistics are not available for this geometry");
+  }
   if (dw_fwd_rows_path(c, r, s, stride)) {
-    EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream);
+    EMBNET_TRACE(stride == 1 && dwt::tile_applies(g, stats ? 1 : 0) ? "embnet::dwt::dw_tile_kernel" : "embnet::dwconv_row4_kernel", TRACE_BYTES, 4.0 * total + 4.0 * n * h * wd * c, stream);
     if (r == 3 && stride == 1) launch_dw_rows<3, 1, false>(x, w, g, y, S(stream), stats);
     else if (r == 3) launch_dw_rows<3, 2, false>(x, w, g, y, S(stream), stats);
     else if (stride == 1) launch_dw_rows<5, 1, false>(x, w, g, y, S(stream), stats);
@@ -908,6 +906,10 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, in
     return grid < 0x7FFFFFFF ? (int)grid : 0;
   }
   DwGeom gf{n, 0, 0, c, r, s, 1, 0, 0, h, wd};
+  {
+    const DwGeom gs{n, h, wd, c, r, s, 1, (r - 1) / 2, (s - 1) / 2, h, wd};
+    if (dwt::tile_applies(gs, 2)) return dwt::tile_stats_rows(gs, 2);
+  }
   if (!dw_rows2(gf)) return 0;
   const long grid = dw_rows2_grid(gf);
   return grid < 0x7FFFFFFF ? (int)grid : 0;
@@ -939,8 +941,12 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_f32(const float* dy, const float* w,
     }
     return check_launch("dwconv2d_dgrad_bnsums");
   }
-  EMBNET_TRACE("embnet::dwconv_row4_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
   const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
+  {                                                        // the rows function assumed a same-size layer
+    const DwGeom gs{n, h, wd, c, r, s, 1, (r - 1) / 2, (s - 1) / 2, h, wd};
+    EMBNET_CHECK_ARG(dwt::tile_applies(gs, 2) == dwt::tile_applies(gf, 2), "dwconv2d_dgrad_bnsums: sums are not available for this geometry");
+  }
+  EMBNET_TRACE(dwt::tile_applies(gf, 2) ? "embnet::dwt::dw_tile_kernel" : "embnet::dwconv_row4_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
   if (r == 3) launch_dw_rows<3, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
   else launch_dw_rows<5, 1, true>(dy, w, gf, dx, S(stream), bn_partial, &bn);
   return check_launch("dwconv2d_dgrad_bnsums");
@@ -955,8 +961,9 @@ extern "C" int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float*
   const int grid4 = cdiv(total / 4, 256);
   if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
     const int gridr = cdiv((long)n * h * cdiv(wd, DW_TW) * (c / 4), 256);
-    EMBNET_TRACE(stride == 1 ? "embnet::dwconv_row4_kernel" : "embnet::dwconv_dgrad4_s2_row_kernel", TRACE_BYTES,
-                 4.0 * total + 4.0 * n * oh * ow * c, stream);
+    const DwGeom gt{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
+    EMBNET_TRACE(stride != 1 ? "embnet::dwconv_dgrad4_s2_row_kernel" : (dwt::tile_applies(gt, 0) ? "embnet::dwt::dw_tile_kernel" : "embnet::dwconv_row4_kernel"),
+                 TRACE_BYTES, 4.0 * total + 4.0 * n * oh * ow * c, stream);
     if (stride == 1) {         // correlation of dy with the flipped kernel: the forward loop with the roles swapped
       const DwGeom gf{n, oh, ow, c, r, s, 1, r - 1 - pad_t, s - 1 - pad_l, h, wd};
       if (r == 3) launch_dw_rows<3, 1, true>(dy, w, gf, dx, S(stream));
