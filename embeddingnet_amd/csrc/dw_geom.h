@@ -29,6 +29,9 @@ namespace dwt {
 bool tile_applies(const DwGeom& g, int stats_kind);
 int tile_stats_rows(const DwGeom& g, int stats_kind);
 void launch_tile(const float* x, const float* w, const DwGeom& g, bool flip, float* y, float* stats, const DwBn* bn, hipStream_t st);
+// the weight gradient of the same layers: partial slabs [tile_wgrad_slabs][R*S*C] (0: does not apply), summed by the caller
+int tile_wgrad_slabs(const DwGeom& g);
+void launch_tile_wgrad(const float* x, const float* dy, const DwGeom& g, float* slabs, hipStream_t st);
 }  // namespace dwt
 
 }  // namespace embnet

@@ -1025,7 +1025,10 @@ extern "C" size_t embnet_dwconv2d_wgrad_workspace_bytes(int n, int c, int r, int
   int ppb, cql, cg;            // the larger of the two kernels' slab counts (the query does not know the stride)
   const int b0 = dw_wgrad_blocks((long)n * oh * ow, ppb);
   const int b1 = (c & 3) ? 0 : dw_wave_slabs((long)n * oh * cdiv(ow, DW_TW), c, cql, cg, ppb);
-  return (size_t)(b0 > b1 ? b0 : b1) * r * s * c * sizeof(float);
+  const DwGeom gs{n, oh, ow, c, r, s, 1, (r - 1) / 2, (s - 1) / 2, oh, ow};       // ... nor the input size: a same-size stride-1 layer
+  const int b2 = dwt::tile_wgrad_slabs(gs);
+  const int b = b0 > b1 ? b0 : b1;
+  return (size_t)(b > b2 ? b : b2) * r * s * c * sizeof(float);
 }
 
 extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace,
@@ -1037,6 +1040,12 @@ extern "C" int embnet_dwconv2d_wgrad_f32(const float* x, const float* dy, float*
   if (workspace_bytes < embnet_dwconv2d_wgrad_workspace_bytes(n, c, r, s, oh, ow))
     return fail(EMBNET_EWORKSPACE, "dwconv2d_wgrad: workspace too small");
   int ppb;
+  if (const int slabs = dwt::tile_wgrad_slabs(g)) {                              // small maps, stride 1: LDS-tile kernel (dwconv_tile.hip)
+    const long cnt = (long)r * s * c;
+    { EMBNET_TRACE("embnet::dwt::dw_tile_wgrad_kernel", TRACE_BYTES, 4.0 * n * c * ((double)h * wd + (double)oh * ow), stream); dwt::launch_tile_wgrad(x, dy, g, (float*)workspace, S(stream)); }
+    { EMBNET_TRACE("embnet::dw_slab_sum_kernel", TRACE_BYTES, 4.0 * cnt * (slabs + 1), stream); dw_slab_sum_kernel<<<cdiv(cnt, 16), 256, 0, S(stream)>>>((const float*)workspace, slabs, cnt, dw); }
+    return check_launch("dwconv2d_wgrad");
+  }
   if ((c & 3) == 0 && r == s && (r == 3 || r == 5) && (stride == 1 || stride == 2) && dw_rows()) {
     int upb, cql, cgroups;
     const int blocks = dw_wave_slabs((long)n * oh * cdiv(ow, DW_TW), c, cql, cgroups, upb);

@@ -114,6 +114,27 @@ def test_data_gradient_and_batchnorm_backward_sums_vs_float64(dev, n, h, w, c, k
     assert (s[1] - (dz * ehat).sum((0, 1, 2))).abs().max().item() <= 1e-5 * (dz * ehat).abs().sum((0, 1, 2)).max().item()
 
 
+@pytest.mark.parametrize("n,h,w,c,k", SHAPES)
+def test_weight_gradient_vs_float64(dev, n, h, w, c, k):
+    """dW[r,s,c] = sum x[o + (r,s) - pad] dy[o]: the tile kernel's slabs + the slab sum, against float64 autograd; tiles that take
+    two passes (the 30x30 bands) stay on the wave kernel."""
+    lib = _lib.lib()
+    torch.manual_seed(n * 1000 + h * 10 + k + 7)
+    x = torch.randn(n, h, w, c, device=dev)
+    dy = torch.randn(n, h, w, c, device=dev)
+    pad = (k - 1) // 2
+    wr = torch.zeros(k, k, c, 1, dtype=torch.float64, requires_grad=True)
+    _ref_fwd(x.cpu(), wr, k).backward(dy.cpu().double())
+    want = wr.grad
+    ws = torch.empty(max(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, k, k, h, w) // 4, 4), device=dev)
+    dw = torch.full((k, k, c, 1), float("nan"), device=dev)
+    _, names = _names(lambda: check(lib.embnet_dwconv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                                  n, h, w, c, k, k, 1, pad, pad, h, w, stream())))
+    two_pass = h == 30                       # 15-row bands x 5 column blocks = 75 units for 64 slots
+    assert names[-1] == "embnet::dw_slab_sum_kernel" and ("dw_tile_wgrad" in names[0]) == (not two_pass), names
+    assert _err(dw, want) < 5e-6
+
+
 def test_asymmetric_padding_and_what_stays_on_the_row_kernels(dev):
     """pad_t / pad_l other than (k - 1) / 2 (the C ABI takes them; same-size output) run on the tile kernel too; stride 2, maps
     above 32 x 32 and C % 16 != 0 stay on the per-thread row kernels."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Back-to-back timing of the stride-1 depthwise layers of EfficientNet-B0 at batch 256 from 28x28 down (forward with statistics,
-data gradient with the BatchNorm-backward sums): run once with EMBNET_DW_TILE=0 (row kernels) and once with =1 (LDS-tile kernel);
+data gradient with the BatchNorm-backward sums, weight gradient with its slab sum): run once with EMBNET_DW_TILE=0 (row kernels) and once with =1 (LDS-tile kernel);
 the knob is read once per process.  GPU box only."""
 import argparse
 import json
@@ -62,11 +62,21 @@ def main():
                                                        es[j].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
                                                        vec[3].data_ptr(), 2, st_b.data_ptr(), rows_b, stream()))
 
+        ws = torch.empty(max(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, k, k, h, h) // 4, 4), device=dev)
+        dwt = torch.empty(k, k, c, 1, device=dev)
+
+        def wgr():
+            j = i[0] = (i[0] + 1) % 6
+            check(lib.embnet_dwconv2d_wgrad_f32(xs[j].data_ptr(), es[j].data_ptr(), dwt.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                n, h, h, c, k, k, 1, pad, pad, h, h, stream()))
+
+        tw = min(timeit(wgr, args.iters), timeit(wgr, args.iters))
         tf = min(timeit(fwd, args.iters), timeit(fwd, args.iters))
         tb = min(timeit(bwd, args.iters), timeit(bwd, args.iters))
         el = n * h * h * c * 4.0
         print(json.dumps({"h": h, "c": c, "k": k, "fwd_us": round(tf, 1), "fwd_GBs": round(2 * el / tf / 1e3, 0), "fwd_rows": rows_f,
-                          "dgrad_us": round(tb, 1), "dgrad_GBs": round(3 * el / tb / 1e3, 0), "dgrad_rows": rows_b}))
+                          "dgrad_us": round(tb, 1), "dgrad_GBs": round(3 * el / tb / 1e3, 0), "dgrad_rows": rows_b,
+                          "wgrad_us": round(tw, 1), "wgrad_GBs": round(2 * el / tw / 1e3, 0)}))
 
 
 if __name__ == "__main__":
