@@ -344,7 +344,7 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN],
 // (bn_bwd_reduce4, 8 bytes per element).  The data-gradient epilogue holds d(conv input) in registers, so it reads x (4 bytes
 // per element) and emits the partial sums per row band in the forward statistics' layout [2][C][rows]; the BatchNormalization
 // backward then starts at its finalize kernel (embnet_bn_bwd_partials).  x == NULL: off.
-struct BnSums { const float* x; const float* scale; const float* shift; const float* mean; const float* rstd; int act; float* partial; int rows; };
+// (struct BnSums: conv_geom.h)
 
 __device__ __forceinline__ void bn_sums_add(int act, float4 v, float4 xq, float4 sc, float4 sh, float4 mu, float4 rs,
                                             float4& s1, float4& s2) {      // the arithmetic of bn_bwd_reduce4_kernel
@@ -811,10 +811,10 @@ using namespace embnet;
 namespace embnet {
 void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
                        const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
-                       hipStream_t st) {
-  EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (parts + 1 + (residual ? 1 : 0)), st);
+                       const BnSums& bsum, hipStream_t st) {
+  EMBNET_TRACE("embnet::tail_fixup_kernel", TRACE_BYTES, 4.0 * rem * bm * bn * (parts + 1 + (residual ? 1 : 0) + (bsum.x ? 1 : 0)), st);
   tail_fixup_kernel<<<rem * (bm * bn / 1024), 256, 0, st>>>(ws, parts, bm, bn, wtm, n_full, tiles_n, m, cols, bias, relu,
-                                                           residual, out, stats, stats_rows, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
+                                                           residual, out, stats, stats_rows, bsum);
 }
 // host helper for conv_wgrad_planes.hip: the fixed-order sum of split-K slabs into the gradient
 void launch_slab_reduce(const float* slabs, int splits, long n, float* out, hipStream_t st) {

@@ -33,10 +33,14 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
   r = (int)rr; s = (int)ss; c = (int)cc;
 }
 
+// BatchNorm-backward sums riding on a data gradient (conv.hip's conv_dgrad_kernel / tail_fixup_kernel, conv_patch.hip's
+// epilogue): see the comment at conv.hip's bn_sums_add.  x == NULL: off.
+struct BnSums { const float* x; const float* scale; const float* shift; const float* mean; const float* rstd; int act; float* partial; int rows; };
+
 // conv.hip: fix-up pass over left-over tiles computed as K-split partial tiles (used by conv.hip and conv_patch.hip)
 void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,
                        const float* bias, int relu, const float* residual, float* out, float* stats, int stats_rows,
-                       hipStream_t st);
+                       const BnSums& bsum, hipStream_t st);
 
 // conv_thin.hip: 1x1 convolutions with a thin reduction as an HBM stream (EfficientNet's expand forward / project data gradient)
 bool thin_gemm_applies(int red, int ncols);

@@ -50,6 +50,7 @@ struct PatchParams {
   int PH, PW; FastDiv dPHW, dPW;
   int LR;                        // LDS patch rows (multiple of 32)
   int n_full, parts, cc_part, n_pieces, grid; float* ws;
+  BnSums bn;                     // data-gradient use: the BatchNorm-backward sums of the layer in front (bn.x == NULL: off)
 };
 
 typedef const PatchParams __attribute__((address_space(4)))* kargp;
@@ -88,7 +89,9 @@ __device__ __forceinline__ int padded_pos(int m) {            // padded-image po
   return (int)n * (pp->PH * pp->PW) + (int)oh * pp->PW + (int)ow;
 }
 
-template <int BN, int R, int S, int TPS, int NBS>
+// BNS: the data-gradient form that also emits the BatchNorm-backward sums (PatchParams::bn) — an instantiation of its own: the
+// 64 extra epilogue registers and scalar spills cost the plain kernel ~10 % when both forms share one body
+template <int BN, int R, int S, int TPS, int NBS, bool BNS = false>
 __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
   using G = GeomP<BN>;
   constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
@@ -278,6 +281,25 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
         const bool cok = col < K;
         const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        // BNS — data gradient: the outputs are d(act(BN(e))): the BatchNorm-backward sums  sum dz, sum dz * ehat  of this row band
+        // (dz = v * act'(scale e + shift)), e read here at 4 bytes per element (conv.hip's BnSums; the arithmetic of bn_sums_add).
+        // All of the column block's e values are requested BEFORE the first store (the stores may alias them as far as hipcc
+        // knows, and one exposed memory latency per 16 values costs 10 us per tile)
+        constexpr bool bnm = BNS;
+        float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
+        float ev[BNS ? TM : 1][16];
+        if (BNS) {
+          if (cok) { bsc = p.bn.scale[col]; bsh = p.bn.shift[col]; bmu = p.bn.mean[col]; brs = p.bn.rstd[col]; }
+#pragma unroll
+          for (int im = 0; im < TM; ++im) {
+            const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              ev[BNS ? im : 0][rr] = (inner || (row < M && cok)) ? p.bn.x[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] : 0.f;
+            }
+          }
+        }
 #pragma unroll
         for (int im = 0; im < TM; ++im) {
           const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
@@ -292,7 +314,10 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
               p.y[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] = v[rr];
-              s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+              if (BNS) {
+                const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
+                s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
+              } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
             }
           } else {
 #pragma unroll
@@ -302,17 +327,21 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
                 const long o = o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K;
                 if (p.residual) v[rr] += p.residual[o];
                 p.y[o] = v[rr];
-                s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2);
+                if (BNS) {
+                  const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
+                  s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
+                } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
               }
             }
           }
         }
-        if (p.stats) {                                    // BatchNorm statistics of the layer that follows (as conv.hip's epilogue)
+        if (p.stats || bnm) {             // BatchNorm statistics of the layer that follows (as conv.hip's epilogue) / backward sums
           s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
           if (h == 0 && cok) {
-            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = p.stats_rows;
-            p.stats[(long)col * P + prow] = s1;
-            p.stats[((long)K + col) * P + prow] = s2;
+            float* const dst = bnm ? p.bn.partial : p.stats;
+            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = bnm ? p.bn.rows : p.stats_rows;
+            dst[(long)col * P + prow] = s1;
+            dst[((long)K + col) * P + prow] = s2;
           }
         }
       }
@@ -460,14 +489,19 @@ extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const
 template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  conv_patch_kernel<BN, 3, 3, TPS, NBS><<<p.grid, 640, lds, st>>>(p);
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  if (p.bn.x) conv_patch_kernel<BN, 3, 3, TPS, NBS, true><<<p.grid, 640, lds, st>>>(p);
+  else conv_patch_kernel<BN, 3, 3, TPS, NBS, false><<<p.grid, 640, lds, st>>>(p);
 }
 
-extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
-                                       int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu,
-                                       const float* residual, float* stats, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
+                             int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu,
+                             const float* residual, float* stats, const BnSums& bsum, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   EMBNET_CHECK_ARG(xp && wp && y, "conv2d_patch: null pointer");
   Plan pl;
   EMBNET_CHECK_ARG(make_plan(n, c, r, s, k, 1, oh, ow, pl), "conv2d_patch: unsupported geometry (see embnet_conv2d_patch_supported)");
@@ -480,6 +514,7 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
   p.dPHW = FastDiv::make(p.PH * p.PW); p.dPW = FastDiv::make(p.PW);
   p.LR = pl.LR;
   p.stats_rows = cdiv(M, 256) * 4;
+  p.bn = bsum;
   p.grid = pl.grid;
   if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
   p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
@@ -497,6 +532,29 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
   }
   if (p.n_pieces > 0)
     launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
-                      stats, p.stats_rows, st);
+                      stats, p.stats_rows, bsum, st);
   return check_launch("conv2d_patch");
+}
+
+extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
+                                       int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu,
+                                       const float* residual, float* stats, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  return conv2d_patch_impl(xp, wp, bias, y, n, h, wd, c, r, s, k, pad_t, pad_l, oh, ow, relu, residual, stats,
+                           BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}, workspace, workspace_bytes, stream);
+}
+
+// The patch kernel as a stride-1 DATA GRADIENT (xp: planes of dy [n,h,wd,c], wp: the flipped kernel planes, y: the gradient
+// [n,oh,ow,k] of the conv's input a = act(BN(bn_x))) that also emits the BatchNorm-backward sums of that BatchNormalization —
+// embnet_conv2d_dgrad_bnsums_f32's contract, partial [2][k][bn_rows], bn_rows = embnet_conv2d_patch_stats_rows(n, oh, ow).
+extern "C" int embnet_conv2d_patch_bnsums_f32(const void* xp, const void* wp, float* y, int n, int h, int wd, int c, int r, int s, int k,
+                                              int pad_t, int pad_l, int oh, int ow, const float* bn_x, const float* bn_scale,
+                                              const float* bn_shift, const float* bn_mean, const float* bn_rstd, int bn_act,
+                                              float* bn_partial, int bn_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(bn_x && bn_scale && bn_shift && bn_mean && bn_rstd && bn_partial, "conv2d_patch_bnsums: null pointer");
+  EMBNET_CHECK_ARG(bn_act >= 0 && bn_act <= 2, "conv2d_patch_bnsums: activation code %d", bn_act);
+  EMBNET_CHECK_ARG(bn_rows > 0 && bn_rows == embnet_conv2d_patch_stats_rows(n, oh, ow),
+                   "conv2d_patch_bnsums: rows %d for this geometry (see embnet_conv2d_patch_stats_rows)", bn_rows);
+  return conv2d_patch_impl(xp, wp, nullptr, y, n, h, wd, c, r, s, k, pad_t, pad_l, oh, ow, 0, nullptr, nullptr,
+                           BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows}, workspace, workspace_bytes, stream);
 }

@@ -333,6 +333,11 @@ def _done(out, notify):
 # receives exactly that tensor starts at its finalize kernel.  (The entry keeps an alias of dx: autograd then never
 # accumulates a second consumer's gradient into it in place, so a hit means dy IS that data gradient.)
 FUSE_BN_SUMS = [__import__("os").environ.get("EMBNET_FUSE_BN_SUMS", "1") == "1"]
+# ... and a stride-1 3x3 Conv2D on the patch kernel to embnet_conv2d_patch_bnsums_f32 (the same sums from that kernel's epilogue).
+# OFF by default: the epilogue's reads of the BatchNormalization's input cost the data-gradient launches more (+0.5 ms per
+# ResNet18 step) than the thirteen reduction launches they replace (0.3 ms): C2 10.75 -> 10.97 ms, C3 106.1 -> 107.1
+# (profiles/r05_exp_patch_bnsums.txt).
+PATCH_BN_SUMS = [__import__("os").environ.get("EMBNET_PATCH_BN_SUMS", "0") == "1"]
 # the pooled branch's gradient (squeeze-and-excite) added inside the BatchNorm-backward passes instead of by a pass of its own
 # the squeeze-and-excite multiply's backward (dy * gate) applied inside the BatchNorm backward too (MBConv opts in: lazy_scale)
 # BatchNorm apply + DropConnect + Add of an MBConv tail as one pass, the drop factor applied inside the BatchNorm backward
@@ -446,11 +451,25 @@ def patch_ok(n, h, wd, c, r, s, k, stride, oh, ow):
     return bool(_lib.lib().embnet_conv2d_patch_supported(n, c, r, s, k, stride, oh, ow))
 
 
-def _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dx_add):
+def _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dx_add, bn_src=None):
     """dx[n,h,wd,c] (+ dx_add) = stride-1 data gradient through the patch kernel: the correlation of the dy planes
-    [n,oh,ow,k] with the flipped kernel planes."""
+    [n,oh,ow,k] with the flipped kernel planes.
+    bn_src = (bn_x, bn_stats, bn_act) (dx_add None): the conv's input was act(BatchNorm(bn_x)) — the kernel's epilogue also emits
+    that layer's backward sums (BN_SUMS, as the gather-loop data gradient does)."""
     lib = _lib.lib()
     ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, k, r, s, c, h, wd), dx.device)
+    if bn_src is not None and dx_add is None and PATCH_BN_SUMS[0]:
+        bn_x, bn_stats, bn_act = bn_src
+        rows = lib.embnet_conv2d_patch_stats_rows(n, h, wd)
+        partial = torch.empty((2, c, rows), device=dx.device, dtype=torch.float32)
+        sp = bn_stats.data_ptr()
+        check(lib.embnet_conv2d_patch_bnsums_f32(ptr(dy_planes), ptr(weight_planes(w, 1)), ptr(dx), n, oh, ow, k, r, s, c,
+                                                 r - 1 - pt, s - 1 - pl, h, wd, ptr(bn_x), sp + 8 * c, sp + 12 * c, sp, sp + 4 * c,
+                                                 int(bn_act), ptr(partial), rows, ptr(ws), ws.numel() * 4, stream()))
+        while len(BN_SUMS) >= 8:     # unclaimed entries (the gradient got a second contribution) pin a dx each: keep few
+            BN_SUMS.pop(next(iter(BN_SUMS)))
+        BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
+        return
     check(lib.embnet_conv2d_patch_f32(ptr(dy_planes), ptr(weight_planes(w, 1)), None, ptr(dx), n, oh, ow, k, r, s, c,
                                       r - 1 - pt, s - 1 - pl, h, wd, 0, ptr(dx_add), None, ptr(ws), ws.numel() * 4, stream()))
 
@@ -579,7 +598,8 @@ class _Conv2dFn(torch.autograd.Function):
         if need_dx:
             dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
             if dy_planes is not None and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
-                _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dskip)
+                _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dskip,
+                             getattr(ctx, "bn_src", None) if dskip is None else None)
             else:
                 # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
                 dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 18
+#define EMBNET_ABI_VERSION 19
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -257,6 +257,14 @@ int embnet_conv2d_patch_stats_rows(int n, int oh, int ow);
 int embnet_conv2d_patch_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
                             int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu, const float* residual,
                             float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* The patch kernel as a stride-1 data gradient (dy planes, flip-1 kernel planes, c and k swapped as above) whose epilogue ALSO
+ * emits the BatchNorm-backward sums of the BatchNormalization in front of the conv — the conv's input was
+ * act(bn_scale * bn_x + bn_shift): embnet_conv2d_dgrad_bnsums_f32's contract on this kernel, bn_partial [2][k][bn_rows] with
+ * bn_rows = embnet_conv2d_patch_stats_rows(n, oh, ow); embnet_bn_bwd_partials consumes it (ABI 19). */
+int embnet_conv2d_patch_bnsums_f32(const void* x_planes, const void* w_planes, float* y, int n, int h, int wd, int c, int r, int s,
+                                   int k, int pad_t, int pad_l, int oh, int ow, const float* bn_x, const float* bn_scale,
+                                   const float* bn_shift, const float* bn_mean, const float* bn_rstd, int bn_act,
+                                   float* bn_partial, int bn_rows, void* workspace, size_t workspace_bytes, void* stream);
 int embnet_planes_from_f32(const float* x, long pixels, int c, void* planes, void* stream);
 int embnet_conv_weight_planes_chunk_elems(void);
 int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);

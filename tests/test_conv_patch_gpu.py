@@ -214,6 +214,73 @@ def test_unit_with_planes_equals_unit_on_gather_kernels(dev, n, h, c, k):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
         assert rel < 2e-5, rel                     # same operands and split; fp32 accumulation order differs
 
+@pytest.mark.parametrize("n,h,w,c,k", [(8, 28, 28, 128, 128), (5, 11, 13, 64, 96), (32, 7, 7, 512, 512), (128, 14, 14, 256, 256)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_patch_data_gradient_emits_batchnorm_backward_sums(dev, n, h, w, c, k, act):
+    """embnet_conv2d_patch_bnsums_f32: the data gradient of a 3x3 conv whose input was act(scale * e + shift), and the
+    BatchNorm-backward sums  sum dz,  sum dz * (e - mean) * rstd  (dz = dx * act'(...)) from the kernel's epilogue (whole tiles and
+    the fix-up pass over split tiles), against float64; dx bit for bit what the plain data gradient writes."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(n + h + act)
+    wt = (rng.standard_normal((3, 3, c, k)) / np.sqrt(9 * c)).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, k)).astype(np.float32)
+    e = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    scale, shift = np.linspace(0.5, 1.5, c).astype(np.float32), np.linspace(-0.3, 0.3, c).astype(np.float32)
+    mean, rstd = np.linspace(-0.1, 0.1, c).astype(np.float32), np.linspace(0.8, 1.2, c).astype(np.float32)
+    wd, dyd, ed = (torch.from_numpy(a).to(dev) for a in (wt, dy, e))
+    vec = [torch.from_numpy(a).to(dev) for a in (scale, shift, mean, rstd)]
+    dyp = planes_of(dyd)
+    ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, k, 3, 3, c, h, w), 4) // 4, device=dev)
+    plain = torch.empty((n, h, w, c), device=dev)
+    L._patch_dgrad(dyp, wd, plain, n, h, w, c, 3, 3, k, 1, 1, h, w, None)
+    rows = lib.embnet_conv2d_patch_stats_rows(n, h, w)
+    part = torch.full((2, c, rows), float("nan"), device=dev)
+    dx = torch.empty_like(plain)
+    _lib.check(lib.embnet_conv2d_patch_bnsums_f32(dyp.data_ptr(), L.weight_planes(wd, 1).data_ptr(), dx.data_ptr(), n, h, w, k, 3, 3, c, 1, 1,
+                                                  h, w, ed.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                  vec[3].data_ptr(), act, part.data_ptr(), rows, ws.data_ptr(), ws.numel() * 4, _lib.stream()))
+    assert torch.equal(dx, plain) and torch.isfinite(part).all()
+    want = dgrad64(dy.astype(np.float64), wt.astype(np.float64), 1)
+    z = e.astype(np.float64) * scale + shift
+    dz = want * (z > 0) if act else want
+    ehat = (e.astype(np.float64) - mean) * rstd
+    got = part.double().sum(-1).cpu().numpy()
+    assert np.abs(got[0] - dz.sum((0, 1, 2))).max() <= 1e-5 * np.abs(dz).sum((0, 1, 2)).max()
+    assert np.abs(got[1] - (dz * ehat).sum((0, 1, 2))).max() <= 1e-5 * np.abs(dz * ehat).sum((0, 1, 2)).max()
+
+
+def test_unit_backward_skips_the_batchnorm_reduction_pass(dev):
+    """BatchNormalization(ReLU) -> patch conv: with the sums from the data gradient's epilogue the BatchNormalization backward
+    starts at its finalize kernel (no bn_bwd_reduce launch for bn2), and every gradient equals the separate-pass chain within
+    fp32 summation order."""
+    gen = torch.Generator().manual_seed(5)
+    net = _Pair(64, 96, gen).to(dev).train()
+    x0 = torch.randn(6, 14, 14, 64, generator=gen).to(dev)
+    dy = torch.randn(6, 14, 14, 64, generator=gen).to(dev)
+    out, names = {}, {}
+    default = L.PATCH_BN_SUMS[0]                  # (off: the epilogue costs more than the reduction launches it replaces)
+    for on in (True, False):
+        L.PATCH_BN_SUMS[0] = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            _lib.trace_reset(); _lib.trace_enable(True)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            names[on] = [r[0] for r in _lib.trace_records()]
+            _lib.trace_enable(False)
+            out[on] = [x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            L.PATCH_BN_SUMS[0] = default
+            L.BN_SUMS.clear()
+    count = lambda on: sum("bn_bwd_reduce" in nm for nm in names[on])
+    assert count(False) - count(True) >= 1, (names[True], names[False])
+    for a, b in zip(out[True], out[False]):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-5
+
+
 
 def test_resnet18_patch_on_equals_off(dev):
     """Whole backbone, training mode: embeddings and every parameter gradient with the patch convs against the gather convs.
