@@ -4,7 +4,7 @@
 
 namespace embnet {
 
-struct DwGeom { int N, H, W, C, R, S, stride, pad_t, pad_l, OH, OW; int img_major; };   // img_major: dwconv_row4x2_kernel's thread order
+struct DwGeom { int N, H, W, C, R, S, stride, pad_t, pad_l, OH, OW; int img_major; int L; };   // img_major: dwconv_row4x2_kernel's thread order; L: 256-thread chunks per workgroup (statistics variants; 0 = 1)
 
 // the BatchNormalization in front of a depthwise layer (its input was act(BN(e))): what a data-gradient kernel needs to emit
 // that layer's backward sums (sum dz, sum dz * ehat)

@@ -223,9 +223,16 @@ __global__ __launch_bounds__(256) void dwconv_row4_kernel(const float* __restric
 // against (3*10 + 9) per 8 for 3x3.  A real loop over the input rows (one row's loads in flight; unrolled, hipcc hoists
 // every row's loads: 330-490 VGPRs), so the kernel row of an (input row, output row) pair is a run-time, wave-uniform
 // index and the weights are loaded where they are used (L1 hits), as in the one-row kernel.
-// Row blockIdx.x of stats[2][C][gridDim.x] from the per-thread float4 sums of a workgroup whose thread t handles channel quad
-// (256 * blockIdx.x + t) % c4: threads t, t + c4, .. share a quad and are added in order (every thread of the workgroup calls this)
-__device__ __forceinline__ void dw_block_sums(float4 s1, float4 s2, int c4, int C, float* __restrict__ stats) {
+// Row blockIdx.x of stats[2][C][gridDim.x] from the per-thread float4 sums of a workgroup that walks L chunks of 256 threads:
+// in chunk k thread t handles channel quad (256 k + t) % c4; threads t, t + c4, .. share a quad and are added in order, the
+// chunk's sum per quad is added to the quad's LDS accumulator by ONE thread (fixed order over the chunks), and the row is
+// written once at the end.  One row per 256 threads (L = 1) cost a 14x14x672 stride-2 data gradient 37 % extra traffic in
+// 4-byte writes 37 KB apart (9 408 rows): 229 us at 1.3 TB/s.  accq: 2 * c4 float4 of dynamic LDS.
+__device__ __forceinline__ void dw_block_begin(int c4, float4* accq) {
+  for (int q = threadIdx.x; q < 2 * c4; q += 256) accq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+}
+__device__ __forceinline__ void dw_block_accumulate(float4 s1, float4 s2, int c4, long chunk, float4* accq) {
   __shared__ float4 red[2][256];
   red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
   __syncthreads();
@@ -236,9 +243,19 @@ __device__ __forceinline__ void dw_block_sums(float4 s1, float4 s2, int c4, int 
       a1.x += o1.x; a1.y += o1.y; a1.z += o1.z; a1.w += o1.w;
       a2.x += o2.x; a2.y += o2.y; a2.z += o2.z; a2.w += o2.w;
     }
-    const int col = 4 * (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
-    const long P = gridDim.x;
-    float* d1 = stats + (long)col * P + blockIdx.x;
+    const int q = (int)((chunk * 256 + threadIdx.x) % c4);
+    float4 b1 = accq[q], b2 = accq[c4 + q];
+    b1.x += a1.x; b1.y += a1.y; b1.z += a1.z; b1.w += a1.w;
+    b2.x += a2.x; b2.y += a2.y; b2.z += a2.z; b2.w += a2.w;
+    accq[q] = b1; accq[c4 + q] = b2;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void dw_block_flush(int c4, int C, const float4* accq, float* __restrict__ stats) {
+  const long P = gridDim.x;
+  for (int q = threadIdx.x; q < c4; q += 256) {
+    const float4 a1 = accq[q], a2 = accq[c4 + q];
+    float* d1 = stats + (long)(4 * q) * P + blockIdx.x;
     float* d2 = d1 + (long)C * P;
     d1[0] = a1.x; d1[P] = a1.y; d1[2 * P] = a1.z; d1[3 * P] = a1.w;
     d2[0] = a2.x; d2[P] = a2.y; d2[2 * P] = a2.z; d2[3 * P] = a2.w;
@@ -256,9 +273,13 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
                                                             DwGeom g, float* __restrict__ y, float* __restrict__ stats = nullptr,
                                                             const DwBn bn = DwBn{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   constexpr int NX = (TW - 1) * ST + KS, TH = 2, NR = (TH - 1) * ST + KS;
+  extern __shared__ float4 dw_accq[];                     // STATS: 2 * c4 float4
   const int c4 = g.C >> 2, wb_n = (g.OW + TW - 1) / TW, hb_n = (g.OH + TH - 1) / TH;
   const long total = (long)g.N * hb_n * wb_n * c4;
-  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int L = STATS ? (g.L > 1 ? g.L : 1) : 1;
+  if (STATS) dw_block_begin(c4, dw_accq);
+  for (int lc = 0; lc < L; ++lc) {
+  const long i0 = ((long)blockIdx.x * L + lc) * 256 + threadIdx.x;
   const bool live = i0 < total;
   if (!STATS && !live) return;
   const long i = STATS ? (live ? i0 : total - 1) : i0;
@@ -346,7 +367,9 @@ __global__ __launch_bounds__(256) void dwconv_row4x2_kernel(const float* __restr
         if (STATS == 2) dw_bn_sums_add(bn, v, ev[q], bsc, bsh, bmu, brs, s1, s2);
       }
   }
-  if (STATS) dw_block_sums(s1, s2, c4, g.C, stats);
+  if (STATS) dw_block_accumulate(s1, s2, c4, (long)blockIdx.x * L + lc, dw_accq);
+  }
+  if (STATS) dw_block_flush(c4, g.C, dw_accq, stats);
 }
 
 // Stride-2 data gradient: dx[ih,iw] = sum over (r,s) with (ih+pt-r) and (iw+pl-s) even of dy[(ih+pt-r)/2, (iw+pl-s)/2] * w[r,s].
@@ -359,9 +382,13 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
                                                                    DwGeom g, float* __restrict__ dx, float* __restrict__ stats = nullptr,
                                                                    const DwBn bn = DwBn{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   constexpr int TW = DW_TW, OFF = (KS - 1) / 2, MAXE = PLP ? 2 : 1, NX = MAXE + OFF + 1;
+  extern __shared__ float4 dw_accq[];                     // STATS: 2 * c4 float4
   const int c4 = g.C >> 2, wb_n = (g.W + TW - 1) / TW;
   const long total = (long)g.N * g.H * wb_n * c4;
-  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int L = STATS ? (g.L > 1 ? g.L : 1) : 1;
+  if (STATS) dw_block_begin(c4, dw_accq);
+  for (int lc = 0; lc < L; ++lc) {
+  const long i0 = ((long)blockIdx.x * L + lc) * 256 + threadIdx.x;
   const bool live = i0 < total;
   if (!STATS && !live) return;
   const long i = STATS ? (live ? i0 : total - 1) : i0;
@@ -377,6 +404,14 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
   for (int q = 0; q < TW; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r0 = (ih + g.pad_t) & 1;                     // rows r = r0, r0+2, .. reach this dx row
   const int base = (w0 >> 1) + ((g.pad_l - PLP) >> 1) - OFF;
+  const long o0 = (((long)n * g.H + ih) * g.W + w0) * c4 + cq;
+  // STATS = 2: the BatchNormalization input at this thread's outputs, requested in FRONT of the taps (behind them, under the
+  // `live` branch, it was one more exposed memory latency per thread: 14x14x672 5x5 at 1.3 TB/s)
+  float4 ev[STATS == 2 ? TW : 1];
+  if (STATS == 2) {
+#pragma unroll
+    for (int q = 0; q < TW; ++q) ev[q] = reinterpret_cast<const float4*>(bn.e)[o0 + (long)(w0 + q < g.W ? q : 0) * c4];
+  }
 #pragma unroll KS == 3 ? 2 : 1
   for (int a = 0; a < (KS + 1) / 2; ++a) {
     const int r = r0 + 2 * a;
@@ -408,7 +443,6 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
       }
     }
   }
-  const long o0 = (((long)n * g.H + ih) * g.W + w0) * c4 + cq;
   float4* xo = reinterpret_cast<float4*>(dx) + o0;
   if (!STATS) {
 #pragma unroll
@@ -420,17 +454,16 @@ __global__ __launch_bounds__(256) void dwconv_dgrad4_s2_row_kernel(const float* 
   if (live) {
     const float4 bsc = reinterpret_cast<const float4*>(bn.scale)[cq], bsh = reinterpret_cast<const float4*>(bn.shift)[cq];
     const float4 bmu = reinterpret_cast<const float4*>(bn.mean)[cq], brs = reinterpret_cast<const float4*>(bn.rstd)[cq];
-    float4 ev[TW];
-#pragma unroll
-    for (int q = 0; q < TW; ++q) ev[q] = reinterpret_cast<const float4*>(bn.e)[o0 + (long)(w0 + q < g.W ? q : 0) * c4];
 #pragma unroll
     for (int q = 0; q < TW; ++q)
       if (w0 + q < g.W) {
         xo[(long)q * c4] = acc[q];
-        dw_bn_sums_add(bn, acc[q], ev[q], bsc, bsh, bmu, brs, s1, s2);
+        dw_bn_sums_add(bn, acc[q], ev[STATS == 2 ? q : 0], bsc, bsh, bmu, brs, s1, s2);
       }
   }
-  dw_block_sums(s1, s2, c4, g.C, stats);
+  dw_block_accumulate(s1, s2, c4, (long)blockIdx.x * L + lc, dw_accq);
+  }
+  dw_block_flush(c4, g.C, dw_accq, stats);
 }
 
 // Weight gradient, same column blocking, one WAVE per kernel row (workgroup = KS waves): wave r accumulates dw[r, 0..KS)
@@ -800,6 +833,11 @@ static bool dw_wide(const DwGeom& g) {
   return forced ? forced == 8 : (g.OW >= 7 && cdiv(g.OW, 8) * 8 <= cdiv(g.OW, 4) * 4 + g.OW / 8);
 }
 static bool dw_rows2(const DwGeom& g) { static const int rows2 = (int)env_long("EMBNET_DW_ROWS2", 1); return rows2 && g.OH >= 2; }
+// statistics variants: 256-thread chunks per workgroup, so that a launch writes at most ~2048 rows of partials (dw_block_accumulate)
+static int dw_stats_chunks(long chunks) {
+  static const long target = env_long("EMBNET_DW_STATS_ROWS", 2048);
+  return chunks > target && target > 0 ? (int)cdiv(chunks, target) : 1;
+}
 static long dw_rows2_grid(const DwGeom& g) {
   return cdiv((long)g.N * cdiv(g.OH, 2) * (g.C / 4) * cdiv(g.OW, dw_wide(g) ? 8 : 4), 256);
 }
@@ -817,14 +855,17 @@ static void launch_dw_rows(const float* x, const float* w, const DwGeom& g_in, f
   const bool wide = dw_wide(g);
   if (dw_rows2(g)) {                                                      // two output rows per thread
     const long grid = dw_rows2_grid(g);
+    g.L = dw_stats_chunks(grid);
+    const long sgrid = cdiv(grid, g.L);                                  // the statistics variants' workgroups = rows of partials
+    const size_t accq = (size_t)g.C * 8;                                  // 2 * C/4 float4
     if (stats && !FLIP) {
-      if (wide) dwconv_row4x2_kernel<KS, ST, false, 8, 1><<<grid, 256, 0, st>>>(x, w, g, y, stats);
-      else dwconv_row4x2_kernel<KS, ST, false, 4, 1><<<grid, 256, 0, st>>>(x, w, g, y, stats);
+      if (wide) dwconv_row4x2_kernel<KS, ST, false, 8, 1><<<sgrid, 256, accq, st>>>(x, w, g, y, stats);
+      else dwconv_row4x2_kernel<KS, ST, false, 4, 1><<<sgrid, 256, accq, st>>>(x, w, g, y, stats);
       return;
     }
     if (stats && FLIP && ST == 1 && bn) {                                // data gradient + BatchNorm-backward sums
-      if (wide) dwconv_row4x2_kernel<KS, 1, true, 8, 2><<<grid, 256, 0, st>>>(x, w, g, y, stats, *bn);
-      else dwconv_row4x2_kernel<KS, 1, true, 4, 2><<<grid, 256, 0, st>>>(x, w, g, y, stats, *bn);
+      if (wide) dwconv_row4x2_kernel<KS, 1, true, 8, 2><<<sgrid, 256, accq, st>>>(x, w, g, y, stats, *bn);
+      else dwconv_row4x2_kernel<KS, 1, true, 4, 2><<<sgrid, 256, accq, st>>>(x, w, g, y, stats, *bn);
       return;
     }
     if (wide) dwconv_row4x2_kernel<KS, ST, FLIP, 8><<<grid, 256, 0, st>>>(x, w, g, y);
@@ -853,7 +894,7 @@ extern "C" int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int st
   }
   if (!dw_rows2(g)) return 0;
   const long grid = dw_rows2_grid(g);
-  return grid < 0x7FFFFFFF ? (int)grid : 0;
+  return (int)cdiv(grid, dw_stats_chunks(grid));
 }
 
 static int dwconv2d_fwd_impl(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r,
@@ -903,7 +944,7 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, in
   if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || (stride != 1 && stride != 2) || !dw_fwd_rows_path(c, r, s, stride)) return 0;
   if (stride == 2) {                                     // dwconv_dgrad4_s2_row_kernel: one thread per (row, 4-column block, quad)
     const long grid = cdiv((long)n * h * cdiv(wd, DW_TW) * (c / 4), 256);
-    return grid < 0x7FFFFFFF ? (int)grid : 0;
+    return (int)cdiv(grid, dw_stats_chunks(grid));
   }
   DwGeom gf{n, 0, 0, c, r, s, 1, 0, 0, h, wd};
   {
@@ -912,7 +953,7 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, in
   }
   if (!dw_rows2(gf)) return 0;
   const long grid = dw_rows2_grid(gf);
-  return grid < 0x7FFFFFFF ? (int)grid : 0;
+  return (int)cdiv(grid, dw_stats_chunks(grid));
 }
 
 // Stride-1 depthwise data gradient that also emits the BatchNorm-backward sums of the layer in front of the depthwise conv (its
@@ -932,12 +973,14 @@ extern "C" int embnet_dwconv2d_dgrad_bnsums_f32(const float* dy, const float* w,
   if (stride == 2) {
     EMBNET_TRACE("embnet::dwconv_dgrad4_s2_row_kernel", TRACE_BYTES, 8.0 * total + 4.0 * n * oh * ow * c, stream);
     const int gridr = bn_rows;
+    g.L = dw_stats_chunks(cdiv((long)n * h * cdiv(wd, DW_TW) * (c / 4), 256));
+    const size_t accq = (size_t)c * 8;                                    // 2 * C/4 float4
     if (r == 3) {
-      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<3, 1, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
-      else dwconv_dgrad4_s2_row_kernel<3, 0, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<3, 1, 2><<<gridr, 256, accq, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      else dwconv_dgrad4_s2_row_kernel<3, 0, 2><<<gridr, 256, accq, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
     } else {
-      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<5, 1, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
-      else dwconv_dgrad4_s2_row_kernel<5, 0, 2><<<gridr, 256, 0, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      if (pad_l & 1) dwconv_dgrad4_s2_row_kernel<5, 1, 2><<<gridr, 256, accq, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
+      else dwconv_dgrad4_s2_row_kernel<5, 0, 2><<<gridr, 256, accq, S(stream)>>>(dy, w, g, dx, bn_partial, bn);
     }
     return check_launch("dwconv2d_dgrad_bnsums");
   }
