@@ -85,7 +85,7 @@ class MBConv(nn.Module):
         # BN + swish, the squeeze-and-excite pooling of its output and the gating in two passes over the depthwise output (the
         # activated tensor is never written); in backward two more (layers.BatchNormalization.se_gate)
         x = self.bn.se_gate(self.dwconv(x, emit_stats=self.training),          # (the BN's statistics from the depthwise kernel)
-                            lambda g: L.sigmoid(self.se_expand(L.swish(self.se_reduce(g)))))
+                            lambda g: L.se_mlp(g, self.se_reduce, self.se_expand))           # (one launch; three in backward)
         x = self.project_conv(x, emit_stats=self.training)
         if self.skip:                # BN apply + drop-connect + Add in one pass (layers.BatchNormalization.drop_add)
             return self.project_bn.drop_add(x, inp, self.drop)

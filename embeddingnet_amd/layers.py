@@ -966,6 +966,55 @@ class _DenseFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+# The squeeze-and-excite gate sigmoid(Dense(swish(Dense(pooled)))) as one forward and two backward launches (csrc/se_mlp.hip)
+# instead of twelve dense / activation / column-sum launches of 6-16 us each (EMBNET_SE_MLP=0: the composed form).
+SE_MLP = [__import__("os").environ.get("EMBNET_SE_MLP", "1") == "1"]
+
+
+class _SEMlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pooled, w1, b1, w2, b2):
+        pooled, w1, w2 = _c(pooled), _c(w1), _c(w2)
+        n, c = pooled.shape
+        s = w1.shape[1]
+        z1 = torch.empty((n, s), device=pooled.device, dtype=torch.float32)
+        gate = torch.empty((n, c), device=pooled.device, dtype=torch.float32)
+        check(_lib.lib().embnet_se_mlp_fwd(ptr(pooled), ptr(w1), ptr(b1), ptr(w2), ptr(b2), n, c, s, ptr(z1), ptr(gate), stream()))
+        ctx.refs = (w1, b1, w2, b2)
+        ctx.save_for_backward(pooled, w1, w2, z1, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        pooled, w1, w2, z1, gate = ctx.saved_tensors
+        n, c = pooled.shape
+        s = w1.shape[1]
+        dgate = _c(dgate)
+        dev = pooled.device
+        outs, notes = [], []
+        for i, ref in enumerate(ctx.refs):                 # dw1, db1, dw2, db2: the parameters' gradient sinks, or scratch
+            if ctx.needs_input_grad[1 + i]:
+                t, note = _sink(ref)
+            else:
+                t, note = torch.empty(ref.shape, device=dev, dtype=torch.float32), None
+            outs.append(t); notes.append(note)
+        dz1 = torch.empty_like(z1)
+        dpooled = torch.empty_like(pooled)
+        check(_lib.lib().embnet_se_mlp_bwd(ptr(dgate), ptr(gate), ptr(z1), ptr(pooled), ptr(w1), ptr(w2), n, c, s, ptr(dz1),
+                                           ptr(dpooled), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), stream()))
+        grads = [(_done(t, note) if ctx.needs_input_grad[1 + i] else None) for i, (t, note) in enumerate(zip(outs, notes))]
+        return (dpooled if ctx.needs_input_grad[0] else None, *grads)
+
+
+def se_mlp(pooled, reduce, expand):
+    """sigmoid(expand(swish(reduce(pooled)))) for two Dense layers with bias — an MBConv block's squeeze-and-excite gate
+    (reference backbones.py:84-98 via efficientnet's MBConv)."""
+    if (SE_MLP[0] and pooled.dim() == 2 and pooled.is_cuda and not reduce.relu and not expand.relu
+            and _lib.lib().embnet_se_mlp_supported(pooled.shape[0], pooled.shape[1], reduce.kernel.shape[1])):
+        return _SEMlpFn.apply(pooled, reduce.kernel, reduce.bias, expand.kernel, expand.bias)
+    return sigmoid(expand(swish(reduce(pooled))))
+
+
 class Dense(nn.Module):
     def __init__(self, in_features, units, activation=None, l2=0.0, gen=None):
         super().__init__()

@@ -265,6 +265,15 @@ int embnet_conv2d_patch_bnsums_f32(const void* x_planes, const void* w_planes, f
                                    int k, int pad_t, int pad_l, int oh, int ow, const float* bn_x, const float* bn_scale,
                                    const float* bn_shift, const float* bn_mean, const float* bn_rstd, int bn_act,
                                    float* bn_partial, int bn_rows, void* workspace, size_t workspace_bytes, void* stream);
+/* The squeeze-and-excite gate of an MBConv block, gate = sigmoid(swish(pooled w1 + b1) w2 + b2) (pooled [n,c], w1 [c,s], w2 [s,c]),
+ * as one forward launch (z1 [n,s]: the first layer's pre-activation, kept for backward) and two backward launches (dz1 [n,s]:
+ * scratch; writes dpooled [n,c], dw1 [c,s], db1 [s], dw2 [s,c], db2 [c]; sums over the samples in sample order) instead of
+ * twelve dense / activation / column-sum launches.  embnet_se_mlp_supported: 1 where they apply (s <= 160, LDS). */
+int embnet_se_mlp_supported(int n, int c, int s);
+int embnet_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, int n, int c, int s,
+                      float* z1, float* gate, void* stream);
+int embnet_se_mlp_bwd(const float* dgate, const float* gate, const float* z1, const float* pooled, const float* w1, const float* w2,
+                      int n, int c, int s, float* dz1, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 int embnet_planes_from_f32(const float* x, long pixels, int c, void* planes, void* stream);
 int embnet_conv_weight_planes_chunk_elems(void);
 int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);
