@@ -288,7 +288,8 @@ extern "C" int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* 
   const int grid = (pl.tiles * pl.splits + 7) / 8 * 8;
   {
     const double m = (double)n * h * wd;
-    EMBNET_TRACE_FLOP("embnet::wgp::conv_wgrad_planes_kernel(embnet::wgp::Params)", 2.0 * m * k * 9.0 * c,
+    EMBNET_TRACE_FLOP((knobs & 4) ? "void embnet::wgp::conv_wgrad_planes_kernel<true>(embnet::wgp::Params)"
+                                  : "void embnet::wgp::conv_wgrad_planes_kernel<false>(embnet::wgp::Params)", 2.0 * m * k * 9.0 * c,
                       6.0 * m * (c + k) + 4.0 * 9.0 * c * k * pl.splits, st);
     if (knobs & 4) conv_wgrad_planes_kernel<true><<<grid, 512, LDS_BYTES, st>>>(p);
     else conv_wgrad_planes_kernel<false><<<grid, 512, LDS_BYTES, st>>>(p);
