@@ -6,11 +6,14 @@
 // backward x 2 — of 6-16 us each for 2.5-28 MFLOP of work: 127 us per block, 2.0 ms of a 24.8 ms EfficientNet-B0 step at
 // 64 x 4 images, all of it launch latency on one stream.  The arithmetic is fp32 FMA chains (no matrix instruction: the
 // reductions are 4-160 or C long and the matrices 256 rows).
-//  * forward: a workgroup takes SB = 2 samples (pooled rows in LDS); z1 = pooled W1 with the CHANNELS spread over the threads —
-//    a thread requests the S weights of each of its channels at once and holds SB x 64 partial sums, which meet in LDS
-//    (block_sum_units); gate = sigmoid(h W2 + b2) one channel quad per thread.  z1 (pre-activation) and gate are what backward needs.
-//  * backward A (per 2 samples): dz2 = dgate gate (1 - gate); dh = dz2 W2^T (channel quads over the threads, the same partial
-//    sums); dz1 = dh swish'(z1) (stored); dpooled = dz1 W1^T one channel per thread.
+//  * forward (1024 threads per two samples, pooled rows in LDS): z1 = pooled W1 + b1 with W1 [C][S] streamed through LDS in chunks
+//    of whole rows — copied with consecutive lanes on consecutive addresses and re-laid at an odd row pitch — and threads =
+//    (unit lane, one of 16 channel lanes) walking the chunk's rows, the 16 lanes' sums added in lane order;
+//    gate = sigmoid(swish(z1) W2 + b2) with thread = (channel quad, unit group): W2 [S][C] is read coalesced along the channels,
+//    the groups' sums meet in LDS in group order.  z1 (pre-activation) and gate are what backward needs.
+//  * backward A (same geometry): dz2 = dgate gate (1 - gate); dh = dz2 W2^T by (channel quad, unit group) threads whose products
+//    are summed over the quads by 16 row slices in order; dz1 = dh swish'(z1) (stored); dpooled = dz1 W1^T from LDS chunks of W1,
+//    one row per thread.
 //  * backward B (per 16 channels): dW2[:, chunk] = h^T dz2, db2, dW1[chunk, :] = pooled^T dz1, db1 — sums over the samples in
 //    sample order from LDS tiles of 64 samples held transposed (four samples per ds_read_b128): bitwise reproducible.
 #include "common.h"
@@ -28,11 +31,12 @@ constexpr int NTP = NT + 4;      // its row pitch in floats: 16-byte aligned row
 
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// Everything here is bound by memory LATENCY, not bytes or FLOP: 2.5-28 MFLOP and < 1 MB per launch.  Measured forms
-// (profiles/r05_exp_se_mlp.txt): one (unit, channel-lane) pair per thread walking C / 4 channels with four loads in flight —
-// 34 / 66 us forward / backward A; 256 threads each owning C / 256 channels with all their weights requested at once, the second
-// layer still a loop of S dependent batches — 21 / 62 us.  This form: 1024 threads, every thread's weights of a phase in ONE or two
-// batches of requests, the per-thread partial sums meeting in LDS in a fixed order (bitwise reproducible).
+// Everything here is bound by memory LATENCY and by the access pattern, not by bytes or FLOP (2.5-28 MFLOP, < 1 MB per launch).
+// Measured forms (profiles/r05_exp_se_mlp.txt, forward / backward A in the C5 step's trace): one (unit, channel-lane) pair per thread
+// walking C / 4 channels with four loads in flight 34 / 66 us; 256 threads each owning C / 256 channels (a thread per W1 row: 64
+// different cache lines per load instruction) 21 / 62 us; 1024 such threads 28 / 51 us; this form 17 / 48 us (8-21 / 10-27 us back
+// to back, tools/exp/se_mlp_bench.py).  Requesting more per round trip (first chunk and first W2 batch at kernel start, chunk
+// prefetch, z1 through LDS) and rotating the chunk order per workgroup measured the same in the step and are not kept.
 
 // rc rows of S floats (contiguous in memory) -> LDS rows of pitch SP; consecutive threads on consecutive addresses, four
 // requests per thread and round in flight
