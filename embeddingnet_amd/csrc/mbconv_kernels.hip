@@ -264,7 +264,7 @@ __device__ __forceinline__ void dw_block_flush(int c4, int C, const float4* accq
 // STATS (forward only): the workgroup also writes the per-channel sum and sum of squares of the outputs it produced as row
 // blockIdx.x of stats[2][C][gridDim.x] — the statistics partials of the BatchNormalization that follows (the layout the conv
 // epilogues write, embnet_bn_train_fwd's `partials`), so that layer does not read the tensor for them.  Threads i, i + c4, ..
-// of a workgroup hold the same channel quad; quads a workgroup does not touch (C/4 > 256) stay as the caller zeroed them.
+// of a workgroup hold the same channel quad; every (channel, row) is written (dw_block_flush: quads a workgroup never touched as zeros).
 // STATS = 2 (stride-1 data gradient, FLIP): y is the gradient of the depthwise layer's INPUT a = act(BN(e)); the workgroup writes
 // the BatchNorm-backward sums of that layer instead — sum dz and sum dz * ehat with dz = y * act'(BN(e)) — reading e once per
 // output (conv.hip's BnSums for the depthwise data gradient): the BatchNormalization backward skips its reduction pass.
@@ -884,7 +884,7 @@ static bool dw_fwd_rows_path(int c, int r, int s, int stride) {
 }
 
 // rows P of the statistics partials [2][c][P] embnet_dwconv2d_fwd_stats_f32 writes for this geometry (0: not available — the
-// two-rows-per-thread kernels only); when c / 4 > 256 the caller zeroes the buffer first (a workgroup covers 256 channel quads)
+// two-rows-per-thread kernels only).  Every (channel, row) is written; callers that zero wide buffers first (c / 4 > 256: older ABI) still may
 extern "C" int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int stride, int oh, int ow) {
   if (n <= 0 || c <= 0 || oh <= 0 || ow <= 0 || !dw_fwd_rows_path(c, r, s, stride)) return 0;
   DwGeom g{n, 0, 0, c, r, s, stride, 0, 0, oh, ow};

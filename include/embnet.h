@@ -469,8 +469,8 @@ int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int
                             int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
 /* DepthwiseConv2D forward that also writes the statistics partials [2][c][P] (sum, sum of squares of y per channel, one row per
  * workgroup; P = embnet_dwconv2d_fwd_stats_rows(...), 0 = not available for the geometry) of the BatchNormalization that follows
- * (embnet_bn_train_fwd's `partials`): that layer then does not read y for its statistics.  When c / 4 > 256 the caller zeroes
- * `stats` first. */
+ * (embnet_bn_train_fwd's `partials`): that layer then does not read y for its statistics.  Every (channel, row) is written
+ * (since ABI 19; earlier, wide layers — c / 4 > 256 — wanted `stats` zeroed first, which remains harmless). */
 int embnet_dwconv2d_fwd_stats_rows(int n, int c, int r, int s, int stride, int oh, int ow);
 int embnet_dwconv2d_fwd_stats_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s, int stride,
                                   int pad_t, int pad_l, int oh, int ow, float* stats, void* stream);
@@ -479,7 +479,8 @@ int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n,
 /* Depthwise data gradient (stride 1 or 2) that also emits the BatchNorm-backward sums of the layer in front of the depthwise conv (its
  * input was act(bn_x*bn_scale + bn_shift): an MBConv block's expand BatchNormalization), as embnet_conv2d_dgrad_bnsums_f32 does
  * for the gather convs: bn_partial [2][c][bn_rows], bn_rows = embnet_dwconv2d_dgrad_bnsums_rows(...) (0: not available); when
- * c / 4 > 256 the caller zeroes bn_partial first.  For embnet_bn_bwd_partials. */
+ * every (channel, row) of bn_partial is written (ABI 19; zeroing it first, as wide layers once required, stays harmless).  For
+ * embnet_bn_bwd_partials. */
 int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int stride);
 int embnet_dwconv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
                                      int stride, int pad_t, int pad_l, int oh, int ow, const float* bn_x, const float* bn_scale,
