@@ -478,7 +478,7 @@ int embnet_dwconv2d_dgrad_f32(const float* dy, const float* w, float* dx, int n,
                               int stride, int pad_t, int pad_l, int oh, int ow, void* stream);
 /* Depthwise data gradient (stride 1 or 2) that also emits the BatchNorm-backward sums of the layer in front of the depthwise conv (its
  * input was act(bn_x*bn_scale + bn_shift): an MBConv block's expand BatchNormalization), as embnet_conv2d_dgrad_bnsums_f32 does
- * for the gather convs: bn_partial [2][c][bn_rows], bn_rows = embnet_dwconv2d_dgrad_bnsums_rows(...) (0: not available); when
+ * for the gather convs: bn_partial [2][c][bn_rows], bn_rows = embnet_dwconv2d_dgrad_bnsums_rows(...) (0: not available);
  * every (channel, row) of bn_partial is written (ABI 19; zeroing it first, as wide layers once required, stays harmless).  For
  * embnet_bn_bwd_partials. */
 int embnet_dwconv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int r, int s, int stride);
