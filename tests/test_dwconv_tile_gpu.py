@@ -156,3 +156,53 @@ def test_asymmetric_padding_and_what_stays_on_the_row_kernels(dev):
         pt = max((oh - 1) * st + 3 - hh, 0) // 2
         _, names = _names(lambda: check(lib.embnet_dwconv2d_fwd_f32(x.data_ptr(), wt.data_ptr(), y.data_ptr(), 2, hh, hh, cc, 3, 3, st, pt, pt, oh, oh, stream())))
         assert names and "dw_tile" not in names[0], (hh, cc, st, names)
+
+
+_FULL_SIZE_SCRIPT = r"""
+import json, sys, torch
+from embeddingnet_amd import _lib
+from embeddingnet_amd._lib import check, stream
+lib = _lib.lib(); dev = torch.device("cuda:0"); out = {}
+for (h, c, k) in [(28, 240, 5), (14, 480, 3), (14, 672, 5), (7, 1152, 5)]:
+    n, pad = 256, (k - 1) // 2
+    g = torch.Generator(device=dev).manual_seed(h * 1000 + c)
+    x = torch.randn(n, h, h, c, device=dev, generator=g); dy = torch.randn(n, h, h, c, device=dev, generator=g)
+    w = torch.randn(k, k, c, 1, device=dev, generator=g) * 0.2
+    y = torch.empty_like(x); dx = torch.empty_like(x); dw = torch.empty_like(w)
+    rows = lib.embnet_dwconv2d_fwd_stats_rows(n, c, k, k, 1, h, h)
+    st = torch.zeros(2, c, rows, device=dev)
+    check(lib.embnet_dwconv2d_fwd_stats_f32(x.data_ptr(), w.data_ptr(), y.data_ptr(), n, h, h, c, k, k, 1, pad, pad, h, h, st.data_ptr(), stream()))
+    check(lib.embnet_dwconv2d_dgrad_f32(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), n, h, h, c, k, k, 1, pad, pad, h, h, stream()))
+    ws = torch.empty(max(lib.embnet_dwconv2d_wgrad_workspace_bytes(n, c, k, k, h, h) // 4, 4), device=dev)
+    check(lib.embnet_dwconv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, h, h, c, k, k, 1, pad, pad, h, h, stream()))
+    torch.cuda.synchronize()
+    pick = lambda t: t.flatten()[:: max(t.numel() // 4096, 1)][:4096].double().cpu().tolist()
+    out[f"{h}x{c}k{k}"] = dict(y=pick(y), dx=pick(dx), dw=dw.flatten().double().cpu().tolist(), s=st.double().sum(-1).flatten().cpu().tolist(),
+                               ysum=float(y.double().sum()), dxsum=float(dx.double().sum()))
+json.dump(out, open(sys.argv[1], "w"))
+"""
+
+
+def test_tile_kernels_equal_row_kernels_at_full_size(dev, tmp_path):
+    """BASELINE config C5's stride-1 small-map layers at the full local batch (256 images): forward + statistics, data gradient and
+    weight gradient from the LDS-tile kernels against the per-thread row kernels (EMBNET_DW_TILE=0; the knob is read once per
+    process, so each side runs in a child process on the same seeded tensors): sampled elements, whole-tensor sums, every
+    statistic and every weight-gradient element within fp32 summation order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for on in ("1", "0"):
+        path = tmp_path / f"dw_{on}.json"
+        env = dict(os.environ, EMBNET_DW_TILE=on, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        subprocess.run([sys.executable, "-c", _FULL_SIZE_SCRIPT, str(path)], check=True, env=env, cwd=root, timeout=600)
+        res[on] = json.load(open(path))
+    for layer, a in res["1"].items():
+        b = res["0"][layer]
+        for key in ("y", "dx", "dw", "s"):
+            ta, tb = torch.tensor(a[key]), torch.tensor(b[key])
+            assert float((ta - tb).abs().max() / tb.abs().max().clamp_min(1e-30)) < 2e-5, (layer, key)
+        for key in ("ysum", "dxsum"):
+            assert abs(a[key] - b[key]) <= 1e-6 * max(abs(b[key]), 1.0) + 1e-2, (layer, key, a[key], b[key])
