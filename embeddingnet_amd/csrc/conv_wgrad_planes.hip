@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
       if (t + 1 < 9) load_a(t + 1, a[(t + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);          // the next tap's reads go out BEFORE this tap's MFMAs
 #pragma unroll
-      for (int e = 0; e < 6; ++e)
+      for (int e = 6 - EMBNET_EXP_TERMS; e < 6; ++e)      // (EMBNET_EXP_TERMS: gemm_engine.h; 6 in the product)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][PA[e]], b[PB[e]], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);          // one tap's fragments ahead, not all nine (registers)
     }

@@ -449,6 +449,12 @@ template <int R> struct SplitTile<TileKM<R>> { using type = TileKM3<R>; };
 template <class TA, class TB>
 constexpr int MAIN3_BYTES = SplitTile<TA>::type::BYTES + SplitTile<TB>::type::BYTES;
 
+// EMBNET_EXP_TERMS (build-time experiment, tools/exp/run_r05_terms3.sh): 3 executes only the three largest of the six terms —
+// NOT the product's arithmetic (16-bit products) — to measure what a three-term scheme (an fp16 x 2 split) would
+// run at.  The product is built with 6.
+#ifndef EMBNET_EXP_TERMS
+#define EMBNET_EXP_TERMS 6
+#endif
 // one k16-step: six terms per accumulator, smallest first; the accumulators of a wave alternate inside a term so
 // consecutive MFMAs are independent
 template <class G>
@@ -456,7 +462,7 @@ __device__ __forceinline__ void mfma_step3(const bf16x8 (&a)[G::TM][3], const bf
                                            f32x16 (&acc)[G::TM][G::TN]) {
   constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+  for (int t = 6 - EMBNET_EXP_TERMS; t < 6; ++t)
 #pragma unroll
     for (int im = 0; im < G::TM; ++im)
 #pragma unroll
