@@ -17,8 +17,9 @@ Rank 0 prints ONE JSON line; details go to stderr.
 
 roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
 one to three of the timed steps (by the length of the timed region); the kernel with the largest total time is reported against the roofline that bounds it — for the
-convolution kernels the bf16 MFMA peak (16 x 157.3 TFLOP/s) with the bf16 FLOP they execute (each fp32 product = 6 bf16
-MFMA terms of an exact operand split: 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
+convolution kernels the 16-bit MFMA peak (16 x 157.3 TFLOP/s) with the 16-bit FLOP they execute (each fp32 product = 3 fp16
+MFMA terms of a two-piece split in the kernels that read pre-split planes, 6 bf16 terms of an exact three-way split in the others:
+3 or 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
 fp32 (157.3 TFLOP/s) for the distance / dense GEMMs with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
 copy rate also given) for the streaming kernels with their algorithmic bytes.
 """
@@ -129,7 +130,7 @@ def cpu_baseline(args):
             "sample": f"{what}, {n} steps of {dt:.2f} s"}
 
 
-def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms=1):
+def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms=1, planes_terms=None):
     """records: [(kernel, ms, work, unit, bytes)] over `traced_steps` steps -> (roofline dict, per-kernel table)."""
     by = {}
     detail = os.environ.get("EMBNET_BENCH_DETAIL")       # substring of a kernel name: list its launches one by one
@@ -156,13 +157,17 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
     if d["unit"] == 0:
         achieved = d["work"] / d["ms"] / 1e9              # algorithmic (fp32) FLOP: 2 * M * N * K per launch
         terms = conv_terms if "conv_" in name else 1
+        planes = planes_terms is not None and ("conv_patch_kernel" in name or "conv_wgrad_planes_kernel" in name)
+        if planes:
+            terms = planes_terms
         if terms > 1:
-            # the conv kernels form every fp32 product from `terms` bf16 MFMA terms (exact 3-way split, include/embnet.h):
-            # the matrix pipe executes terms x the algorithmic FLOP, on the bf16 instruction -> priced against the bf16 peak
+            # the conv kernels form every fp32 product from `terms` 16-bit MFMA terms of an operand split (include/embnet.h): the
+            # matrix pipe executes terms x the algorithmic FLOP, on the bf16 / fp16 instruction -> priced against that peak
+            how = ("3 v_mfma_f32_32x32x16_f16 terms of a two-piece fp16 split (22 mantissa bits, a power-of-two scale per tensor)"
+                   if planes and terms == 3 else f"{terms} v_mfma_f32_32x32x16_bf16 terms of an exact three-way bf16 split")
             roof = {"bound": "mfma", "kernel": name, "achieved": round(terms * achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(terms * achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "arithmetic": f"fp32 operands and accumulation; each product = {terms} v_mfma_f32_32x32x16_bf16 terms of an "
-                                  "exact three-way bf16 split; `achieved` counts the executed bf16 MFMA FLOP",
+                    "arithmetic": f"fp32 operands and accumulation; each product = {how}; `achieved` counts the executed 16-bit MFMA FLOP",
                     "fp32_equivalent_tflops": round(achieved, 2),
                     "fp32_equivalent_over_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                     "flop_per_launch": d["work"] / d["launches"]}
@@ -432,15 +437,17 @@ def main():
     roofline = None
     if trace:
         roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at), ms_per_step, args.config,
-                                          _lib.lib().embnet_conv_mfma_terms())
+                                          _lib.lib().embnet_conv_mfma_terms(), _lib.lib().embnet_conv_planes_mfma_terms())
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
                                                              (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+    SPLIT_NOTE = ("3x3 stride-1 convs and their weight gradients: two fp16 pieces + a per-tensor power-of-two scale, 3 terms; other convs: "
+                  "three bf16 pieces, 6 terms" if _lib.lib().embnet_conv_planes_mfma_terms() == 3 else "three exact bf16 pieces, 6 terms")
     if args.mode == "siamese":
         metric = f"images/sec training ({args.backbone}, {args.image}², Siamese contrastive) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), SiameseNet 'l2' head + contrastive_loss, "
                     f"{args.pairs} pairs per GPU (first half same class) = {n_local} images, {pool} resident batches cycled, E={args.encodings_len}, "
-                    f"{args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
+                    f"{args.optimizer}, fp32 tensors (conv products on 16-bit MFMA from operand splits, fp32 accumulate: " + SPLIT_NOTE + ")")
     else:
         label = {"resnet18": "ResNet18", "resnet50": "ResNet50", "efficientnet-b0": "EfficientNet-B0"}.get(args.backbone, args.backbone)
         # (BASELINE.json's metric string says "batch-hard"; the reference's own rule for it is 'hardest' — config.mining and
@@ -449,7 +456,7 @@ def main():
         metric = f"images/sec training ({label}, {args.image}², triplet {mining}) @ 1/2/4/8 GPU"
         workload = (f"{args.backbone} {args.image}x{args.image}x3 synthetic U[0,1), 107-class P x K sampling, local batch "
                     f"{args.k_classes}x{args.k_samples}={n_local} ({pool} resident batches cycled), E={args.encodings_len}, margin {args.margin}, mining "
-                    f"'{args.mining}' per local batch, {args.optimizer}, fp32 tensors (conv products: 6-term exact bf16 split, fp32 accumulate)")
+                    f"'{args.mining}' per local batch, {args.optimizer}, fp32 tensors (conv products on 16-bit MFMA from operand splits, fp32 accumulate: " + SPLIT_NOTE + ")")
     out = {
         "metric": metric, "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",

@@ -52,6 +52,10 @@ struct TraceScope {
 
 // tuning knobs: read once per process (each call site keeps its own `static const`)
 inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+// The format of the pre-split planes of this process (gemm_engine.h): two fp16 pieces + a power-of-two scale per tensor, three matrix
+// products per fp32 product (default), or EMBNET_PLANES_F16=0: three bf16 pieces, six products (rounds 2-5).  Read once: every
+// producer and consumer of planes in a process uses the same format.
+inline bool planes_f16() { static const bool on = env_long("EMBNET_PLANES_F16", 1) != 0; return on; }
 
 // ---- device helpers ------------------------------------------------------
 constexpr int WAVE = 64;

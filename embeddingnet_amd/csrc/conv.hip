@@ -970,6 +970,8 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
 static bool wgrad_k32() { static const bool v = env_long("EMBNET_WGRAD_K32", 0) != 0; return v; }
 
 extern "C" int embnet_conv_mfma_terms(void) { return EMBNET_CONV_SPLIT ? 6 : 1; }
+// ... of the kernels that read pre-split planes (conv_patch.hip, conv_wgrad_planes.hip): 3 in the two-piece fp16 format
+extern "C" int embnet_conv_planes_mfma_terms(void) { return planes_f16() ? 3 : 6; }
 
 extern "C" size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow) {
   if (n <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || oh <= 0 || ow <= 0 || ((c | k) & 3)) return 0;

@@ -89,14 +89,32 @@ __device__ __forceinline__ int padded_pos(int m) {            // padded-image po
   return (int)n * (pp->PH * pp->PW) + (int)oh * pp->PW + (int)ow;
 }
 
+// one step of the main loop in the planes' format: six bf16 terms, or three fp16 terms (the fragments are bit patterns either way)
+template <class G, bool F16, int NP>
+__device__ __forceinline__ void step_planes(const bf16x8 (&a)[G::TM][NP], const bf16x8 (&b)[G::TN][NP], f32x16 (&acc)[G::TM][G::TN]) {
+  if constexpr (F16) {
+    f16x8 ah[G::TM][2], bh[G::TN][2];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) { ah[i][0] = __builtin_bit_cast(f16x8, a[i][0]); ah[i][1] = __builtin_bit_cast(f16x8, a[i][1]); }
+#pragma unroll
+    for (int i = 0; i < G::TN; ++i) { bh[i][0] = __builtin_bit_cast(f16x8, b[i][0]); bh[i][1] = __builtin_bit_cast(f16x8, b[i][1]); }
+    mfma_step_h<G::TM, G::TN>(ah, bh, acc);
+  } else {
+    mfma_step3<G>(a, b, acc);
+  }
+}
+
 // BNS: the data-gradient form that also emits the BatchNorm-backward sums (PatchParams::bn) — an instantiation of its own: the
 // 64 extra epilogue registers and scalar spills cost the plain kernel ~10 % when both forms share one body
-template <int BN, int R, int S, int TPS, int NBS, bool BNS = false>
+// F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): NP = 2 planes are fetched and read (the LDS
+// layout keeps its three-plane pitch), three matrix products per step instead of six, the accumulators x 1 / (s_x s_w) in the epilogue
+template <int BN, int R, int S, int TPS, int NBS, bool BNS = false, bool F16 = false>
 __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
   using G = GeomP<BN>;
+  constexpr int NP = F16 ? 2 : 3;
   constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
   constexpr int SBY = TPS * 3 * BN * 32;                 // one weight slot: TPS taps x 3 planes x BN rows x 32 bytes
-  constexpr int NBI = TPS * 3 * (BN / 32);               // DMA instructions per weight slot
+  constexpr int NBI = TPS * NP * (BN / 32);              // DMA instructions per weight slot
   static_assert((R * S) % TPS == 0 && SPC >= 2, "steps per chunk");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
         const int tap = st * TPS + tp, r = tap / S, s = tap % S;
         const unsigned so = 32u * (unsigned)(((r * NCC + cc) * S + s) * K);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
           for (int gb = 0; gb < BN / 32; ++gb)
             dma16(wr, slot + ((tp * 3 + q) * BN + gb * 32) * 32, live ? rowoff[gb] : OOB, q * wpb + so);
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
     auto issue = [&](int cc, int gc) {
       unsigned char* buf = smem + (gc & 1) * PB;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int gI = 0; gI < 16; ++gI)
           if (gI < NG) dma16(xr, buf + q * PLP + gI * 1024, poff[gI], q * xpb + (unsigned)cc * chunk_bytes);
@@ -240,22 +258,22 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
 #pragma unroll
         for (int tp = 0; tp < TPS; ++tp) {
           const int tap = st * TPS + tp, r = tap / S, s = tap % S;
-          bf16x8 a[TM][3], bb[TN][3];
+          bf16x8 a[TM][NP], bb[TN][NP];
 #pragma unroll
           for (int im = 0; im < TM; ++im) {
             const int idx = rowidx[im] + r * PW + s;
             const unsigned char* ap = pbuf + idx * 32 + ((h ^ ((idx >> 3) & 1)) << 4);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[im][q] = *reinterpret_cast<const bf16x8*>(ap + q * PLP);
+            for (int q = 0; q < NP; ++q) a[im][q] = *reinterpret_cast<const bf16x8*>(ap + q * PLP);
           }
 #pragma unroll
           for (int in = 0; in < TN; ++in) {
             const int row = wn + in * 32 + (lane & 31);
             const unsigned char* bp = bs + (tp * 3 * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bb[in][q] = *reinterpret_cast<const bf16x8*>(bp + q * BN * 32);
+            for (int q = 0; q < NP; ++q) bb[in][q] = *reinterpret_cast<const bf16x8*>(bp + q * BN * 32);
           }
-          mfma_step3<G>(a, bb, acc);
+          step_planes<G, F16>(a, bb, acc);
           if (TPS > 1) __builtin_amdgcn_sched_barrier(0);     // one tap's fragments at a time (all taps' reads hoisted: spills)
         }
         ++gs;
@@ -264,6 +282,15 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
     }
     // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
     // lane & 31, so a store instruction writes two 128-byte row segments
+    if (F16) {                                           // 1 / (s_x s_w): powers of two, exact
+      const float osc = planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1] * planes_scale_slot(p.wp, (long)(p.w_plane_bytes >> 1))[1];
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) acc[im][in][rr] *= osc;
+    }
     if (cur.part) {
       float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
 #pragma unroll
@@ -355,7 +382,8 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
 //           the correlation of dy with the flipped kernel, channel roles swapped)
 struct WPlanesTensor { const float* w; unsigned short* out; int R, S, C, K, flip, pad; };
 static_assert(sizeof(WPlanesTensor) == 40, "descriptor layout is part of the ABI (include/embnet.h)");
-__global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor* __restrict__ table, const int* __restrict__ chunks) {
+// f16: two fp16 pieces of w x 2^8 + the scale slot (gemm_engine.h)
+__global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor* __restrict__ table, const int* __restrict__ chunks, int f16) {
   const WPlanesTensor t = table[chunks[2 * blockIdx.x]];
   const int rows = t.flip ? t.C : t.K, red = t.flip ? t.K : t.C, ncc = red / 16;
   const long plane = (long)t.R * t.S * t.C * t.K, total4 = plane / 4;
@@ -376,9 +404,16 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor*
       v[q] = t.flip ? t.w[((long)((t.R - 1 - r) * t.S + (t.S - 1 - s)) * t.C + row) * t.K + ch]
                     : t.w[((long)(r * t.S + s) * t.C + ch) * t.K + row];
     }
-    const Split4 sp = split4(make_float4(v[0], v[1], v[2], v[3]));
+    if (f16) {
+      const Split4H sp = split4h(make_float4(v[0], v[1], v[2], v[3]), 256.f);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
+      for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
+      if (i4 == 0) { float* sl = planes_scale_slot(t.out, plane); sl[0] = 256.f; sl[1] = 1.f / 256.f; }
+    } else {
+      const Split4 sp = split4(make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
+    }
   }
 }
 
@@ -393,6 +428,49 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
     const long o = ((long)(c >> 4) * pixels + pix) * 16 + (c & 15);
 #pragma unroll
     for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(planes + q * plane + o) = s.p[q];
+  }
+}
+
+// the same in the two-piece fp16 format: MODE 2 leaves the workgroups' max |x| behind the scale slot, planes_scale_of_kernel turns
+// them into (s, 1 / s), MODE 1 writes the pieces of x s
+template <int MODE>
+__global__ __launch_bounds__(256) void planes16_from_f32_kernel(const float* __restrict__ x, long pixels, int C,
+                                                                unsigned short* __restrict__ planes) {
+  const long total4 = pixels * C / 4, plane = pixels * C;
+  const int c4 = C / 4;
+  float amax = 0.f;
+  const float sc = MODE == 1 ? planes_scale_slot(planes, plane)[0] : 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (MODE == 2) { amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); continue; }
+    const long pix = i / c4; const int c = (int)(i % c4) * 4;
+    const Split4H s = split4h(v, sc);
+    const long o = ((long)(c >> 4) * pixels + pix) * 16 + (c & 15);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(planes + q * plane + o) = s.p[q];
+  }
+  if (MODE == 2) {
+    amax = wave_max(amax);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) planes_scale_slot(planes, plane)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  }
+}
+__global__ __launch_bounds__(256) void planes_scale_of_kernel(float* __restrict__ slot, int blocks) {   // nn_kernels.hip's planes_scale_kernel
+  float m = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[16 + i]);
+  m = wave_max(m);
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    int e = 0;
+    const bool ok = m > 0.f && m <= 3.4028234e38f;
+    if (ok) (void)frexpf(m, &e);
+    const int k = ok ? max(-120, min(120, 15 - e)) : 0;
+    slot[0] = ldexpf(1.f, k); slot[1] = ldexpf(1.f, -k);
   }
 }
 
@@ -474,7 +552,17 @@ extern "C" int embnet_planes_from_f32(const float* x, long pixels, int c, void* 
   EMBNET_CHECK_ARG((size_t)pixels * c * 2 < 0x7FFFFFF0ull / 3, "planes_from_f32: tensor too large");
   const long n4 = pixels * c / 4;
   EMBNET_TRACE("embnet::patch::planes_from_f32_kernel", TRACE_BYTES, 10.0 * pixels * c, stream);
-  planes_from_f32_kernel<<<(int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1), 256, 0, (hipStream_t)stream>>>(x, pixels, c, (unsigned short*)planes);
+  const int blocks = (int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1);
+  if (planes_f16()) {                                       // the tensor's range first (its largest |x| -> [2^14, 2^15)), then the pieces
+    hipStream_t st = (hipStream_t)stream;
+    float* slot = planes_scale_slot(planes, pixels * c);
+    const bool room = 2 * n4 >= 16 + blocks;                // (the third plane's space holds the slot and the workgroup maxima)
+    if (room) planes16_from_f32_kernel<2><<<blocks, 256, 0, st>>>(x, pixels, c, (unsigned short*)planes);
+    planes_scale_of_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0);
+    planes16_from_f32_kernel<1><<<blocks, 256, 0, st>>>(x, pixels, c, (unsigned short*)planes);
+    return check_launch("planes_from_f32");
+  }
+  planes_from_f32_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, pixels, c, (unsigned short*)planes);
   return check_launch("planes_from_f32");
 }
 
@@ -482,7 +570,7 @@ extern "C" int embnet_conv_weight_planes_chunk_elems(void) { return 4096; }
 extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream) {
   EMBNET_CHECK_ARG(table && chunks && n_tensors > 0 && n_chunks > 0, "conv_weight_planes: bad argument");
   EMBNET_TRACE("embnet::patch::weight_planes_kernel", TRACE_BYTES, 10.0 * 4096 * n_chunks, stream);
-  weight_planes_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const WPlanesTensor*)table, chunks);
+  weight_planes_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const WPlanesTensor*)table, chunks, planes_f16() ? 1 : 0);
   return check_launch("conv_weight_planes");
 }
 
@@ -490,12 +578,19 @@ template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  if (p.bn.x) conv_patch_kernel<BN, 3, 3, TPS, NBS, true><<<p.grid, 640, lds, st>>>(p);
-  else conv_patch_kernel<BN, 3, 3, TPS, NBS, false><<<p.grid, 640, lds, st>>>(p);
+  if (planes_f16()) {
+    if (p.bn.x) conv_patch_kernel<BN, 3, 3, TPS, NBS, true, true><<<p.grid, 640, lds, st>>>(p);
+    else conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true><<<p.grid, 640, lds, st>>>(p);
+    return;
+  }
+  if (p.bn.x) conv_patch_kernel<BN, 3, 3, TPS, NBS, true, false><<<p.grid, 640, lds, st>>>(p);
+  else conv_patch_kernel<BN, 3, 3, TPS, NBS, false, false><<<p.grid, 640, lds, st>>>(p);
 }
 
 static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
@@ -521,15 +616,10 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
   hipStream_t st = (hipStream_t)stream;
   {
     // (the names rocprofv3 prints: bench.py looks the kernel's measured HBM traffic up by them)
-    const bool bns = p.bn.x != nullptr;
-    EMBNET_TRACE_FLOP(pl.bn == 128 && pl.tps == 3 ? (bns ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 3, 2, true>(embnet::patch::PatchParams)"
-                                                         : "void embnet::patch::conv_patch_kernel<128, 3, 3, 3, 2, false>(embnet::patch::PatchParams)") :
-                      pl.bn == 128 ? (pl.nbs == 6 ? (bns ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6, true>(embnet::patch::PatchParams)"
-                                                         : "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 6, false>(embnet::patch::PatchParams)")
-                                                  : (bns ? "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 4, true>(embnet::patch::PatchParams)"
-                                                         : "void embnet::patch::conv_patch_kernel<128, 3, 3, 1, 4, false>(embnet::patch::PatchParams)"))
-                                   : (bns ? "void embnet::patch::conv_patch_kernel<64, 3, 3, 3, 3, true>(embnet::patch::PatchParams)"
-                                          : "void embnet::patch::conv_patch_kernel<64, 3, 3, 3, 3, false>(embnet::patch::PatchParams)"),
+    static thread_local char kname[160];
+    snprintf(kname, sizeof kname, "void embnet::patch::conv_patch_kernel<%d, 3, 3, %d, %d, %s%s>(embnet::patch::PatchParams)", pl.bn, pl.tps, pl.nbs,
+             p.bn.x ? "true" : "false", planes_f16() ? ", true" : "");
+    EMBNET_TRACE_FLOP(kname,
                       2.0 * M * k * r * s * c,
                       6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
     if (pl.bn == 128 && pl.tps == 3) launch_patch<128, 3, 2>(p, pl.lds, st);

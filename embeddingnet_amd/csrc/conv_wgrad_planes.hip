@@ -67,8 +67,12 @@ struct Params {
   int knobs;                   // experiments (EMBNET_WGP_KNOBS): bit 0 = s_setprio 1 for waves 4-7, bit 1 = for the x loaders (0-3), bit 2 = stagger
 };
 
-template <bool STAG>
+// F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): a loader wave places two (plane, chunk) images
+// per unit instead of three (the LDS layout keeps its twelve-image pitch), three matrix products per tap instead of six, the sums
+// x 1 / (s_x s_dy) on the way out
+template <bool STAG, bool F16 = false>
 __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) {
+  constexpr int NP = F16 ? 2 : 3;                           // planes = (plane, chunk) images per loader wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
   // s_waitcnt vmcnt(0) — it cannot tell the ring block being filled from the ones being read — which would wait for the
   // request just issued.  What orders reads behind the DMA here is the counted wait + barrier at the top of each stage.)
   const bool is_x = wave < 4;
-  const int id0 = 3 * (wave & 3);                          // this wave's three (plane, chunk) images: id = plane * 4 + chunk
+  const int id0 = NP * (wave & 3);                         // this wave's NP (plane, chunk) images: id = plane * 4 + chunk
   const unsigned plane_b = is_x ? p.x_plane_bytes : p.dy_plane_bytes;
   const unsigned chunk_b = is_x ? p.x_chunk_bytes : p.dy_chunk_bytes;
   const uint64_t gbase = (uint64_t)(is_x ? p.xp : p.dyp);
@@ -96,9 +100,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
                     __builtin_amdgcn_readfirstlane((int)(3u * plane_b)), 0x00020000};
   const int DH = is_x ? p.H : p.OH, DW = is_x ? p.W : p.OW, dp = is_x ? 1 : 0;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-  unsigned soff[3], loff[3];                               // per image: source offset of (plane, chunk), LDS offset in a block / slot
+  unsigned soff[NP], loff[NP];                             // per image: source offset of (plane, chunk), LDS offset in a block / slot
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NP; ++i) {
     const int im = id0 + i;
     soff[i] = (unsigned)(im >> 2) * plane_b + ((unsigned)((is_x ? c0 : k0) >> 4) + (unsigned)(im & 3)) * chunk_b;
     loff[i] = lds0 + (is_x ? im * XCH : X_BYTES + im * DCH);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
     const unsigned vo = ok ? 32u * (unsigned)(((int)n * DH + iy) * DW + ix) + 16u * (lane & 1) : OOB;
     const unsigned slot = is_x ? (unsigned)(u & 7) * 1024u : (unsigned)(t & (NS - 1)) * (unsigned)DY_SLOT;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dma16(rs, loff[i] + slot, vo, soff[i]);
+    for (int i = 0; i < NP; ++i) dma16(rs, loff[i] + slot, vo, soff[i]);
   };
 
   // ---- this wave's block and fragment addresses -------------------------------------------------------------------------
@@ -143,50 +147,57 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
   const bool late = STAG && wave >= 4;
   for (int u = 0; u < HB + D; ++u) issue(u);
   if (late) {                                                    // tick 0 belongs to the early waves' first half stage
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP * (D - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
   }
   for (int j = 0; j < nst; ++j) {
-    if (!late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");   // unit j + HB has landed (this wave's part)
+    if (!late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP * (D - 1)) : "memory");   // unit j + HB has landed (this wave's part)
     __builtin_amdgcn_s_barrier();                                            // ... everybody's; stage j - 1 is done everywhere
     if (!STAG || late) issue(j + HB + D);
     const unsigned char* bs = ba + (j & (NS - 1)) * DY_SLOT;
-    bf16x8 b[3];
+    bf16x8 b[NP];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NP; ++q) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bs + q * 4 * DCH));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bs + q * 4 * DCH + 4 * 32));
       const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       b[q] = __builtin_bit_cast(bf16x8, w);
     }
     const int base_row = 32 * j + row_in_stage;
-    auto load_a = [&](int tap, bf16x8 (&a)[3]) {
+    auto load_a = [&](int tap, bf16x8 (&a)[NP]) {
       const int sh = (tap / 3) * PWs + tap % 3;
       const unsigned char* lo_p = xa + ((base_row + sh) & (XR - 1)) * 32;
       const unsigned char* hi_p = xa + ((base_row + sh + 4) & (XR - 1)) * 32;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NP; ++q) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lo_p + q * 4 * XCH));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(hi_p + q * 4 * XCH));
         const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         a[q] = __builtin_bit_cast(bf16x8, w);
       }
     };
-    bf16x8 a[2][3];
+    bf16x8 a[2][NP];
     load_a(0, a[0]);
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if (STAG && t == 5) {                                      // the stage's middle = the other group's stage start
-        if (late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (D - 1)) : "memory");
+        if (late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP * (D - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
         if (!late) issue(j + HB + D);
       }
       if (t + 1 < 9) load_a(t + 1, a[(t + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);          // the next tap's reads go out BEFORE this tap's MFMAs
+      if constexpr (F16) {
+        constexpr int FA[3] = {0, 1, 0}, FB[3] = {1, 0, 0};      // smallest first
 #pragma unroll
-      for (int e = 6 - EMBNET_EXP_TERMS; e < 6; ++e)      // (EMBNET_EXP_TERMS: gemm_engine.h; 6 in the product)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][PA[e]], b[PB[e]], acc[t], 0, 0, 0);
+        for (int e = 0; e < 3; ++e)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t & 1][FA[e]]), __builtin_bit_cast(f16x8, b[FB[e]]), acc[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 6 - EMBNET_EXP_TERMS; e < 6; ++e)      // (EMBNET_EXP_TERMS: gemm_engine.h; 6 in the product)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][PA[e]], b[PB[e]], acc[t], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);          // one tap's fragments ahead, not all nine (registers)
     }
   }
@@ -205,13 +216,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
   __syncthreads();
   if (par == 0) {
     const int h = lane >> 5;
+    const float osc = F16 ? planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1] * planes_scale_slot(p.dyp, (long)(p.dy_plane_bytes >> 1))[1] : 1.f;
     float* o = p.out + (long)split * p.slab_elems + (long)(c0 + 32 * cb + 4 * h) * p.K + k0 + 32 * kb + (lane & 31);
     const long tap_stride = (long)p.C * p.K;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        o[t * tap_stride + (long)((r & 3) + 8 * (r >> 2)) * p.K] = acc[t][r] + red[(t * 16 + r) * 64];
+        o[t * tap_stride + (long)((r & 3) + 8 * (r >> 2)) * p.K] = F16 ? (acc[t][r] + red[(t * 16 + r) * 64]) * osc : acc[t][r] + red[(t * 16 + r) * 64];
   }
 }
 
@@ -283,15 +295,18 @@ extern "C" int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* 
   if (!once) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   const int grid = (pl.tiles * pl.splits + 7) / 8 * 8;
   {
     const double m = (double)n * h * wd;
-    EMBNET_TRACE_FLOP((knobs & 4) ? "void embnet::wgp::conv_wgrad_planes_kernel<true>(embnet::wgp::Params)"
+    EMBNET_TRACE_FLOP(planes_f16() ? "void embnet::wgp::conv_wgrad_planes_kernel<false, true>(embnet::wgp::Params)" :
+                      (knobs & 4) ? "void embnet::wgp::conv_wgrad_planes_kernel<true>(embnet::wgp::Params)"
                                   : "void embnet::wgp::conv_wgrad_planes_kernel<false>(embnet::wgp::Params)", 2.0 * m * k * 9.0 * c,
                       6.0 * m * (c + k) + 4.0 * 9.0 * c * k * pl.splits, st);
-    if (knobs & 4) conv_wgrad_planes_kernel<true><<<grid, 512, LDS_BYTES, st>>>(p);
+    if (planes_f16()) conv_wgrad_planes_kernel<false, true><<<grid, 512, LDS_BYTES, st>>>(p);
+    else if (knobs & 4) conv_wgrad_planes_kernel<true><<<grid, 512, LDS_BYTES, st>>>(p);
     else conv_wgrad_planes_kernel<false><<<grid, 512, LDS_BYTES, st>>>(p);
   }
   if (pl.splits > 1 && reduce) launch_slab_reduce((const float*)workspace, pl.splits, 9l * c * k, dw, st);

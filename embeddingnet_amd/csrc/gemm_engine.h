@@ -326,6 +326,50 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 struct Split4 { uint2 p[3]; };                 // four consecutive elements: 8 bytes per plane
 
+// ---- the two-piece fp16 format of the planes (EMBNET_PLANES_F16=1) ----------------------------------------------------
+// x = (h1 + h2) / s with s a power of two per tensor: h1 = fp16(x s) (round to nearest), h2 = fp16(x s - h1) — 22 mantissa bits;
+// a product keeps three of the four piece products (h1 h1', h1 h2', h2 h1') on v_mfma_f32_32x32x16_f16 and is multiplied by
+// 1 / (s s') in the epilogue (exact).  The planes buffers keep their three-plane size: planes 0 and 1 hold h1 and h2, and the
+// first two floats of the third plane's space hold (s, 1 / s) — written by whoever writes the planes, read by whoever multiplies.
+// |x s| is clamped to fp16's largest finite value; s is chosen so that the clamp never acts (activations behind a
+// BatchNormalization and weights x 2^8: fixed; gradients: from the tensor's own maximum).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct Split4H { uint2 p[2]; };
+__device__ __forceinline__ Split4H split4h(const float4 v, float s) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  _Float16 hi[4], lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float c = fminf(fmaxf(x[i], -65504.f), 65504.f);
+    hi[i] = (_Float16)c;
+    lo[i] = (_Float16)(c - (float)hi[i]);
+  }
+  Split4H r;
+  r.p[0] = make_uint2(__builtin_bit_cast(uint32_t, h2v{hi[0], hi[1]}), __builtin_bit_cast(uint32_t, h2v{hi[2], hi[3]}));
+  r.p[1] = make_uint2(__builtin_bit_cast(uint32_t, h2v{lo[0], lo[1]}), __builtin_bit_cast(uint32_t, h2v{lo[2], lo[3]}));
+  return r;
+}
+// where a planes buffer of `plane_elems` 16-bit elements per plane keeps (s, 1 / s)
+__host__ __device__ __forceinline__ float* planes_scale_slot(void* planes, long plane_elems) {
+  return reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(planes) + 2 * plane_elems);
+}
+__host__ __device__ __forceinline__ const float* planes_scale_slot(const void* planes, long plane_elems) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(planes) + 2 * plane_elems);
+}
+// three-term step of the fp16 format (the counterpart of mfma_step3 below)
+template <int TM_, int TN_>
+__device__ __forceinline__ void mfma_step_h(const f16x8 (&a)[TM_][2], const f16x8 (&b)[TN_][2], f32x16 (&acc)[TM_][TN_]) {
+  constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};      // smallest first
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int im = 0; im < TM_; ++im)
+#pragma unroll
+      for (int in = 0; in < TN_; ++in)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[im][PA[t]], b[in][PB[t]], acc[im][in], 0, 0, 0);
+}
+
 __device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) {      // {top half of a, top half of b}
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }

@@ -209,6 +209,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
   });
 }
 
+// MODE 0: as described.  MODE 1: dx_planes in the two-piece fp16 format, scaled by the s the slot holds.  MODE 2: the dry run in front
+// of MODE 1 — the same arithmetic, nothing stored but the workgroup's max |dx| (floats 16 + blockIdx.x behind the slot); the scale
+// kernel below turns the maxima into s.  (8 bytes per element read once more: the price of an exact range for the gradient's planes.)
+template <int MODE = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             long total4, int c4, float inv_m, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     }
   };
   if (fixed) consts((int)(((long)blockIdx.x * 256 + threadIdx.x) % c4));
+  float amax = 0.f;
+  const float pscale = MODE == 1 ? planes_scale_slot(dx_planes, total4 * 4)[0] : 1.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     if (!fixed) consts((int)(i % c4));
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
@@ -251,14 +257,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       const float4 a = reinterpret_cast<const float4*>(dx_add)[i];
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
+    if (MODE == 2) { amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))); continue; }
     if (dx) reinterpret_cast<float4*>(dx)[i] = o;        // (NULL: planes only — every consumer of dx reads the planes)
     if (dx_planes) {                                     // the same values as bf16 pieces, chunk-major: dy operand of the
       const long pix = i / c4; const int q = (int)(i - pix * c4);      // patch data gradient of the convolution in front
-      const Split4 s = split4(o);
       const long e = ((long)(q >> 2) * (total4 / c4) + pix) * 16 + 4 * (q & 3);
+      if (MODE == 1) {
+        const Split4H s = split4h(o, pscale);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(dx_planes + k * total4 * 4 + e) = s.p[k];
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<uint2*>(dx_planes + k * total4 * 4 + e) = s.p[k];
+      } else {
+        const Split4 s = split4(o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(dx_planes + k * total4 * 4 + e) = s.p[k];
+      }
     }
+  }
+  if (MODE == 2) {
+    amax = wave_max(amax);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) planes_scale_slot(dx_planes, total4 * 4)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  }
+}
+
+// (s, 1 / s) of a planes tensor from the workgroup maxima a dry run left behind its slot: the largest |value| lands in [2^14, 2^15)
+__global__ __launch_bounds__(256) void planes_scale_kernel(float* __restrict__ slot, int blocks) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[16 + i]);
+  m = wave_max(m);
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    int e = 0;
+    const bool ok = m > 0.f && m <= 3.4028234e38f;         // (zero, infinite or NaN gradients: s = 1)
+    if (ok) (void)frexpf(m, &e);                           // m = f 2^e, f in [0.5, 1)
+    const int k = ok ? max(-120, min(120, 15 - e)) : 0;    // (s and 1 / s stay normal numbers)
+    slot[0] = ldexpf(1.f, k); slot[1] = ldexpf(1.f, -k);
   }
 }
 
@@ -1072,10 +1110,13 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
 // y = act(x*scale + shift) written as fp32 (y, optional) AND as the three bf16 pieces of every value in the chunk-major
 // layout conv_patch.hip consumes ([plane][C/16][pixels][16]): the BatchNormalization in front of a patch convolution
 // produces the convolution's operand in its final form, once.  C % 16 == 0; one thread per (pixel, channel quad).
+// F16: the two-piece fp16 format (gemm_engine.h), scale 1: activations behind a BatchNormalization lie far inside fp16's range
+template <bool F16>
 __global__ __launch_bounds__(256) void affine_act_planes_kernel(const float* __restrict__ x, long pixels, int c4,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 int act, float* __restrict__ y, unsigned short* __restrict__ planes) {
   const long total4 = pixels * c4, plane = total4 * 4, stride = (long)gridDim.x * 256;
+  if (F16 && blockIdx.x == 0 && threadIdx.x == 0) { float* sl = planes_scale_slot(planes, plane); sl[0] = 1.f; sl[1] = 1.f; }
   const bool fixed = stride % c4 == 0;
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
   if (fixed) {
@@ -1089,10 +1130,16 @@ __global__ __launch_bounds__(256) void affine_act_planes_kernel(const float* __r
     float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
     if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
     if (y) reinterpret_cast<float4*>(y)[i] = o;
-    const Split4 s = split4(o);
     const long e = ((long)(q >> 2) * pixels + pix) * 16 + 4 * (q & 3);
+    if (F16) {
+      const Split4H s = split4h(o, 1.f);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
+    } else {
+      const Split4 s = split4(o);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
+    }
   }
 }
 
@@ -1327,8 +1374,31 @@ extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const flo
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 15) == 0, "affine_act_planes: m=%ld c=%d (c %% 16 == 0)", m, c);
   EMBNET_CHECK_ARG((size_t)m * c * 2 < 0x7FFFFFF0ull / 3, "affine_act_planes: tensor too large");
   EMBNET_TRACE("embnet::affine_act_planes_kernel", TRACE_BYTES, (y ? 14.0 : 10.0) * m * c, stream);
-  affine_act_planes_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
+  if (planes_f16()) affine_act_planes_kernel<true><<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
+  else affine_act_planes_kernel<false><<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
   return check_launch("affine_act_planes");
+}
+
+// bn_bwd_apply4_kernel in the planes format of the process: with EMBNET_PLANES_F16 a dry run finds the gradient's range first
+static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                                 const float* scale, const float* shift, const float* dbeta, const float* dgamma, int relu,
+                                 int training, const float* dx_add, float* dx, void* dx_planes, hipStream_t st) {
+  const long total4 = m * c / 4;
+  const int blocks = ew_blocks_c4(total4, c / 4);
+  const float inv_m = 1.f / (float)m;
+  unsigned short* pl = (unsigned short*)dx_planes;
+  if (dx_planes && planes_f16()) {
+    float* slot = planes_scale_slot(dx_planes, total4 * 4);
+    const bool room = 2 * total4 >= 16 + blocks;          // the third plane's space holds the slot and the workgroup maxima
+    if (room) bn_bwd_apply4_kernel<2><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma,
+                                                             relu, training, dx_add, nullptr, pl);
+    planes_scale_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0);
+    bn_bwd_apply4_kernel<1><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
+                                                   training, dx_add, dx, pl);
+    return;
+  }
+  bn_bwd_apply4_kernel<0><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
+                                                 training, dx_add, dx, pl);
 }
 
 extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
@@ -1361,8 +1431,8 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
-                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, (unsigned short*)dx_planes); }
+    { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream);
+      launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream)); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
@@ -1456,8 +1526,8 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
   bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1);
-  { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply4_kernel<<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(dy, x, m * c / 4, c / 4, 1.f / (float)m, save_mean,
-                                                                      save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, (unsigned short*)dx_planes); }
+  { EMBNET_TRACE("embnet::bn_bwd_apply4_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream);
+    launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream)); }
   return check_launch("bn_bwd_partials");
 }
 

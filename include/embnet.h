@@ -169,6 +169,9 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * `tiles mod 256` left-over output tiles along K so the last round of workgroups fills every CU
  * (partial tiles + fixed-order fix-up; results differ from the unsplit launch only in fp32 summation order). */
 int embnet_conv_mfma_terms(void);
+/* ... per fp32 product in the kernels that read pre-split planes (embnet_conv2d_patch_f32, embnet_conv2d_wgrad_planes_f32):
+ * 3 in the default planes format (two fp16 pieces + a power-of-two scale per tensor), 6 with EMBNET_PLANES_F16=0 (three bf16 pieces). */
+int embnet_conv_planes_mfma_terms(void);
 size_t embnet_conv2d_fwd_workspace_bytes(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, int oh, int ow);
 int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
@@ -238,11 +241,21 @@ int embnet_conv1x1_thin_supported(int red, int ncols);
  * The zoo ResNets' 3x3 stride-1 layers (backbones.py:99-104), forward and data gradient, 1.1-1.25x faster than the kernels
  * above: every fp32 operand value is split into its three bf16 pieces ONCE, by the kernel that produces the tensor, and the
  * convolution keeps a patch of the padded input in LDS so that each input value is fetched once per output tile instead of
- * once per tap.  Same six-term products (fp32 accuracy as documented above); summation order (chunk, r, s, channel).
- *   planes of an activation / gradient x[pixels, c] (c % 16 == 0):  bf16 [3][c/16][pixels][16]  (piece, 16-channel chunk,
+ * once per tap.  Summation order (chunk, r, s, channel).
+ * FORMAT OF THE PLANES (one per process, csrc/common.h planes_f16()).  Default (ABI 19, end of round 5): TWO fp16 pieces of x s,
+ * s a power of two per tensor — x = (h1 + h2) / s, h1 = fp16(x s) rounded to nearest, h2 = fp16(x s - h1): 22 mantissa bits —
+ * and THREE products per fp32 product (h1 h1' + h1 h2' + h2 h1', v_mfma_f32_32x32x16_f16), the result x 1 / (s s') (exact).
+ * Error on top of fp32 accumulation <= 2^-21 sum|x||y| (each operand kept to 2^-23 of itself, the dropped product <= 2^-22);
+ * measured on the adversarial input above 4.1e-7 / 3.0e-7 / 1.7e-7 (forward / data gradient / weight gradient, K = 4608;
+ * tests/test_round3_gpu.py::test_planes_split_worst_case, profiles/r05_split_worst_case_planes_*.json).  s: 1 for activations
+ * (embnet_affine_act_planes; |x s| is clamped at 65504), 2^8 for kernels, from the tensor's own largest element for gradients
+ * (embnet_bn_bwd's dx_planes: a dry run of the pass; embnet_planes_from_f32: an abs-max pass) so that it lands in [2^14, 2^15).
+ * The buffers keep the three-plane size below: planes 0 and 1 hold the pieces, the first two floats of the third plane's space
+ * hold (s, 1 / s).  EMBNET_PLANES_F16=0: three bf16 pieces (exact split by truncation) and the six-term products documented above.
+ *   planes of an activation / gradient x[pixels, c] (c % 16 == 0):  16-bit [3][c/16][pixels][16]  (piece, 16-channel chunk,
  *     pixel, channel in chunk) — written by embnet_affine_act_planes, by embnet_bn_bwd(dx_planes), or from an fp32 tensor by
  *     embnet_planes_from_f32;
- *   planes of a kernel w[r,s,c,k]:  bf16 [3][r][red/16][s][rows][16] — flip 0 (forward: rows = k, reduction channels = c) or
+ *   planes of a kernel w[r,s,c,k]:  16-bit [3][r][red/16][s][rows][16] — flip 0 (forward: rows = k, reduction channels = c) or
  *     flip 1 (stride-1 data gradient: rows = c, reduction = k, taps flipped) — written for any number of kernels by ONE launch
  *     of embnet_conv_weight_planes over a device table of 40-byte descriptors
  *       { const float* w; void* out; int32 r, s, c, k, flip, pad; }   and a chunk list int32 [n_chunks][2] =
@@ -286,8 +299,8 @@ int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, 
  * Every operand byte is fetched once per (64 channels x 64 filters) tile and all nine taps are accumulated from one window
  * of positions in LDS; split over pixel ranges into fp32 slabs [splits][9*c*k] in `workspace` and summed in fixed order
  * (bitwise reproducible).  reduce = 0 leaves the slabs for embnet_slab_reduce_multi (descriptor: workspace, dw, 9*c*k,
- * embnet_conv2d_wgrad_planes_splits).  Same six-term products as embnet_conv2d_wgrad_f32; the order of the pixel sum
- * differs, so results agree within fp32 rounding, not bitwise.  supported: 1 for r = s = 3, stride 1, pad 1, oh = h,
+ * embnet_conv2d_wgrad_planes_splits).  Products in the planes' format (above); against embnet_conv2d_wgrad_f32 the order of the
+ * pixel sum differs too, so results agree within fp32 rounding, not bitwise.  supported: 1 for r = s = 3, stride 1, pad 1, oh = h,
  * ow = wd <= 62, c % 64 == 0, k % 64 == 0. */
 int embnet_conv2d_wgrad_planes_supported(int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
                                          int oh, int ow);

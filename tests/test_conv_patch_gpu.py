@@ -12,6 +12,8 @@ through the C ABI:
 Reference behaviour being matched: keras Conv2D / BatchNormalization inside image-classifiers' ResNet
 (reference embedding_net/backbones.py:99-104).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,12 +40,25 @@ def planes_of(x):
     return p
 
 
+F16 = os.environ.get("EMBNET_PLANES_F16", "1") != "0"      # the planes' format of this process (csrc/gemm_engine.h, csrc/common.h)
+
+
+def pieces(raw16, lead):
+    """uint16 planes [3][...] -> float64 sum of the pieces: three bf16 pieces, or (EMBNET_PLANES_F16=1) two fp16 pieces / s with
+    (s, 1 / s) in the first two floats of the third plane's space."""
+    flat = raw16.reshape(3, -1)
+    if F16:
+        s, inv = flat[2][:4].view(np.float32)[:2]
+        assert s > 0 and s * inv == 1.0 and np.log2(s) == np.round(np.log2(s)), (s, inv)
+        return (flat[0].view(np.float16).astype(np.float64) + flat[1].view(np.float16).astype(np.float64)).reshape(lead) * float(inv)
+    return (flat.astype(np.uint32) << 16).view(np.float32).astype(np.float64).sum(axis=0).reshape(lead)
+
+
 def decode(planes, shape):
-    """planes -> float64 NHWC (sum of the three bf16 pieces)."""
+    """planes -> float64 NHWC."""
     c = shape[-1]
     m = int(np.prod(shape)) // c
-    raw = planes.cpu().numpy().view(np.uint16).astype(np.uint32).reshape(3, c // 16, m, 16)
-    f = (raw << 16).view(np.float32).astype(np.float64).sum(axis=0)         # [c/16][m][16]
+    f = pieces(planes.cpu().numpy().view(np.uint16), (c // 16, m, 16))         # [c/16][m][16]
     return f.transpose(1, 0, 2).reshape(shape)
 
 
@@ -65,6 +80,14 @@ def test_planes_decode_exactly(dev):
     x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, 3.0e38], device=dev)     # (fp32 subnormals lose their low bits: below bf16's range)
     p = planes_of(x)
     torch.cuda.synchronize()
+    if F16:
+        # two fp16 pieces of x s, the tensor's largest |x| scaled into [2^14, 2^15): 22 bits of every element that is within
+        # 2^-14 of the largest, absolute error <= 2^-25 of the scaled range below that (this tensor spans 10^12 by design)
+        got, want = decode(p, x.shape), x.cpu().numpy().astype(np.float64)
+        top = np.abs(want).max()
+        err = np.abs(got - want)
+        assert (err <= np.maximum(np.abs(want) * 2.0 ** -21, top * 2.0 ** -39)).all()
+        return
     assert np.array_equal(decode(p, x.shape), x.cpu().numpy().astype(np.float64))
 
 
@@ -340,7 +363,26 @@ def test_weight_planes_follow_the_weights(dev):
     torch.cuda.synchronize()
     assert not torch.equal(p1, p0)
     # forward layout [3][R][C/16][S][K][16]: decode and compare with the weights
-    raw = p1.cpu().numpy().view(np.uint16).astype(np.uint32).reshape(3, 3, 2, 3, 64, 16)
-    f = (raw << 16).view(np.float32).astype(np.float64).sum(axis=0)          # [r][cc][s][k][j]
+    f = pieces(p1.cpu().numpy().view(np.uint16), (3, 2, 3, 64, 16))          # [r][cc][s][k][j]
     back = f.transpose(0, 2, 1, 4, 3).reshape(3, 3, 32, 64)                  # [r][s][cc*16+j][k]
-    assert np.array_equal(back, w.cpu().numpy().astype(np.float64))
+    want = w.cpu().numpy().astype(np.float64)
+    if F16:
+        assert (np.abs(back - want) <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -33)).all()      # (weights x 2^8: subnormal pieces below 2^-32)
+    else:
+        assert np.array_equal(back, want)
+
+
+def test_three_piece_bf16_planes_in_a_child_process(dev):
+    """The other planes format (EMBNET_PLANES_F16=0: three bf16 pieces, six products — the knob is read once per process): this
+    file, the planes weight gradient's tests and the planes worst-case test run in a child pytest."""
+    import subprocess
+    import sys
+    if not F16:
+        pytest.skip("this process already runs the three-piece format")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMBNET_PLANES_F16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_conv_patch_gpu.py", "tests/test_wgrad_planes_gpu.py",
+                        "tests/test_round3_gpu.py", "-k", "not child_process and (patch or planes or decode or unit or resnet18_patch)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]

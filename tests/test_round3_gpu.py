@@ -95,6 +95,68 @@ def test_conv_split_worst_case(dev, shape):
     _record(f"r04_split_worst_case_K{k * k * cin}.json", rec)
 
 
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64, 64, 3), (2, 8, 8, 512, 128, 3)], ids=["K576", "K4608"])
+def test_planes_split_worst_case(dev, shape):
+    """The same adversarial operands through the PLANES kernels (csrc/conv_patch.hip forward and data gradient,
+    csrc/conv_wgrad_planes.hip) in the planes' format of this process: three bf16 pieces / six products (dropped terms <= 2^-20
+    |x||y|), or with EMBNET_PLANES_F16=1 two fp16 pieces / three products — each operand kept to 2^-23 of itself (two pieces
+    rounded to nearest), the dropped product <= 2^-22 |x||y|: 2^-21 in all — on top of fp32 accumulation priced as above.
+    Recorded in gpurun_out/r05_split_worst_case_planes_*.json."""
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd import layers as L
+    n, h, w, cin, cout, k = shape
+    f16 = os.environ.get("EMBNET_PLANES_F16", "1") != "0"
+    bound = 2.0 ** -21 if f16 else SPLIT_BOUND
+    rs = np.random.RandomState(11)
+
+    def adversarial(*dims):
+        v = rs.uniform(0.5, 2.0, dims).astype(np.float32)
+        return (v.view(np.uint32) | np.uint32(0xFFFF)).view(np.float32)
+
+    x, kern, dy = adversarial(n, h, w, cin), adversarial(k, k, cin, cout) * np.float32(2.0 ** -6), adversarial(n, h, w, cout)
+    kern = (kern.view(np.uint32) | np.uint32(0xFFFF)).view(np.float32)
+
+    def run(dt):
+        xr = torch.tensor(x, dtype=dt, requires_grad=True)
+        kr = torch.tensor(kern, dtype=dt, requires_grad=True)
+        yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), kr.permute(3, 2, 0, 1), padding=k // 2).permute(0, 2, 3, 1)
+        yr.backward(torch.tensor(dy, dtype=dt))
+        return [t.detach().double().numpy() for t in (yr, xr.grad, kr.grad)]
+
+    want, cpu32 = run(torch.float64), run(torch.float32)
+    lib = _lib.lib()
+    xd, wd, dyd = g(x, dev), g(kern, dev), g(dy, dev)
+
+    def planes_of(t):
+        p = torch.empty(3 * t.numel(), device=dev, dtype=torch.int16)
+        _lib.check(lib.embnet_planes_from_f32(t.data_ptr(), t.numel() // t.shape[-1], t.shape[-1], p.data_ptr(), _lib.stream()))
+        return p
+
+    xp, dyp = planes_of(xd), planes_of(dyd)
+    y = torch.empty((n, h, w, cout), device=dev)
+    ws = torch.empty(max(lib.embnet_conv2d_patch_workspace_bytes(n, cin, k, k, cout, h, w), 4) // 4, device=dev)
+    _lib.check(lib.embnet_conv2d_patch_f32(xp.data_ptr(), L.weight_planes(wd, 0).data_ptr(), None, y.data_ptr(), n, h, w, cin, k, k, cout,
+                                           k // 2, k // 2, h, w, 0, None, None, ws.data_ptr(), ws.numel() * 4, _lib.stream()))
+    dx = torch.empty((n, h, w, cin), device=dev)
+    L._patch_dgrad(dyp, wd, dx, n, h, w, cin, k, k, cout, k // 2, k // 2, h, w, None)
+    dw = torch.empty((k, k, cin, cout), device=dev)
+    assert lib.embnet_conv2d_wgrad_planes_supported(n, h, w, cin, k, k, cout, 1, k // 2, k // 2, h, w)
+    ws2 = torch.empty(max(lib.embnet_conv2d_wgrad_planes_workspace_bytes(n, h, w, cin, cout), 4) // 4, device=dev)
+    _lib.check(lib.embnet_conv2d_wgrad_planes_f32(xp.data_ptr(), dyp.data_ptr(), dw.data_ptr(), ws2.data_ptr(), ws2.numel() * 4, n, h, w, cin, cout, 1,
+                                                  _lib.stream()))
+    got = [t.cpu().double().numpy() for t in (y, dx, dw)]
+    rec = {"shape": list(shape), "bound": bound, "format": "fp16 x 2 pieces, 3 products" if f16 else "bf16 x 3 pieces, 6 products"}
+    for name, a, c32, ref in zip(("fwd", "dgrad", "wgrad"), got, cpu32, want):
+        rel, rel32 = (a - ref) / ref, (c32 - ref) / ref
+        rec[name] = {"max_abs_rel_err": float(np.abs(rel).max()), "mean_rel_err_bias": float(rel.mean()),
+                     "float32_cpu_conv_max_abs_rel_err": float(np.abs(rel32).max()),
+                     "float32_cpu_conv_mean_rel_err": float(rel32.mean())}
+        r = rec[name]
+        assert r["max_abs_rel_err"] <= bound + 2 * r["float32_cpu_conv_max_abs_rel_err"] + 2.0 ** -23, (name, r)
+        assert abs(r["mean_rel_err_bias"]) <= bound + 2 * abs(r["float32_cpu_conv_mean_rel_err"]) + 2.0 ** -23, (name, r)
+    _record(f"r05_split_worst_case_planes_{'fp16x2' if f16 else 'bf16x3'}_K{k * k * cin}.json", rec)
+
+
 # ------------------------------------------------------------------------------------------------ per-stage gradients
 @pytest.mark.parametrize("name,shape,enc,batch", [("simple2", (64, 64, 3), 64, 8), ("resnet18", (64, 64, 3), 64, 8),
                                                    ("resnet50", (96, 96, 3), 32, 6), ("efficientnet-b0", (64, 64, 3), 32, 6)])
