@@ -621,7 +621,7 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
              p.bn.x ? "true" : "false", planes_f16() ? ", true" : "");
     EMBNET_TRACE_FLOP(kname,
                       2.0 * M * k * r * s * c,
-                      6.0 * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
+                      (planes_f16() ? 4.0 : 6.0) * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
     if (pl.bn == 128 && pl.tps == 3) launch_patch<128, 3, 2>(p, pl.lds, st);
     else if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
     else launch_patch<64, 3, 3>(p, pl.lds, st);

@@ -304,7 +304,7 @@ extern "C" int embnet_conv2d_wgrad_planes_f32(const void* x_planes, const void* 
     EMBNET_TRACE_FLOP(planes_f16() ? "void embnet::wgp::conv_wgrad_planes_kernel<false, true>(embnet::wgp::Params)" :
                       (knobs & 4) ? "void embnet::wgp::conv_wgrad_planes_kernel<true>(embnet::wgp::Params)"
                                   : "void embnet::wgp::conv_wgrad_planes_kernel<false>(embnet::wgp::Params)", 2.0 * m * k * 9.0 * c,
-                      6.0 * m * (c + k) + 4.0 * 9.0 * c * k * pl.splits, st);
+                      (planes_f16() ? 4.0 : 6.0) * m * (c + k) + 4.0 * 9.0 * c * k * pl.splits, st);
     if (planes_f16()) conv_wgrad_planes_kernel<false, true><<<grid, 512, LDS_BYTES, st>>>(p);
     else if (knobs & 4) conv_wgrad_planes_kernel<true><<<grid, 512, LDS_BYTES, st>>>(p);
     else conv_wgrad_planes_kernel<false><<<grid, 512, LDS_BYTES, st>>>(p);
