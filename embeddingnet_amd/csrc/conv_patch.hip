@@ -382,7 +382,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
 //           the correlation of dy with the flipped kernel, channel roles swapped)
 struct WPlanesTensor { const float* w; unsigned short* out; int R, S, C, K, flip, pad; };
 static_assert(sizeof(WPlanesTensor) == 40, "descriptor layout is part of the ABI (include/embnet.h)");
-// f16: two fp16 pieces of w x 2^8 + the scale slot (gemm_engine.h)
+// f16 = 1: two fp16 pieces of w s, s from the slot (gemm_engine.h) — weight_absmax_kernel / weight_scale_kernel below put it there
 __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor* __restrict__ table, const int* __restrict__ chunks, int f16) {
   const WPlanesTensor t = table[chunks[2 * blockIdx.x]];
   const int rows = t.flip ? t.C : t.K, red = t.flip ? t.K : t.C, ncc = red / 16;
@@ -405,16 +405,52 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlanesTensor*
                     : t.w[((long)(r * t.S + s) * t.C + ch) * t.K + row];
     }
     if (f16) {
-      const Split4H sp = split4h(make_float4(v[0], v[1], v[2], v[3]), 256.f);
+      const Split4H sp = split4h(make_float4(v[0], v[1], v[2], v[3]), planes_scale_slot(t.out, plane)[0]);
 #pragma unroll
       for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
-      if (i4 == 0) { float* sl = planes_scale_slot(t.out, plane); sl[0] = 256.f; sl[1] = 1.f / 256.f; }
     } else {
       const Split4 sp = split4(make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
       for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(t.out + q * plane + 4 * i4) = sp.p[q];
     }
   }
+}
+
+// the largest |w| of each kernel: a workgroup per chunk of 4096 elements (the chunk list of the planes pass), one atomic per workgroup
+// — an unsigned maximum of bit patterns: independent of the order, so reproducible
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const WPlanesTensor* __restrict__ table, const int* __restrict__ chunks) {
+  const WPlanesTensor t = table[chunks[2 * blockIdx.x]];
+  const long plane = (long)t.R * t.S * t.C * t.K, total4 = plane / 4;
+  const long i = (long)chunks[2 * blockIdx.x + 1] * 1024 + threadIdx.x;
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i4 = i + u * 256;
+    if (i4 < total4) {
+      const float4 v = reinterpret_cast<const float4*>(t.w)[i4];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  }
+  m = wave_max(m);
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned*>(planes_scale_slot(t.out, plane)) + 2, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+// phase 0: zero the max word of every kernel's slot; phase 1: max word -> (s, 1 / s)
+__global__ __launch_bounds__(256) void weight_scale_kernel(const WPlanesTensor* __restrict__ table, int n, int phase) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const WPlanesTensor t = table[i];
+  float* sl = planes_scale_slot(t.out, (long)t.R * t.S * t.C * t.K);
+  if (phase == 0) { reinterpret_cast<unsigned*>(sl)[2] = 0u; return; }
+  const float m = sl[2];
+  int e = 0;
+  const bool ok = m > 0.f && m <= 3.4028234e38f;
+  if (ok) (void)frexpf(m, &e);
+  const int k = ok ? max(-120, min(120, 15 - e)) : 0;
+  sl[0] = ldexpf(1.f, k); sl[1] = ldexpf(1.f, -k);
 }
 
 // fp32 NHWC [pixels][C] -> chunk-major planes [3][C/16][pixels][16] bf16; one thread per (pixel, 4 channels)
@@ -570,7 +606,15 @@ extern "C" int embnet_conv_weight_planes_chunk_elems(void) { return 4096; }
 extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream) {
   EMBNET_CHECK_ARG(table && chunks && n_tensors > 0 && n_chunks > 0, "conv_weight_planes: bad argument");
   EMBNET_TRACE("embnet::patch::weight_planes_kernel", TRACE_BYTES, 10.0 * 4096 * n_chunks, stream);
-  weight_planes_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const WPlanesTensor*)table, chunks, planes_f16() ? 1 : 0);
+  if (planes_f16()) {                                       // each kernel's own range first (both layouts of a kernel find the same)
+    hipStream_t st = (hipStream_t)stream;
+    weight_scale_kernel<<<cdiv(n_tensors, 256), 256, 0, st>>>((const WPlanesTensor*)table, n_tensors, 0);
+    weight_absmax_kernel<<<n_chunks, 256, 0, st>>>((const WPlanesTensor*)table, chunks);
+    weight_scale_kernel<<<cdiv(n_tensors, 256), 256, 0, st>>>((const WPlanesTensor*)table, n_tensors, 1);
+    weight_planes_kernel<<<n_chunks, 256, 0, st>>>((const WPlanesTensor*)table, chunks, 1);
+    return check_launch("conv_weight_planes");
+  }
+  weight_planes_kernel<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const WPlanesTensor*)table, chunks, 0);
   return check_launch("conv_weight_planes");
 }
 

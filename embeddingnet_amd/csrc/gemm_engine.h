@@ -332,7 +332,7 @@ struct Split4 { uint2 p[3]; };                 // four consecutive elements: 8 b
 // 1 / (s s') in the epilogue (exact).  The planes buffers keep their three-plane size: planes 0 and 1 hold h1 and h2, and the
 // first two floats of the third plane's space hold (s, 1 / s) — written by whoever writes the planes, read by whoever multiplies.
 // |x s| is clamped to fp16's largest finite value; s is chosen so that the clamp never acts (activations behind a
-// BatchNormalization and weights x 2^8: fixed; gradients: from the tensor's own maximum).
+// BatchNormalization: s = 1, |gamma x^ + beta| <= |gamma| sqrt(m) + |beta|; kernels and gradients: from the tensor's own maximum).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct Split4H { uint2 p[2]; };
 __device__ __forceinline__ Split4H split4h(const float4 v, float s) {

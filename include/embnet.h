@@ -248,10 +248,11 @@ int embnet_conv1x1_thin_supported(int red, int ncols);
  * Error on top of fp32 accumulation <= 2^-21 sum|x||y| (each operand kept to 2^-23 of itself, the dropped product <= 2^-22);
  * measured on the adversarial input above 4.1e-7 / 3.0e-7 / 1.7e-7 (forward / data gradient / weight gradient, K = 4608;
  * tests/test_round3_gpu.py::test_planes_split_worst_case, profiles/r05_split_worst_case_planes_*.json).  s: 1 for activations
- * (embnet_affine_act_planes; |x s| is clamped at 65504), 2^8 for kernels, from the tensor's own largest element for gradients
- * (embnet_bn_bwd's dx_planes: a dry run of the pass; embnet_planes_from_f32: an abs-max pass) so that it lands in [2^14, 2^15).
+ * (embnet_affine_act_planes; |x s| is clamped at 65504), from the tensor's own largest element for kernels (embnet_conv_weight_planes:
+ * a max pass) and gradients (embnet_bn_bwd's dx_planes: a dry run of the pass; embnet_planes_from_f32: an abs-max pass) so that it
+ * lands in [2^14, 2^15).
  * The buffers keep the three-plane size below: planes 0 and 1 hold the pieces, the first two floats of the third plane's space
- * hold (s, 1 / s).  EMBNET_PLANES_F16=0: three bf16 pieces (exact split by truncation) and the six-term products documented above.
+ * hold (s, 1 / s) (and a scratch word).  EMBNET_PLANES_F16=0: three bf16 pieces (exact split by truncation) and the six-term products documented above.
  *   planes of an activation / gradient x[pixels, c] (c % 16 == 0):  16-bit [3][c/16][pixels][16]  (piece, 16-channel chunk,
  *     pixel, channel in chunk) — written by embnet_affine_act_planes, by embnet_bn_bwd(dx_planes), or from an fp32 tensor by
  *     embnet_planes_from_f32;
