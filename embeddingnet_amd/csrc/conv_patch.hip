@@ -546,7 +546,9 @@ static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int
   pl.tps = pl.bn == 64 ? 3 : 1;
   pl.nbs = pl.bn == 64 ? 3 : 6;
   pl.LR = patch_rows(n, oh, ow, r, s);
-  static const int tps3 = (int)env_long("EMBNET_PATCH_TPS3", 0);       // experiment: three taps per barrier at BN = 128 too (two 36 KB slots)
+  // three taps per barrier at BN = 128 too (two 36 KB slots): level with one tap per barrier while a step held six products per
+  // fragment pair (10.39 vs 10.39 ms), + 1 % with three (C2 8.14 -> 8.06 ms, three alternating pairs): the default in that format
+  static const int tps3 = (int)env_long("EMBNET_PATCH_TPS3", planes_f16() ? 1 : 0);
   if (pl.bn == 128 && tps3 && 2 * (size_t)3 * pl.LR * 32 + (size_t)2 * 3 * 3 * 128 * 32 <= 160 * 1024) { pl.tps = 3; pl.nbs = 2; }
   pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
   if (pl.bn == 128 && pl.tps == 1 && pl.lds > 160 * 1024) {             // a long patch (small maps: many image seams per tile): shorter weight ring
