@@ -106,20 +106,20 @@ __device__ __forceinline__ void step_planes(const bf16x8 (&a)[G::TM][NP], const 
 
 // BNS: the data-gradient form that also emits the BatchNorm-backward sums (PatchParams::bn) — an instantiation of its own: the
 // 64 extra epilogue registers and scalar spills cost the plain kernel ~10 % when both forms share one body
-// F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): NP = 2 planes are fetched and read (the LDS
-// layout keeps its three-plane pitch), three matrix products per step instead of six, the accumulators x 1 / (s_x s_w) in the epilogue
+// F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): NP = 2 planes are fetched, held in LDS and read,
+// three matrix products per step instead of six, the accumulators x 1 / (s_x s_w) in the epilogue
 template <int BN, int R, int S, int TPS, int NBS, bool BNS = false, bool F16 = false>
 __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
   using G = GeomP<BN>;
   constexpr int NP = F16 ? 2 : 3;
   constexpr int TM = G::TM, TN = G::TN, SPC = R * S / TPS, D = NBS - 1;
-  constexpr int SBY = TPS * 3 * BN * 32;                 // one weight slot: TPS taps x 3 planes x BN rows x 32 bytes
+  constexpr int SBY = TPS * NP * BN * 32;                // one weight slot: TPS taps x NP planes x BN rows x 32 bytes
   constexpr int NBI = TPS * NP * (BN / 32);              // DMA instructions per weight slot
   static_assert((R * S) % TPS == 0 && SPC >= 2, "steps per chunk");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int LR = p.LR, PLP = LR * 32, PB = 3 * PLP;      // patch plane / patch buffer bytes
+  const int LR = p.LR, PLP = LR * 32, PB = NP * PLP;     // patch plane / patch buffer bytes
   unsigned char* const bslot0 = smem + 2 * PB;
   const int b = blockIdx.x;
   const int n_mine = b < p.n_full ? (p.n_full - b + p.grid - 1) / p.grid : 0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
         for (int q = 0; q < NP; ++q)
 #pragma unroll
           for (int gb = 0; gb < BN / 32; ++gb)
-            dma16(wr, slot + ((tp * 3 + q) * BN + gb * 32) * 32, live ? rowoff[gb] : OOB, q * wpb + so);
+            dma16(wr, slot + ((tp * NP + q) * BN + gb * 32) * 32, live ? rowoff[gb] : OOB, q * wpb + so);
       }
       if (live && ++st == SPC) {
         st = 0;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
 #pragma unroll
           for (int in = 0; in < TN; ++in) {
             const int row = wn + in * 32 + (lane & 31);
-            const unsigned char* bp = bs + (tp * 3 * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
+            const unsigned char* bp = bs + (tp * NP * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
 #pragma unroll
             for (int q = 0; q < NP; ++q) bb[in][q] = *reinterpret_cast<const bf16x8*>(bp + q * BN * 32);
           }
@@ -542,6 +542,7 @@ static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int
   for (int i = 0; i < used; ++i)
     if (keys[i].n == n && keys[i].c == c && keys[i].k == k && keys[i].oh == oh && keys[i].ow == ow) { pl = plans[i]; return pl.bn != 0; }
   pl = Plan{};
+  const size_t np = planes_f16() ? 2 : 3;                   // planes held in LDS
   pl.bn = k >= 128 ? 128 : 64;
   pl.tps = pl.bn == 64 ? 3 : 1;
   pl.nbs = pl.bn == 64 ? 3 : 6;
@@ -549,11 +550,14 @@ static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int
   // three taps per barrier at BN = 128 too (two 36 KB slots): level with one tap per barrier while a step held six products per
   // fragment pair (10.39 vs 10.39 ms), + 1 % with three (C2 8.14 -> 8.06 ms, three alternating pairs): the default in that format
   static const int tps3 = (int)env_long("EMBNET_PATCH_TPS3", planes_f16() ? 1 : 0);
-  if (pl.bn == 128 && tps3 && 2 * (size_t)3 * pl.LR * 32 + (size_t)2 * 3 * 3 * 128 * 32 <= 160 * 1024) { pl.tps = 3; pl.nbs = 2; }
-  pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
+  if (pl.bn == 128 && tps3 && 2 * np * pl.LR * 32 + (size_t)2 * 3 * np * 128 * 32 <= 160 * 1024) {
+    pl.tps = 3; pl.nbs = 2;
+    if (np == 2 && 2 * np * pl.LR * 32 + (size_t)3 * 3 * np * 128 * 32 <= 160 * 1024) pl.nbs = 3;      // two planes: room for a third slot
+  }
+  pl.lds = 2 * np * pl.LR * 32 + (size_t)pl.nbs * pl.tps * np * pl.bn * 32;
   if (pl.bn == 128 && pl.tps == 1 && pl.lds > 160 * 1024) {             // a long patch (small maps: many image seams per tile): shorter weight ring
     pl.nbs = 4;
-    pl.lds = 2 * (size_t)3 * pl.LR * 32 + (size_t)pl.nbs * pl.tps * 3 * pl.bn * 32;
+    pl.lds = 2 * np * pl.LR * 32 + (size_t)pl.nbs * pl.tps * np * pl.bn * 32;
   }
   bool ok = pl.LR <= 512 && pl.lds <= 160 * 1024;
   if (ok) {
@@ -668,7 +672,7 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
     EMBNET_TRACE_FLOP(kname,
                       2.0 * M * k * r * s * c,
                       (planes_f16() ? 4.0 : 6.0) * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
-    if (pl.bn == 128 && pl.tps == 3) launch_patch<128, 3, 2>(p, pl.lds, st);
+    if (pl.bn == 128 && pl.tps == 3) { if (pl.nbs == 3) launch_patch<128, 3, 3>(p, pl.lds, st); else launch_patch<128, 3, 2>(p, pl.lds, st); }
     else if (pl.bn == 128) { if (pl.nbs == 6) launch_patch<128, 1, 6>(p, pl.lds, st); else launch_patch<128, 1, 4>(p, pl.lds, st); }
     else launch_patch<64, 3, 3>(p, pl.lds, st);
   }
