@@ -128,8 +128,12 @@ RESNET = {"resnet18": ("basic", (2, 2, 2, 2)), "resnet34": ("basic", (3, 4, 6, 3
 
 
 def _rn_conv(cin, c, k, stride, pad, gen):
-    return L.Conv2D(cin, c, k, strides=stride, padding=pad if pad else "valid", use_bias=False,
+    conv = L.Conv2D(cin, c, k, strides=stride, padding=pad if pad else "valid", use_bias=False,
                     kernel_initializer="he_uniform", gen=gen)
+    # every conv of the zoo ResNets sits between BatchNormalizations: where it does not run the patch kernel (stem, stride-2 3x3,
+    # 1x1) its gather kernels multiply on three products per fp32 product, the ranges coming from its neighbours (layers.CONV_F16)
+    conv.f16 = True
+    return conv
 
 
 class ResidualUnit(nn.Module):

@@ -81,6 +81,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Range emission (conv.hip "Ranges"): this wave's max |value| joins the tensor's range slot — the bit pattern of a non-negative float
+// under an unsigned maximum, independent of the order, so reproducible.  The slot is read first: the maximum only grows, so a wave
+// whose own maximum is not above what it sees has nothing to add (all but the first few waves of a launch skip the atomic).
+// Every lane of the wave must call it (amax >= 0; lanes without an element pass 0).
+__device__ __forceinline__ void range_emit(uint32_t* slot, float amax) {
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t b = __float_as_uint(amax);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
+}
+__device__ __forceinline__ float amax4(float m, float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 // Activation fused behind the BN affine: 0 none, 1 ReLU, 2 swish (z * sigmoid(z)).  Backward recomputes
 // z = x*scale + shift from the saved input, so no activation tensor or mask is stored.
 __device__ __forceinline__ float act_apply(int act, float z) {

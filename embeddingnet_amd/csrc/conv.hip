@@ -296,14 +296,43 @@ constexpr int SMEM_FLOATS = CONV_MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? CONV_MAIN
 template <class G>
 constexpr int CONV_OCC = !EMBNET_CONV_SPLIT ? 1 : (G::BM * G::BN >= 192 * 64 ? 2 : (G::BM * G::BN >= 128 * 64 ? EMBNET_OCC_12864 : 4));
 
-template <class G, class TA, class TB, class LA, class LB>
+template <class G, class TA, class TB, class LA, class LB, bool H = false>
 __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end, float* smem,
-                                              f32x16 (&acc)[G::TM][G::TN], bool fair = false, bool zero_acc = true) {
+                                              f32x16 (&acc)[G::TM][G::TN], bool fair = false, bool zero_acc = true,
+                                              float sa = 1.f, float sb = 1.f) {
 #if EMBNET_CONV_SPLIT
-  gemm_mainloop3<G, TA, TB>(la, lb, kt_begin, kt_end, reinterpret_cast<unsigned char*>(smem), acc, fair, zero_acc);
+  gemm_mainloop3<G, TA, TB, LA, LB, H>(la, lb, kt_begin, kt_end, reinterpret_cast<unsigned char*>(smem), acc, fair, zero_acc, sa, sb);
 #else
   gemm_mainloop<G, TA, TB>(la, lb, kt_begin, kt_end, smem, acc, fair, zero_acc);
 #endif
+}
+
+// ---- three products per fp32 product for the gather kernels ("H" instantiations) ---------------------------------
+// An operand RANGE SLOT is one uint32 in device memory holding the bit pattern of max |element| of a tensor, left there by the
+// tensor's producer (embnet_range_emit: the BatchNorm backward passes; embnet_range_multi: kernels, once per optimizer step).
+// A conv launched with both operands' ranges known (embnet_conv2d_ranges; a NULL slot = scale 1, for activations behind a
+// BatchNormalization, |x| << 65 504) splits each fp32 element, on the fly, into the two fp16 pieces of x * s — s the power of two
+// that puts the tensor's maximum into [2^14, 2^15) — keeps three of the four piece products and multiplies the sums by
+// 1 / (s s') (exact) in front of its epilogue.  Same arithmetic as the planes kernels' two-piece format; half the matrix
+// instructions of the six-term split, two instead of three LDS planes written and read per operand.
+struct Ranges { const uint32_t* a; const uint32_t* b; };
+// (s, 1 / s) of a slot: amax = f 2^(e - 127), f in [1, 2) -> s = 2^(141 - e); zero / infinite / NaN / missing ranges: 1
+__device__ __forceinline__ float2 range_scale(const uint32_t* slot) {
+  if (!slot) return make_float2(1.f, 1.f);
+  const uint32_t bits = __builtin_nontemporal_load(slot) & 0x7fffffffu;
+  const int e = (int)(bits >> 23);
+  if (bits == 0u || e >= 255) return make_float2(1.f, 1.f);
+  const int k = max(-60, min(60, 141 - max(e, 1)));                 // (s, 1 / s and the product of two of them stay normal numbers)
+  return make_float2(__uint_as_float((uint32_t)(127 + k) << 23), __uint_as_float((uint32_t)(127 - k) << 23));
+}
+template <class G>
+__device__ __forceinline__ void scale_acc(f32x16 (&acc)[G::TM][G::TN], float f) {
+#pragma unroll
+  for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
 }
 
 // Remainder split ("tail"): workgroups finish in waves of 256 (one per CU), so `tiles mod 256` left-over
@@ -314,7 +343,7 @@ __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt
 // fixed order and applies the epilogue.  Bitwise reproducible; no atomics.
 struct SplitTail { int n_full, parts, kt_part; float* ws; };
 
-struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; float* stats; int stats_rows; int fair_from; };
+struct ConvFwdParams { const float* x; const float* w; const float* bias; float* y; ConvGeom g; int relu; SplitTail tail; const float* residual; InputTransform tf; float* stats; int stats_rows; int fair_from; Ranges rg; };
 
 // Decode blockIdx -> (tile, k range, partial destination).  Full tiles keep the XCD-aware order.
 template <class G>
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
   }
 }
 
-template <class G, bool VEC, bool TF>
+template <class G, bool VEC, bool TF, bool H = false>
 __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   using TA = TileKC<G::BM>;
   using TB = TileKM<G::BN>;
@@ -437,7 +466,13 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   LoadRowsKM<G::BN, VEC> lb; lb.init(p.w, p.g.K, p.g.K, Kg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
-  conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  if constexpr (H) {                                     // x = operand a, the kernel = operand b
+    const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
+    conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from, true, sa.x, sb.x);
+    scale_acc<G>(acc, sa.y * sb.y);
+  } else {
+    conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
+  }
   stamp(4);
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   if (VEC) {                                             // K % 4 == 0: 16-byte row stores
@@ -512,11 +547,14 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_fwd_kernel(Co
 // same, reading act(x*in_scale + in_shift) (InputTransform); its own symbol so the plain kernel keeps its code
 template <class G, bool VEC>
 __global__ __launch_bounds__(256, CONV_OCC<G>) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
+// the three-product form (16-byte loads only)
+template <class G>
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_fwd_h_kernel(ConvFwdParams p) { conv_fwd_body<G, true, false, true>(p); }
 
-struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; BnSums bn; };
+struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; BnSums bn; Ranges rg; };
 
-template <class G, bool VEC>
-__global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(ConvDgradParams p) {
+template <class G, bool VEC, bool H = false>
+__device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
   using TA = TileKC<G::BM>;
   using TB = TileKC<G::BN>;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS<G, TA, TB>];
@@ -534,7 +572,14 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
   LoadConvDgradB<G::BN, VEC> lb; lb.init(p.w, p.g, cg, n0, threadIdx.x);
   f32x16 acc[G::TM][G::TN];
   stamp(2);
-  conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
+  if constexpr (H) {                                     // dy = operand a, the kernel = operand b
+    const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
+    conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from,
+                                                               true, sa.x, sb.x);
+    scale_acc<G>(acc, sa.y * sb.y);
+  } else {
+    conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
+  }
   stamp(4);
   if (part) { store_partial<G>(acc, smem, part); stamp(5); return; }
   const int st = p.g.stride;
@@ -610,8 +655,12 @@ __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(
     if (row < M && col < p.g.C) p.dx[row_base + col] = p.accumulate ? p.add_src[row_base + col] + v : v;
   });
 }
+template <class G, bool VEC>
+__global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(ConvDgradParams p) { conv_dgrad_body<G, VEC>(p); }
+template <class G>
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_dgrad_h_kernel(ConvDgradParams p) { conv_dgrad_body<G, true, true>(p); }
 
-struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; int stagger; };
+struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; int stagger; Ranges rg; };
 
 // The weight gradient on the 16x16x32 MFMA shape (gemm_engine.h, "K32"): same tiles, loaders, slabs and summation order per
 // output element over k tiles; inside a k tile the 32 pixels are summed by one instruction per term instead of two.
@@ -646,7 +695,7 @@ template <class G>
 __global__ __launch_bounds__(256) void conv_wgrad_k32_tf_kernel(ConvWgradParams p) { conv_wgrad_k32_body<G, true>(p); }
 
 // VA: 16-byte gathers of X (C % 4 == 0); VB: 16-byte loads of dY (K % 4 == 0)
-template <class G, bool VA, bool VB, bool TF>
+template <class G, bool VA, bool VB, bool TF, bool H = false>
 __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   using TA = TileKM<G::BM>;
   using TB = TileKM<G::BN>;
@@ -676,8 +725,15 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
   // tiles apart (wrapping around), so they want different L2 lines at any instant but the same ones within a few
   // tiles' time.  Two passes over the rotated range; the accumulators carry over.
   const int rot = p.stagger > 0 ? min((tile * p.stagger) % max(kt1 - kt0, 1), kt1 - kt0) : 0;
-  conv_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
-  if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
+  if constexpr (H) {                                     // x = operand a, dy = operand b
+    const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
+    conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from, true, sa.x, sb.x);
+    if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, kt0, kt0 + rot, smem, acc, false, false, sa.x, sb.x); }
+    scale_acc<G>(acc, sa.y * sb.y);
+  } else {
+    conv_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
+    if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
+  }
   stamp(4);
   float* out = p.out + (long)split * M * p.g.K;
   if (VB) {                                              // K % 4 == 0
@@ -698,6 +754,8 @@ template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256, (VA && VB) ? CONV_OCC<G> : 1) void conv_wgrad_kernel(ConvWgradParams p) { conv_wgrad_body<G, VA, VB, false>(p); }
 template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
+template <class G>
+__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_h_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, false, true>(p); }
 
 // out[i] = sum_s slabs[s][i], fixed order.  A workgroup owns 32 float4 columns (512 contiguous bytes of
 // every slab) and spreads the slabs over 8 thread groups (slab s goes to group s % 8, each group keeping
@@ -965,6 +1023,67 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
     default: KERNEL<G64x64, VECARGS><<<grid, 256, 0, st>>>(p); break;                 \
   }
 
+#define LAUNCH_TILED_H(KERNEL, tile, grid, st, p)                                     \
+  switch (tile) {                                                                     \
+    case 0: KERNEL<G128x128><<<grid, 256, 0, st>>>(p); break;                         \
+    case 1: KERNEL<G128x64><<<grid, 256, 0, st>>>(p); break;                          \
+    case 2: KERNEL<G128x32><<<grid, 256, 0, st>>>(p); break;                          \
+    case 4: KERNEL<G192x64><<<grid, 256, 0, st>>>(p); break;                          \
+    default: KERNEL<G64x64><<<grid, 256, 0, st>>>(p); break;                          \
+  }
+static const char* conv_h_kernel_name(const char* kernel, const char* params, int tile) {
+  static thread_local char buf[160];
+  snprintf(buf, sizeof buf, "void embnet::%s<embnet::Geom<%s> >(embnet::%s)", kernel, GEOM_NAME[tile], params);
+  return buf;
+}
+
+// Operand ranges of the NEXT embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad, wgrad_slabs, wgrad_reduce}_f32 call of the calling
+// thread (see Ranges above): a = the first tensor argument of that call (x / dy / x), b = the second (w / w / dy); NULL = scale 1.
+// The call consumes them whatever path it takes; a launch that cannot use them (scalar-load kernels, fused input transform, thin
+// 1x1 streams, K32 experiment) computes the six-term products as if they had not been given.
+static thread_local Ranges t_ranges{nullptr, nullptr};
+static thread_local bool t_ranges_set = false;
+extern "C" int embnet_conv2d_ranges(const uint32_t* a, const uint32_t* b) {
+  EMBNET_CHECK_ARG(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3), "conv2d_ranges: slots are 4-byte aligned");
+  t_ranges = Ranges{a, b}; t_ranges_set = true;
+  return 0;
+}
+static bool take_ranges(Ranges& r) {
+  const bool set = t_ranges_set && EMBNET_CONV_SPLIT;
+  r = set ? t_ranges : Ranges{nullptr, nullptr};
+  t_ranges = Ranges{nullptr, nullptr}; t_ranges_set = false;
+  return set;
+}
+
+// Ranges of many tensors in two launches (the kernels of a model's gather convs, once per optimizer step): table rows
+// (tensor, elements, slot), chunks = (row, chunk of 4096 elements) pairs — the layout of embnet_conv_weight_planes' lists.
+struct RangeTensor { const float* x; long n; uint32_t* slot; };
+static_assert(sizeof(RangeTensor) == 24, "descriptor layout is part of the ABI (include/embnet.h)");
+__global__ __launch_bounds__(256) void range_zero_kernel(const RangeTensor* __restrict__ table, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) *table[i].slot = 0u;
+}
+__global__ __launch_bounds__(256) void range_multi_kernel(const RangeTensor* __restrict__ table, const int* __restrict__ chunks) {
+  const RangeTensor t = table[chunks[2 * blockIdx.x]];
+  const long e0 = (long)chunks[2 * blockIdx.x + 1] * 4096;
+  float m = 0.f;
+#pragma unroll 4
+  for (int u = 0; u < 16; ++u) {
+    const long e = e0 + u * 256 + threadIdx.x;
+    m = fmaxf(m, e < t.n ? fabsf(t.x[e]) : 0.f);
+  }
+  range_emit(t.slot, m);
+}
+extern "C" int embnet_range_chunk_elems(void) { return 4096; }
+extern "C" int embnet_range_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream) {
+  EMBNET_CHECK_ARG(table && chunks && n_tensors > 0 && n_chunks > 0, "range_multi: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  EMBNET_TRACE("embnet::range_multi_kernel", TRACE_BYTES, 4.0 * 4096 * n_chunks, stream);
+  range_zero_kernel<<<cdiv(n_tensors, 256), 256, 0, st>>>((const RangeTensor*)table, n_tensors);
+  range_multi_kernel<<<n_chunks, 256, 0, st>>>((const RangeTensor*)table, chunks);
+  return check_launch("range_multi");
+}
+
 // Off by default: 1-6 % faster per layer back to back (profiles/r04_exp_wgrad_k32.txt), 2 % SLOWER inside the training step
 // (same box, alternating runs: 123.9-124.9 vs 121.7-122.1 us for the 128x128 tile, step time equal) — see DESIGN 3.12.
 static bool wgrad_k32() { static const bool v = env_long("EMBNET_WGRAD_K32", 0) != 0; return v; }
@@ -997,6 +1116,7 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
                                      int ow, int relu, const float* residual, const float* in_scale,
                                      const float* in_shift, int in_act, float* stats, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  Ranges rg; const bool ranged = take_ranges(rg);
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_fwd: in_scale and in_shift go together");
   EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace) && aligned16(residual),
@@ -1026,11 +1146,15 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
   p.fair_from = fair_from(grid, tile, false);
   const double flop = 2.0 * M * k * r * s * c;
+  const bool hform = ranged && vec && !in_scale;
+  p.rg = rg;
   {
-    EMBNET_TRACE_FLOP(conv_kernel_name(in_scale ? "conv_fwd_tf_kernel" : "conv_fwd_kernel", "ConvFwdParams", tile,
+    EMBNET_TRACE_FLOP(hform ? conv_h_kernel_name("conv_fwd_h_kernel", "ConvFwdParams", tile) :
+                      conv_kernel_name(in_scale ? "conv_fwd_tf_kernel" : "conv_fwd_kernel", "ConvFwdParams", tile,
                                        (vec || in_scale) ? "true" : "false"), flop,
                       4.0 * ((double)n * h * wd * c + (double)r * s * c * k + (double)M * k * (residual ? 2 : 1)), st);
-    if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
+    if (hform) { LAUNCH_TILED_H(conv_fwd_h_kernel, tile, grid, st, p) }
+    else if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
     else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
     else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
   }
@@ -1057,6 +1181,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int n, 
                              int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                              int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
                              void* stream, const BnSums bn) {
+  Ranges rg; const bool ranged = take_ranges(rg);
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dx) && aligned16(workspace), "conv2d_dgrad: output and workspace must be 16-byte aligned");
   EMBNET_CHECK_ARG(!(accumulate && dx_add), "conv2d_dgrad: accumulate (into dx) or dx_add (another tensor), not both");
@@ -1097,11 +1222,15 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int n, 
   p.tail.ws = (float*)workspace;
   const dim3 grid(p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts, stride * stride);
   p.fair_from = fair_from((long)grid.x * grid.y, tile, false);
+  const bool hform = ranged && vec;
+  p.rg = rg;
   {
-    EMBNET_TRACE_FLOP(conv_kernel_name("conv_dgrad_kernel", "ConvDgradParams", tile, vec ? "true" : "false"),
+    EMBNET_TRACE_FLOP(hform ? conv_h_kernel_name("conv_dgrad_h_kernel", "ConvDgradParams", tile) :
+                      conv_kernel_name("conv_dgrad_kernel", "ConvDgradParams", tile, vec ? "true" : "false"),
                       2.0 * n * oh * ow * (double)k * r * s * c,
                       4.0 * ((double)n * oh * ow * k + (double)r * s * c * k + (double)n * h * wd * c * (p.accumulate ? 2 : 1)), st);
-    if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
+    if (hform) { LAUNCH_TILED_H(conv_dgrad_h_kernel, tile, grid, st, p) }
+    else if (vec) { LAUNCH_TILED(conv_dgrad_kernel, true, tile, grid, st, p) }
     else { LAUNCH_TILED(conv_dgrad_kernel, false, tile, grid, st, p) }
   }
   if (p.tail.parts > 1) {
@@ -1204,6 +1333,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
                       int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                       const float* in_scale, const float* in_shift, int in_act, void* stream, bool do_main,
                       bool do_reduce) {
+  Ranges rg; const bool ranged = take_ranges(rg);
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
@@ -1254,15 +1384,19 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     // (not the 128x64 tile: at three workgroups per CU its K32 form spills 9 registers in the loop — the ResNet stem's
     // weight gradient ran 455-472 us on it against 300-320, profiles/r04_bench_kernel_stats.md)
     const bool k32 = wgrad_k32() && tile != 1;
+    const bool hform = ranged && va && vb && !in_scale && !(k32 && !p.xcd_order);
+    p.rg = rg;
     char k32name[160];
     snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
     if (in_scale) snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_tf_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
-    EMBNET_TRACE_FLOP(((in_scale || (va && vb)) && k32 && !p.xcd_order) ? k32name :
+    EMBNET_TRACE_FLOP(hform ? conv_h_kernel_name("conv_wgrad_h_kernel", "ConvWgradParams", tile) :
+                      ((in_scale || (va && vb)) && k32 && !p.xcd_order) ? k32name :
                       conv_kernel_name(in_scale ? "conv_wgrad_tf_kernel" : "conv_wgrad_kernel", "ConvWgradParams", tile,
                                        (in_scale || (va && vb)) ? "true, true" : (vb ? "false, true" : "false, false")),
                       2.0 * n * oh * ow * (double)k * rows,
                       4.0 * ((double)n * h * wd * c + (double)n * oh * ow * k + (double)rows * k * p.splits), st);
-    if (in_scale && k32 && !p.xcd_order) {              // same arithmetic as the plain K32 kernels: deferred BN stays bit-identical
+    if (hform) { LAUNCH_TILED_H(conv_wgrad_h_kernel, tile, grid, st, p) }
+    else if (in_scale && k32 && !p.xcd_order) {         // same arithmetic as the plain K32 kernels: deferred BN stays bit-identical
       switch (tile) {
         case 0: conv_wgrad_k32_tf_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
         case 2: conv_wgrad_k32_tf_kernel<G128x32><<<grid, 256, 0, st>>>(p); break;

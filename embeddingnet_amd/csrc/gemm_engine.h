@@ -36,6 +36,7 @@
 #error "tools/exp/gemm_engine_diag.h is the round-3 engine; build the diagnostic variants from a round-3 checkout"
 #else
 #include "common.h"
+#include <type_traits>
 
 namespace embnet {
 
@@ -409,18 +410,22 @@ struct TileKC3 {
   using Map = TileKC<ROWS>;
   static constexpr int PASSES = Map::PASSES, PITCH = 64, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
   __device__ static __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> 2) & 3)) << 4); }
-  __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
+  // (SP: Split4 — three bf16 planes — or Split4H — the two fp16 planes of the three-product format, which use planes 0 and 1)
+  template <class SP>
+  __device__ static __forceinline__ void store(unsigned char* s, const SP (&r)[PASSES], int tid) {
+    constexpr int NP = sizeof(SP) / sizeof(uint2);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       unsigned char* d = s + off(Map::row_of(tid, p), (tid & 7) >> 1) + (tid & 1) * 8;      // k_of(tid) = 4 * (tid & 7)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
     }
   }
-  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
+  template <class V, int NP>
+  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, V (&v)[NP]) {
     const unsigned char* a = s + off(r0 + (lane & 31), 2 * st + (lane >> 5));
 #pragma unroll
-    for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const bf16x8*>(a + q * PLANE);
+    for (int q = 0; q < NP; ++q) v[q] = *reinterpret_cast<const V*>(a + q * PLANE);
   }
 };
 
@@ -446,26 +451,29 @@ struct TileKM3 {
     if (!SWZ) return k * PITCH + b;
     return k * PITCH + (ROWS == 64 ? (b ^ (((k >> 1) & 1) << 6)) : (b ^ ((k & 3) << 6)));
   }
-  __device__ static __forceinline__ void store(unsigned char* s, const Split4 (&r)[PASSES], int tid) {
+  template <class SP>
+  __device__ static __forceinline__ void store(unsigned char* s, const SP (&r)[PASSES], int tid) {
+    constexpr int NP = sizeof(SP) / sizeof(uint2);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       unsigned char* d = s + off(Map::k_of(tid, p), Map::row_of(tid, p));
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(d + q * PLANE) = r[p].p[q];
     }
   }
-  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, bf16x8 (&v)[3]) {
+  template <class V, int NP>
+  __device__ static __forceinline__ void frag(const unsigned char* s, int r0, int st, int lane, V (&v)[NP]) {
     const int k = 16 * st + 8 * (lane >> 5) + ((lane & 15) >> 2);
     const int row = r0 + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
     const unsigned char* a = s + off(k, row);
     const unsigned char* a4 = s + off(k + 4, row);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NP; ++q) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + q * PLANE));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a4 + q * PLANE));
       const s16x8 w = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      v[q] = __builtin_bit_cast(bf16x8, w);
+      v[q] = __builtin_bit_cast(V, w);
     }
   }
   // the A/B operand of v_mfma_f32_16x16x32_bf16 for rows r0 .. r0+15 over ALL 32 k of the tile: lane (i = lane & 15,
@@ -522,12 +530,17 @@ __device__ __forceinline__ void mfma_step3(const bf16x8 (&a)[G::TM][3], const bf
 // Measured and not adopted (tools/exp/gemm_engine_diag.h, profiles/r02_exp_ab_split_*.txt): two register sets in flight
 // (EMBNET_SPLIT_DIST=2: +48..130 registers, a workgroup per CU fewer, 5-30 % slower), rounded instead of truncated
 // pieces (same error, 6-7 % slower).  Round 3: what bounds this loop is the per-CU gather rate / latency.
-template <class G, class TA, class TB, class LA, class LB>
+// H = true: the operands are split into the TWO fp16 pieces of x * s (split4h; sa / sb: each operand's power-of-two scale, chosen by
+// the caller so that the tensor's largest element lands in [2^14, 2^15)) and a product keeps three piece products — the planes
+// kernels' format, here made on the fly from fp32 operands.  The accumulators then hold sa * sb times the result:
+// the caller multiplies by 1 / (sa sb) — exact, a power of two — before its epilogue.
+template <class G, class TA, class TB, class LA, class LB, bool H = false>
 __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int kt_begin, int kt_end,
                                                unsigned char* smem, f32x16 (&acc)[G::TM][G::TN], bool fair = false,
-                                               bool zero_acc = true) {
+                                               bool zero_acc = true, float sa = 1.f, float sb = 1.f) {
   using SA = typename SplitTile<TA>::type;
   using SB = typename SplitTile<TB>::type;
+  using SP = typename std::conditional<H, Split4H, Split4>::type;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / G::WAVES_N) * G::WTM, wn = (wave % G::WAVES_N) * G::WTN;
@@ -541,15 +554,22 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
   if (kt_begin >= kt_end) { prio_hi(); return; }
-  Split4 pa[TA::PASSES], pb[TB::PASSES];
+  SP pa[TA::PASSES], pb[TB::PASSES];
   unsigned char* sA = smem;
   unsigned char* sB = smem + SA::BYTES;
   float4 ra[TA::PASSES], rb[TB::PASSES];
   auto split_all = [&]() {
+    if constexpr (H) {
 #pragma unroll
-    for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
+      for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4h(ra[p], sa);
 #pragma unroll
-    for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
+      for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4h(rb[p], sb);
+    } else {
+#pragma unroll
+      for (int p = 0; p < TA::PASSES; ++p) pa[p] = split4(ra[p]);
+#pragma unroll
+      for (int p = 0; p < TB::PASSES; ++p) pb[p] = split4(rb[p]);
+    }
   };
   la.load(kt_begin, ra); lb.load(kt_begin, rb); la.fix(ra); lb.fix(rb);
   split_all();
@@ -563,12 +583,21 @@ __device__ __forceinline__ void gemm_mainloop3(const LA& la, const LB& lb, int k
     prio_by_progress(fair, kt, kt_begin, kt_end);
 #pragma unroll
     for (int st = 0; st < BK / 16; ++st) {
-      bf16x8 a[G::TM][3], b[G::TN][3];
+      if constexpr (H) {
+        f16x8 a[G::TM][2], b[G::TN][2];
 #pragma unroll
-      for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, st, lane, a[i]);
+        for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, st, lane, a[i]);
 #pragma unroll
-      for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
-      mfma_step3<G>(a, b, acc);
+        for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
+        mfma_step_h<G::TM, G::TN>(a, b, acc);
+      } else {
+        bf16x8 a[G::TM][3], b[G::TN][3];
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) SA::frag(sA, wm + 32 * i, st, lane, a[i]);
+#pragma unroll
+        for (int i = 0; i < G::TN; ++i) SB::frag(sB, wn + 32 * i, st, lane, b[i]);
+        mfma_step3<G>(a, b, acc);
+      }
     }
     la.fix(ra); lb.fix(rb);
     if (kt + 1 < kt_end) split_all();        // tile kt+1, requested one iteration ago

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
 // MODE 0: as described.  MODE 1: dx_planes in the two-piece fp16 format, scaled by the s the slot holds.  MODE 2: the dry run in front
 // of MODE 1 — the same arithmetic, nothing stored but the workgroup's max |dx| (floats 16 + blockIdx.x behind the slot); the scale
 // kernel below turns the maxima into s.  (8 bytes per element read once more: the price of an exact range for the gradient's planes.)
+// MODE 3: MODE 0 + the range of dx into `range_slot` (common.h range_emit) for the three-product gather convs that read dx (conv.hip Ranges).
 template <int MODE = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             long total4, int c4, float inv_m, const float* __restrict__ mean,
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ shift, const float* __restrict__ dbeta,
                                                             const float* __restrict__ dgamma, int relu, int training,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx,
-                                                            unsigned short* __restrict__ dx_planes) {
+                                                            unsigned short* __restrict__ dx_planes, uint32_t* __restrict__ range_slot = nullptr) {
   const long stride = (long)gridDim.x * 256;
   // (the launcher makes the stride a multiple of c4 whenever c4 divides a power of two, so a thread keeps its channel
   // quad and the six per-channel constants are loaded once; otherwise they are re-read per element)
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
     if (MODE == 2) { amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))); continue; }
+    if (MODE == 3) amax = amax4(amax, o);
     if (dx) reinterpret_cast<float4*>(dx)[i] = o;        // (NULL: planes only — every consumer of dx reads the planes)
     if (dx_planes) {                                     // the same values as bf16 pieces, chunk-major: dy operand of the
       const long pix = i / c4; const int q = (int)(i - pix * c4);      // patch data gradient of the convolution in front
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) planes_scale_slot(dx_planes, total4 * 4)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   }
+  if (MODE == 3) range_emit(range_slot, amax);
 }
 
 // (s, 1 / s) of a planes tensor from the workgroup maxima a dry run left behind its slot: the largest |value| lands in [2^14, 2^15)
@@ -628,12 +631,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                              int by_channel = 0) {
+                                                              int by_channel = 0, uint32_t* __restrict__ zero_slot = nullptr) {
   const int col = blockIdx.x;
   double s, ss;
   block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
   if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
+  if (zero_slot && col == 0 && threadIdx.x == 0) *zero_slot = 0u;      // the apply pass behind this kernel emits dx's range there
 }
+
+// The range slot (conv.hip Ranges) the NEXT embnet_bn_bwd / embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling
+// thread fills with max |dx| of the fp32 dx it writes (four-channel kernels, dx != NULL; otherwise the request is dropped and the
+// slot holds 0 = "no range": a conv given it multiplies that operand with scale 1).  Every embnet_bn_bwd* entry point consumes it.
+static thread_local uint32_t* t_emit_slot = nullptr;
+extern "C" int embnet_range_emit(uint32_t* slot) {
+  EMBNET_CHECK_ARG(!(reinterpret_cast<uintptr_t>(slot) & 3), "range_emit: the slot is 4-byte aligned");
+  t_emit_slot = slot;
+  return 0;
+}
+static uint32_t* take_emit_slot() { uint32_t* s = t_emit_slot; t_emit_slot = nullptr; return s; }
 
 // dx = scale * (dz - dbeta/M - xhat*dgamma/M)     (12 B/elem)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -887,10 +902,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply4_kernel(
     const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ x, int n, int h, int w,
     int c4, int k, int stride, int pad, int oh, int ow, float inv_m, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ dbeta, const float* __restrict__ dgamma, int act, int training, float* __restrict__ dx) {
+    const float* __restrict__ dbeta, const float* __restrict__ dgamma, int act, int training, float* __restrict__ dx,
+    uint32_t* __restrict__ range_slot) {
   const long total = (long)n * h * w * c4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i0 < total;                         // (no early return: every lane takes part in the range's wave maximum)
+  const long i = valid ? i0 : total - 1;
   const int q = (int)(i % c4);
   long t = i / c4;
   const int iw = (int)(t % w); t /= w;
@@ -947,7 +964,8 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply4_kernel(
   } else {
     o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
   }
-  reinterpret_cast<float4*>(dx)[i] = o;
+  if (valid) reinterpret_cast<float4*>(dx)[i] = o;
+  if (range_slot) range_emit(range_slot, valid ? amax4(0.f, o) : 0.f);
 }
 
 // y[n,c] = mean over hw.  Workgroup = one sample x 64 channels (16 channel-quad lanes x 16 pixel lanes).
@@ -1382,7 +1400,8 @@ extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const flo
 // bn_bwd_apply4_kernel in the planes format of the process: with EMBNET_PLANES_F16 a dry run finds the gradient's range first
 static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                                  const float* scale, const float* shift, const float* dbeta, const float* dgamma, int relu,
-                                 int training, const float* dx_add, float* dx, void* dx_planes, hipStream_t st) {
+                                 int training, const float* dx_add, float* dx, void* dx_planes, hipStream_t st,
+                                 uint32_t* range_slot = nullptr) {
   const long total4 = m * c / 4;
   const int blocks = ew_blocks_c4(total4, c / 4);
   const float inv_m = 1.f / (float)m;
@@ -1397,6 +1416,11 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
                                                    training, dx_add, dx, pl);
     return;
   }
+  if (range_slot && dx && !dx_planes) {
+    bn_bwd_apply4_kernel<3><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
+                                                   training, dx_add, dx, pl, range_slot);
+    return;
+  }
   bn_bwd_apply4_kernel<0><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
                                                  training, dx_add, dx, pl);
 }
@@ -1405,6 +1429,9 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
                              const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                              const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
                              size_t workspace_bytes, void* stream) {
+  uint32_t* const emit = take_emit_slot();
+  EMBNET_CHECK_ARG(!emit || (dx && !dx_planes && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd),
+                   "bn_bwd: a range of dx was requested (embnet_range_emit) but this call cannot emit one (fp32 dx without planes, c %% 4 == 0, saved statistics)");
   EMBNET_CHECK_ARG(dy && x && scale && shift && (dx || dx_planes) && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   EMBNET_CHECK_ARG(dx || ((c & 3) == 0 && !bn_scalar()), "bn_bwd: dx = NULL (planes only) needs the four-channel kernels");
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd: dx_planes needs c %% 16 == 0");
@@ -1421,7 +1448,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);
       { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, DropArg{0, nullptr, 0u, 1.f}); }
-      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
+      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma, 0, emit);
     } else {
       { EMBNET_TRACE("embnet::bn_bwd_reduce_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial); }
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
@@ -1431,8 +1458,8 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    { EMBNET_TRACE(dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
-      launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream)); }
+    { EMBNET_TRACE(emit ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+      launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream), emit); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
@@ -1443,6 +1470,7 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
                               const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                               float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
                               size_t workspace_bytes, void* stream, const DropArg drop) {
+  EMBNET_CHECK_ARG(!take_emit_slot(), "bn_bwd_inrelu: this pass cannot emit the range requested by embnet_range_emit");
   EMBNET_CHECK_ARG(dy && x && scale && shift && dz && dgamma && dbeta && dbias && workspace, "bn_bwd_inrelu: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0, "bn_bwd_inrelu: m=%ld c=%d (c %% 4 == 0 required)", m, c);
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd_inrelu: training needs saved statistics");
@@ -1468,6 +1496,7 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
 extern "C" int embnet_bn_bwd_gap(const float* dy, const float* dpool, const float* gate, int n, int hw, const float* x, int c, const float* save_mean,
                                  const float* save_rstd, const float* scale, const float* shift, int relu, float* dx,
                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(!take_emit_slot(), "bn_bwd_gap: this pass cannot emit the range requested by embnet_range_emit");
   EMBNET_CHECK_ARG(dy && dpool && x && save_mean && save_rstd && scale && shift && dx && dgamma && dbeta && workspace, "bn_bwd_gap: null pointer");
   EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "bn_bwd_gap: n=%d hw=%d c=%d (c %% 4 == 0)", n, hw, c);
   const long m = (long)n * hw;
@@ -1503,6 +1532,7 @@ extern "C" int embnet_se_bn_sums(const float* dg, const float* x, int n, int hw,
 extern "C" int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const float* gate, const float* sums, int n, int hw,
                                       const float* x, int c, const float* save_mean, const float* save_rstd, const float* scale,
                                       const float* shift, int relu, float* dx, float* dgamma, float* dbeta, void* stream) {
+  EMBNET_CHECK_ARG(!take_emit_slot(), "bn_bwd_gap_sums: this pass cannot emit the range requested by embnet_range_emit");
   EMBNET_CHECK_ARG(dy && dpool && gate && sums && x && save_mean && save_rstd && scale && shift && dx && dgamma && dbeta, "bn_bwd_gap_sums: null pointer");
   EMBNET_CHECK_ARG(n > 0 && hw > 0 && c > 0 && (c & 3) == 0, "bn_bwd_gap_sums: n=%d hw=%d c=%d (c %% 4 == 0)", n, hw, c);
   const long m = (long)n * hw;
@@ -1522,12 +1552,14 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
                                       const float* save_rstd, const float* scale, const float* shift, int relu,
                                       const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
                                       float* dbeta, void* dx_planes, void* stream) {
+  uint32_t* const emit = take_emit_slot();
+  EMBNET_CHECK_ARG(!emit || (dx && !dx_planes), "bn_bwd_partials: a range of dx was requested (embnet_range_emit) but dx is not an fp32 tensor without planes");
   EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && (dx || dx_planes) && dgamma && dbeta, "bn_bwd_partials: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
-  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1);
-  { EMBNET_TRACE(dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
-    launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream)); }
+  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1, emit);
+  { EMBNET_TRACE(emit ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+    launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream), emit); }
   return check_launch("bn_bwd_partials");
 }
 
@@ -1621,6 +1653,8 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
                                          const float* save_rstd, const float* scale, const float* shift, int act,
                                          int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
                                          void* workspace, size_t workspace_bytes, void* stream) {
+  uint32_t* const emit = take_emit_slot();
+  EMBNET_CHECK_ARG(!emit || (save_mean && save_rstd), "bn_act_maxpool_bwd: a range of dx was requested (embnet_range_emit) without saved statistics");
   EMBNET_CHECK_ARG(dy && argmax && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_act_maxpool_bwd: null pointer");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_act_maxpool_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "bn_act_maxpool_bwd: bad geometry");
@@ -1632,7 +1666,7 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
     const ColGeom g4 = col_geom(mp, c / 4);
     { EMBNET_TRACE("embnet::pool_bn_bwd_reduce4_kernel", TRACE_BYTES, 9.0 * mp * c, stream); pool_bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, x, mp, h, w, c / 4, k, stride, pad, oh, ow, g4,
                                                                  save_mean, save_rstd, scale, shift, act, xwin, (float*)workspace); }
-    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma);
+    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma, 0, emit);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
@@ -1640,7 +1674,7 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
   const long total = (long)n * h * w * (c / 4);
   { EMBNET_TRACE("embnet::pool_bn_bwd_apply4_kernel", TRACE_BYTES, 32.0 * total + 5.0 * mp * c, stream); pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
                                                                     1.f / (float)((long)n * h * w), save_mean, save_rstd,
-                                                                    scale, shift, dbeta, dgamma, act, training, dx); }
+                                                                    scale, shift, dbeta, dgamma, act, training, dx, emit); }
   return check_launch("bn_act_maxpool_bwd");
 }
 

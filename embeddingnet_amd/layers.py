@@ -76,8 +76,8 @@ def workspace(nbytes, device):
 #     when THAT backward ends — the first entry made during a backward queues an end-of-backward callback on the autograd
 #     engine — and counted in `context.unclaimed`, so entries neither pile up nor pin activation-sized tensors.
 class StepContext:
-    DICTS = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "bn_fwd_stats", "act_planes")
-    BACKWARD = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes")      # made and consumed inside one backward
+    DICTS = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "dy_range", "bn_fwd_stats", "act_planes")
+    BACKWARD = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "dy_range")      # made and consumed inside one backward
 
     def __init__(self, name="default"):
         self.name = name
@@ -229,11 +229,15 @@ def wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow):
 
 
 def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0,
-               x_planes=None, dz_planes=None):
+               x_planes=None, dz_planes=None, dz_range=None):
     """dw[r,s,c,k] = weight gradient of a convolution, its slab sum deferred when SLAB_DEFER.  With the planes of BOTH operands
     (x_planes: kept by the forward patch conv, dz_planes: left by the BatchNormalization behind the conv) and a geometry
     embnet_conv2d_wgrad_planes_supported accepts, the planes kernel computes it (csrc/conv_wgrad_planes.hip) and the fp32
-    tensors are not read; otherwise embnet_conv2d_wgrad_f32."""
+    tensors are not read; otherwise embnet_conv2d_wgrad_f32 — with dz_range (the range slot of dz, DY_RANGE) on three products.
+    """
+    def ranged():
+        if dz_range is not None and in_scale is None:
+            check(lib.embnet_conv2d_ranges(None, ptr(dz_range)))
     planes = x_planes is not None and dz_planes is not None and in_scale is None and \
         wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow)
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
@@ -255,6 +259,7 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
                                                          n, h, wd, c, k, 0, stream()))
             else:
                 buf = _slab_buffer(w, lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4, x.device)
+                ranged()
                 check(lib.embnet_conv2d_wgrad_slabs_f32(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
                                                         stride, pt, pl, oh, ow, in_scale, in_shift, in_act, stream()))
             # (an alias of dw, not dw itself: autograd adopts a returned gradient as .grad only while nobody else holds that
@@ -267,6 +272,7 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
                                                  1, stream()))
         return
     ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+    ranged()
     check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl,
                                       oh, ow, in_scale, in_shift, in_act, stream()))
 
@@ -401,6 +407,7 @@ def refresh_weight_planes(module):
     """Rebuild the planes of every kernel that has them, in ONE launch (called by the trainer right after the optimizer
     step, so that the next forward finds them current; inside a captured step this launch is part of the graph)."""
     import numpy as np
+    refresh_weight_ranges(module)               # (the gather convs' kernel ranges ride along)
     ws = []
     for m in module.modules():
         if isinstance(m, Conv2D):
@@ -423,6 +430,92 @@ def refresh_weight_planes(module):
     for w in ws:
         e = w._embnet_wplanes
         e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+# ---- three products per fp32 product on the gather convs (csrc/conv.hip "Ranges"; include/embnet.h ABI 20) --------------------------
+# A Conv2D with `f16 = True` (the zoo ResNets' convs, backbones._rn_conv) that does NOT run the patch kernel tells the library the
+# RANGE of both operands of each of its three passes, and the kernels then multiply in the planes kernels' two-piece fp16 format
+# (three matrix products per fp32 product instead of six).  Kernel ranges: one uint32 slot per kernel, refreshed like the kernel
+# planes (tensor version / WEIGHT_EPOCH; refresh_weight_planes does all of a model's in two launches).  Gradient ranges: the conv
+# tags its output (`y._wants_dy_range`), the BatchNormalization (or BatchNorm + MaxPool) that reads y makes its backward leave
+# max |dx| in a slot (embnet_range_emit) and files it in DY_RANGE under dx's address — with an alias of dx, so that address cannot
+# pass to another tensor while the entry lives; the conv's backward claims it.  Activations take scale 1 (as the planes do).
+# A gradient that reaches the conv from anywhere else has no entry: that pass runs the six-term kernel.
+CONV_F16 = [_os.environ.get("EMBNET_CONV_F16", "1") != "0"]           # [False]: six-term products everywhere (A/B)
+DY_RANGE = _CtxDict("dy_range")
+
+
+def _range_entry(w):
+    e = getattr(w, "_embnet_wrange", None)
+    if e is None or e["ptr"] != w.data_ptr() or e["n"] != w.numel():
+        import numpy as np
+        dev = w.device
+        slot = torch.zeros(1, dtype=torch.int32, device=dev)
+        ce = _lib.lib().embnet_range_chunk_elems()
+        rows = [(w.data_ptr(), w.numel(), slot.data_ptr())]
+        e = dict(ptr=w.data_ptr(), n=w.numel(), epoch=-1, version=-1, slot=slot, rows=rows,
+                 table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
+                 chunks=torch.tensor([(0, j) for j in range(-(-w.numel() // ce))], dtype=torch.int32, device=dev))
+        w._embnet_wrange = e
+    return e
+
+
+def weight_range(w):
+    """The range slot of kernel tensor `w` (uint32 bit pattern of max |w|, on the device), refreshed when the kernel changed."""
+    e = _range_entry(w)
+    if e["epoch"] != WEIGHT_EPOCH[0] or e["version"] != w._version:
+        check(_lib.lib().embnet_range_multi(e["table"].data_ptr(), 1, e["chunks"].data_ptr(), e["chunks"].shape[0], stream()))
+        e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+    return e["slot"]
+
+
+def refresh_weight_ranges(module):
+    """Every kernel range of `module` that exists, in one call (two launches) — the trainer calls it with refresh_weight_planes."""
+    import numpy as np
+    ws = []
+    for m in module.modules():
+        if isinstance(m, Conv2D):
+            e = getattr(m.kernel, "_embnet_wrange", None)
+            if e is not None and e["ptr"] == m.kernel.data_ptr():
+                ws.append(m.kernel)
+    if not ws:
+        return
+    key = tuple(id(w._embnet_wrange) for w in ws)
+    plan = getattr(module, "_wrange_plan", None)
+    if plan is None or plan["key"] != key:
+        rows = [w._embnet_wrange["rows"][0] for w in ws]
+        ce = _lib.lib().embnet_range_chunk_elems()
+        dev = ws[0].device
+        plan = dict(key=key, n=len(rows), table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
+                    chunks=torch.tensor([(i, j) for i, w in enumerate(ws) for j in range(-(-w.numel() // ce))],
+                                        dtype=torch.int32, device=dev))
+        module._wrange_plan = plan
+    check(_lib.lib().embnet_range_multi(plan["table"].data_ptr(), plan["n"], plan["chunks"].data_ptr(), plan["chunks"].shape[0], stream()))
+    for w in ws:
+        e = w._embnet_wrange
+        e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+def _take_dy_range(dy, keep=False):
+    """keep: the same gradient tensor goes on to a second conv (the projection shortcut behind a fused Add) — the entry stays for
+    it; an identity shortcut's BatchNormalization releases it instead (_BatchNormFn.backward)."""
+    if not DY_RANGE:
+        return None
+    e = DY_RANGE.get(dy.data_ptr()) if keep else DY_RANGE.pop(dy.data_ptr(), None)
+    return e[0] if (e is not None and e[1].shape == dy.shape) else None
+
+
+def _emit_dx_range(dx):
+    """A fresh range slot for `dx`, announced to the library (the next embnet_bn_bwd* call fills it) and filed in DY_RANGE."""
+    slot = torch.empty(1, dtype=torch.int32, device=dx.device)
+    check(_lib.lib().embnet_range_emit(ptr(slot)))
+    if len(DY_RANGE) > 64:
+        DY_RANGE.clear()
+    DY_RANGE[dx.data_ptr()] = (slot, dx.detach())
+    return slot
+
+
+_BN_SCALAR = _os.environ.get("EMBNET_BN_SCALAR", "0") not in ("0", "")
 
 
 PLANES_ONLY = [_os.environ.get("EMBNET_PLANES_ONLY", "1") != "0"]     # [False]: every planes tensor keeps its fp32 copy (A/B)
@@ -490,9 +583,11 @@ def same_pad(n, k, s):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False,
-                planes=None, bn_src=None):
+                planes=None, bn_src=None, w_range=None):
         """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward.
-        bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums."""
+        bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums.
+        w_range: the kernel's range slot (weight_range) -> the gather kernels of all three passes multiply on three products
+        where the other operand's range is known too (x: scale 1; dy: DY_RANGE)."""
         w = _c(w)
         if not (planes is not None and _is_placeholder(x)):       # (a planes-only input has no fp32 values to read)
             x = _c(x)
@@ -520,10 +615,13 @@ class _Conv2dFn(torch.autograd.Function):
                                               ws.numel() * 4, stream()))
         else:
             ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+            if w_range is not None and in_stats is None:
+                check(lib.embnet_conv2d_ranges(None, ptr(w_range)))
             check(lib.embnet_conv2d_fwd_f32(
                 ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
                 in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
         ctx.patch = planes is not None
+        ctx.w_range = w_range if (planes is None and in_stats is None) else None
         ctx.x_planes = planes                # kept for the weight gradient (conv_wgrad)
         ctx.bn_src = bn_src
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
@@ -572,6 +670,9 @@ class _Conv2dFn(torch.autograd.Function):
 
         # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
         dy_planes = _take_dy_planes(dy) if (ctx.patch and not ctx.relu) else None
+        # ... or its range, for the three-product gather kernels (same condition)
+        w_range = getattr(ctx, "w_range", None)
+        dy_range = _take_dy_range(dy, keep=ctx.has_res) if (w_range is not None and not ctx.relu and not dy_only_planes) else None
         if dy_only_planes and dy_planes is None:
             raise _lib.EmbnetError("conv2d backward: the gradient exists only as planes and they are gone (DY_PLANES)")
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -583,7 +684,7 @@ class _Conv2dFn(torch.autograd.Function):
 
         def run_wgrad():
             conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
-                       getattr(ctx, "x_planes", None), dy_planes)
+                       getattr(ctx, "x_planes", None), dy_planes, dy_range)
 
         dw_note = None
         if need_dw:
@@ -609,6 +710,8 @@ class _Conv2dFn(torch.autograd.Function):
                     bn_x, bn_stats, bn_act = bn_src
                     partial = torch.empty((2, c, rows), device=x.device, dtype=torch.float32)
                     sp = bn_stats.data_ptr()
+                    if dy_range is not None:
+                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
                     check(lib.embnet_conv2d_dgrad_bnsums_f32(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(bn_x), sp + 8 * c, sp + 12 * c,
                         sp, sp + 4 * c, int(bn_act), ptr(partial), rows, ptr(dws), dws.numel() * 4, stream()))
@@ -616,6 +719,8 @@ class _Conv2dFn(torch.autograd.Function):
                         BN_SUMS.pop(next(iter(BN_SUMS)))
                     BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
                 else:
+                    if dy_range is not None:
+                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
                     check(lib.embnet_conv2d_dgrad_f32(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
                         dws.numel() * 4, stream()))
@@ -631,7 +736,7 @@ class _Conv2dFn(torch.autograd.Function):
             db = _done(db, db_note)
         if dskip is not None and dx is None and ctx.needs_input_grad[0]:
             dx = dskip
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -641,8 +746,10 @@ class _ConvPairFn(torch.autograd.Function):
     for autograd to add."""
 
     @staticmethod
-    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1, planes=None):
-        """planes: pre-split planes of x -> the FIRST conv (the 3x3) runs the patch kernel."""
+    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1, planes=None, w_ranges=None):
+        """planes: pre-split planes of x -> the FIRST conv (the 3x3) runs the patch kernel.
+        w_ranges = (range slot of w1 or None, of w2 or None): see _Conv2dFn.forward."""
+        w_ranges = tuple(w_ranges) if (w_ranges is not None and in_stats is None) else (None, None)
         x, w1, w2 = _c(x), _c(w1), _c(w2)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -661,11 +768,15 @@ class _ConvPairFn(torch.autograd.Function):
                                                   pt, pl, oh, ow, 0, None, ptr(st), ptr(ws), ws.numel() * 4, stream()))
             else:
                 ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
+                wr = w_ranges[0 if w is w1 else 1]
+                if wr is not None:
+                    check(lib.embnet_conv2d_ranges(None, ptr(wr)))
                 check(lib.embnet_conv2d_fwd_f32(
                     ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
                     int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
             ys.append(y)
         ctx.patch = planes is not None
+        ctx.w_ranges = (w_ranges[0] if planes is None else None, w_ranges[1])
         ctx.x_planes = planes
         ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
         ctx.save_for_backward(x, w1, w2, in_stats)
@@ -692,11 +803,15 @@ class _ConvPairFn(torch.autograd.Function):
             dy_planes = _take_dy_planes(dy) if (ctx.patch and w is w1) else None
             if _is_placeholder(dy) and dy_planes is None:
                 raise _lib.EmbnetError("conv_pair backward: the gradient exists only as planes and they are gone (DY_PLANES)")
+            w_range = getattr(ctx, "w_ranges", (None, None))[0 if w is w1 else 1]
+            dy_range = _take_dy_range(dy) if (w_range is not None and not _is_placeholder(dy)) else None
             if dx is not None:
                 if dy_planes is not None and first and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
                     _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, None)
                 else:
                     sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
+                    if dy_range is not None:
+                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
                     check(lib.embnet_conv2d_dgrad_f32(
                         ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
                         ptr(sc), sc.numel() * 4, stream()))
@@ -705,12 +820,12 @@ class _ConvPairFn(torch.autograd.Function):
             if need_dw:
                 dw, note = _sink(w)
                 conv_wgrad(lib, x, dy, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
-                           getattr(ctx, "x_planes", None) if w is w1 else None, dy_planes)
+                           getattr(ctx, "x_planes", None) if w is w1 else None, dy_planes, dy_range)
                 dw = _done(dw, note)
             dws.append(dw)
         if dx is not None and first:
             dx.zero_()
-        return dx, dws[0], None, dws[1], None, None, None, None, None
+        return dx, dws[0], None, dws[1], None, None, None, None, None, None
 
 
 def conv_pair(x, conv1, conv2, emit_stats=False):
@@ -737,9 +852,15 @@ def conv_pair(x, conv1, conv2, emit_stats=False):
             rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, g1[3], g1[4])
         if rows > 0:
             out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
-    y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats, planes)
+    wr = (conv1.range_for(x, planes, in_stats), conv2.range_for(x, None, in_stats))
+    y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats, planes,
+                               wr if (wr[0] is not None or wr[1] is not None) else None)
     if out_stats is not None:
         y1._bn_partials = out_stats
+    if wr[0] is not None and torch.is_grad_enabled():
+        y1._wants_dy_range = True
+    if wr[1] is not None and torch.is_grad_enabled():
+        y2._wants_dy_range = True
     if planes is not None:
         y1._wants_dy_planes = True
         if conv1.planes_only_gradient(x.shape, g1):
@@ -817,6 +938,15 @@ class Conv2D(nn.Module):
         {"he_uniform": he_uniform_, "conv_normal": conv_normal_}.get(kernel_initializer, glorot_uniform_)(w, gen)
         self.kernel = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(filters)) if use_bias else None
+        self.f16 = False          # True: three-product gather kernels where the operands' ranges are known (layers.CONV_F16 note)
+
+    def range_for(self, x, planes, in_stats):
+        """The kernel's range slot when this conv, on that input, runs the gather kernels on three products; else None."""
+        if not (CONV_F16[0] and getattr(self, "f16", False)) or planes is not None or in_stats is not None or self.relu:
+            return None
+        if self.kernel.shape[2] % 4 or self.kernel.shape[3] % 4 or x.shape[-1] % 4 or _BN_SCALAR:
+            return None
+        return weight_range(self.kernel)
 
     def geometry(self, h, w):
         k, s = self.k, self.stride
@@ -868,11 +998,14 @@ class Conv2D(nn.Module):
         if not (FUSE_BN_SUMS[0] and bn_src is not None and in_stats is None and self.stride == 1 and not with_skip
                 and torch.is_grad_enabled() and x.requires_grad and kernel is self.kernel):
             bn_src = None
+        w_range = self.range_for(x, planes, in_stats)      # (a channel-padded kernel has its source's range: the padding is zeros)
         out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
-                              planes, bn_src)
+                              planes, bn_src, w_range)
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
+        if w_range is not None and torch.is_grad_enabled():
+            y._wants_dy_range = True           # the BatchNormalization reading y leaves the range of its dx in DY_RANGE (backward)
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
             # ... and ONLY as planes when this conv takes both of its gradients from them and the BatchNormalization is told
@@ -1065,7 +1198,7 @@ class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, training, partials=None,
                 with_skip=False, emit_planes=False, emit_dx_planes=False, in_relu_bias=None, dropout=None,
-                planes_only=False, dx_planes_only=False):
+                planes_only=False, dx_planes_only=False, emit_dx_range=False):
         """dropout=(rate, seed): a Dropout layer directly behind this one rides on its passes (embnet_affine_act_dropout,
         embnet_bn_bwd_inrelu_dropout; the mask and arithmetic of embnet_dropout).
         emit_planes: the output is ALSO written as bf16 planes for a patch conv (left in _ACT_PLANES under the output's
@@ -1102,6 +1235,7 @@ class _BatchNormFn(torch.autograd.Function):
             if len(_BN_FWD_STATS) > 64:
                 _BN_FWD_STATS.clear()
             _BN_FWD_STATS[y.data_ptr()] = (x, stats, int(relu))
+        ctx.emit_dx_range = bool(emit_dx_range) and c % 4 == 0 and training and not _BN_SCALAR
         ctx.emit_dx_planes = bool(emit_dx_planes) and c % 16 == 0
         ctx.dx_planes_only = bool(dx_planes_only) and ctx.emit_dx_planes and not with_skip
         ctx.in_relu_bias = in_relu_bias if (in_relu_bias is not None and not with_skip and c % 4 == 0) else None
@@ -1122,6 +1256,8 @@ class _BatchNormFn(torch.autograd.Function):
         m = x.numel() // c
         dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
+        if dskip is not None and DY_RANGE:
+            DY_RANGE.pop(dskip.data_ptr(), None)      # (the identity shortcut ends here: nobody else will claim that gradient's range)
         only = getattr(ctx, "dx_planes_only", False) and dskip is None
         dx = _placeholder(x.shape, x.device) if only else torch.empty_like(x)
         dxp = None if only else ptr(dx)
@@ -1141,11 +1277,13 @@ class _BatchNormFn(torch.autograd.Function):
         if (hit is not None and hit[2] == x.data_ptr() and hit[3].shape == dy.shape and ctx.training and c % 4 == 0
                 and not inrelu and drop is None):
             # dy is the data gradient of the conv behind this layer, which already produced the column sums
+            if getattr(ctx, "emit_dx_range", False) and planes is None and not only:
+                _emit_dx_range(dx)
             check(lib.embnet_bn_bwd_partials(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
                                              int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
                                              stream()))
             dgamma, dbeta = finish()
-            return (dx, dgamma, dbeta) + (None,) * 14
+            return (dx, dgamma, dbeta) + (None,) * 15
         if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
             dyd = torch.empty_like(dy)
             check(lib.embnet_dropout(ptr(dy), dy.numel(), drop[0], drop[1], drop[2], ptr(dyd), stream()))
@@ -1167,11 +1305,13 @@ class _BatchNormFn(torch.autograd.Function):
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
         else:
+            if getattr(ctx, "emit_dx_range", False) and planes is None and not only:
+                _emit_dx_range(dx)
             check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                     int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
                                     ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return (dx, dgamma, dbeta) + (None,) * 14
+        return (dx, dgamma, dbeta) + (None,) * 15
 
 
 class _BNGapFn(torch.autograd.Function):
@@ -1505,6 +1645,7 @@ class BatchNormalization(nn.Module):
             y = self.forward(x)
             return y, _GapFn.apply(y)
         want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
+        want_dx_range = bool(getattr(x, "_wants_dy_range", False)) and torch.is_grad_enabled() and not want_dx_planes
         dx_only = bool(want_dx_planes and owns_input and PLANES_ONLY[0] and getattr(x, "_dy_planes_only", False)
                        and x.shape[-1] % 16 == 0)
 
@@ -1517,7 +1658,7 @@ class BatchNormalization(nn.Module):
             y_only = bool(sole and PLANES_ONLY[0] and planes_for.planes_only_input(x.shape))
             out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), with_skip,
-                                     True, want_dx_planes, None, None, y_only, dx_only)
+                                     True, want_dx_planes, None, None, y_only, dx_only, want_dx_range)
             y = out[0] if with_skip else out
             y._planes = _ACT_PLANES.pop(y.data_ptr())
             tag(y)
@@ -1525,7 +1666,7 @@ class BatchNormalization(nn.Module):
         if with_skip and not defer:
             out = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                      self.momentum, self.relu, self.training, _partials_of(x, self.training), True,
-                                     False, want_dx_planes)
+                                     False, want_dx_planes, None, None, False, False, want_dx_range)
             tag(out[0])
             return out
         if with_skip:
@@ -1538,7 +1679,7 @@ class BatchNormalization(nn.Module):
         y = _BatchNormFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps,
                                self.momentum, self.relu, self.training, _partials_of(x, self.training), False,
                                False, want_dx_planes, in_relu_bias, dropout.take() if dropout is not None else None,
-                               False, dx_only and in_relu_bias is None and dropout is None)
+                               False, dx_only and in_relu_bias is None and dropout is None, want_dx_range)
         tag(y)
         return y
 
@@ -1568,7 +1709,8 @@ class _InputBNConvFn(torch.autograd.Function):
     _ones = {}
 
     @staticmethod
-    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False):
+    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False, w_range=None):
+        """w_range: the kernel's range slot (_Conv2dFn.forward); the channel-padded copy has the same range."""
         x, w = _c(x), _c(w)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -1604,9 +1746,12 @@ class _InputBNConvFn(torch.autograd.Function):
             moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
+        if w_range is not None:
+            check(lib.embnet_conv2d_ranges(None, ptr(w_range)))
         check(lib.embnet_conv2d_fwd_f32(
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
             ptr(out_stats), ptr(cws), cws.numel() * 4, stream()))
+        ctx.w_range = w_range
         ctx.geom, ctx.c, ctx.zero_sum_dy = geom, c, bool(zero_sum_dy)
         ctx.beta_ref = beta
         ctx.save_for_backward(a, w)
@@ -1622,6 +1767,9 @@ class _InputBNConvFn(torch.autograd.Function):
         dy = _c(dy)
         dw_p = torch.empty((r, s, cp, k), device=a.device, dtype=torch.float32)
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, cp, r, s, k, oh, ow), a.device)
+        dy_range = _take_dy_range(dy) if getattr(ctx, "w_range", None) is not None else None
+        if dy_range is not None:
+            check(lib.embnet_conv2d_ranges(None, ptr(dy_range)))
         check(lib.embnet_conv2d_wgrad_f32(
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
             None, None, 0, stream()))
@@ -1649,7 +1797,7 @@ class _InputBNConvFn(torch.autograd.Function):
                 None, None, 0, stream()))
         dbeta, db_note = _sink(ctx.beta_ref)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
-        return None, _done(dbeta, db_note), None, None, dw, None, None, None, None, None
+        return None, _done(dbeta, db_note), None, None, dw, None, None, None, None, None, None
 
 
 def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
@@ -1669,10 +1817,15 @@ def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
         rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], cp, r, s, k, geom[3], geom[4])
         if rows > 0:
             out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+    w_range = None
+    if CONV_F16[0] and getattr(conv, "f16", False) and conv.kernel.shape[3] % 4 == 0 and not _BN_SCALAR:
+        w_range = weight_range(conv.kernel)
     y = _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum, geom,
-                             out_stats, zero_sum_dy)
+                             out_stats, zero_sum_dy, w_range)
     if out_stats is not None:
         y._bn_partials = out_stats
+    if w_range is not None:
+        y._wants_dy_range = True
     return y
 
 
@@ -1741,11 +1894,12 @@ class _BNActMaxPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, act, training, k, stride, pad,
-                partials=None):
+                partials=None, emit_dx_range=False):
         x = _c(x)
         lib = _lib.lib()
         n, h, w, c = x.shape
         m = n * h * w
+        ctx.emit_dx_range = bool(emit_dx_range) and training
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
         if oh <= 0 or ow <= 0:
             raise _lib.EmbnetError(f"MaxPool {k}x{k}/{stride} does not fit a {h}x{w} input")
@@ -1781,12 +1935,14 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         ws = workspace(lib.embnet_bn_act_maxpool_bwd_workspace_bytes(n, oh, ow, c), x.device)
         mean = stats.data_ptr() if training else None
         rstd = (stats.data_ptr() + 4 * stats.shape[1]) if training else None
+        if getattr(ctx, "emit_dx_range", False):
+            _emit_dx_range(dx)
         check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
                                             (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), act, int(training),
                                             ptr(xwin) if training else None, ptr(dx),
                                             ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return (dx, dgamma, dbeta) + (None,) * 10
+        return (dx, dgamma, dbeta) + (None,) * 11
 
 
 def bn_act_maxpool(x, bn, pool):
@@ -1795,7 +1951,8 @@ def bn_act_maxpool(x, bn, pool):
     if x.shape[-1] % 4:
         return pool(bn(x))
     return _BNActMaxPoolFn.apply(x, bn.gamma, bn.beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum,
-                                 bn.relu, bn.training, pool.k, pool.s, pool.p, _partials_of(x, bn.training))
+                                 bn.relu, bn.training, pool.k, pool.s, pool.p, _partials_of(x, bn.training),
+                                 bool(getattr(x, "_wants_dy_range", False)) and torch.is_grad_enabled())
 
 
 class _GapFn(torch.autograd.Function):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 19
+#define EMBNET_ABI_VERSION 20
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -223,6 +223,29 @@ int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow
  * (bit-identical).  The descriptors travel as kernel arguments (112 per launch), so nothing has to stay alive for a
  * captured graph.  slabs and out 16-byte aligned when n % 4 == 0. */
 int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream);
+
+/* ---- three products per fp32 product for the implicit-GEMM ("gather") convolutions above (ABI 20; csrc/conv.hip "Ranges") -------
+ * The layers of backbones.py:99-104 the patch kernels do not take — the 7x7 stem, the stride-2 3x3 convs, every 1x1 conv — split
+ * their fp32 operands inside the kernel.  Given the RANGE of both operands they use the planes kernels' arithmetic (below: two fp16
+ * pieces of x s, three products, the sums x 1 / (s s')) instead of three bf16 pieces and six products: half the matrix instructions.
+ * A RANGE SLOT is one uint32 in device memory holding the bit pattern of max |element| of a tensor (0: unknown -> scale 1).
+ *   embnet_range_emit(slot): the NEXT embnet_bn_bwd / embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling
+ *     thread also leaves the range of the fp32 dx it writes in *slot (zeroed by its finalize kernel, joined by the apply pass with
+ *     an order-independent unsigned maximum).  The call fails if it cannot (planes-only dx, c % 4 != 0, no saved statistics).
+ *   embnet_range_multi: ranges of many tensors (a model's kernels, once per optimizer step) in two launches; device table of
+ *     24-byte rows { const float* x; int64 n; uint32* slot; }, chunk list int32 [n_chunks][2] = (row, chunk of
+ *     embnet_range_chunk_elems() elements).
+ *   embnet_conv2d_ranges(a, b): ranges of the first / second tensor argument (x, w | dy, w | x, dy) of the NEXT
+ *     embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad, wgrad_slabs, wgrad_reduce}_f32 call of the calling thread; NULL = scale 1
+ *     (activations behind a BatchNormalization: |x| << 65504, as for embnet_affine_act_planes).  The scale of a tensor puts its
+ *     largest element into [2^14, 2^15); elements more than 2^29 below it fall into fp16's subnormals (absolute error <= 2^-39 of
+ *     the maximum).  The call consumes the ranges whatever kernel it launches: the scalar-load kernels (c or k % 4 != 0), a fused
+ *     input transform and the thin 1x1 streams compute as if none had been given.  Results differ from the six-term kernels' in
+ *     the last bits (tests/test_conv_ranges_gpu.py: both against float64). */
+int embnet_range_emit(uint32_t* slot);
+int embnet_range_chunk_elems(void);
+int embnet_range_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);
+int embnet_conv2d_ranges(const uint32_t* a, const uint32_t* b);
 
 /* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
