@@ -81,16 +81,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// Range emission (conv.hip "Ranges"): this wave's max |value| joins the tensor's range slot — the bit pattern of a non-negative float
-// under an unsigned maximum, independent of the order, so reproducible.  The slot is read first: the maximum only grows, so a wave
-// whose own maximum is not above what it sees has nothing to add (all but the first few waves of a launch skip the atomic).
-// Every lane of the wave must call it (amax >= 0; lanes without an element pass 0).
-__device__ __forceinline__ void range_emit(uint32_t* slot, float amax) {
+// Range emission (conv.hip "Ranges"): the workgroup's max |value| joins a range word — the bit pattern of a non-negative float
+// under an unsigned maximum, independent of the order, so reproducible.  One atomic per workgroup (256 threads, every thread
+// calls; amax >= 0, threads without an element pass 0).  A kernel of thousands of workgroups must NOT aim them all at one word
+// (same-address atomics serialise at the memory side: a BatchNorm-backward pass ran 4x longer): the BatchNorm passes spread
+// theirs over the RANGE_PARTIALS words behind the slot's first (word 1 + blockIdx % RANGE_PARTIALS, zeroed by the finalize kernel
+// in front) and a one-workgroup kernel folds them into word 0, which is what the consumers read.
+constexpr int RANGE_PARTIALS = 1024;
+__device__ __forceinline__ void range_emit_block(uint32_t* word, float amax) {
+  __shared__ float range_wm[4];
   amax = wave_max(amax);
-  if ((threadIdx.x & 63) == 0) {
-    const uint32_t b = __float_as_uint(amax);
-    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
-  }
+  if ((threadIdx.x & 63) == 0) range_wm[(threadIdx.x >> 6) & 3] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(word, __float_as_uint(fmaxf(fmaxf(range_wm[0], range_wm[1]), fmaxf(range_wm[2], range_wm[3]))));
 }
 __device__ __forceinline__ float amax4(float m, float4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));

@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void range_multi_kernel(const RangeTensor* __r
     const long e = e0 + u * 256 + threadIdx.x;
     m = fmaxf(m, e < t.n ? fabsf(t.x[e]) : 0.f);
   }
-  range_emit(t.slot, m);
+  range_emit_block(t.slot, m);                           // (a kernel has a few hundred chunks at most: one word takes them)
 }
 extern "C" int embnet_range_chunk_elems(void) { return 4096; }
 extern "C" int embnet_range_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream) {

@@ -282,11 +282,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) planes_scale_slot(dx_planes, total4 * 4)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   }
-  if (MODE == 3) range_emit(range_slot, amax);
+  if (MODE == 3) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
 
 // (s, 1 / s) of a planes tensor from the workgroup maxima a dry run left behind its slot: the largest |value| lands in [2^14, 2^15)
-__global__ __launch_bounds__(256) void planes_scale_kernel(float* __restrict__ slot, int blocks) {
+// range_out (conv.hip Ranges): the same maximum for the gather convs that read the fp32 copy of the tensor
+__global__ __launch_bounds__(256) void planes_scale_kernel(float* __restrict__ slot, int blocks, uint32_t* __restrict__ range_out = nullptr) {
   float m = 0.f;
   for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[16 + i]);
   m = wave_max(m);
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void planes_scale_kernel(float* __restrict__ s
     if (ok) (void)frexpf(m, &e);                           // m = f 2^e, f in [0.5, 1)
     const int k = ok ? max(-120, min(120, 15 - e)) : 0;    // (s and 1 / s stay normal numbers)
     slot[0] = ldexpf(1.f, k); slot[1] = ldexpf(1.f, -k);
+    if (range_out) *range_out = ok ? __float_as_uint(m) : 0u;
   }
 }
 
@@ -636,12 +638,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   double s, ss;
   block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
   if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
-  if (zero_slot && col == 0 && threadIdx.x == 0) *zero_slot = 0u;      // the apply pass behind this kernel emits dx's range there
+  if (zero_slot && col == 0)                                           // the apply pass behind this kernel emits dx's range there
+    for (int i = threadIdx.x; i < 1 + RANGE_PARTIALS; i += 256) zero_slot[i] = 0u;
+}
+// word 0 of a range slot = the maximum of the workgroup partials behind it (common.h range_emit_block)
+__global__ __launch_bounds__(256) void range_fold_kernel(uint32_t* __restrict__ slot) {
+  uint32_t m = 0u;
+  for (int i = threadIdx.x; i < RANGE_PARTIALS; i += 256) m = max(m, slot[1 + i]);
+  range_emit_block(slot, __uint_as_float(m));                           // (bit patterns of non-negative floats order like the floats)
 }
 
-// The range slot (conv.hip Ranges) the NEXT embnet_bn_bwd / embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling
-// thread fills with max |dx| of the fp32 dx it writes (four-channel kernels, dx != NULL; otherwise the request is dropped and the
-// slot holds 0 = "no range": a conv given it multiplies that operand with scale 1).  Every embnet_bn_bwd* entry point consumes it.
+// The range slot (conv.hip Ranges; embnet_range_slot_words() uint32 words: the range + the workgroup partials) the NEXT embnet_bn_bwd /
+// embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling thread fills with max |dx| of the fp32 dx it writes (a call
+// that cannot — planes-only dx, scalar kernels, no saved statistics — fails).  Every embnet_bn_bwd* entry point consumes the request.
+extern "C" int embnet_range_slot_words(void) { return 1 + RANGE_PARTIALS; }
 static thread_local uint32_t* t_emit_slot = nullptr;
 extern "C" int embnet_range_emit(uint32_t* slot) {
   EMBNET_CHECK_ARG(!(reinterpret_cast<uintptr_t>(slot) & 3), "range_emit: the slot is 4-byte aligned");
@@ -965,7 +975,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply4_kernel(
     o = make_float4(sc.x * dz.x, sc.y * dz.y, sc.z * dz.z, sc.w * dz.w);
   }
   if (valid) reinterpret_cast<float4*>(dx)[i] = o;
-  if (range_slot) range_emit(range_slot, valid ? amax4(0.f, o) : 0.f);
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, valid ? amax4(0.f, o) : 0.f);
 }
 
 // y[n,c] = mean over hw.  Workgroup = one sample x 64 channels (16 channel-quad lanes x 16 pixel lanes).
@@ -1411,7 +1421,7 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
     const bool room = 2 * total4 >= 16 + blocks;          // the third plane's space holds the slot and the workgroup maxima
     if (room) bn_bwd_apply4_kernel<2><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma,
                                                              relu, training, dx_add, nullptr, pl);
-    planes_scale_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0);
+    planes_scale_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0, room ? range_slot : nullptr);   // (no dry run: the slot stays 0 = unknown)
     bn_bwd_apply4_kernel<1><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
                                                    training, dx_add, dx, pl);
     return;
@@ -1419,6 +1429,7 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
   if (range_slot && dx && !dx_planes) {
     bn_bwd_apply4_kernel<3><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
                                                    training, dx_add, dx, pl, range_slot);
+    range_fold_kernel<<<1, 256, 0, st>>>(range_slot);
     return;
   }
   bn_bwd_apply4_kernel<0><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
@@ -1430,8 +1441,9 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
                              const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
                              size_t workspace_bytes, void* stream) {
   uint32_t* const emit = take_emit_slot();
-  EMBNET_CHECK_ARG(!emit || (dx && !dx_planes && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd),
-                   "bn_bwd: a range of dx was requested (embnet_range_emit) but this call cannot emit one (fp32 dx without planes, c %% 4 == 0, saved statistics)");
+  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || (planes_f16() && m * c >= 65536)) && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd),
+                   "bn_bwd: a range of dx was requested (embnet_range_emit) but this call cannot emit one (an fp32 dx — beside planes only in "
+                   "the two-piece format, from 65536 elements —, c %% 4 == 0, saved statistics)");
   EMBNET_CHECK_ARG(dy && x && scale && shift && (dx || dx_planes) && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   EMBNET_CHECK_ARG(dx || ((c & 3) == 0 && !bn_scalar()), "bn_bwd: dx = NULL (planes only) needs the four-channel kernels");
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd: dx_planes needs c %% 16 == 0");
@@ -1553,7 +1565,8 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
                                       const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
                                       float* dbeta, void* dx_planes, void* stream) {
   uint32_t* const emit = take_emit_slot();
-  EMBNET_CHECK_ARG(!emit || (dx && !dx_planes), "bn_bwd_partials: a range of dx was requested (embnet_range_emit) but dx is not an fp32 tensor without planes");
+  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || (planes_f16() && m * c >= 65536))),
+                   "bn_bwd_partials: a range of dx was requested (embnet_range_emit) but this call cannot emit one (see embnet_bn_bwd)");
   EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && (dx || dx_planes) && dgamma && dbeta, "bn_bwd_partials: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
@@ -1675,6 +1688,7 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
   { EMBNET_TRACE("embnet::pool_bn_bwd_apply4_kernel", TRACE_BYTES, 32.0 * total + 5.0 * mp * c, stream); pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
                                                                     1.f / (float)((long)n * h * w), save_mean, save_rstd,
                                                                     scale, shift, dbeta, dgamma, act, training, dx, emit); }
+  if (emit) range_fold_kernel<<<1, 256, 0, S(stream)>>>(emit);
   return check_launch("bn_act_maxpool_bwd");
 }
 

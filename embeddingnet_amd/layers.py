@@ -507,7 +507,7 @@ def _take_dy_range(dy, keep=False):
 
 def _emit_dx_range(dx):
     """A fresh range slot for `dx`, announced to the library (the next embnet_bn_bwd* call fills it) and filed in DY_RANGE."""
-    slot = torch.empty(1, dtype=torch.int32, device=dx.device)
+    slot = torch.empty(_lib.lib().embnet_range_slot_words(), dtype=torch.int32, device=dx.device)
     check(_lib.lib().embnet_range_emit(ptr(slot)))
     if len(DY_RANGE) > 64:
         DY_RANGE.clear()
@@ -516,6 +516,12 @@ def _emit_dx_range(dx):
 
 
 _BN_SCALAR = _os.environ.get("EMBNET_BN_SCALAR", "0") not in ("0", "")
+
+
+def _planes_range_ok(x):
+    """A BatchNorm backward that writes dx as planes AND as fp32 can leave dx's range too: in the two-piece format its dry run
+    finds the maximum anyway (tensors from 65536 elements: smaller ones skip the dry run)."""
+    return x.numel() >= 65536 and _lib.lib().embnet_conv_planes_mfma_terms() == 3
 
 
 PLANES_ONLY = [_os.environ.get("EMBNET_PLANES_ONLY", "1") != "0"]     # [False]: every planes tensor keeps its fp32 copy (A/B)
@@ -1004,8 +1010,10 @@ class Conv2D(nn.Module):
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
-        if w_range is not None and torch.is_grad_enabled():
-            y._wants_dy_range = True           # the BatchNormalization reading y leaves the range of its dx in DY_RANGE (backward)
+        if torch.is_grad_enabled() and (w_range is not None or (residual is not None and getattr(residual, "_wants_dy_range", False))):
+            # the BatchNormalization reading y leaves the range of its dx in DY_RANGE (backward) — for this conv, or for the conv
+            # behind the fused Add (the projection shortcut), which receives the same gradient tensor
+            y._wants_dy_range = True
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
             # ... and ONLY as planes when this conv takes both of its gradients from them and the BatchNormalization is told
@@ -1277,7 +1285,7 @@ class _BatchNormFn(torch.autograd.Function):
         if (hit is not None and hit[2] == x.data_ptr() and hit[3].shape == dy.shape and ctx.training and c % 4 == 0
                 and not inrelu and drop is None):
             # dy is the data gradient of the conv behind this layer, which already produced the column sums
-            if getattr(ctx, "emit_dx_range", False) and planes is None and not only:
+            if getattr(ctx, "emit_dx_range", False) and not only and (planes is None or _planes_range_ok(x)):
                 _emit_dx_range(dx)
             check(lib.embnet_bn_bwd_partials(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
                                              int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
@@ -1305,7 +1313,7 @@ class _BatchNormFn(torch.autograd.Function):
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
         else:
-            if getattr(ctx, "emit_dx_range", False) and planes is None and not only:
+            if getattr(ctx, "emit_dx_range", False) and not only and (planes is None or _planes_range_ok(x)):
                 _emit_dx_range(dx)
             check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                     int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
@@ -1645,7 +1653,7 @@ class BatchNormalization(nn.Module):
             y = self.forward(x)
             return y, _GapFn.apply(y)
         want_dx_planes = bool(getattr(x, "_wants_dy_planes", False)) and torch.is_grad_enabled()
-        want_dx_range = bool(getattr(x, "_wants_dy_range", False)) and torch.is_grad_enabled() and not want_dx_planes
+        want_dx_range = bool(getattr(x, "_wants_dy_range", False)) and torch.is_grad_enabled()
         dx_only = bool(want_dx_planes and owns_input and PLANES_ONLY[0] and getattr(x, "_dy_planes_only", False)
                        and x.shape[-1] % 16 == 0)
 

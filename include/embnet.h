@@ -230,8 +230,10 @@ int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream
  * pieces of x s, three products, the sums x 1 / (s s')) instead of three bf16 pieces and six products: half the matrix instructions.
  * A RANGE SLOT is one uint32 in device memory holding the bit pattern of max |element| of a tensor (0: unknown -> scale 1).
  *   embnet_range_emit(slot): the NEXT embnet_bn_bwd / embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling
- *     thread also leaves the range of the fp32 dx it writes in *slot (zeroed by its finalize kernel, joined by the apply pass with
- *     an order-independent unsigned maximum).  The call fails if it cannot (planes-only dx, c % 4 != 0, no saved statistics).
+ *     thread also leaves the range of the fp32 dx it writes in slot[0].  `slot` has embnet_range_slot_words() words: the
+ *     workgroups of the apply pass join their maxima into the words behind the first (zeroed by the finalize kernel; an
+ *     order-independent unsigned maximum, spread over many words because same-address atomics serialise) and a one-workgroup
+ *     launch folds them into slot[0].  The call fails if it cannot emit (planes-only dx, c % 4 != 0, no saved statistics).
  *   embnet_range_multi: ranges of many tensors (a model's kernels, once per optimizer step) in two launches; device table of
  *     24-byte rows { const float* x; int64 n; uint32* slot; }, chunk list int32 [n_chunks][2] = (row, chunk of
  *     embnet_range_chunk_elems() elements).
@@ -242,6 +244,7 @@ int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream
  *     the maximum).  The call consumes the ranges whatever kernel it launches: the scalar-load kernels (c or k % 4 != 0), a fused
  *     input transform and the thin 1x1 streams compute as if none had been given.  Results differ from the six-term kernels' in
  *     the last bits (tests/test_conv_ranges_gpu.py: both against float64). */
+int embnet_range_slot_words(void);
 int embnet_range_emit(uint32_t* slot);
 int embnet_range_chunk_elems(void);
 int embnet_range_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);

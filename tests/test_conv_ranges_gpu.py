@@ -78,18 +78,18 @@ def test_bn_backward_emits_the_range_of_its_dx(dev):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty(c, device=dev), torch.empty(c, device=dev)
         ws = torch.empty(max(lib.embnet_bn_workspace_bytes(m, c) // 4, 4), device=dev)
-        slot = torch.full((1,), 0x7F000000, dtype=torch.int32, device=dev)          # (stale content: the finalize kernel zeroes it)
+        slot = torch.full((lib.embnet_range_slot_words(),), 0x7F000000, dtype=torch.int32, device=dev)   # (stale content: zeroed by the call)
         _lib.check(lib.embnet_range_emit(slot.data_ptr()))
         _lib.check(lib.embnet_bn_bwd(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      1, 1, _lib.ptr(dx_add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), None, ws.data_ptr(),
                                      ws.numel() * 4, _lib.stream()))
-        assert bits(slot) == bits(dx.abs().max())
+        assert bits(slot[0]) == bits(dx.abs().max())
         # the request is consumed: a second call leaves the slot alone
         slot.fill_(7)
         _lib.check(lib.embnet_bn_bwd(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      1, 1, _lib.ptr(dx_add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), None, ws.data_ptr(),
                                      ws.numel() * 4, _lib.stream()))
-        assert bits(slot) == 7
+        assert bits(slot[0]) == 7 and bits(slot[-1]) == 7
 
 
 def test_a_range_request_that_cannot_be_met_fails_loudly(dev):
@@ -100,7 +100,7 @@ def test_a_range_request_that_cannot_be_met_fails_loudly(dev):
     one, zero = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     dx, dg, db = torch.empty_like(x), torch.empty(c, device=dev), torch.empty(c, device=dev)
     ws = torch.empty(max(lib.embnet_bn_workspace_bytes(m, c) // 4, 4), device=dev)
-    slot = torch.zeros(1, dtype=torch.int32, device=dev)
+    slot = torch.zeros(lib.embnet_range_slot_words(), dtype=torch.int32, device=dev)
     _lib.check(lib.embnet_range_emit(slot.data_ptr()))
     rc = lib.embnet_bn_bwd(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, 1,
                            None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), ws.numel() * 4, _lib.stream())
@@ -290,10 +290,10 @@ def test_resnet18_step_runs_its_gather_convs_on_three_products(dev):
     h = [s for s in names3 if "_h_kernel" in s]
     six = [s for s in names3 if ("conv_fwd_kernel" in s or "conv_dgrad_kernel" in s or "conv_wgrad_kernel" in s)]
     assert not any("_h_kernel" in s for s in names6)
-    # forward: stem + 3 stride-2 3x3 + 4 shortcuts = 8 launches; backward: their data / weight gradients where the gradient's range
-    # is known (the shortcut convs behind a patch conv's fused Add take their gradient from a planes-writing BatchNormalization)
-    assert sum("conv_fwd_h_kernel" in s for s in h) == 8, (h, six)
-    assert sum("conv_wgrad_h_kernel" in s for s in h) >= 4 and sum("conv_dgrad_h_kernel" in s for s in h) >= 3, (h, six)
+    # forward: stem + 3 stride-2 3x3 + 4 shortcuts = 8 launches; backward: their data / weight gradients (the stem has no data gradient)
+    # (at 64x64 the last stages' maps are too small for the patch kernel: their 3x3 convs are gather launches too)
+    assert sum("conv_fwd_h_kernel" in s for s in h) >= 8, (h, six)
+    assert sum("conv_wgrad_h_kernel" in s for s in h) >= 8 and sum("conv_dgrad_h_kernel" in s for s in h) >= 7, (h, six)
     assert not any("conv_fwd_kernel" in s for s in six), six
     for a, b in zip(l3, l6):
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (l3, l6)
