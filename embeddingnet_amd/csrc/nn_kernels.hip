@@ -1470,7 +1470,7 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    { EMBNET_TRACE(emit ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+    { EMBNET_TRACE(emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
       launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream), emit); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
@@ -1571,7 +1571,7 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
   bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1, emit);
-  { EMBNET_TRACE(emit ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+  { EMBNET_TRACE(emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
     launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream), emit); }
   return check_launch("bn_bwd_partials");
 }
