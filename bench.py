@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line; details go to stderr.
 roofline: every kernel launch of libembnet_hip.so is timed with HIP events on the launch stream (embnet_trace_*), on
 one to three of the timed steps (by the length of the timed region); the kernel with the largest total time is reported against the roofline that bounds it — for the
 convolution kernels the 16-bit MFMA peak (16 x 157.3 TFLOP/s) with the 16-bit FLOP they execute (each fp32 product = 3 fp16
-MFMA terms of a two-piece split in the kernels that read pre-split planes, 6 bf16 terms of an exact three-way split in the others:
+MFMA terms of a two-piece split in the kernels that read pre-split planes or know their operands' ranges (conv_*_h_kernel), 6 bf16
+terms of an exact three-way split in the others:
 3 or 6 x the algorithmic 2*M*N*K; the fp32-equivalent rate is given beside it), MFMA
 fp32 (157.3 TFLOP/s) for the distance / dense GEMMs with their algorithmic FLOP, HBM (8.0 TB/s spec; 6.29 TB/s measured
 copy rate also given) for the streaming kernels with their algorithmic bytes.
@@ -160,6 +161,9 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
         planes = planes_terms is not None and ("conv_patch_kernel" in name or "conv_wgrad_planes_kernel" in name)
         if planes:
             terms = planes_terms
+        hform = "_h_kernel" in name          # gather convs given both operands' ranges (embnet_conv2d_ranges): the planes' arithmetic
+        if hform:
+            planes, terms = True, 3
         if terms > 1:
             # the conv kernels form every fp32 product from `terms` 16-bit MFMA terms of an operand split (include/embnet.h): the
             # matrix pipe executes terms x the algorithmic FLOP, on the bf16 / fp16 instruction -> priced against that peak
@@ -441,7 +445,8 @@ def main():
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
                                                              (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
-    SPLIT_NOTE = ("3x3 stride-1 convs and their weight gradients: two fp16 pieces + a per-tensor power-of-two scale, 3 terms; other convs: "
+    SPLIT_NOTE = ("3x3 stride-1 convs and their weight gradients, and the ResNets' other convs where both operands' ranges are known: two fp16 "
+                  "pieces + a per-tensor power-of-two scale, 3 terms; other convs: "
                   "three bf16 pieces, 6 terms" if _lib.lib().embnet_conv_planes_mfma_terms() == 3 else "three exact bf16 pieces, 6 terms")
     if args.mode == "siamese":
         metric = f"images/sec training ({args.backbone}, {args.image}², Siamese contrastive) @ 1/2/4/8 GPU"
