@@ -296,6 +296,17 @@ constexpr int SMEM_FLOATS = CONV_MAIN_FLOATS<TA, TB> > EPI_FLOATS<G> ? CONV_MAIN
 template <class G>
 constexpr int CONV_OCC = !EMBNET_CONV_SPLIT ? 1 : (G::BM * G::BN >= 192 * 64 ? 2 : (G::BM * G::BN >= 128 * 64 ? EMBNET_OCC_12864 : 4));
 
+// the three-product ("H") kernels hold two LDS planes and two-piece fragments: their own register budget (build-time knobs for A/B)
+#ifndef EMBNET_OCC_H_128128
+#define EMBNET_OCC_H_128128 2
+#endif
+#ifndef EMBNET_OCC_H_12864
+#define EMBNET_OCC_H_12864 EMBNET_OCC_12864
+#endif
+template <class G>
+constexpr int CONV_OCC_H = G::BM * G::BN >= 192 * 64 ? (G::BM == 128 && G::BN == 128 ? EMBNET_OCC_H_128128 : 2)
+                                                      : (G::BM * G::BN >= 128 * 64 ? EMBNET_OCC_H_12864 : 4);
+
 template <class G, class TA, class TB, class LA, class LB, bool H = false>
 __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt_begin, int kt_end, float* smem,
                                               f32x16 (&acc)[G::TM][G::TN], bool fair = false, bool zero_acc = true,
@@ -549,7 +560,7 @@ template <class G, bool VEC>
 __global__ __launch_bounds__(256, CONV_OCC<G>) void conv_fwd_tf_kernel(ConvFwdParams p) { conv_fwd_body<G, true, true>(p); }
 // the three-product form (16-byte loads only)
 template <class G>
-__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_fwd_h_kernel(ConvFwdParams p) { conv_fwd_body<G, true, false, true>(p); }
+__global__ __launch_bounds__(256, CONV_OCC_H<G>) void conv_fwd_h_kernel(ConvFwdParams p) { conv_fwd_body<G, true, false, true>(p); }
 
 struct ConvDgradParams { const float* dy; const float* w; float* dx; ConvGeom g; DgradClass cls[MAX_CLASSES]; SplitTail tail; int accumulate; const float* add_src; int fair_from; BnSums bn; Ranges rg; };
 
@@ -658,7 +669,7 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
 template <class G, bool VEC>
 __global__ __launch_bounds__(256, VEC ? CONV_OCC<G> : 1) void conv_dgrad_kernel(ConvDgradParams p) { conv_dgrad_body<G, VEC>(p); }
 template <class G>
-__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_dgrad_h_kernel(ConvDgradParams p) { conv_dgrad_body<G, true, true>(p); }
+__global__ __launch_bounds__(256, CONV_OCC_H<G>) void conv_dgrad_h_kernel(ConvDgradParams p) { conv_dgrad_body<G, true, true>(p); }
 
 struct ConvWgradParams { const float* x; const float* dy; float* out; ConvGeom g; int kt_per_split, splits, xcd_order; InputTransform tf; int fair_from; int stagger; Ranges rg; };
 
@@ -755,7 +766,7 @@ __global__ __launch_bounds__(256, (VA && VB) ? CONV_OCC<G> : 1) void conv_wgrad_
 template <class G, bool VA, bool VB>
 __global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_tf_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, true>(p); }
 template <class G>
-__global__ __launch_bounds__(256, CONV_OCC<G>) void conv_wgrad_h_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, false, true>(p); }
+__global__ __launch_bounds__(256, CONV_OCC_H<G>) void conv_wgrad_h_kernel(ConvWgradParams p) { conv_wgrad_body<G, true, true, false, true>(p); }
 
 // out[i] = sum_s slabs[s][i], fixed order.  A workgroup owns 32 float4 columns (512 contiguous bytes of
 // every slab) and spreads the slabs over 8 thread groups (slab s goes to group s % 8, each group keeping
