@@ -390,6 +390,7 @@ def _wplanes_entry(w):
         e["table"] = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
         e["chunks"] = torch.tensor([(i, j) for i in range(len(rows)) for j in range(-(-w.numel() // ce))], dtype=torch.int32, device=dev)
         w._embnet_wplanes = e
+        _SIDE_GEN[0] += 1
     return e
 
 
@@ -403,21 +404,18 @@ def weight_planes(w, flip):
     return e["bwd"] if flip else e["fwd"]
 
 
-def refresh_weight_planes(module):
-    """Rebuild the planes of every kernel that has them, in ONE launch (called by the trainer right after the optimizer
-    step, so that the next forward finds them current; inside a captured step this launch is part of the graph)."""
+def _current(e, w):
+    return e["epoch"] == WEIGHT_EPOCH[0] and e["version"] == w._version
+
+
+def _refresh_planes_of(ws, holder):
+    """ONE launch for the planes of the kernels `ws` (all of them have planes); the launch plan is cached on `holder`.  Nothing is
+    launched when every entry is current (a trainer and its optimizer may both ask after the same update)."""
     import numpy as np
-    refresh_weight_ranges(module)               # (the gather convs' kernel ranges ride along)
-    ws = []
-    for m in module.modules():
-        if isinstance(m, Conv2D):
-            e = getattr(m.kernel, "_embnet_wplanes", None)
-            if e is not None and e["ptr"] == m.kernel.data_ptr():
-                ws.append(m.kernel)
-    if not ws:
+    if not ws or all(_current(w._embnet_wplanes, w) for w in ws):
         return
     key = tuple(id(w._embnet_wplanes) for w in ws)
-    plan = getattr(module, "_wplanes_plan", None)
+    plan = getattr(holder, "_wplanes_plan", None)
     if plan is None or plan["key"] != key:
         rows = [r for w in ws for r in w._embnet_wplanes["rows"]]
         ce = _lib.lib().embnet_conv_weight_planes_chunk_elems()
@@ -425,11 +423,42 @@ def refresh_weight_planes(module):
         dev = ws[0].device
         plan = dict(key=key, n=len(rows), table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
                     chunks=torch.tensor([(i, j) for i, n in enumerate(sizes) for j in range(-(-n // ce))], dtype=torch.int32, device=dev))
-        module._wplanes_plan = plan
+        holder._wplanes_plan = plan
     check(_lib.lib().embnet_conv_weight_planes(plan["table"].data_ptr(), plan["n"], plan["chunks"].data_ptr(), plan["chunks"].shape[0], stream()))
     for w in ws:
         e = w._embnet_wplanes
         e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+def _with_entry(tensors, attr):
+    out = []
+    for w in tensors:
+        e = getattr(w, attr, None)
+        if e is not None and e["ptr"] == w.data_ptr():
+            out.append(w)
+    return out
+
+
+def refresh_weight_planes(module):
+    """Rebuild the planes of every kernel that has them, in ONE launch (called by the trainer right after the optimizer
+    step, so that the next forward finds them current; inside a captured step this launch is part of the graph)."""
+    kernels = [m.kernel for m in module.modules() if isinstance(m, Conv2D)]
+    _refresh_ranges_of(_with_entry(kernels, "_embnet_wrange"), module)        # (the gather convs' kernel ranges ride along)
+    _refresh_planes_of(_with_entry(kernels, "_embnet_wplanes"), module)
+
+
+_SIDE_GEN = [0]             # bumped whenever a kernel tensor gains a planes / range entry
+
+
+def refresh_tensors(tensors, holder):
+    """The same for a list of parameter tensors — what KerasOptimizer.step() calls on its own parameters right after the update
+    launch, so that ANY training loop (SiameseNet's, a user's) gets the one-launch refresh instead of one lazy launch per kernel
+    at the next forward (ResNet50: 53 kernels -> 2 + 4 launches).  Which tensors have entries is cached on `holder`."""
+    plan = getattr(holder, "_side_plan", None)
+    if plan is None or plan[0] != _SIDE_GEN[0]:
+        plan = holder._side_plan = (_SIDE_GEN[0], _with_entry(tensors, "_embnet_wrange"), _with_entry(tensors, "_embnet_wplanes"))
+    _refresh_ranges_of(plan[1], holder)
+    _refresh_planes_of(plan[2], holder)
 
 
 # ---- three products per fp32 product on the gather convs (csrc/conv.hip "Ranges"; include/embnet.h ABI 20) --------------------------
@@ -457,6 +486,7 @@ def _range_entry(w):
                  table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
                  chunks=torch.tensor([(0, j) for j in range(-(-w.numel() // ce))], dtype=torch.int32, device=dev))
         w._embnet_wrange = e
+        _SIDE_GEN[0] += 1
     return e
 
 
@@ -469,19 +499,13 @@ def weight_range(w):
     return e["slot"]
 
 
-def refresh_weight_ranges(module):
-    """Every kernel range of `module` that exists, in one call (two launches) — the trainer calls it with refresh_weight_planes."""
+def _refresh_ranges_of(ws, holder):
+    """Every kernel range of `ws` in one call (two launches); nothing when all are current."""
     import numpy as np
-    ws = []
-    for m in module.modules():
-        if isinstance(m, Conv2D):
-            e = getattr(m.kernel, "_embnet_wrange", None)
-            if e is not None and e["ptr"] == m.kernel.data_ptr():
-                ws.append(m.kernel)
-    if not ws:
+    if not ws or all(_current(w._embnet_wrange, w) for w in ws):
         return
     key = tuple(id(w._embnet_wrange) for w in ws)
-    plan = getattr(module, "_wrange_plan", None)
+    plan = getattr(holder, "_wrange_plan", None)
     if plan is None or plan["key"] != key:
         rows = [w._embnet_wrange["rows"][0] for w in ws]
         ce = _lib.lib().embnet_range_chunk_elems()
@@ -489,11 +513,16 @@ def refresh_weight_ranges(module):
         plan = dict(key=key, n=len(rows), table=torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev),
                     chunks=torch.tensor([(i, j) for i, w in enumerate(ws) for j in range(-(-w.numel() // ce))],
                                         dtype=torch.int32, device=dev))
-        module._wrange_plan = plan
+        holder._wrange_plan = plan
     check(_lib.lib().embnet_range_multi(plan["table"].data_ptr(), plan["n"], plan["chunks"].data_ptr(), plan["chunks"].shape[0], stream()))
     for w in ws:
         e = w._embnet_wrange
         e["epoch"], e["version"] = WEIGHT_EPOCH[0], w._version
+
+
+def refresh_weight_ranges(module):
+    """Every kernel range of `module` that exists, in one call (two launches)."""
+    _refresh_ranges_of(_with_entry([m.kernel for m in module.modules() if isinstance(m, Conv2D)], "_embnet_wrange"), module)
 
 
 def _take_dy_range(dy, keep=False):

@@ -149,6 +149,8 @@ class KerasOptimizer(torch.optim.Optimizer):
                                                self._chunks.shape[0], lr, b1, b2, self.eps, c1, c2,
                                                self.coef_dev.data_ptr() if self.coef_dev is not None else None,
                                                _lib.stream()))
+        # planes and ranges of the conv kernels among the parameters, current again in one launch each (layers.refresh_tensors)
+        L.refresh_tensors(self._tensors, self)
         return loss
 
     def prepare_capture(self):
