@@ -43,9 +43,17 @@ def block_list(name):
     return out, round_filters(32, width), round_filters(1280, width)
 
 
+EFFNET_F16 = __import__("os").environ.get("EMBNET_EFFNET_F16", "1") != "0"
+
+
 def _conv(cin, cout, k, stride, gen):
-    return L.Conv2D(cin, cout, k, strides=stride, padding="same", use_bias=False, kernel_initializer="conv_normal",
+    conv = L.Conv2D(cin, cout, k, strides=stride, padding="same", use_bias=False, kernel_initializer="conv_normal",
                     gen=gen)
+    # the 1x1 convs that run the implicit-GEMM kernels multiply on three products where the operands' ranges are known
+    # (layers.CONV_F16): forward always (kernel range; activations scale 1), backward where the gradient comes out of a plain
+    # BatchNormalization backward (expand convs, project convs of blocks without a skip, the top conv); the thin streams ignore it
+    conv.f16 = EFFNET_F16
+    return conv
 
 
 class MBConv(nn.Module):

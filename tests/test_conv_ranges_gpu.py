@@ -297,3 +297,38 @@ def test_resnet18_step_runs_its_gather_convs_on_three_products(dev):
     assert not any("conv_fwd_kernel" in s for s in six), six
     for a, b in zip(l3, l6):
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (l3, l6)
+
+
+def test_optimizer_step_leaves_kernel_ranges_and_planes_current(dev):
+    """KerasOptimizer.step() refreshes, in one launch each, the planes and ranges that its conv kernels have: the next forward
+    launches no per-kernel refresh (trace), and every range slot holds the updated kernel's exact maximum."""
+    from embeddingnet_amd import layers as L
+    from embeddingnet_amd.backbones import get_backbone
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    base, _ = get_backbone((64, 64, 3), encodings_len=32, backbone_name="resnet18", backbone_weights=None, seed=2, device=dev)
+    base.train()
+    opt = KerasOptimizer(base.parameters(), "sgd", 0.05)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):
+        x = torch.rand(8, 64, 64, 3, generator=g).to(dev)
+        opt.zero_grad(set_to_none=True)
+        base(x).square().sum().backward()
+        opt.step()
+    kernels = [m.kernel for m in base.modules() if isinstance(m, L.Conv2D)]
+    ranged = [w for w in kernels if getattr(w, "_embnet_wrange", None) is not None]
+    planed = [w for w in kernels if getattr(w, "_embnet_wplanes", None) is not None]
+    assert len(ranged) >= 8
+    for w in ranged:
+        e = w._embnet_wrange
+        assert e["epoch"] == L.WEIGHT_EPOCH[0] and e["version"] == w._version
+        assert bits(e["slot"]) == bits(w.detach().abs().max())
+    for w in planed:
+        e = w._embnet_wplanes
+        assert e["epoch"] == L.WEIGHT_EPOCH[0] and e["version"] == w._version
+    _lib.trace_reset(); _lib.trace_enable(True)
+    try:
+        base(torch.rand(8, 64, 64, 3, generator=g).to(dev))
+        names = [r[0] for r in _lib.trace_records()]
+    finally:
+        _lib.trace_enable(False)
+    assert not any("range_multi" in s or "weight_planes" in s for s in names), [s for s in names if "range" in s or "planes" in s]
