@@ -1039,8 +1039,12 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
     case 0: KERNEL<G128x128><<<grid, 256, 0, st>>>(p); break;                         \
     case 1: KERNEL<G128x64><<<grid, 256, 0, st>>>(p); break;                          \
     case 2: KERNEL<G128x32><<<grid, 256, 0, st>>>(p); break;                          \
-    case 4: KERNEL<G192x64><<<grid, 256, 0, st>>>(p); break;                          \
     default: KERNEL<G64x64><<<grid, 256, 0, st>>>(p); break;                          \
+  }
+#define LAUNCH_WGRAD_H(KERNEL, tile, grid, st, p)          /* + the 192-row tile only the weight gradient plans */ \
+  switch (tile) {                                                                     \
+    case 4: KERNEL<G192x64><<<grid, 256, 0, st>>>(p); break;                          \
+    default: LAUNCH_TILED_H(KERNEL, tile, grid, st, p)                                \
   }
 static const char* conv_h_kernel_name(const char* kernel, const char* params, int tile) {
   static thread_local char buf[160];
@@ -1406,7 +1410,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
                                        (in_scale || (va && vb)) ? "true, true" : (vb ? "false, true" : "false, false")),
                       2.0 * n * oh * ow * (double)k * rows,
                       4.0 * ((double)n * h * wd * c + (double)n * oh * ow * k + (double)rows * k * p.splits), st);
-    if (hform) { LAUNCH_TILED_H(conv_wgrad_h_kernel, tile, grid, st, p) }
+    if (hform) { LAUNCH_WGRAD_H(conv_wgrad_h_kernel, tile, grid, st, p) }
     else if (in_scale && k32 && !p.xcd_order) {         // same arithmetic as the plain K32 kernels: deferred BN stays bit-identical
       switch (tile) {
         case 0: conv_wgrad_k32_tf_kernel<G128x128><<<grid, 256, 0, st>>>(p); break;
