@@ -174,6 +174,7 @@ LAYERS = [  # n, h, w, c, k, kernel, stride, pad, gradient magnitude
     (3, 14, 14, 64, 256, 1, 1, 0, 1e-2),      # bottleneck conv3
     (2, 9, 7, 512, 128, 1, 1, 0, 1e-5),       # ragged map, long reduction
     (1, 7, 7, 128, 512, 3, 2, 1, 1.0),
+    (2, 16, 16, 64, 64, 3, 2, 1, 1e-3),       # 576 gradient rows x 64 filters: the weight gradient's 192-row tile
 ]
 
 
