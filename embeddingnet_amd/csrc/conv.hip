@@ -318,32 +318,27 @@ __device__ __forceinline__ void conv_mainloop(const LA& la, const LB& lb, int kt
 #endif
 }
 
-// ---- three products per fp32 product for the gather kernels ("H" instantiations) ---------------------------------
-// An operand RANGE SLOT is one uint32 in device memory holding the bit pattern of max |element| of a tensor, left there by the
-// tensor's producer (embnet_range_emit: the BatchNorm backward passes; embnet_range_multi: kernels, once per optimizer step).
-// A conv launched with both operands' ranges known (embnet_conv2d_ranges; a NULL slot = scale 1, for activations behind a
-// BatchNormalization, |x| << 65 504) splits each fp32 element, on the fly, into the two fp16 pieces of x * s — s the power of two
-// that puts the tensor's maximum into [2^14, 2^15) — keeps three of the four piece products and multiplies the sums by
-// 1 / (s s') (exact) in front of its epilogue.  Same arithmetic as the planes kernels' two-piece format; half the matrix
-// instructions of the six-term split, two instead of three LDS planes written and read per operand.
+// ---- three products per fp32 product for the gather kernels ("H" instantiations) -------------------------
+// An operand RANGE SLOT is one uint32 in device memory holding the bit pattern of a float B >= max |element| of a tensor, left
+// there by the tensor's producer: the exact maximum for kernels (embnet_range_multi, once per optimizer step) and for gradients
+// (the BatchNorm backward passes, `dx_range` of embnet_bn_bwd_ex), an upper bound for activations (the BatchNorm forward,
+// `y_range` of embnet_bn_train_fwd_ex / embnet_affine_act_planes_ex: nn_kernels.hip bn_finalize_kernel).  A conv launched with
+// BOTH operands' slots (the *_ex entry points) splits each fp32 element, on the fly, into the two fp16 pieces of x * s — s the
+// power of two that puts B into [2^14, 2^15) — keeps three of the four piece products and multiplies the sums by 1 / s and
+// 1 / s' (exact) in front of its epilogue: the planes kernels' two-piece format (gemm_engine.h, PRECISION).  A conv that lacks
+// either slot runs the six-term bf16 kernels: there is no default scale.
 struct Ranges { const uint32_t* a; const uint32_t* b; };
-// (s, 1 / s) of a slot: amax = f 2^(e - 127), f in [1, 2) -> s = 2^(141 - e); zero / infinite / NaN / missing ranges: 1
 __device__ __forceinline__ float2 range_scale(const uint32_t* slot) {
-  if (!slot) return make_float2(1.f, 1.f);
-  const uint32_t bits = __builtin_nontemporal_load(slot) & 0x7fffffffu;
-  const int e = (int)(bits >> 23);
-  if (bits == 0u || e >= 255) return make_float2(1.f, 1.f);
-  const int k = max(-60, min(60, 141 - max(e, 1)));                 // (s, 1 / s and the product of two of them stay normal numbers)
-  return make_float2(__uint_as_float((uint32_t)(127 + k) << 23), __uint_as_float((uint32_t)(127 - k) << 23));
+  return scale_pair(scale_exponent_of(__uint_as_float(__builtin_nontemporal_load(slot))));
 }
 template <class G>
-__device__ __forceinline__ void scale_acc(f32x16 (&acc)[G::TM][G::TN], float f) {
+__device__ __forceinline__ void scale_acc(f32x16 (&acc)[G::TM][G::TN], float fa, float fb) {   // (one factor after the other)
 #pragma unroll
   for (int i = 0; i < G::TM; ++i)
 #pragma unroll
     for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * fb) * fa;
 }
 
 // Remainder split ("tail"): workgroups finish in waves of 256 (one per CU), so `tiles mod 256` left-over
@@ -480,7 +475,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdParams& p) {
   if constexpr (H) {                                     // x = operand a, the kernel = operand b
     const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
     conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from, true, sa.x, sb.x);
-    scale_acc<G>(acc, sa.y * sb.y);
+    scale_acc<G>(acc, sa.y, sb.y);
   } else {
     conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)blockIdx.x >= p.fair_from);
   }
@@ -587,7 +582,7 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
     const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
     conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from,
                                                                true, sa.x, sb.x);
-    scale_acc<G>(acc, sa.y * sb.y);
+    scale_acc<G>(acc, sa.y, sb.y);
   } else {
     conv_mainloop<G, TA, TB>(la, lb, k0, k1, smem, acc, (int)(blockIdx.y * gridDim.x + blockIdx.x) >= p.fair_from);
   }
@@ -740,7 +735,7 @@ __device__ __forceinline__ void conv_wgrad_body(const ConvWgradParams& p) {
     const float2 sa = range_scale(p.rg.a), sb = range_scale(p.rg.b);
     conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from, true, sa.x, sb.x);
     if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB, decltype(la), decltype(lb), true>(la, lb, kt0, kt0 + rot, smem, acc, false, false, sa.x, sb.x); }
-    scale_acc<G>(acc, sa.y * sb.y);
+    scale_acc<G>(acc, sa.y, sb.y);
   } else {
     conv_mainloop<G, TA, TB>(la, lb, kt0 + rot, kt1, smem, acc, (int)blockIdx.x >= p.fair_from);
     if (rot > 0) { prio_lo(); conv_mainloop<G, TA, TB>(la, lb, kt0, kt0 + rot, smem, acc, false, false); }
@@ -1052,22 +1047,24 @@ static const char* conv_h_kernel_name(const char* kernel, const char* params, in
   return buf;
 }
 
-// Operand ranges of the NEXT embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad, wgrad_slabs, wgrad_reduce}_f32 call of the calling
-// thread (see Ranges above): a = the first tensor argument of that call (x / dy / x), b = the second (w / w / dy); NULL = scale 1.
-// The call consumes them whatever path it takes; a launch that cannot use them (scalar-load kernels, fused input transform, thin
-// 1x1 streams, K32 experiment) computes the six-term products as if they had not been given.
+// DEPRECATED (ABI 20 form, kept for one round): operand ranges of the NEXT embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad,
+// wgrad_slabs}_f32 call of the calling thread.  New code passes the slots as ARGUMENTS of the *_ex entry points (ABI 21): a
+// per-thread "applies to the next call" request is hidden state — a binding in another language, a second stream on one thread or
+// an exception between the two calls gets the wrong arithmetic silently.  The shim clears itself
+// on every conv entry, whatever that call does; a NULL operand now means UNKNOWN (six-term kernels), no longer "scale 1".
 static thread_local Ranges t_ranges{nullptr, nullptr};
-static thread_local bool t_ranges_set = false;
 extern "C" int embnet_conv2d_ranges(const uint32_t* a, const uint32_t* b) {
   EMBNET_CHECK_ARG(!((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3), "conv2d_ranges: slots are 4-byte aligned");
-  t_ranges = Ranges{a, b}; t_ranges_set = true;
+  t_ranges = Ranges{a, b};
   return 0;
 }
-static bool take_ranges(Ranges& r) {
-  const bool set = t_ranges_set && EMBNET_CONV_SPLIT;
-  r = set ? t_ranges : Ranges{nullptr, nullptr};
-  t_ranges = Ranges{nullptr, nullptr}; t_ranges_set = false;
-  return set;
+static Ranges take_ranges() {
+  const Ranges r = t_ranges;
+  t_ranges = Ranges{nullptr, nullptr};
+  return r;
+}
+static bool ranges_ok(const Ranges& r) {
+  return EMBNET_CONV_SPLIT && r.a && r.b && !((reinterpret_cast<uintptr_t>(r.a) | reinterpret_cast<uintptr_t>(r.b)) & 3);
 }
 
 // Ranges of many tensors in two launches (the kernels of a model's gather convs, once per optimizer step): table rows
@@ -1126,12 +1123,12 @@ extern "C" int embnet_conv2d_fwd_stats_rows(int n, int c, int r, int s, int k, i
   return cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
 }
 
-extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
-                                     int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
-                                     int ow, int relu, const float* residual, const float* in_scale,
-                                     const float* in_shift, int in_act, float* stats, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  Ranges rg; const bool ranged = take_ranges(rg);
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* y, int n, int h,
+                           int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
+                           int ow, int relu, const float* residual, const float* in_scale,
+                           const float* in_shift, int in_act, float* stats, void* workspace,
+                           size_t workspace_bytes, void* stream, const Ranges rg) {
+  const bool ranged = ranges_ok(rg);
   EMBNET_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_fwd: in_scale and in_shift go together");
   EMBNET_CHECK_ARG(aligned16(y) && aligned16(workspace) && aligned16(residual),
@@ -1181,6 +1178,23 @@ extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float
   }
   return check_launch("conv2d_fwd");
 }
+extern "C" int embnet_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int n, int h,
+                                     int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
+                                     int ow, int relu, const float* residual, const float* in_scale,
+                                     const float* in_shift, int in_act, float* stats, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return conv2d_fwd_impl(x, w, bias, y, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, relu, residual, in_scale, in_shift, in_act,
+                         stats, workspace, workspace_bytes, stream, take_ranges());
+}
+extern "C" int embnet_conv2d_fwd_f32_ex(const float* x, const float* w, const float* bias, float* y, int n, int h,
+                                        int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh,
+                                        int ow, int relu, const float* residual, const float* in_scale,
+                                        const float* in_shift, int in_act, float* stats, void* workspace,
+                                        size_t workspace_bytes, const uint32_t* x_range, const uint32_t* w_range, void* stream) {
+  (void)take_ranges();
+  return conv2d_fwd_impl(x, w, bias, y, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, relu, residual, in_scale, in_shift, in_act,
+                         stats, workspace, workspace_bytes, stream, Ranges{x_range, w_range});
+}
 
 extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int c, int r, int s, int k, int stride) {
   if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || r <= 0 || s <= 0 || k <= 0 || stride != 1 || ((c | k) & 3)) return 0;
@@ -1195,8 +1209,8 @@ extern "C" size_t embnet_conv2d_dgrad_workspace_bytes(int n, int h, int wd, int 
 static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
                              int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                              int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
-                             void* stream, const BnSums bn) {
-  Ranges rg; const bool ranged = take_ranges(rg);
+                             void* stream, const BnSums bn, const Ranges rg) {
+  const bool ranged = ranges_ok(rg);
   EMBNET_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dx) && aligned16(workspace), "conv2d_dgrad: output and workspace must be 16-byte aligned");
   EMBNET_CHECK_ARG(!(accumulate && dx_add), "conv2d_dgrad: accumulate (into dx) or dx_add (another tensor), not both");
@@ -1262,7 +1276,15 @@ extern "C" int embnet_conv2d_dgrad_f32(const float* dy, const float* w, float* d
                                        int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
                                        void* stream) {
   return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, accumulate, dx_add, workspace,
-                           workspace_bytes, stream, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0});
+                           workspace_bytes, stream, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}, take_ranges());
+}
+extern "C" int embnet_conv2d_dgrad_f32_ex(const float* dy, const float* w, float* dx, int n, int h, int wd, int c,
+                                          int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                          int accumulate, const float* dx_add, void* workspace, size_t workspace_bytes,
+                                          const uint32_t* dy_range, const uint32_t* w_range, void* stream) {
+  (void)take_ranges();
+  return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, accumulate, dx_add, workspace,
+                           workspace_bytes, stream, BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}, Ranges{dy_range, w_range});
 }
 
 // rows of the [2][C][rows] partial sums embnet_conv2d_dgrad_bnsums_f32 writes for this geometry; 0: not available
@@ -1274,11 +1296,11 @@ extern "C" int embnet_conv2d_dgrad_bnsums_rows(int n, int h, int wd, int c, int 
   return cdiv(M, TILE_BM[tile]) * (TILE_BM[tile] / TILE_WTM[tile]);
 }
 
-extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
-                                              int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
-                                              const float* bn_x, const float* bn_scale, const float* bn_shift,
-                                              const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
-                                              int bn_rows, void* workspace, size_t workspace_bytes, void* stream) {
+static int conv2d_dgrad_bnsums_impl(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
+                                    int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                    const float* bn_x, const float* bn_scale, const float* bn_shift,
+                                    const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
+                                    int bn_rows, void* workspace, size_t workspace_bytes, void* stream, const Ranges rg) {
   EMBNET_CHECK_ARG(bn_x && bn_scale && bn_shift && bn_mean && bn_rstd && bn_partial, "conv2d_dgrad_bnsums: null pointer");
   EMBNET_CHECK_ARG(bn_rows > 0 && bn_rows == embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride),
                    "conv2d_dgrad_bnsums: rows %d for this geometry (see embnet_conv2d_dgrad_bnsums_rows)", bn_rows);
@@ -1286,7 +1308,25 @@ extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, f
                    aligned16(dy) && aligned16(w), "conv2d_dgrad_bnsums: operands must be 16-byte aligned");
   EMBNET_CHECK_ARG(bn_act >= 0 && bn_act <= 2, "conv2d_dgrad_bnsums: activation code %d", bn_act);
   return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, 0, nullptr, workspace, workspace_bytes,
-                           stream, BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows});
+                           stream, BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows}, rg);
+}
+extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
+                                              int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                              const float* bn_x, const float* bn_scale, const float* bn_shift,
+                                              const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
+                                              int bn_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv2d_dgrad_bnsums_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, bn_x, bn_scale, bn_shift, bn_mean,
+                                  bn_rstd, bn_act, bn_partial, bn_rows, workspace, workspace_bytes, stream, take_ranges());
+}
+extern "C" int embnet_conv2d_dgrad_bnsums_f32_ex(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
+                                                 int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
+                                                 const float* bn_x, const float* bn_scale, const float* bn_shift,
+                                                 const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
+                                                 int bn_rows, void* workspace, size_t workspace_bytes,
+                                                 const uint32_t* dy_range, const uint32_t* w_range, void* stream) {
+  (void)take_ranges();
+  return conv2d_dgrad_bnsums_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, bn_x, bn_scale, bn_shift, bn_mean,
+                                  bn_rstd, bn_act, bn_partial, bn_rows, workspace, workspace_bytes, stream, Ranges{dy_range, w_range});
 }
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip
@@ -1347,8 +1387,8 @@ extern "C" size_t embnet_conv2d_wgrad_workspace_bytes(int n, int c, int r, int s
 static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n, int h,
                       int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                       const float* in_scale, const float* in_shift, int in_act, void* stream, bool do_main,
-                      bool do_reduce) {
-  Ranges rg; const bool ranged = take_ranges(rg);
+                      bool do_reduce, const Ranges rg) {
+  const bool ranged = ranges_ok(rg);
   EMBNET_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
   EMBNET_CHECK_ARG(aligned16(dw) && aligned16(workspace), "conv2d_wgrad: dw and workspace must be 16-byte aligned");
   ConvWgradParams p{x, dy, dw, {}, 0, 1, 0};
@@ -1445,8 +1485,15 @@ extern "C" int embnet_conv2d_wgrad_f32(const float* x, const float* dy, float* d
                                        int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
         void* stream) {
   return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
-                    stream,
-                    true, true);
+                    stream, true, true, take_ranges());
+}
+extern "C" int embnet_conv2d_wgrad_f32_ex(const float* x, const float* dy, float* dw, void* workspace,
+                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+        const uint32_t* x_range, const uint32_t* dy_range, void* stream) {
+  (void)take_ranges();
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
+                    stream, true, true, Ranges{x_range, dy_range});
 }
 
 extern "C" int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow) {
@@ -1483,20 +1530,26 @@ extern "C" int embnet_slab_reduce_multi(const void* host_table, int n_tensors, v
 // time the MFMA kernel alone (bench.py's roofline leg).  When the plan has a single split the first call
 // writes dw directly and the second is a no-op.
 extern "C" int embnet_conv2d_wgrad_slabs_f32(const float* x, const float* dy, float* dw, void* workspace,
-                                             size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                             int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
         void* stream) {
   return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
-                    stream,
-                    true, false);
+                    stream, true, false, take_ranges());
+}
+extern "C" int embnet_conv2d_wgrad_slabs_f32_ex(const float* x, const float* dy, float* dw, void* workspace,
+                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+        const uint32_t* x_range, const uint32_t* dy_range, void* stream) {
+  (void)take_ranges();
+  return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
+                    stream, true, false, Ranges{x_range, dy_range});
 }
 extern "C" int embnet_conv2d_wgrad_reduce_f32(const float* x, const float* dy, float* dw, void* workspace,
-                                              size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
-                                              int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                                       size_t workspace_bytes, int n, int h, int wd, int c, int r, int s, int k,
+                                       int stride, int pad_t, int pad_l, int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
         void* stream) {
   return wgrad_impl(x, dy, dw, workspace, workspace_bytes, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, in_scale, in_shift, in_act,
-                    stream,
-                    false, true);
+                    stream, false, true, take_ranges());
 }
 
 // Name (as rocprofv3 prints the template) of the kernel the entry points above launch for a geometry,

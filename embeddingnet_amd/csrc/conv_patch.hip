@@ -283,13 +283,14 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
     // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
     // lane & 31, so a store instruction writes two 128-byte row segments
     if (F16) {                                           // 1 / (s_x s_w): powers of two, exact
-      const float osc = planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1] * planes_scale_slot(p.wp, (long)(p.w_plane_bytes >> 1))[1];
+      // (one after the other: each factor is a normal number, their product need not be — gemm_engine.h scale_exponent_of)
+      const float osx = planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1], osw = planes_scale_slot(p.wp, (long)(p.w_plane_bytes >> 1))[1];
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
-          for (int rr = 0; rr < 16; ++rr) acc[im][in][rr] *= osc;
+          for (int rr = 0; rr < 16; ++rr) acc[im][in][rr] = (acc[im][in][rr] * osw) * osx;
     }
     if (cur.part) {
       float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
@@ -445,12 +446,8 @@ __global__ __launch_bounds__(256) void weight_scale_kernel(const WPlanesTensor* 
   const WPlanesTensor t = table[i];
   float* sl = planes_scale_slot(t.out, (long)t.R * t.S * t.C * t.K);
   if (phase == 0) { reinterpret_cast<unsigned*>(sl)[2] = 0u; return; }
-  const float m = sl[2];
-  int e = 0;
-  const bool ok = m > 0.f && m <= 3.4028234e38f;
-  if (ok) (void)frexpf(m, &e);
-  const int k = ok ? max(-120, min(120, 15 - e)) : 0;
-  sl[0] = ldexpf(1.f, k); sl[1] = ldexpf(1.f, -k);
+  const float2 sp = scale_pair(scale_exponent_of(sl[2]));
+  sl[0] = sp.x; sl[1] = sp.y;
 }
 
 // fp32 NHWC [pixels][C] -> chunk-major planes [3][C/16][pixels][16] bf16; one thread per (pixel, 4 channels)
@@ -490,23 +487,20 @@ __global__ __launch_bounds__(256) void planes16_from_f32_kernel(const float* __r
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
     __syncthreads();
-    if (threadIdx.x == 0) planes_scale_slot(planes, plane)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (threadIdx.x == 0) planes_scale_slot(planes, plane)[2 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   }
 }
 __global__ __launch_bounds__(256) void planes_scale_of_kernel(float* __restrict__ slot, int blocks) {   // nn_kernels.hip's planes_scale_kernel
   float m = 0.f;
-  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[16 + i]);
+  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[2 + i]);
   m = wave_max(m);
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    int e = 0;
-    const bool ok = m > 0.f && m <= 3.4028234e38f;
-    if (ok) (void)frexpf(m, &e);
-    const int k = ok ? max(-120, min(120, 15 - e)) : 0;
-    slot[0] = ldexpf(1.f, k); slot[1] = ldexpf(1.f, -k);
+    const float2 sp = scale_pair(scale_exponent_of(m));
+    slot[0] = sp.x; slot[1] = sp.y;
   }
 }
 
@@ -598,9 +592,10 @@ extern "C" int embnet_planes_from_f32(const float* x, long pixels, int c, void* 
   if (planes_f16()) {                                       // the tensor's range first (its largest |x| -> [2^14, 2^15)), then the pieces
     hipStream_t st = (hipStream_t)stream;
     float* slot = planes_scale_slot(planes, pixels * c);
-    const bool room = 2 * n4 >= 16 + blocks;                // (the third plane's space holds the slot and the workgroup maxima)
-    if (room) planes16_from_f32_kernel<2><<<blocks, 256, 0, st>>>(x, pixels, c, (unsigned short*)planes);
-    planes_scale_of_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0);
+    // (the third plane's space — 2 * n4 floats, >= 8 — holds the slot and the dry run's workgroup maxima: fewer workgroups for a tiny tensor)
+    const int dry = (int)(2 * n4 - 2 < blocks ? 2 * n4 - 2 : blocks);
+    planes16_from_f32_kernel<2><<<dry, 256, 0, st>>>(x, pixels, c, (unsigned short*)planes);
+    planes_scale_of_kernel<<<1, 256, 0, st>>>(slot, dry);
     planes16_from_f32_kernel<1><<<blocks, 256, 0, st>>>(x, pixels, c, (unsigned short*)planes);
     return check_launch("planes_from_f32");
   }

@@ -216,14 +216,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_planes_kernel(const Params p) 
   __syncthreads();
   if (par == 0) {
     const int h = lane >> 5;
-    const float osc = F16 ? planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1] * planes_scale_slot(p.dyp, (long)(p.dy_plane_bytes >> 1))[1] : 1.f;
+    // (the two factors one after the other: each is a normal number, their product need not be — gemm_engine.h scale_exponent_of)
+    const float osx = F16 ? planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1] : 1.f, osd = F16 ? planes_scale_slot(p.dyp, (long)(p.dy_plane_bytes >> 1))[1] : 1.f;
     float* o = p.out + (long)split * p.slab_elems + (long)(c0 + 32 * cb + 4 * h) * p.K + k0 + 32 * kb + (lane & 31);
     const long tap_stride = (long)p.C * p.K;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        o[t * tap_stride + (long)((r & 3) + 8 * (r >> 2)) * p.K] = F16 ? (acc[t][r] + red[(t * 16 + r) * 64]) * osc : acc[t][r] + red[(t * 16 + r) * 64];
+        o[t * tap_stride + (long)((r & 3) + 8 * (r >> 2)) * p.K] = F16 ? ((acc[t][r] + red[(t * 16 + r) * 64]) * osx) * osd : acc[t][r] + red[(t * 16 + r) * 64];
   }
 }
 

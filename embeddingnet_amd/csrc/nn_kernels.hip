@@ -78,10 +78,14 @@ __device__ __forceinline__ void col_reduce2(long m, int c, ColGeom g, float* __r
 
 // Finalize helper: one 256-thread workgroup per channel adds that channel's per-block partials in
 // double (fixed order: thread-strided, then a shuffle tree) — thread 0 gets the totals.
+// q_max (optional): the LARGEST second partial — for the forward statistics the largest per-band sum of squares, an upper bound of
+// max x^2 over the tensor's elements of this channel (every element's square is a term of exactly one band's sum).
 __device__ __forceinline__ void block_partial_sums(const float* __restrict__ partial, int blocks, int c, int col,
-                                                   double& s_out, double& ss_out, bool by_channel = false) {
+                                                   double& s_out, double& ss_out, bool by_channel = false, float* q_max = nullptr) {
   __shared__ double red[2][4];
+  __shared__ float redq[4];
   double s = 0.0, ss = 0.0;
+  float qm = 0.f;
   if (by_channel) {                  // [2][c][blocks]: this channel's partials are contiguous (conv epilogue layout)
     const float* p1 = partial + (long)col * blocks;
     const float* p2 = p1 + (long)c * blocks;
@@ -95,21 +99,50 @@ __device__ __forceinline__ void block_partial_sums(const float* __restrict__ par
         const float4 u = q1[b], v = q2[b];
         s += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
         ss += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        qm = fmaxf(fmaxf(qm, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
       }
     } else {
-      for (int b = threadIdx.x; b < blocks; b += 256) { s += (double)p1[b]; ss += (double)p2[b]; }
+      for (int b = threadIdx.x; b < blocks; b += 256) { s += (double)p1[b]; ss += (double)p2[b]; qm = fmaxf(qm, p2[b]); }
     }
   } else {                           // [blocks][2][c]
     for (int b = threadIdx.x; b < blocks; b += 256) {
+      const float q = partial[((long)b * 2 + 1) * c + col];
       s += (double)partial[((long)b * 2) * c + col];
-      ss += (double)partial[((long)b * 2 + 1) * c + col];
+      ss += (double)q;
+      qm = fmaxf(qm, q);
     }
   }
-  s = wave_sum(s); ss = wave_sum(ss);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+  s = wave_sum(s); ss = wave_sum(ss); qm = wave_max(qm);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; redq[threadIdx.x >> 6] = qm; }
   __syncthreads();
   s_out = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   ss_out = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (q_max) *q_max = fmaxf(fmaxf(redq[0], redq[1]), fmaxf(redq[2], redq[3]));
+}
+
+// ---- the range of a BatchNormalization's OUTPUT, known before the apply pass runs -----------------------------------
+// The two-piece fp16 operand format (gemm_engine.h) needs an upper bound B of max |y| of the tensor BEFORE the pass that writes y's
+// planes starts, and the three-product gather convs that read the fp32 y need it as their range slot.  The statistics partials hold
+// it: max x^2 <= the largest per-band sum of squares q_c of channel c (block_partial_sums), so for y = act(scale_c x + shift_c) with
+// act in {identity, ReLU, swish} (|act(z)| <= |z|):
+//     |y| <= |scale_c| sqrt(q_c) + |shift_c| =: bound_c,        B = max_c bound_c.
+// Never below the true maximum (the 2^-10 margin covers the roundings of q_c and of this arithmetic); above it by at most
+// sqrt(rows per band) x (a band of 32 ... 96 rows from a conv epilogue: <= 3.3 binades; a statistics-pass block of up to a few
+// thousand rows: <= 6) plus the share of a large |mean| — looseness costs precision only at the subnormal floor, 2^-39 B absolute.
+// bn_finalize_kernel leaves bound_c per channel; the apply passes fold them (tensor_bound: every workgroup reads <= 2048 floats from
+// L2 — no atomics, no extra launch, order-independent).
+__device__ __forceinline__ float channel_bound(float sc, float sh, float q_max) {
+  return (fabsf(sc) * sqrtf(q_max) + fabsf(sh)) * 1.0009765625f;
+}
+// max of bound[0 .. c) for every thread of a 256-thread workgroup (all threads call)
+__device__ __forceinline__ float tensor_bound(const float* __restrict__ bound, int c) {
+  __shared__ float tb_w[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < c; i += 256) m = fmaxf(m, bound[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) tb_w[threadIdx.x >> 6] = m;
+  __syncthreads();
+  return fmaxf(fmaxf(tb_w[0], tb_w[1]), fmaxf(tb_w[2], tb_w[3]));
 }
 
 // ---------------------------------------------------------------- BatchNorm
@@ -210,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
 }
 
 // MODE 0: as described.  MODE 1: dx_planes in the two-piece fp16 format, scaled by the s the slot holds.  MODE 2: the dry run in front
-// of MODE 1 — the same arithmetic, nothing stored but the workgroup's max |dx| (floats 16 + blockIdx.x behind the slot); the scale
+// of MODE 1 — the same arithmetic, nothing stored but the workgroup's max |dx| (floats 2 + blockIdx.x behind the slot); the scale
 // kernel below turns the maxima into s.  (8 bytes per element read once more: the price of an exact range for the gradient's planes.)
 // MODE 3: MODE 0 + the range of dx into `range_slot` (common.h range_emit) for the three-product gather convs that read dx (conv.hip Ranges).
 template <int MODE = 0>
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
     __syncthreads();
-    if (threadIdx.x == 0) planes_scale_slot(dx_planes, total4 * 4)[16 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (threadIdx.x == 0) planes_scale_slot(dx_planes, total4 * 4)[2 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   }
   if (MODE == 3) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
@@ -289,19 +322,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // range_out (conv.hip Ranges): the same maximum for the gather convs that read the fp32 copy of the tensor
 __global__ __launch_bounds__(256) void planes_scale_kernel(float* __restrict__ slot, int blocks, uint32_t* __restrict__ range_out = nullptr) {
   float m = 0.f;
-  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[16 + i]);
+  for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, slot[2 + i]);
   m = wave_max(m);
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    int e = 0;
-    const bool ok = m > 0.f && m <= 3.4028234e38f;         // (zero, infinite or NaN gradients: s = 1)
-    if (ok) (void)frexpf(m, &e);                           // m = f 2^e, f in [0.5, 1)
-    const int k = ok ? max(-120, min(120, 15 - e)) : 0;    // (s and 1 / s stay normal numbers)
-    slot[0] = ldexpf(1.f, k); slot[1] = ldexpf(1.f, -k);
-    if (range_out) *range_out = ok ? __float_as_uint(m) : 0u;
+    const float2 sp = scale_pair(scale_exponent_of(m));    // (zero, infinite or NaN: s = 1)
+    slot[0] = sp.x; slot[1] = sp.y;
+    if (range_out) *range_out = __float_as_uint(m);
   }
 }
 
@@ -553,10 +583,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float momentum, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ moving_mean,
-                                                          float* __restrict__ moving_var, int by_channel) {
+                                                          float* __restrict__ moving_var, int by_channel,
+                                                          float* __restrict__ bound = nullptr) {
   const int col = blockIdx.x;
   double s, ss;
-  block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
+  float qmax;
+  block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0, &qmax);
   if (threadIdx.x) return;
   const double mean = s / (double)m;
   double var = ss / (double)m - mean * mean;            // biased, as Keras uses in training
@@ -564,7 +596,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = (gamma ? gamma[col] : 1.f) * rstd;
   mean_out[col] = (float)mean; rstd_out[col] = rstd;
-  scale[col] = sc; shift[col] = (beta ? beta[col] : 0.f) - (float)mean * sc;
+  const float sh = (beta ? beta[col] : 0.f) - (float)mean * sc;
+  scale[col] = sc; shift[col] = sh;
+  if (bound) bound[col] = channel_bound(sc, sh, qmax);     // |act(scale x + shift)| of this channel (see channel_bound)
   if (moving_mean) moving_mean[col] = momentum * moving_mean[col] + (1.f - momentum) * (float)mean;
   if (moving_var) moving_var[col] = momentum * moving_var[col] + (1.f - momentum) * (float)var;
 }
@@ -584,9 +618,14 @@ __global__ __launch_bounds__(256) void bn_infer_prepare_kernel(int c, const floa
 // y = [relu](x*scale[c] + shift[c])   (8 B/elem)
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, long total, int c,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int relu, float* __restrict__ y, const DropArg drop) {
+                                                         int relu, float* __restrict__ y, const DropArg drop,
+                                                         const float* __restrict__ bound = nullptr, uint32_t* __restrict__ range_out = nullptr) {
   const long stride = (long)gridDim.x * 256;
   const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
+  if (range_out && blockIdx.x == 0) {                      // the range slot of y for the convs that read it (conv.hip Ranges): B = max_c bound_c,
+    const float b = tensor_bound(bound, c) * drop.keep_scale;   // x 1 / (1 - rate) behind a fused Dropout
+    if (threadIdx.x == 0) *range_out = __float_as_uint(b);
+  }
   if ((c & 3) == 0) {
     const long n4 = total >> 2;
     const int c4 = c >> 2;
@@ -648,9 +687,11 @@ __global__ __launch_bounds__(256) void range_fold_kernel(uint32_t* __restrict__ 
   range_emit_block(slot, __uint_as_float(m));                           // (bit patterns of non-negative floats order like the floats)
 }
 
-// The range slot (conv.hip Ranges; embnet_range_slot_words() uint32 words: the range + the workgroup partials) the NEXT embnet_bn_bwd /
-// embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling thread fills with max |dx| of the fp32 dx it writes (a call
-// that cannot — planes-only dx, scalar kernels, no saved statistics — fails).  Every embnet_bn_bwd* entry point consumes the request.
+// A gradient's range slot (conv.hip Ranges) is embnet_range_slot_words() uint32 words: the range + the workgroup partials.  The BatchNorm
+// backward entry points that write an fp32 dx take it as their `dx_range` ARGUMENT (embnet_bn_bwd_ex, embnet_bn_bwd_partials_ex,
+// embnet_bn_act_maxpool_bwd_ex; ABI 21) and leave max |dx| in its first word; a call that cannot (planes-only dx, scalar kernels, no
+// saved statistics) fails.  DEPRECATED: embnet_range_emit(slot) arms the same request for the NEXT non-_ex call of the calling
+// thread (ABI 20; hidden per-thread state — see embnet_conv2d_ranges in conv.hip); every embnet_bn_bwd* entry point clears it.
 extern "C" int embnet_range_slot_words(void) { return 1 + RANGE_PARTIALS; }
 static thread_local uint32_t* t_emit_slot = nullptr;
 extern "C" int embnet_range_emit(uint32_t* slot) {
@@ -1138,29 +1179,48 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
 // y = act(x*scale + shift) written as fp32 (y, optional) AND as the three bf16 pieces of every value in the chunk-major
 // layout conv_patch.hip consumes ([plane][C/16][pixels][16]): the BatchNormalization in front of a patch convolution
 // produces the convolution's operand in its final form, once.  C % 16 == 0; one thread per (pixel, channel quad).
-// F16: the two-piece fp16 format (gemm_engine.h), scale 1: activations behind a BatchNormalization lie far inside fp16's range
-template <bool F16>
+// F16: the two-piece fp16 format (gemm_engine.h).  Where the scale comes from (SRC):
+//   0: `bound` [c] — the per-channel output bounds bn_finalize_kernel left (channel_bound): every workgroup folds them and derives
+//      s itself; workgroup 0 writes (s, 1 / s) into the planes' slot and the bound's bit pattern into range_out (the range slot of
+//      the fp32 y for the gather convs that read it);
+//   1: the slot, filled by planes_scale_kernel from a dry run (SRC 2) — no statistics partials exist (inference mode: moving
+//      statistics), so the exact maximum is taken by one more read of x;
+//   2: the dry run: nothing stored but the workgroup's max |y| (floats 2 + blockIdx.x behind the slot).
+template <bool F16, int SRC = 0>
 __global__ __launch_bounds__(256) void affine_act_planes_kernel(const float* __restrict__ x, long pixels, int c4,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                int act, float* __restrict__ y, unsigned short* __restrict__ planes) {
+                                                                int act, float* __restrict__ y, unsigned short* __restrict__ planes,
+                                                                const float* __restrict__ bound = nullptr, uint32_t* __restrict__ range_out = nullptr) {
   const long total4 = pixels * c4, plane = total4 * 4, stride = (long)gridDim.x * 256;
-  if (F16 && blockIdx.x == 0 && threadIdx.x == 0) { float* sl = planes_scale_slot(planes, plane); sl[0] = 1.f; sl[1] = 1.f; }
+  float ps = 1.f;
+  if (F16 && SRC == 0) {
+    const float b = tensor_bound(bound, 4 * c4);
+    const float2 sp = scale_pair(scale_exponent_of(b));
+    ps = sp.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float* sl = planes_scale_slot(planes, plane); sl[0] = sp.x; sl[1] = sp.y;
+      if (range_out) *range_out = __float_as_uint(b);
+    }
+  }
+  if (F16 && SRC == 1) ps = planes_scale_slot(planes, plane)[0];
   const bool fixed = stride % c4 == 0;
   float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
   if (fixed) {
     const int q = (int)(((long)blockIdx.x * 256 + threadIdx.x) % c4);
     sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q];
   }
+  float amax = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     const long pix = i / c4; const int q = (int)(i - pix * c4);
     if (!fixed) { sc = reinterpret_cast<const float4*>(scale)[q]; sh = reinterpret_cast<const float4*>(shift)[q]; }
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
     if (act) { o.x = act_apply(act, o.x); o.y = act_apply(act, o.y); o.z = act_apply(act, o.z); o.w = act_apply(act, o.w); }
+    if (SRC == 2) { amax = amax4(amax, o); continue; }
     if (y) reinterpret_cast<float4*>(y)[i] = o;
     const long e = ((long)(q >> 2) * pixels + pix) * 16 + 4 * (q & 3);
     if (F16) {
-      const Split4H s = split4h(o, 1.f);
+      const Split4H s = split4h(o, ps);
 #pragma unroll
       for (int k = 0; k < 2; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
     } else {
@@ -1168,6 +1228,13 @@ __global__ __launch_bounds__(256) void affine_act_planes_kernel(const float* __r
 #pragma unroll
       for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(planes + k * plane + e) = s.p[k];
     }
+  }
+  if (SRC == 2) {
+    amax = wave_max(amax);
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) planes_scale_slot(planes, plane)[2 + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
   }
 }
 
@@ -1340,13 +1407,15 @@ extern "C" size_t embnet_bn_workspace_bytes(long m, int c) {
   return (size_t)col_geom(m, c).blocks * 2 * c * sizeof(float);
 }
 
-extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
-                                   float momentum, int relu, float* y, float* save_mean, float* save_rstd,
-                                   float* scale, float* shift, float* moving_mean, float* moving_var,
-                                   const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+static int bn_train_fwd_impl(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                             float momentum, int relu, float* y, float* save_mean, float* save_rstd,
+                             float* scale, float* shift, float* moving_mean, float* moving_var,
+                             const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
+                             float* y_bound, uint32_t* y_range, void* stream) {
   EMBNET_CHECK_ARG(x && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_train_fwd: m=%ld c=%d", m, c);
+  EMBNET_CHECK_ARG(!y_range || (y_bound && y && !(reinterpret_cast<uintptr_t>(y_range) & 3)),
+                   "bn_train_fwd: y_range (the range slot of the fp32 y) goes with y_bound and y");
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "bn_train_fwd: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
@@ -1363,10 +1432,26 @@ extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* g
     { EMBNET_TRACE("embnet::bn_stats_kernel", TRACE_BYTES, 4.0 * m * c, stream); bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace); }
   }
   { EMBNET_TRACE("embnet::bn_finalize_kernel", TRACE_BYTES, 8.0 * nblocks * c, stream); bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
-                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr); }
+                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr, y_bound); }
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
-    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y, DropArg{0, nullptr, 0u, 1.f}); }
+    { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y, DropArg{0, nullptr, 0u, 1.f}, y_bound, y_range); }
   return check_launch("bn_train_fwd");
+}
+extern "C" int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                                   float momentum, int relu, float* y, float* save_mean, float* save_rstd,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var,
+                                   const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  return bn_train_fwd_impl(x, m, c, gamma, beta, eps, momentum, relu, y, save_mean, save_rstd, scale, shift, moving_mean, moving_var,
+                           partial_in, partial_rows, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+extern "C" int embnet_bn_train_fwd_ex(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                                      float momentum, int relu, float* y, float* save_mean, float* save_rstd,
+                                      float* scale, float* shift, float* moving_mean, float* moving_var,
+                                      const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
+                                      float* y_bound, uint32_t* y_range, void* stream) {
+  return bn_train_fwd_impl(x, m, c, gamma, beta, eps, momentum, relu, y, save_mean, save_rstd, scale, shift, moving_mean, moving_var,
+                           partial_in, partial_rows, workspace, workspace_bytes, y_bound, y_range, stream);
 }
 
 extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
@@ -1396,15 +1481,41 @@ extern "C" int embnet_affine_act_dropout(const float* x, long m, int c, const fl
   return check_launch("affine_act_dropout");
 }
 
-extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
-                                        void* planes, void* stream) {
+static int affine_act_planes_impl(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                  void* planes, const float* y_bound, uint32_t* y_range, void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && planes, "affine_act_planes: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 15) == 0, "affine_act_planes: m=%ld c=%d (c %% 16 == 0)", m, c);
   EMBNET_CHECK_ARG((size_t)m * c * 2 < 0x7FFFFFF0ull / 3, "affine_act_planes: tensor too large");
-  EMBNET_TRACE(planes_f16() ? "void embnet::affine_act_planes_kernel<true>" : "void embnet::affine_act_planes_kernel<false>", TRACE_BYTES, ((y ? 8.0 : 4.0) + (planes_f16() ? 4.0 : 6.0)) * m * c, stream);
-  if (planes_f16()) affine_act_planes_kernel<true><<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
-  else affine_act_planes_kernel<false><<<ew_blocks_c4(m * c / 4, c / 4), 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, (unsigned short*)planes);
+  EMBNET_CHECK_ARG(!y_range || (y && !(reinterpret_cast<uintptr_t>(y_range) & 3)),
+                   "affine_act_planes: y_range is the range slot of the fp32 y (4-byte aligned)");
+  const long total4 = m * c / 4;
+  const int blocks = ew_blocks_c4(total4, c / 4);
+  unsigned short* pl = (unsigned short*)planes;
+  if (!planes_f16()) {
+    EMBNET_TRACE("void embnet::affine_act_planes_kernel<false>", TRACE_BYTES, ((y ? 8.0 : 4.0) + 6.0) * m * c, stream);
+    affine_act_planes_kernel<false><<<blocks, 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, pl);
+    return check_launch("affine_act_planes");
+  }
+  if (y_bound) {                                            // the range is known before the pass (bn_finalize_kernel's bounds)
+    EMBNET_TRACE("void embnet::affine_act_planes_kernel<true>", TRACE_BYTES, ((y ? 8.0 : 4.0) + 4.0) * m * c, stream);
+    affine_act_planes_kernel<true, 0><<<blocks, 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, pl, y_bound, y_range);
+    return check_launch("affine_act_planes");
+  }
+  // no bound (inference-mode statistics, or a caller without the BatchNorm's partials): the exact maximum from a dry run
+  EMBNET_TRACE("void embnet::affine_act_planes_kernel<true, 1>", TRACE_BYTES, ((y ? 8.0 : 4.0) + 8.0) * m * c, stream);
+  const int dry = (int)(2 * total4 - 2 < blocks ? 2 * total4 - 2 : blocks);
+  affine_act_planes_kernel<true, 2><<<dry, 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, nullptr, pl);
+  planes_scale_kernel<<<1, 256, 0, S(stream)>>>(planes_scale_slot(planes, total4 * 4), dry, y_range);
+  affine_act_planes_kernel<true, 1><<<blocks, 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, pl);
   return check_launch("affine_act_planes");
+}
+extern "C" int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                        void* planes, void* stream) {
+  return affine_act_planes_impl(x, m, c, scale, shift, act, y, planes, nullptr, nullptr, stream);
+}
+extern "C" int embnet_affine_act_planes_ex(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                           void* planes, const float* y_bound, uint32_t* y_range, void* stream) {
+  return affine_act_planes_impl(x, m, c, scale, shift, act, y, planes, y_bound, y_range, stream);
 }
 
 // bn_bwd_apply4_kernel in the planes format of the process: with EMBNET_PLANES_F16 a dry run finds the gradient's range first
@@ -1418,10 +1529,11 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
   unsigned short* pl = (unsigned short*)dx_planes;
   if (dx_planes && planes_f16()) {
     float* slot = planes_scale_slot(dx_planes, total4 * 4);
-    const bool room = 2 * total4 >= 16 + blocks;          // the third plane's space holds the slot and the workgroup maxima
-    if (room) bn_bwd_apply4_kernel<2><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma,
-                                                             relu, training, dx_add, nullptr, pl);
-    planes_scale_kernel<<<1, 256, 0, st>>>(slot, room ? blocks : 0, room ? range_slot : nullptr);   // (no dry run: the slot stays 0 = unknown)
+    // (the third plane's space — 2 * total4 floats, >= 8 — holds the slot and the dry run's workgroup maxima: fewer workgroups for a tiny tensor)
+    const int dry = (int)(2 * total4 - 2 < blocks ? 2 * total4 - 2 : blocks);
+    bn_bwd_apply4_kernel<2><<<dry, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma,
+                                                relu, training, dx_add, nullptr, pl);
+    planes_scale_kernel<<<1, 256, 0, st>>>(slot, dry, range_slot);
     bn_bwd_apply4_kernel<1><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
                                                    training, dx_add, dx, pl);
     return;
@@ -1436,14 +1548,14 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
                                                  training, dx_add, dx, pl);
 }
 
-extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
-                             const float* save_rstd, const float* scale, const float* shift, int relu, int training,
-                             const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
-                             size_t workspace_bytes, void* stream) {
-  uint32_t* const emit = take_emit_slot();
-  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || (planes_f16() && m * c >= 65536)) && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd),
-                   "bn_bwd: a range of dx was requested (embnet_range_emit) but this call cannot emit one (an fp32 dx — beside planes only in "
-                   "the two-piece format, from 65536 elements —, c %% 4 == 0, saved statistics)");
+static int bn_bwd_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
+                       const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                       const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
+                       size_t workspace_bytes, uint32_t* emit, void* stream) {
+  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || planes_f16()) && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd &&
+                             !(reinterpret_cast<uintptr_t>(emit) & 3)),
+                   "bn_bwd: a range of dx was requested but this call cannot emit one (an fp32 dx — beside planes only in the two-piece "
+                   "format —, c %% 4 == 0, saved statistics, a 4-byte aligned slot)");
   EMBNET_CHECK_ARG(dy && x && scale && shift && (dx || dx_planes) && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   EMBNET_CHECK_ARG(dx || ((c & 3) == 0 && !bn_scalar()), "bn_bwd: dx = NULL (planes only) needs the four-channel kernels");
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd: dx_planes needs c %% 16 == 0");
@@ -1476,6 +1588,21 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
   return check_launch("bn_bwd");
+}
+extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean,
+                             const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                             const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return bn_bwd_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dx_add, dx, dgamma, dbeta, dx_planes, workspace,
+                     workspace_bytes, take_emit_slot(), stream);
+}
+extern "C" int embnet_bn_bwd_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
+                                size_t workspace_bytes, uint32_t* dx_range, void* stream) {
+  (void)take_emit_slot();
+  return bn_bwd_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dx_add, dx, dgamma, dbeta, dx_planes, workspace,
+                     workspace_bytes, dx_range, stream);
 }
 
 static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
@@ -1560,13 +1687,12 @@ extern "C" int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const
 
 // BatchNorm backward whose sums were produced by the data gradient of the conv behind it (embnet_conv2d_dgrad_bnsums_f32):
 // finalize over the [2][c][rows] partials, then the apply pass of embnet_bn_bwd.  c % 4 == 0, training statistics.
-extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean,
-                                      const float* save_rstd, const float* scale, const float* shift, int relu,
-                                      const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
-                                      float* dbeta, void* dx_planes, void* stream) {
-  uint32_t* const emit = take_emit_slot();
-  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || (planes_f16() && m * c >= 65536))),
-                   "bn_bwd_partials: a range of dx was requested (embnet_range_emit) but this call cannot emit one (see embnet_bn_bwd)");
+static int bn_bwd_partials_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                const float* save_rstd, const float* scale, const float* shift, int relu,
+                                const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
+                                float* dbeta, void* dx_planes, uint32_t* emit, void* stream) {
+  EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || planes_f16()) && !(reinterpret_cast<uintptr_t>(emit) & 3)),
+                   "bn_bwd_partials: a range of dx was requested but this call cannot emit one (see embnet_bn_bwd_ex)");
   EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && (dx || dx_planes) && dgamma && dbeta, "bn_bwd_partials: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
@@ -1574,6 +1700,21 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
   { EMBNET_TRACE(emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
     launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream), emit); }
   return check_launch("bn_bwd_partials");
+}
+extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                      const float* save_rstd, const float* scale, const float* shift, int relu,
+                                      const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
+                                      float* dbeta, void* dx_planes, void* stream) {
+  return bn_bwd_partials_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, partials, rows, dx_add, dx, dgamma, dbeta, dx_planes,
+                              take_emit_slot(), stream);
+}
+extern "C" int embnet_bn_bwd_partials_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                         const float* save_rstd, const float* scale, const float* shift, int relu,
+                                         const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
+                                         float* dbeta, void* dx_planes, uint32_t* dx_range, void* stream) {
+  (void)take_emit_slot();
+  return bn_bwd_partials_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, partials, rows, dx_add, dx, dgamma, dbeta, dx_planes,
+                              dx_range, stream);
 }
 
 extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,
@@ -1661,13 +1802,13 @@ extern "C" size_t embnet_bn_act_maxpool_bwd_workspace_bytes(int n, int oh, int o
   return embnet_bn_workspace_bytes((long)n * oh * ow, c);
 }
 
-extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
-                                         int k, int stride, int pad, int oh, int ow, const float* save_mean,
-                                         const float* save_rstd, const float* scale, const float* shift, int act,
-                                         int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
-  uint32_t* const emit = take_emit_slot();
-  EMBNET_CHECK_ARG(!emit || (save_mean && save_rstd), "bn_act_maxpool_bwd: a range of dx was requested (embnet_range_emit) without saved statistics");
+static int bn_act_maxpool_bwd_impl(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
+                                   int k, int stride, int pad, int oh, int ow, const float* save_mean,
+                                   const float* save_rstd, const float* scale, const float* shift, int act,
+                                   int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
+                                   void* workspace, size_t workspace_bytes, uint32_t* emit, void* stream) {
+  EMBNET_CHECK_ARG(!emit || (save_mean && save_rstd && !(reinterpret_cast<uintptr_t>(emit) & 3)),
+                   "bn_act_maxpool_bwd: a range of dx was requested without saved statistics (or the slot is not 4-byte aligned)");
   EMBNET_CHECK_ARG(dy && argmax && x && scale && shift && dx && dgamma && dbeta && workspace, "bn_act_maxpool_bwd: null pointer");
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_act_maxpool_bwd: training needs saved statistics");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0, "bn_act_maxpool_bwd: bad geometry");
@@ -1690,6 +1831,23 @@ extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax,
                                                                     scale, shift, dbeta, dgamma, act, training, dx, emit); }
   if (emit) range_fold_kernel<<<1, 256, 0, S(stream)>>>(emit);
   return check_launch("bn_act_maxpool_bwd");
+}
+extern "C" int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
+                                         int k, int stride, int pad, int oh, int ow, const float* save_mean,
+                                         const float* save_rstd, const float* scale, const float* shift, int act,
+                                         int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return bn_act_maxpool_bwd_impl(dy, argmax, x, n, h, w, c, k, stride, pad, oh, ow, save_mean, save_rstd, scale, shift, act, training,
+                                 xwin, dx, dgamma, dbeta, workspace, workspace_bytes, take_emit_slot(), stream);
+}
+extern "C" int embnet_bn_act_maxpool_bwd_ex(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c,
+                                            int k, int stride, int pad, int oh, int ow, const float* save_mean,
+                                            const float* save_rstd, const float* scale, const float* shift, int act,
+                                            int training, const float* xwin, float* dx, float* dgamma, float* dbeta,
+                                            void* workspace, size_t workspace_bytes, uint32_t* dx_range, void* stream) {
+  (void)take_emit_slot();
+  return bn_act_maxpool_bwd_impl(dy, argmax, x, n, h, w, c, k, stride, pad, oh, ow, save_mean, save_rstd, scale, shift, act, training,
+                                 xwin, dx, dgamma, dbeta, workspace, workspace_bytes, dx_range, stream);
 }
 
 extern "C" int embnet_gap_fwd(const float* x, int n, int hw, int c, float* y, void* stream) {

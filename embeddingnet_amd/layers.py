@@ -76,7 +76,7 @@ def workspace(nbytes, device):
 #     when THAT backward ends — the first entry made during a backward queues an end-of-backward callback on the autograd
 #     engine — and counted in `context.unclaimed`, so entries neither pile up nor pin activation-sized tensors.
 class StepContext:
-    DICTS = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "dy_range", "bn_fwd_stats", "act_planes")
+    DICTS = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "dy_range", "bn_fwd_stats", "act_planes", "act_range")
     BACKWARD = ("bn_sums", "relu_done", "gate_pending", "pool_pending", "dy_planes", "dy_range")      # made and consumed inside one backward
 
     def __init__(self, name="default"):
@@ -229,15 +229,14 @@ def wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow):
 
 
 def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale=None, in_shift=None, in_act=0,
-               x_planes=None, dz_planes=None, dz_range=None):
+               x_planes=None, dz_planes=None, dz_range=None, x_range=None):
     """dw[r,s,c,k] = weight gradient of a convolution, its slab sum deferred when SLAB_DEFER.  With the planes of BOTH operands
     (x_planes: kept by the forward patch conv, dz_planes: left by the BatchNormalization behind the conv) and a geometry
     embnet_conv2d_wgrad_planes_supported accepts, the planes kernel computes it (csrc/conv_wgrad_planes.hip) and the fp32
-    tensors are not read; otherwise embnet_conv2d_wgrad_f32 — with dz_range (the range slot of dz, DY_RANGE) on three products.
+    tensors are not read; otherwise embnet_conv2d_wgrad_f32_ex — on three products when the range slots of BOTH operands are
+    given (x_range: the BatchNormalization that wrote x, layers._range_of; dz_range: the range slot of dz, DY_RANGE).
     """
-    def ranged():
-        if dz_range is not None and in_scale is None:
-            check(lib.embnet_conv2d_ranges(None, ptr(dz_range)))
+    xr, dr = (_rptr(x_range), _rptr(dz_range)) if (x_range is not None and dz_range is not None and in_scale is None) else (None, None)
     planes = x_planes is not None and dz_planes is not None and in_scale is None and \
         wgrad_planes_ok(n, h, wd, c, r, s, k, stride, pt, pl, oh, ow)
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
@@ -259,9 +258,8 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
                                                          n, h, wd, c, k, 0, stream()))
             else:
                 buf = _slab_buffer(w, lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow) // 4, x.device)
-                ranged()
-                check(lib.embnet_conv2d_wgrad_slabs_f32(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
-                                                        stride, pt, pl, oh, ow, in_scale, in_shift, in_act, stream()))
+                check(lib.embnet_conv2d_wgrad_slabs_f32_ex(ptr(x), ptr(dz), ptr(dw), ptr(buf), buf.numel() * 4, n, h, wd, c, r, s, k,
+                                                           stride, pt, pl, oh, ow, in_scale, in_shift, in_act, xr, dr, stream()))
             # (an alias of dw, not dw itself: autograd adopts a returned gradient as .grad only while nobody else holds that
             # tensor object — a second reference would make it clone the still-unreduced buffer)
             _SLAB_PENDING.append((buf, dw.detach(), r * s * c * k, splits, w))
@@ -272,9 +270,8 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
                                                  1, stream()))
         return
     ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-    ranged()
-    check(lib.embnet_conv2d_wgrad_f32(ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl,
-                                      oh, ow, in_scale, in_shift, in_act, stream()))
+    check(lib.embnet_conv2d_wgrad_f32_ex(ptr(x), ptr(dz), ptr(dw), ptr(ws), ws.numel() * 4, n, h, wd, c, r, s, k, stride, pt, pl,
+                                         oh, ow, in_scale, in_shift, in_act, xr, dr, stream()))
 
 
 def flush_slab_reduces():
@@ -368,6 +365,7 @@ RELU_DONE = _CtxDict("relu_done")
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
 DY_PLANES = _CtxDict("dy_planes")
 _ACT_PLANES = _CtxDict("act_planes")
+_ACT_RANGE = _CtxDict("act_range")
 WEIGHT_EPOCH = [0]
 
 
@@ -461,15 +459,21 @@ def refresh_tensors(tensors, holder):
     _refresh_planes_of(plan[2], holder)
 
 
-# ---- three products per fp32 product on the gather convs (csrc/conv.hip "Ranges"; include/embnet.h ABI 20) --------------------------
-# A Conv2D with `f16 = True` (the zoo ResNets' convs, backbones._rn_conv) that does NOT run the patch kernel tells the library the
-# RANGE of both operands of each of its three passes, and the kernels then multiply in the planes kernels' two-piece fp16 format
-# (three matrix products per fp32 product instead of six).  Kernel ranges: one uint32 slot per kernel, refreshed like the kernel
-# planes (tensor version / WEIGHT_EPOCH; refresh_weight_planes does all of a model's in two launches).  Gradient ranges: the conv
-# tags its output (`y._wants_dy_range`), the BatchNormalization (or BatchNorm + MaxPool) that reads y makes its backward leave
-# max |dx| in a slot (embnet_range_emit) and files it in DY_RANGE under dx's address — with an alias of dx, so that address cannot
-# pass to another tensor while the entry lives; the conv's backward claims it.  Activations take scale 1 (as the planes do).
-# A gradient that reaches the conv from anywhere else has no entry: that pass runs the six-term kernel.
+# ---- three products per fp32 product on the gather convs (csrc/conv.hip "Ranges"; include/embnet.h ABI 21) --------------------------
+# A Conv2D with `f16 = True` (the zoo ResNets' convs, backbones._rn_conv) that does NOT run the patch kernel hands the library the
+# RANGE SLOT of both operands of each of its three passes as ARGUMENTS (embnet_conv2d_*_f32_ex), and the kernels then multiply in
+# the planes kernels' two-piece fp16 format (three matrix products per fp32 product instead of six).  EVERY operand has a range
+# — there is no default scale (round 5 ran activations at scale 1: a precision cliff below amplitude 2^-3):
+#   * kernels: one uint32 slot per kernel, refreshed like the kernel planes (tensor version / WEIGHT_EPOCH; refresh_weight_planes
+#     does all of a model's in two launches) — the exact maximum;
+#   * activations: the training-mode BatchNormalization that writes the tensor leaves an upper bound of max |y| in a slot before
+#     its apply pass runs (nn_kernels.hip channel_bound: from the statistics partials) and hangs it on the tensor (`y._range`);
+#   * gradients: the conv tags its output (`y._wants_dy_range`), the BatchNormalization (or BatchNorm + MaxPool) that reads y makes
+#     its backward leave max |dx| in a slot (`dx_range` of embnet_bn_bwd_ex) and files it in DY_RANGE under dx's address — with an
+#     alias of dx, so that address cannot pass to another tensor while the entry lives; the conv's backward claims it.
+# A pass that lacks either operand's range (an inference-mode BatchNormalization, a gradient that reaches the conv from anywhere
+# else) runs the six-term kernel.  Entries a backward leaves unclaimed are dropped — and counted — by the step context's
+# end-of-backward sweep (StepContext.unclaimed['dy_range']); nothing is ever dropped by size.
 CONV_F16 = [_os.environ.get("EMBNET_CONV_F16", "1") != "0"]           # [False]: six-term products everywhere (A/B)
 DY_RANGE = _CtxDict("dy_range")
 
@@ -525,6 +529,19 @@ def refresh_weight_ranges(module):
     _refresh_ranges_of(_with_entry([m.kernel for m in module.modules() if isinstance(m, Conv2D)], "_embnet_wrange"), module)
 
 
+def _rptr(r):
+    """Raw device address of a range slot: a uint32 tensor, or (owner tensor, address) for a slot that lives inside another
+    tensor (a BatchNormalization's statistics rows: no allocation of its own per layer and step)."""
+    if r is None:
+        return None
+    return r[1] if isinstance(r, tuple) else ptr(r)
+
+
+def _range_of(x):
+    """The range slot the producer of activation tensor x left on it (BatchNormalization.forward), or None."""
+    return getattr(x, "_range", None)
+
+
 def _take_dy_range(dy, keep=False):
     """keep: the same gradient tensor goes on to a second conv (the projection shortcut behind a fused Add) — the entry stays for
     it; an identity shortcut's BatchNormalization releases it instead (_BatchNormFn.backward)."""
@@ -535,11 +552,8 @@ def _take_dy_range(dy, keep=False):
 
 
 def _emit_dx_range(dx):
-    """A fresh range slot for `dx`, announced to the library (the next embnet_bn_bwd* call fills it) and filed in DY_RANGE."""
+    """A fresh range slot for `dx` (the caller passes it to the embnet_bn_bwd*_ex call that writes dx), filed in DY_RANGE."""
     slot = torch.empty(_lib.lib().embnet_range_slot_words(), dtype=torch.int32, device=dx.device)
-    check(_lib.lib().embnet_range_emit(ptr(slot)))
-    if len(DY_RANGE) > 64:
-        DY_RANGE.clear()
     DY_RANGE[dx.data_ptr()] = (slot, dx.detach())
     return slot
 
@@ -549,8 +563,8 @@ _BN_SCALAR = _os.environ.get("EMBNET_BN_SCALAR", "0") not in ("0", "")
 
 def _planes_range_ok(x):
     """A BatchNorm backward that writes dx as planes AND as fp32 can leave dx's range too: in the two-piece format its dry run
-    finds the maximum anyway (tensors from 65536 elements: smaller ones skip the dry run)."""
-    return x.numel() >= 65536 and _lib.lib().embnet_conv_planes_mfma_terms() == 3
+    finds the maximum anyway."""
+    return _lib.lib().embnet_conv_planes_mfma_terms() == 3
 
 
 PLANES_ONLY = [_os.environ.get("EMBNET_PLANES_ONLY", "1") != "0"]     # [False]: every planes tensor keeps its fp32 copy (A/B)
@@ -618,11 +632,12 @@ def same_pad(n, k, s):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False,
-                planes=None, bn_src=None, w_range=None):
+                planes=None, bn_src=None, w_range=None, x_range=None):
         """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward.
         bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums.
-        w_range: the kernel's range slot (weight_range) -> the gather kernels of all three passes multiply on three products
-        where the other operand's range is known too (x: scale 1; dy: DY_RANGE)."""
+        w_range: the kernel's range slot (weight_range), x_range: the input's (layers._range_of) -> the gather kernels multiply
+        on three products in every pass whose two operands both have a range (forward: x, w; data gradient: dy (DY_RANGE), w;
+        weight gradient: x, dy)."""
         w = _c(w)
         if not (planes is not None and _is_placeholder(x)):       # (a planes-only input has no fp32 values to read)
             x = _c(x)
@@ -650,13 +665,14 @@ class _Conv2dFn(torch.autograd.Function):
                                               ws.numel() * 4, stream()))
         else:
             ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
-            if w_range is not None and in_stats is None:
-                check(lib.embnet_conv2d_ranges(None, ptr(w_range)))
-            check(lib.embnet_conv2d_fwd_f32(
+            fr = w_range is not None and x_range is not None and in_stats is None
+            check(lib.embnet_conv2d_fwd_f32_ex(
                 ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
-                in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
+                in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4,
+                _rptr(x_range) if fr else None, _rptr(w_range) if fr else None, stream()))
         ctx.patch = planes is not None
         ctx.w_range = w_range if (planes is None and in_stats is None) else None
+        ctx.x_range = x_range if (planes is None and in_stats is None) else None
         ctx.x_planes = planes                # kept for the weight gradient (conv_wgrad)
         ctx.bn_src = bn_src
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
@@ -719,7 +735,7 @@ class _Conv2dFn(torch.autograd.Function):
 
         def run_wgrad():
             conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
-                       getattr(ctx, "x_planes", None), dy_planes, dy_range)
+                       getattr(ctx, "x_planes", None), dy_planes, dy_range, getattr(ctx, "x_range", None))
 
         dw_note = None
         if need_dw:
@@ -745,20 +761,17 @@ class _Conv2dFn(torch.autograd.Function):
                     bn_x, bn_stats, bn_act = bn_src
                     partial = torch.empty((2, c, rows), device=x.device, dtype=torch.float32)
                     sp = bn_stats.data_ptr()
-                    if dy_range is not None:
-                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
-                    check(lib.embnet_conv2d_dgrad_bnsums_f32(
+                    check(lib.embnet_conv2d_dgrad_bnsums_f32_ex(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(bn_x), sp + 8 * c, sp + 12 * c,
-                        sp, sp + 4 * c, int(bn_act), ptr(partial), rows, ptr(dws), dws.numel() * 4, stream()))
+                        sp, sp + 4 * c, int(bn_act), ptr(partial), rows, ptr(dws), dws.numel() * 4,
+                        _rptr(dy_range), _rptr(w_range) if dy_range is not None else None, stream()))
                     while len(BN_SUMS) >= 8:     # unclaimed entries (the gradient got a second contribution) pin a dx each: keep few
                         BN_SUMS.pop(next(iter(BN_SUMS)))
                     BN_SUMS[dx.data_ptr()] = (partial, rows, bn_x.data_ptr(), dx.detach())
                 else:
-                    if dy_range is not None:
-                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
-                    check(lib.embnet_conv2d_dgrad_f32(
+                    check(lib.embnet_conv2d_dgrad_f32_ex(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, ptr(dskip), ptr(dws),
-                        dws.numel() * 4, stream()))
+                        dws.numel() * 4, _rptr(dy_range), _rptr(w_range) if dy_range is not None else None, stream()))
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
         elif need_dw:
@@ -771,7 +784,11 @@ class _Conv2dFn(torch.autograd.Function):
             db = _done(db, db_note)
         if dskip is not None and dx is None and ctx.needs_input_grad[0]:
             dx = dskip
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None
+        if ctx.has_res and dy_only_planes:
+            # (the residual branch would receive a placeholder — three uninitialised floats behind zero strides)
+            raise _lib.EmbnetError("conv2d backward: a conv with a fused Add received its gradient as planes only; the Add's other "
+                                   "branch needs the fp32 gradient (BatchNormalization(owns_input=True) behind conv(residual=...))")
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -781,10 +798,10 @@ class _ConvPairFn(torch.autograd.Function):
     for autograd to add."""
 
     @staticmethod
-    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1, planes=None, w_ranges=None):
+    def forward(ctx, x, w1, geom1, w2, geom2, in_stats, in_act, out_stats1, planes=None, w_ranges=None, x_range=None):
         """planes: pre-split planes of x -> the FIRST conv (the 3x3) runs the patch kernel.
-        w_ranges = (range slot of w1 or None, of w2 or None): see _Conv2dFn.forward."""
-        w_ranges = tuple(w_ranges) if (w_ranges is not None and in_stats is None) else (None, None)
+        w_ranges = (range slot of w1 or None, of w2 or None), x_range: the input's: see _Conv2dFn.forward."""
+        w_ranges = tuple(w_ranges) if (w_ranges is not None and in_stats is None and x_range is not None) else (None, None)
         x, w1, w2 = _c(x), _c(w1), _c(w2)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -804,14 +821,13 @@ class _ConvPairFn(torch.autograd.Function):
             else:
                 ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
                 wr = w_ranges[0 if w is w1 else 1]
-                if wr is not None:
-                    check(lib.embnet_conv2d_ranges(None, ptr(wr)))
-                check(lib.embnet_conv2d_fwd_f32(
+                check(lib.embnet_conv2d_fwd_f32_ex(
                     ptr(x), ptr(w), None, ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0, None, in_scale, in_shift,
-                    int(in_act), ptr(st), ptr(ws), ws.numel() * 4, stream()))
+                    int(in_act), ptr(st), ptr(ws), ws.numel() * 4, _rptr(x_range) if wr is not None else None, _rptr(wr), stream()))
             ys.append(y)
         ctx.patch = planes is not None
         ctx.w_ranges = (w_ranges[0] if planes is None else None, w_ranges[1])
+        ctx.x_range = x_range
         ctx.x_planes = planes
         ctx.geoms, ctx.in_act = (geom1, geom2), int(in_act)
         ctx.save_for_backward(x, w1, w2, in_stats)
@@ -845,22 +861,21 @@ class _ConvPairFn(torch.autograd.Function):
                     _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, None)
                 else:
                     sc = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
-                    if dy_range is not None:
-                        check(lib.embnet_conv2d_ranges(ptr(dy_range), ptr(w_range)))
-                    check(lib.embnet_conv2d_dgrad_f32(
+                    check(lib.embnet_conv2d_dgrad_f32_ex(
                         ptr(dy), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 0 if first else 1, None,
-                        ptr(sc), sc.numel() * 4, stream()))
+                        ptr(sc), sc.numel() * 4, _rptr(dy_range), _rptr(w_range) if dy_range is not None else None, stream()))
                 first = False
             dw = None
             if need_dw:
                 dw, note = _sink(w)
                 conv_wgrad(lib, x, dy, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, in_scale, in_shift, ctx.in_act,
-                           getattr(ctx, "x_planes", None) if w is w1 else None, dy_planes, dy_range)
+                           getattr(ctx, "x_planes", None) if w is w1 else None, dy_planes, dy_range,
+                           getattr(ctx, "x_range", None) if w_range is not None else None)
                 dw = _done(dw, note)
             dws.append(dw)
         if dx is not None and first:
             dx.zero_()
-        return dx, dws[0], None, dws[1], None, None, None, None, None, None
+        return dx, dws[0], None, dws[1], None, None, None, None, None, None, None
 
 
 def conv_pair(x, conv1, conv2, emit_stats=False):
@@ -889,7 +904,7 @@ def conv_pair(x, conv1, conv2, emit_stats=False):
             out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
     wr = (conv1.range_for(x, planes, in_stats), conv2.range_for(x, None, in_stats))
     y1, y2 = _ConvPairFn.apply(x, conv1.kernel, g1, conv2.kernel, g2, in_stats, in_act, out_stats, planes,
-                               wr if (wr[0] is not None or wr[1] is not None) else None)
+                               wr if (wr[0] is not None or wr[1] is not None) else None, _range_of(x))
     if out_stats is not None:
         y1._bn_partials = out_stats
     if wr[0] is not None and torch.is_grad_enabled():
@@ -976,8 +991,11 @@ class Conv2D(nn.Module):
         self.f16 = False          # True: three-product gather kernels where the operands' ranges are known (layers.CONV_F16 note)
 
     def range_for(self, x, planes, in_stats):
-        """The kernel's range slot when this conv, on that input, runs the gather kernels on three products; else None."""
+        """The kernel's range slot when this conv, on that input, runs the gather kernels on three products; else None (among
+        the reasons: the input carries no range — nobody vouches for its magnitude, so six exact bf16 terms it is)."""
         if not (CONV_F16[0] and getattr(self, "f16", False)) or planes is not None or in_stats is not None or self.relu:
+            return None
+        if _range_of(x) is None:
             return None
         if self.kernel.shape[2] % 4 or self.kernel.shape[3] % 4 or x.shape[-1] % 4 or _BN_SCALAR:
             return None
@@ -1035,7 +1053,7 @@ class Conv2D(nn.Module):
             bn_src = None
         w_range = self.range_for(x, planes, in_stats)      # (a channel-padded kernel has its source's range: the padding is zeros)
         out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
-                              planes, bn_src, w_range)
+                              planes, bn_src, w_range, _range_of(x) if w_range is not None else None)
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
@@ -1047,7 +1065,8 @@ class Conv2D(nn.Module):
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
             # ... and ONLY as planes when this conv takes both of its gradients from them and the BatchNormalization is told
             # that nobody else reads its dx (BatchNormalization.forward(owns_input=True))
-            if self.planes_only_gradient(x.shape, geom) and kernel is self.kernel and not with_skip:
+            # (never behind a fused Add: backward hands dy on to the Add's other branch, which needs the fp32 values — ADVICE r05)
+            if self.planes_only_gradient(x.shape, geom) and kernel is self.kernel and not with_skip and residual is None:
                 y._dy_planes_only = True
         if (self.relu and self.bias is not None and (FUSE_RELU_BN[0] or FUSE_RELU_POOL[0]) and self.kernel.shape[3] % 4 == 0
                 and residual is None):
@@ -1199,17 +1218,28 @@ class Dense(nn.Module):
 
 
 # ----------------------------------------------------------------------------- batch norm
-def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mean, moving_var, partials=None):
-    """embnet_bn_train_fwd; partials [2,C,P] = sums / sums of squares of x by row band from the producing conv's
-    epilogue (Conv2D(..., emit_stats=True)), which then replace the statistics pass over x."""
+def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mean, moving_var, partials=None, with_range=False):
+    """embnet_bn_train_fwd_ex; partials [2,C,P] = sums / sums of squares of x by row band from the producing conv's
+    epilogue (Conv2D(..., emit_stats=True)), which then replace the statistics pass over x.
+    stats with >= 5 rows: row 4 receives the per-channel bounds of |act(BN(x))| (nn_kernels.hip channel_bound); with_range (needs a
+    sixth row and y): the apply pass folds them into the range slot of y — the first word of row 5 (_stats_range)."""
     lib = _lib.lib()
     ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
     if partials is not None and tuple(partials.shape[:2]) != (2, c):
         raise _lib.EmbnetError(f"BatchNormalization: statistics partials {tuple(partials.shape)} for {c} channels")
-    check(lib.embnet_bn_train_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), ptr(y),
-                                  stats.data_ptr(), (stats.data_ptr() + 4 * stats.shape[1]), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                  ptr(moving_mean), ptr(moving_var), ptr(partials),
-                                  partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, stream()))
+    sp, sc = stats.data_ptr(), stats.shape[1]
+    bound = sp + 16 * sc if stats.shape[0] >= 5 else None
+    yr = sp + 20 * sc if (with_range and y is not None and stats.shape[0] >= 6) else None
+    check(lib.embnet_bn_train_fwd_ex(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), ptr(y),
+                                     sp, sp + 4 * sc, sp + 8 * sc, sp + 12 * sc,
+                                     ptr(moving_mean), ptr(moving_var), ptr(partials),
+                                     partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, bound, yr, stream()))
+
+
+def _stats_range(stats):
+    """The range slot inside a BatchNormalization's statistics tensor (rows: mean, rstd, scale, shift, bound, [range word]): (owner,
+    address) — see _rptr."""
+    return (stats, stats.data_ptr() + 20 * stats.shape[1])
 
 
 def _partials_of(x, training):
@@ -1250,18 +1280,25 @@ class _BatchNormFn(torch.autograd.Function):
         m = x.numel() // c
         planes_only = bool(planes_only and emit_planes and not dropout)
         y = _placeholder(x.shape, x.device) if planes_only else torch.empty_like(x)
-        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        # mean, rstd, scale, shift; in training also row 4 = the per-channel bounds of |y| and row 5 = y's range slot (first word)
+        ranged = bool(training and c % 4 == 0 and not dropout and not _BN_SCALAR)
+        stats = torch.empty((6 if ranged else 4, c), device=x.device, dtype=torch.float32)
         yk = None if (emit_planes or dropout) else y                         # planes / dropout: statistics first, then one pass
         if training:
-            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, yk, stats, moving_mean, moving_var, partials)
+            _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, yk, stats, moving_mean, moving_var, partials, with_range=ranged)
         else:
             check(lib.embnet_bn_infer_fwd(ptr(x), m, c, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps,
                                           int(relu), ptr(yk), (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), stream()))
         if emit_planes:
             planes = torch.empty(3 * x.numel(), device=x.device, dtype=torch.int16)
-            check(lib.embnet_affine_act_planes(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
-                                               None if planes_only else ptr(y), ptr(planes), stream()))
+            # the planes' scale: from the bounds (training) — or, without them (inference statistics), from a dry run of the pass
+            check(lib.embnet_affine_act_planes_ex(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
+                                                  None if planes_only else ptr(y), ptr(planes),
+                                                  (stats.data_ptr() + 16 * c) if ranged else None,
+                                                  (stats.data_ptr() + 20 * c) if (ranged and not planes_only) else None, stream()))
             _ACT_PLANES[y.data_ptr()] = planes
+        if ranged and not planes_only:
+            _ACT_RANGE[y.data_ptr()] = _stats_range(stats)
         ctx.dropout = None
         if dropout:
             rate, seed = dropout
@@ -1314,11 +1351,12 @@ class _BatchNormFn(torch.autograd.Function):
         if (hit is not None and hit[2] == x.data_ptr() and hit[3].shape == dy.shape and ctx.training and c % 4 == 0
                 and not inrelu and drop is None):
             # dy is the data gradient of the conv behind this layer, which already produced the column sums
+            dxr = None
             if getattr(ctx, "emit_dx_range", False) and not only and (planes is None or _planes_range_ok(x)):
-                _emit_dx_range(dx)
-            check(lib.embnet_bn_bwd_partials(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
-                                             int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
-                                             stream()))
+                dxr = _emit_dx_range(dx)
+            check(lib.embnet_bn_bwd_partials_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
+                                                int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
+                                                ptr(dxr), stream()))
             dgamma, dbeta = finish()
             return (dx, dgamma, dbeta) + (None,) * 15
         if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
@@ -1342,11 +1380,12 @@ class _BatchNormFn(torch.autograd.Function):
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
         else:
+            dxr = None
             if getattr(ctx, "emit_dx_range", False) and not only and (planes is None or _planes_range_ok(x)):
-                _emit_dx_range(dx)
-            check(lib.embnet_bn_bwd(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
-                                    int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
-                                    ws.numel() * 4, stream()))
+                dxr = _emit_dx_range(dx)
+            check(lib.embnet_bn_bwd_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
+                                       int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
+                                       ws.numel() * 4, ptr(dxr), stream()))
         dgamma, dbeta = finish()
         return (dx, dgamma, dbeta) + (None,) * 15
 
@@ -1690,6 +1729,9 @@ class BatchNormalization(nn.Module):
             src = _BN_FWD_STATS.pop(y.data_ptr(), None)
             if src is not None and torch.is_grad_enabled():
                 y._bn_src = src
+            rng = _ACT_RANGE.pop(y.data_ptr(), None)       # the range slot of y (an upper bound of max |y|) for the convs that read it
+            if rng is not None:
+                y._range = rng
 
         if planes_for is not None and not defer and planes_for.patch_capable(x.shape):
             y_only = bool(sole and PLANES_ONLY[0] and planes_for.planes_only_input(x.shape))
@@ -1776,19 +1818,20 @@ class _InputBNConvFn(torch.autograd.Function):
         else:
             xp, beta_p, mm_p, mv_p, w_p = x, beta, moving_mean, moving_var, w
         a = torch.empty_like(xp)
-        stats = torch.empty((4, cp), device=x.device, dtype=torch.float32)
-        _bn_train_fwd(xp, m, cp, None, beta_p, eps, momentum, 0, a, stats, mm_p, mv_p)
+        ranged = w_range is not None and cp % 4 == 0
+        stats = torch.empty((6 if ranged else 4, cp), device=x.device, dtype=torch.float32)
+        _bn_train_fwd(xp, m, cp, None, beta_p, eps, momentum, 0, a, stats, mm_p, mv_p, with_range=ranged)
+        a_range = _stats_range(stats) if ranged else None
         if cp != c:                                # the pad channel is identically 0 after BN (x=0, beta=0)
             moving_mean.copy_(mm_p[:c])
             moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
-        if w_range is not None:
-            check(lib.embnet_conv2d_ranges(None, ptr(w_range)))
-        check(lib.embnet_conv2d_fwd_f32(
+        check(lib.embnet_conv2d_fwd_f32_ex(
             ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
-            ptr(out_stats), ptr(cws), cws.numel() * 4, stream()))
+            ptr(out_stats), ptr(cws), cws.numel() * 4, _rptr(a_range), _rptr(w_range) if a_range is not None else None, stream()))
         ctx.w_range = w_range
+        ctx.a_range = a_range
         ctx.geom, ctx.c, ctx.zero_sum_dy = geom, c, bool(zero_sum_dy)
         ctx.beta_ref = beta
         ctx.save_for_backward(a, w)
@@ -1804,12 +1847,11 @@ class _InputBNConvFn(torch.autograd.Function):
         dy = _c(dy)
         dw_p = torch.empty((r, s, cp, k), device=a.device, dtype=torch.float32)
         ws = workspace(lib.embnet_conv2d_wgrad_workspace_bytes(n, cp, r, s, k, oh, ow), a.device)
-        dy_range = _take_dy_range(dy) if getattr(ctx, "w_range", None) is not None else None
-        if dy_range is not None:
-            check(lib.embnet_conv2d_ranges(None, ptr(dy_range)))
-        check(lib.embnet_conv2d_wgrad_f32(
+        a_range = getattr(ctx, "a_range", None)
+        dy_range = _take_dy_range(dy) if (getattr(ctx, "w_range", None) is not None and a_range is not None) else None
+        check(lib.embnet_conv2d_wgrad_f32_ex(
             ptr(a), ptr(dy), ptr(dw_p), ptr(ws), ws.numel() * 4, n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow,
-            None, None, 0, stream()))
+            None, None, 0, _rptr(a_range) if dy_range is not None else None, _rptr(dy_range), stream()))
         if cp == c:
             dw = dw_p
         else:
@@ -1972,12 +2014,11 @@ class _BNActMaxPoolFn(torch.autograd.Function):
         ws = workspace(lib.embnet_bn_act_maxpool_bwd_workspace_bytes(n, oh, ow, c), x.device)
         mean = stats.data_ptr() if training else None
         rstd = (stats.data_ptr() + 4 * stats.shape[1]) if training else None
-        if getattr(ctx, "emit_dx_range", False):
-            _emit_dx_range(dx)
-        check(lib.embnet_bn_act_maxpool_bwd(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
-                                            (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), act, int(training),
-                                            ptr(xwin) if training else None, ptr(dx),
-                                            ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, stream()))
+        dxr = _emit_dx_range(dx) if getattr(ctx, "emit_dx_range", False) else None
+        check(lib.embnet_bn_act_maxpool_bwd_ex(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, mean, rstd,
+                                               (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]), act, int(training),
+                                               ptr(xwin) if training else None, ptr(dx),
+                                               ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, ptr(dxr), stream()))
         dgamma, dbeta = finish()
         return (dx, dgamma, dbeta) + (None,) * 11
 

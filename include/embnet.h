@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 20
+#define EMBNET_ABI_VERSION 21
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -151,7 +151,8 @@ int embnet_knn_vote(const int32_t* idx, const int32_t* labels, int rows, int k, 
  * K = 4608 forward: 3.3e-5 / -2.2e-5 (float32 CPU: 1.9e-5 / -1.4e-5: fp32 accumulation dominates there), data gradient
  * 2.3e-6 (6.7e-6), weight gradient 5.8e-7 (1.1e-7).  On operands with random mantissas the error is that of the fp32
  * MFMA's k-ordered fma chain (test_conv2d_products_are_fp32_accurate); on integer-valued operands results are exact.
- * The pieces keep fp32's exponent range (no overflow / underflow beyond fp32's own).  INFINITY: an infinite operand yields
+ * The three bf16 pieces of THIS (six-term) form keep fp32's exponent range (no overflow / underflow beyond fp32's own); the
+ * two-piece fp16 form of the *_ex entry points and of the planes kernels does not — its bound is stated under PRECISION below.  INFINITY: an infinite operand yields
  * NaN where an fp32 product would yield inf (inf - inf inside the split) — training has diverged by then either way.
  * embnet_conv_mfma_terms() = bf16 MFMA terms per product in this build (6), or 1 for a build on v_mfma_f32_32x32x2_f32.
  * x[n,h,w,c], w[r,s,c,k], y[n,oh,ow,k]; taps outside the image read 0 (pad_t/pad_l = top/left
@@ -224,31 +225,61 @@ int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow
  * captured graph.  slabs and out 16-byte aligned when n % 4 == 0. */
 int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream);
 
-/* ---- three products per fp32 product for the implicit-GEMM ("gather") convolutions above (ABI 20; csrc/conv.hip "Ranges") -------
+/* ---- three products per fp32 product for the implicit-GEMM ("gather") convolutions above (ABI 21; csrc/conv.hip "Ranges") -------
  * The layers of backbones.py:99-104 the patch kernels do not take — the 7x7 stem, the stride-2 3x3 convs, every 1x1 conv — split
- * their fp32 operands inside the kernel.  Given the RANGE of both operands they use the planes kernels' arithmetic (below: two fp16
- * pieces of x s, three products, the sums x 1 / (s s')) instead of three bf16 pieces and six products: half the matrix instructions.
- * A RANGE SLOT is one uint32 in device memory holding the bit pattern of max |element| of a tensor (0: unknown -> scale 1).
- *   embnet_range_emit(slot): the NEXT embnet_bn_bwd / embnet_bn_bwd_partials / embnet_bn_act_maxpool_bwd call of the calling
- *     thread also leaves the range of the fp32 dx it writes in slot[0].  `slot` has embnet_range_slot_words() words: the
- *     workgroups of the apply pass join their maxima into the words behind the first (zeroed by the finalize kernel; an
- *     order-independent unsigned maximum, spread over many words because same-address atomics serialise) and a one-workgroup
- *     launch folds them into slot[0].  The call fails if it cannot emit (planes-only dx, c % 4 != 0, no saved statistics).
- *   embnet_range_multi: ranges of many tensors (a model's kernels, once per optimizer step) in two launches; device table of
- *     24-byte rows { const float* x; int64 n; uint32* slot; }, chunk list int32 [n_chunks][2] = (row, chunk of
- *     embnet_range_chunk_elems() elements).
- *   embnet_conv2d_ranges(a, b): ranges of the first / second tensor argument (x, w | dy, w | x, dy) of the NEXT
- *     embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad, wgrad_slabs, wgrad_reduce}_f32 call of the calling thread; NULL = scale 1
- *     (activations behind a BatchNormalization: |x| << 65504, as for embnet_affine_act_planes).  The scale of a tensor puts its
- *     largest element into [2^14, 2^15); elements more than 2^29 below it fall into fp16's subnormals (absolute error <= 2^-39 of
- *     the maximum).  The call consumes the ranges whatever kernel it launches: the scalar-load kernels (c or k % 4 != 0), a fused
- *     input transform and the thin 1x1 streams compute as if none had been given.  Results differ from the six-term kernels' in
- *     the last bits (tests/test_conv_ranges_gpu.py: both against float64). */
+ * their fp32 operands inside the kernel.  Given the RANGE of BOTH operands they use the planes kernels' arithmetic (below: two fp16
+ * pieces of x s, three products, the sums x 1 / s x 1 / s') instead of three bf16 pieces and six products: half the matrix
+ * instructions.  Without either range a call computes the six-term products: there is NO default scale (ABI 20 ran activations at
+ * s = 1, which loses precision for tensors of amplitude << 2^-3 and clamps above 65504; see PRECISION under the planes format).
+ * A RANGE SLOT is one uint32 in device memory holding the bit pattern of a float B >= max |element| of a tensor (0: an all-zero
+ * tensor).  Who writes it:
+ *   kernels      embnet_range_multi: the exact maxima of many tensors (a model's kernels, once per optimizer step) in two launches;
+ *                device table of 24-byte rows { const float* x; int64 n; uint32* slot; }, chunk list int32 [n_chunks][2] = (row,
+ *                chunk of embnet_range_chunk_elems() elements);
+ *   gradients    `dx_range` of embnet_bn_bwd_ex / embnet_bn_bwd_partials_ex / embnet_bn_act_maxpool_bwd_ex: the exact max |dx| of the
+ *                fp32 dx the call writes.  The slot has embnet_range_slot_words() words: the workgroups of the apply pass join their
+ *                maxima into the words behind the first (zeroed by the finalize kernel; an order-independent unsigned maximum, spread
+ *                over many words because same-address atomics serialise) and a one-workgroup launch folds them into word 0.  The
+ *                call fails if it cannot emit (planes-only dx, c % 4 != 0, no saved statistics);
+ *   activations  `y_range` of embnet_bn_train_fwd_ex / embnet_affine_act_planes_ex: an UPPER BOUND of max |act(BN(x))|, known before
+ *                the apply pass runs — per channel |scale_c| sqrt(q_c) + |shift_c| with q_c the largest per-band sum of squares
+ *                among the statistics partials (>= max x^2), folded over the channels; above the true maximum by at most
+ *                sqrt(rows per band) (3.3 binades for a conv epilogue's bands), never below it.
+ * Who reads it: the last two pointer arguments (in front of `stream`) of embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad,
+ * wgrad_slabs}_f32_ex — the ranges of the call's first and second tensor argument (x, w | dy, w | x, dy); NULL = unknown.  The
+ * scale of a tensor puts B into [2^14, 2^15).  The scalar-load kernels (c or k % 4 != 0), a fused input transform and the thin
+ * 1x1 streams compute as if no range had been given.  Results differ from the six-term kernels' in the last bits
+ * (tests/test_conv_ranges_gpu.py: both against float64, activation amplitudes 1e-4 ... 1e5).
+ * DEPRECATED, kept for one round: embnet_range_emit(slot) and embnet_conv2d_ranges(a, b) arm the same slots for the NEXT non-_ex
+ * call of the calling thread (ABI 20) — hidden per-thread state: a binding in another language, a second stream on one thread or
+ * an exception between the two calls gets the wrong arithmetic silently.  Every conv / bn_bwd entry point clears the request. */
 int embnet_range_slot_words(void);
 int embnet_range_emit(uint32_t* slot);
 int embnet_range_chunk_elems(void);
 int embnet_range_multi(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);
 int embnet_conv2d_ranges(const uint32_t* a, const uint32_t* b);
+int embnet_conv2d_fwd_f32_ex(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int c,
+                             int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow, int relu,
+                             const float* residual, const float* in_scale, const float* in_shift, int in_act,
+                             float* stats, void* workspace, size_t workspace_bytes, const uint32_t* x_range,
+                             const uint32_t* w_range, void* stream);
+int embnet_conv2d_dgrad_f32_ex(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
+                               int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, const float* dx_add,
+                               void* workspace, size_t workspace_bytes, const uint32_t* dy_range, const uint32_t* w_range,
+                               void* stream);
+int embnet_conv2d_dgrad_bnsums_f32_ex(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
+                                      int k, int stride, int pad_t, int pad_l, int oh, int ow, const float* bn_x,
+                                      const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_rstd,
+                                      int bn_act, float* bn_partial, int bn_rows, void* workspace, size_t workspace_bytes,
+                                      const uint32_t* dy_range, const uint32_t* w_range, void* stream);
+int embnet_conv2d_wgrad_f32_ex(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                               int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                               int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                               const uint32_t* x_range, const uint32_t* dy_range, void* stream);
+int embnet_conv2d_wgrad_slabs_f32_ex(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                     int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l,
+                                     int oh, int ow, const float* in_scale, const float* in_shift, int in_act,
+                                     const uint32_t* x_range, const uint32_t* dy_range, void* stream);
 
 /* Which kernel symbol (as rocprofv3 names it) the conv entry points launch for a geometry:
  * kind 0 = fwd, 1 = dgrad, 2 = wgrad.  Host-only helper for attributing timings. */
@@ -273,10 +304,15 @@ int embnet_conv1x1_thin_supported(int red, int ncols);
  * and THREE products per fp32 product (h1 h1' + h1 h2' + h2 h1', v_mfma_f32_32x32x16_f16), the result x 1 / (s s') (exact).
  * Error on top of fp32 accumulation <= 2^-21 sum|x||y| (each operand kept to 2^-23 of itself, the dropped product <= 2^-22);
  * measured on the adversarial input above 4.1e-7 / 3.0e-7 / 1.7e-7 (forward / data gradient / weight gradient, K = 4608;
- * tests/test_round3_gpu.py::test_planes_split_worst_case, profiles/r05_split_worst_case_planes_*.json).  s: 1 for activations
- * (embnet_affine_act_planes; |x s| is clamped at 65504), from the tensor's own largest element for kernels (embnet_conv_weight_planes:
- * a max pass) and gradients (embnet_bn_bwd's dx_planes: a dry run of the pass; embnet_planes_from_f32: an abs-max pass) so that it
- * lands in [2^14, 2^15).
+ * tests/test_round3_gpu.py::test_planes_split_worst_case, profiles/r05_split_worst_case_planes_*.json).
+ * PRECISION.  s puts a bound B >= max |x| of the tensor into [2^14, 2^15).  Elements with |x s| >= 2^-3 (within 2^17 of B) are
+ * kept to 2^-22 of themselves; below, h2 is an fp16 subnormal and the element carries an ABSOLUTE error <= 2^-25 / s <= 2^-39 B
+ * — not a relative one: a tensor is only as precise as its largest element allows.  |x s| > 65504 cannot happen with a sound B and is
+ * not clamped: it overflows to inf / NaN, loudly.  Where B comes from: the tensor's own largest element for kernels
+ * (embnet_conv_weight_planes: a max pass) and gradients (embnet_bn_bwd's dx_planes: a dry run of the pass; embnet_planes_from_f32:
+ * an abs-max pass); for activations the BatchNormalization's output bound (embnet_affine_act_planes_ex `y_bound`: RANGE SLOT above)
+ * or, without one, a dry run of the pass.  (ABI 20 and earlier fixed s = 1 for activations: tensors of amplitude << 2^-3 sat on
+ * the subnormal floor — 1.8e-4 relative error at amplitude 1e-4)
  * The buffers keep the three-plane size below: planes 0 and 1 hold the pieces, the first two floats of the third plane's space
  * hold (s, 1 / s) (and a scratch word).  EMBNET_PLANES_F16=0: three bf16 pieces (exact split by truncation) and the six-term products documented above.
  *   planes of an activation / gradient x[pixels, c] (c % 16 == 0):  16-bit [3][c/16][pixels][16]  (piece, 16-channel chunk,
@@ -318,9 +354,14 @@ int embnet_planes_from_f32(const float* x, long pixels, int c, void* planes, voi
 int embnet_conv_weight_planes_chunk_elems(void);
 int embnet_conv_weight_planes(const void* table, int n_tensors, const int32_t* chunks, int n_chunks, void* stream);
 /* y (NULL or [m,c]) = act(x*scale + shift) as embnet_affine_act, AND the same values as planes: the BatchNormalization in
- * front of a patch convolution writes the convolution's operand in its final form. */
+ * front of a patch convolution writes the convolution's operand in its final form.
+ * _ex: y_bound (NULL or [c]: the per-channel bounds embnet_bn_train_fwd_ex left) gives the planes' scale without another look at
+ * the data; NULL (and the non-_ex form): a dry run of the pass finds the exact maximum first (+ 4 B per element read).
+ * y_range (NULL or a range slot, needs y): the bound (or the exact maximum) as the range slot of the fp32 y. */
 int embnet_affine_act_planes(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
                              void* planes, void* stream);
+int embnet_affine_act_planes_ex(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
+                                void* planes, const float* y_bound, uint32_t* y_range, void* stream);
 /* Weight gradient of a 3x3, stride-1, pad-1 ('same') convolution FROM THE PLANES (csrc/conv_wgrad_planes.hip):
  * dw[3,3,c,k] = sum over pixels of x[n,h,wd,c] (shifted by the tap) * dy[n,h,wd,k], both operands as planes (layout above).
  * Every operand byte is fetched once per (64 channels x 64 filters) tile and all nine taps are accumulated from one window
@@ -366,6 +407,13 @@ int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const
                         float momentum, int relu, float* y, float* save_mean, float* save_rstd, float* scale,
                         float* shift, float* moving_mean, float* moving_var, const float* partial_in,
                         int partial_rows, void* workspace, size_t workspace_bytes, void* stream);
+/* _ex: y_bound (NULL or [c]) receives, per channel, an upper bound of |act(scale_c x + shift_c)| over the batch (RANGE SLOT above);
+ * y_range (NULL or a range slot; needs y_bound and y): their maximum, as the range slot of y. */
+int embnet_bn_train_fwd_ex(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
+                           float momentum, int relu, float* y, float* save_mean, float* save_rstd, float* scale,
+                           float* shift, float* moving_mean, float* moving_var, const float* partial_in,
+                           int partial_rows, void* workspace, size_t workspace_bytes, float* y_bound, uint32_t* y_range,
+                           void* stream);
 int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
                         const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
                         float* scale, float* shift, void* stream);
@@ -374,6 +422,11 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                   float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
+/* _ex: dx_range (NULL or a range slot of embnet_range_slot_words() words) receives the exact max |dx| of the fp32 dx (RANGE SLOT). */
+int embnet_bn_bwd_ex(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                     const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
+                     float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, uint32_t* dx_range,
+                     void* stream);
 /* BatchNorm backward of a layer whose output is also globally average-pooled (the squeeze-and-excite block of the EfficientNet
  * MBConv, reference backbones.py:84-98): the output gradient is dy[n,p,c] + dpool[n,c] / hw; both passes form it on the fly with
  * embnet_gap_bwd's arithmetic (the result of embnet_gap_bwd(dx_add = dy) followed by embnet_bn_bwd to the last bits), so the
@@ -399,6 +452,10 @@ int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const float* gat
 int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                            const float* scale, const float* shift, int relu, const float* partials, int rows,
                            const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* stream);
+int embnet_bn_bwd_partials_ex(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                              const float* scale, const float* shift, int relu, const float* partials, int rows,
+                              const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, uint32_t* dx_range,
+                              void* stream);
 /* BatchNorm backward for a BN whose input x is the output of a layer with a fused ReLU (conv -> ReLU -> BN, the small
  * backbones' block): dz = d(x) * [x > 0] (the gradient the producer's data / weight gradients consume, ReLU backward
  * included) and dbias[c] = column sums of dz (the producer's bias gradient), in the pass that computes d(x).  c % 4 == 0. */
@@ -446,6 +503,11 @@ int embnet_bn_act_maxpool_bwd(const float* dy, const uint8_t* argmax, const floa
                               int stride, int pad, int oh, int ow, const float* save_mean, const float* save_rstd,
                               const float* scale, const float* shift, int act, int training, const float* xwin, float* dx,
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int embnet_bn_act_maxpool_bwd_ex(const float* dy, const uint8_t* argmax, const float* x, int n, int h, int w, int c, int k,
+                                 int stride, int pad, int oh, int ow, const float* save_mean, const float* save_rstd,
+                                 const float* scale, const float* shift, int act, int training, const float* xwin, float* dx,
+                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, uint32_t* dx_range,
+                                 void* stream);
 
 /* GlobalAveragePooling2D (backbones.py:111): x[n,hw,c] -> y[n,c]. */
 /* act(x*scale + shift) -> y AND its per-image channel means -> gap[n,c], one pass (the BatchNormalization + swish in front

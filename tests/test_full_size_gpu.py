@@ -134,6 +134,153 @@ def test_resnet18_full_batch_conv_geometries(dev):
         torch.cuda.empty_cache()
 
 
+# ---- the DEFAULT arithmetic at full size -------------------------------------------------------------------------
+# The tests above build bare Conv2D layers: six-term gather kernels.  The zoo ResNets run something else (backbones._rn_conv: f16 = True):
+# 3x3 stride-1 convs on the patch kernel / the planes weight gradient, every other conv on the three-product gather kernels — all of
+# them fed operand ranges / planes by the BatchNormalizations around them.  Here every geometry runs THAT way at the benchmark's
+# batch, with the hand-overs a BatchNormalization would make (input planes + range slot on the tensor, gradient planes / range slot
+# in the step context), slice by slice against the small-batch launches and slice 0 against the float64 oracle; the kernel trace
+# must hold no six-term conv kernel.
+def _range_slot(t):
+    from embeddingnet_amd import _lib
+    lib = _lib.lib()
+    slot = torch.zeros(lib.embnet_range_slot_words(), dtype=torch.int32, device=t.device)
+    table = torch.tensor([[t.data_ptr(), t.numel(), slot.data_ptr()]], dtype=torch.int64, device=t.device)
+    ce = lib.embnet_range_chunk_elems()
+    chunks = torch.tensor([(0, j) for j in range(-(-t.numel() // ce))], dtype=torch.int32, device=t.device)
+    _lib.check(lib.embnet_range_multi(table.data_ptr(), 1, chunks.data_ptr(), chunks.shape[0], _lib.stream()))
+    return slot
+
+
+def _planes(t):
+    from embeddingnet_amd import _lib
+    c = t.shape[-1]
+    p = torch.empty(3 * t.numel(), device=t.device, dtype=torch.int16)
+    _lib.check(_lib.lib().embnet_planes_from_f32(t.data_ptr(), t.numel() // c, c, p.data_ptr(), _lib.stream()))
+    return p
+
+
+def _run_default(layer, x, dy):
+    """forward + backward of a zoo-ResNet conv the way the net runs it: x carries its range (and planes, for a patch conv), dy's planes /
+    range wait in the step context under its address, as the BatchNormalization behind the conv would have left them."""
+    from embeddingnet_amd import layers as L
+    xt = x.clone().requires_grad_(True)
+    xt._range = _range_slot(xt)
+    if layer.patch_capable(xt.shape):
+        xt._planes = _planes(xt)
+    y = layer(xt)
+    layer.kernel.grad = None
+    dy = dy.contiguous()
+    if getattr(y, "_wants_dy_planes", False):
+        L.DY_PLANES[dy.data_ptr()] = (_planes(dy), dy)
+    if getattr(y, "_wants_dy_range", False):
+        L.DY_RANGE[dy.data_ptr()] = (_range_slot(dy), dy)
+    y.backward(dy)
+    assert not L.current_context().leftovers(), L.current_context().leftovers()
+    return y.detach(), xt.grad, layer.kernel.grad.clone()
+
+
+SIX_TERM = ("void embnet::conv_fwd_kernel<", "void embnet::conv_dgrad_kernel<", "void embnet::conv_wgrad_kernel<",
+            "void embnet::conv_fwd_tf_kernel<", "void embnet::conv_wgrad_tf_kernel<")
+
+
+def _slice_consistency_default(key, dev, n_full, n_piece, seed, oracle_slice0=True):
+    from embeddingnet_amd import _lib
+    kind, h, w, cin, k, cout, stride, padding = key
+    layer = _layer(key, dev, seed)
+    layer.f16 = True
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.relu(torch.randn((n_full, h, w, cin), device=dev, generator=gen)) * 0.05      # behind BatchNorm + ReLU, small gamma
+    y = _run(layer, x[:1])
+    dy = torch.randn((n_full,) + tuple(y.shape[1:]), device=dev, generator=gen) * 1e-5
+    _lib.trace_reset(); _lib.trace_enable(True)
+    try:
+        yf, dxf, dwf = _run_default(layer, x, dy)
+        names = [r[0] for r in _lib.trace_records()]
+    finally:
+        _lib.trace_enable(False)
+    assert not any(s.startswith(SIX_TERM) for s in names), (key, [s for s in names if s.startswith(SIX_TERM)])
+    assert any(("_h_kernel" in s or "conv_patch_kernel" in s) for s in names), (key, names)
+    dw_sum = torch.zeros_like(dwf, dtype=torch.float64)
+    for s in range(0, n_full, n_piece):
+        ys, dxs, dws = _run_default(layer, x[s:s + n_piece].contiguous(), dy[s:s + n_piece].contiguous())
+        # (the slices' operands carry their own ranges: another power-of-two scale, the same 22 bits — plus the K-split regrouping above)
+        assert rel(yf[s:s + n_piece], ys) < 5e-6, (key, "fwd", s)
+        assert rel(dxf[s:s + n_piece], dxs) < 5e-6, (key, "dgrad", s)
+        dw_sum += dws.double()
+        if s == 0 and oracle_slice0:
+            wt = layer.kernel.detach().cpu().double().requires_grad_(True)
+            ctx = OB.Ctx({"c/kernel": wt})
+            xr = x[:n_piece].cpu().double().requires_grad_(True)
+            yr = OB.conv2d(ctx, "c", xr, cout, k, stride=stride, padding=padding, bias=False)
+            yr.backward(dy[:n_piece].cpu().double())
+            assert rel(ys.cpu(), yr.detach()) < 2e-5, (key, "fwd vs oracle")
+            assert rel(dxs.cpu(), xr.grad) < 2e-5, (key, "dgrad vs oracle")
+            assert rel(dws.cpu(), wt.grad) < 2e-5 * max(1.0, (n_piece * h * w / stride ** 2 / 2048) ** 0.5), (key, "wgrad vs oracle")
+    assert rel(dwf, dw_sum) < 2e-5, (key, "wgrad", rel(dwf, dw_sum))
+
+
+def test_resnet18_full_batch_default_arithmetic(dev):
+    """C2: every conv geometry of ResNet18 @224 at batch 128 on the kernels the net runs (three products: patch / planes /
+    ranged gather kernels) vs 16 launches of 8 images; slice 0 of each against the float64 oracle."""
+    geoms = [g_ for g_ in _geometries("resnet18", dev) if g_[3] % 4 == 0]
+    geoms.append(("conv", 224, 224, 4, 7, 64, 2, 3))              # the fused stem's padded-channel conv0
+    assert len(geoms) >= 11, geoms
+    for i, key in enumerate(geoms):
+        _slice_consistency_default(key, dev, 128, 8, seed=400 + i)
+        torch.cuda.empty_cache()
+
+
+def test_resnet50_full_batch_default_arithmetic(dev):
+    """C3's backbone: every conv geometry of ResNet50 @224 at batch 256 (one Siamese branch) on the kernels the net runs, vs 16
+    launches of 16; slice 0 against the float64 oracle."""
+    geoms = [g_ for g_ in _geometries("resnet50", dev) if g_[3] % 4 == 0]
+    assert len(geoms) >= 19, geoms
+    for i, key in enumerate(geoms):
+        _slice_consistency_default(key, dev, 256, 16, seed=500 + i)
+        torch.cuda.empty_cache()
+
+
+def test_c2_full_size_training_step(dev):
+    """One C2 step at full size (ResNet18, 224x224, 32 x 4 = 128 images, 'hardest') through TripletTrainer: finite, bit for bit
+    repeatable from the same start, and its kernel trace holds no six-term conv kernel — the default arithmetic end to end."""
+    from embeddingnet_amd import _lib
+    from embeddingnet_amd import backbones as B
+    from embeddingnet_amd.optimizers import KerasOptimizer
+    from embeddingnet_amd.train_step import TripletTrainer
+
+    def run(trace):
+        base, _ = B.get_backbone((224, 224, 3), encodings_len=256, backbone_name="resnet18", backbone_weights=None, seed=3, device=dev)
+        base.train()
+        tr = TripletTrainer(base, KerasOptimizer(base.parameters(), "radam", 1e-4), 32, 4, margin=0.5, negatives_selection_mode="hardest",
+                            graph=False, seed=1)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        losses, names = [], []
+        for i in range(3):
+            x = torch.rand((128, 224, 224, 3), device=dev, generator=gen)
+            if trace and i == 1:
+                _lib.trace_reset(); _lib.trace_enable(True)
+            losses.append(float(tr.step(x)))
+            if trace and i == 1:
+                names = [r[0] for r in _lib.trace_records()]
+                _lib.trace_enable(False)
+        left = tr.ctx.leftovers()
+        unclaimed = dict(tr.ctx.unclaimed)
+        del tr, base
+        torch.cuda.empty_cache()
+        return losses, names, left, unclaimed
+
+    l1, names, left, unclaimed = run(True)
+    l2, _, _, _ = run(False)
+    assert all(np.isfinite(l1)) and l1 == l2, (l1, l2)
+    assert not left, left
+    print("unclaimed hand-overs over three steps:", unclaimed)
+    six = [s for s in names if s.startswith(SIX_TERM)]
+    assert not six, six
+    assert sum("conv_patch_kernel" in s for s in names) >= 26 and sum("conv_wgrad_planes_kernel" in s for s in names) >= 13, names
+    assert sum("_h_kernel" in s for s in names) >= 8 + 7 + 8, [s for s in names if "_h_kernel" in s]
+
+
 def test_resnet50_full_batch_conv_geometries(dev):
     """C3's backbone: every conv geometry of ResNet50 @224 at batch 256 (one Siamese branch) vs 16 launches of 16."""
     geoms = _geometries("resnet50", dev)
