@@ -94,6 +94,24 @@ def usable_cores():
     return n
 
 
+def cpu_classes_for(args):
+    """Classes per CPU-baseline step: the GPU step's own P x K where the host can hold the reference step's
+    activations — it trains THREE branches of up to P K (K - 1) / 2 mined triplets each (models.py:181-185), ~30 MB of fp32
+    activations per 224x224 ResNet18 image — else the largest P that fits half of the free memory; --cpu-classes overrides."""
+    if args.cpu_classes:
+        return args.cpu_classes
+    per_image = 30e6 * (args.image / 224.0) ** 2 * {"resnet50": 4.0, "efficientnet-b0": 2.5}.get(args.backbone, 1.0)
+    try:
+        import psutil
+        free = psutil.virtual_memory().available
+    except Exception:
+        free = 16e9
+    p = args.k_classes
+    while p > 2 and 3 * p * args.k_samples * (args.k_samples - 1) / 2 * per_image > 0.5 * free:
+        p //= 2
+    return p
+
+
 def cpu_baseline(args):
     """The oracle's reference-structured step (oracle/step.py) timed on this box's host cores, on a bounded sample:
     same backbone / resolution / K, batch reduced so that a step takes seconds."""
@@ -112,7 +130,7 @@ def cpu_baseline(args):
         what = (f"oracle/step.py SiameseReferenceStep (2 branch fwd/bwd + contrastive + {args.optimizer}) on torch-CPU fp32, "
                 f"{args.backbone} {args.image}x{args.image}, {b} pairs = {unique} images/step")
     else:
-        p, k = args.cpu_classes, args.k_samples
+        p, k = cpu_classes_for(args), args.k_samples
         ref = ReferenceStep(args.backbone, shape, args.encodings_len, p, k, args.margin,
                             args.mining if args.mining != "batch_hard" else "hardest", lr=args.lr, optimizer=args.optimizer)
         x = rs.rand(p * k, *shape).astype(np.float32)
@@ -123,7 +141,7 @@ def cpu_baseline(args):
                 f"unique images/step (the timed GPU step has {args.k_classes}x{k})")
     run(0)                                                        # warm-up (allocator, thread pool)
     t0, n = time.perf_counter(), 0
-    while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
+    while n < 2 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):     # at least two timed steps
         n += 1
         run(n)
     dt = (time.perf_counter() - t0) / n
@@ -236,9 +254,10 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-batch-hard", action="store_true", help="skip the secondary batch-hard timing behind a 'hardest' run")
     ap.add_argument("--no-graph", action="store_true", help="triplet step: do not capture the step into a HIP graph (N = 1)")
     ap.add_argument("--force-graph", action="store_true", help="triplet step: capture the step whatever the probe would decide (A/B)")
-    ap.add_argument("--cpu-classes", type=int, default=4)
+    ap.add_argument("--cpu-classes", type=int, default=0, help="classes per CPU-baseline step (0: the GPU step's own, memory permitting)")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--pool", type=int, default=0,
@@ -301,25 +320,24 @@ def main():
     reducer = GradReducer(params) if world > 1 else None
 
     tick = [0]                       # steps taken so far: step i runs on resident batch i mod pool
+    graph = (False if args.no_graph else True if args.force_graph else "auto")
     if args.mode == "siamese":
+        from embeddingnet_amd.train_step import SiameseTrainer
         model.train()
+        # the step as a trainer (its own step context, one-launch optimizer + planes refresh, HIP graph where the probe says the
+        # host cannot keep up: ResNet50's 900 launches take the host ~70-80 ms to enqueue)
+        trainer = SiameseTrainer(model, opt, contrastive_loss, seed=rank, reducer=reducer, graph=graph)
 
         def step():
             x1, x2 = x1s[tick[0] % pool], x2s[tick[0] % pool]
             tick[0] += 1
-            reducer.zero() if reducer is not None else opt.zero_grad(set_to_none=True)
-            loss = contrastive_loss(y, model([x1, x2])[0])
-            loss.backward()
-            if reducer is not None:
-                reducer.finish()
-            opt.step()
-            return loss.detach()
+            return trainer.step(x1, x2, y)
     else:
         # one GPU: the step is captured into a HIP graph after its warm-up steps (the host needs 2-4 ms to enqueue a step;
         # the small configs are otherwise host-bound); steps whose kernels are being timed run eagerly
         trainer = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin,
                                  negatives_selection_mode=args.mining, seed=rank, reducer=reducer,
-                                 graph=(False if args.no_graph else True if args.force_graph else "auto"))     # N > 1: two graphs around the all-reduce, every
+                                 graph=graph)     # N > 1: two graphs around the all-reduce, every
         # rank takes the same decision (TripletTrainer._agree)
         def step():
             tick[0] += 1
@@ -332,7 +350,7 @@ def main():
         torch.cuda.synchronize()
 
     n_warm = args.warmup
-    if args.mode != "siamese" and getattr(trainer, "graph_mode", False):
+    if getattr(trainer, "graph_mode", False):
         n_warm = max(n_warm, trainer.GRAPH_WARMUP + 8)     # the probe + capture (once, after GRAPH_WARMUP eager steps) stay untimed
     for _ in range(n_warm):
         step()
@@ -346,7 +364,9 @@ def main():
     # A traced C2 step costs ~1.4 ms more than a plain one (13 121 images/s timed with three of 50 steps traced vs 13 235 in
     # the untraced leg), so the number of traced steps follows the length of the timed region: 1 below 40 steps, 2 below
     # 80, else 3 — spread evenly, never the first step.
-    n_traced = 1 if args.steps < 40 else 2 if args.steps < 80 else 3
+    # Round 6: never fewer than three traced steps (a per-kernel average over ONE step is one box's one moment); at
+    # --steps 20 they cost ~2 % of `value`, which is then an under-statement, not an over-statement.
+    n_traced = min(3, max(args.steps - 1, 1))
     traced_at = {(j + 1) * args.steps // (n_traced + 1) for j in range(n_traced)}
     if trace:
         _lib.trace_reset()
@@ -390,6 +410,32 @@ def main():
             sus = float(t.item())
         sustained = {"steps": n_sus, "seconds": round(sus, 3), "ms_per_step": round(1e3 * sus / n_sus, 3),
                      "images_per_sec": round(n_local * world * n_sus / sus, 2)}
+    # BASELINE.json's metric string says "triplet batch-hard": the headline line runs the reference's own rule for it ('hardest',
+    # datagenerators.py:188-190 — SURVEY's C2); the Hermans batch-hard rule (README.md:112 of the reference cites the paper) is
+    # timed here in the SAME process on the same model and batches, as a secondary value — never `value`.
+    batch_hard = None
+    if args.mode == "triplet" and args.mining == "hardest" and not args.no_batch_hard:
+        tr2 = TripletTrainer(model, opt, args.k_classes, args.k_samples, margin=args.margin, negatives_selection_mode="batch_hard",
+                             seed=rank, reducer=reducer, graph=graph)
+        n2 = max(args.steps, 20)
+        for _ in range(max(5, (tr2.GRAPH_WARMUP + 8) if tr2.graph_mode else 0)):
+            tick[0] += 1
+            tr2.step(batches[(tick[0] - 1) % pool])
+        barrier()
+        b0 = time.perf_counter()
+        for _ in range(n2):
+            tick[0] += 1
+            bh_loss = tr2.step(batches[(tick[0] - 1) % pool])
+        barrier()
+        bh = time.perf_counter() - b0
+        if world > 1:
+            t = torch.tensor([bh], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bh = float(t.item())
+        batch_hard = {"mining": "batch_hard (Hermans et al.: hardest positive and hardest negative per anchor)", "steps": n2,
+                      "ms_per_step": round(1e3 * bh / n2, 3), "images_per_sec": round(n_local * world * n2 / bh, 2),
+                      "step_mode": "hip graph" if getattr(tr2, "_graph", None) is not None else "eager",
+                      "last_loss": float(bh_loss.item()), "active_triplets_last": int(tr2.last_triplets[1][0].item())}
     host_all = [host_ms]
     if world > 1:                                             # every rank's host enqueue time (8 Python launch threads share the node's cores)
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -410,8 +456,7 @@ def main():
         dead = t.item() > 0.5
     # per-rank record for rank 0's log: device, core affinity, step mode, how the gradient mean is taken
     mine = {"rank": rank, "device": f"{torch.cuda.get_device_name(dev)} [{dev.index}]", "affinity": _PIN,
-            "step_mode": ("siamese eager" if args.mode == "siamese" else
-                          ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),
+            "step_mode": ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager"),
             "gradient_mean": reducer.mean_mode if reducer is not None else None, "host_enqueue_ms": round(host_ms, 3)}
     ranks_info = [mine]
     if world > 1:
@@ -427,14 +472,13 @@ def main():
         for r in ranks_info:
             log(f"  rank {r['rank']}: {r['device']}, {r['affinity']}, step {r['step_mode']}, gradient mean: {r['gradient_mean']}, "
                 f"host enqueue {r['host_enqueue_ms']} ms/step")
-    if args.mode != "siamese":
-        log(f"  step mode: {'HIP graph replay' if getattr(trainer, '_graph', None) is not None else 'eager'}"
-            + (f" (capture failed: {trainer._graph_error})" if getattr(trainer, "_graph_failed", False) else "")
-            + (f"  probe: {trainer.graph_probe}" if getattr(trainer, "graph_probe", None) else ""))
+    log(f"  step mode: {'HIP graph replay' if getattr(trainer, '_graph', None) is not None else 'eager'}"
+        + (f" (capture failed: {trainer._graph_error})" if getattr(trainer, "_graph_failed", False) else "")
+        + (f"  probe: {trainer.graph_probe}" if getattr(trainer, "graph_probe", None) else ""))
     # the enqueue loop blocks once the HIP queue is full, so on a GPU-bound step its time approaches the step time; the host
     # WORK per step is what the trainer's probe measured on an idle queue (graph_probe['host_ms'], triplet mode)
-    replayed = args.mode != "siamese" and getattr(trainer, "_graph", None) is not None      # a replayed step has no per-kernel host work
-    probe_host = (getattr(trainer, "graph_probe", None) or {}).get("host_ms") if (args.mode != "siamese" and not replayed) else None
+    replayed = getattr(trainer, "_graph", None) is not None      # a replayed step has no per-kernel host work
+    probe_host = (getattr(trainer, "graph_probe", None) or {}).get("host_ms") if not replayed else None
     host_work = probe_host if probe_host is not None else host_ms
     log(f"  enqueue loop {host_ms:.2f} ms/step" + (f", host work {probe_host:.2f} ms/step (probe, idle queue)" if probe_host is not None else "")
         + f", step {ms_per_step:.2f} ms ({'GPU' if host_work < 0.9 * ms_per_step else 'host'}-bound)")
@@ -443,8 +487,14 @@ def main():
         roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at), ms_per_step, args.config,
                                           _lib.lib().embnet_conv_mfma_terms(), _lib.lib().embnet_conv_planes_mfma_terms())
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
-            roofline["end_to_end_frac_of_mfma_peak"] = round(value / world * 6 * FWD_GMAC[args.backbone] * 1e9 /
-                                                             (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+            # the whole step's algorithmic FLOP against (a) the fp32-MFMA ceiling SURVEY 8(d) names — it can exceed 1: the convs
+            # execute as 16-bit MFMA terms — and (b) the peak of the instruction they execute on, x the terms executed per product
+            # (3 on the ResNets' default path): the fraction of the chip's matrix rate the STEP uses
+            e2e = value / world * 6 * FWD_GMAC[args.backbone] * 1e9
+            roofline["end_to_end_frac_of_mfma_peak"] = round(e2e / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)
+            terms = _lib.lib().embnet_conv_planes_mfma_terms() if args.backbone.startswith("resnet") else _lib.lib().embnet_conv_mfma_terms()
+            roofline["end_to_end_executed_terms"] = terms
+            roofline["end_to_end_frac_of_executed_peak"] = round(terms * e2e / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)
     SPLIT_NOTE = ("3x3 stride-1 convs and their weight gradients, and the ResNets' other convs where both operands' ranges are known: two fp16 "
                   "pieces + a per-tensor power-of-two scale, 3 terms; other convs: "
                   "three bf16 pieces, 6 terms" if _lib.lib().embnet_conv_planes_mfma_terms() == 3 else "three exact bf16 pieces, 6 terms")
@@ -469,11 +519,13 @@ def main():
         "config": {"workload": workload, "baseline_config": args.config, "global_batch": n_local * world,
                    "parallelism": f"dp{world}", "final_loss": float(loss.item()), **live,
                    "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_ms_per_step_by_rank": host_all,
-                   "step_mode": ("siamese eager" if args.mode == "siamese" else
-                                 ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager")),
+                   "step_mode": ("hip graph" if getattr(trainer, "_graph", None) is not None else "eager"),
+                   "host_work_ms_per_step": (round(probe_host, 3) if probe_host is not None else None),
+                   "graph_probe": getattr(trainer, "graph_probe", None),
                    "mining": getattr(args, "mining", None) if args.mode != "siamese" else None,
                    "ranks": ranks_info if world > 1 else None,
                    "sustained": sustained,
+                   "batch_hard": batch_hard,
                    "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
                    "sustained_over_timed": round(sustained["ms_per_step"] / ms_per_step, 4) if sustained else None},
         "roofline": roofline,

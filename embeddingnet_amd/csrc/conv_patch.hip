@@ -108,7 +108,12 @@ __device__ __forceinline__ void step_planes(const bf16x8 (&a)[G::TM][NP], const 
 // 64 extra epilogue registers and scalar spills cost the plain kernel ~10 % when both forms share one body
 // F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): NP = 2 planes are fetched, held in LDS and read,
 // three matrix products per step instead of six, the accumulators x 1 / (s_x s_w) in the epilogue
-template <int BN, int R, int S, int TPS, int NBS, bool BNS = false, bool F16 = false>
+// PIPE (F16 only): the MFMA waves read the fragments of tap t + 1 while the matrix pipe works on tap t (two fragment sets in
+// registers, reads and MFMAs interleaved one to one by sched_group_barrier), across the step barriers too for the patch fragments
+// (the patch of a chunk stays put for its nine taps; only the weights of a step become valid at its barrier).  The plain loop reads
+// a tap's eight fragments and then multiplies: hipcc serialises it into read - wait - 2 MFMAs - wait - 2 MFMAs ... with three to
+// four exposed LDS round trips per 12 MFMAs (r05: 43 % MFMA-busy at 2.3 GHz).  DESIGN 3.14.
+template <int BN, int R, int S, int TPS, int NBS, bool BNS = false, bool F16 = false, bool PIPE = false>
 __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
   using G = GeomP<BN>;
   constexpr int NP = F16 ? 2 : 3;
@@ -251,6 +256,58 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int cc = cur.cc_b; cc < cur.cc_e; ++cc) {
       const unsigned char* pbuf = smem + (gc & 1) * PB;
+      if constexpr (F16 && PIPE) {
+        // all R * S taps of the chunk unrolled; fragment set (t & 1) holds tap t.  A fragments (patch) of tap t + 1 are requested
+        // during tap t whatever step t + 1 belongs to; B fragments (weights) of the first tap of a step right behind its barrier.
+        f16x8 fa[2][TM][2], fb[2][TN][2];
+        auto load_a = [&](int tap, f16x8 (&a)[TM][2]) {
+          const int r = tap / S, s2 = tap % S;
+#pragma unroll
+          for (int im = 0; im < TM; ++im) {
+            const int idx = rowidx[im] + r * PW + s2;
+            const unsigned char* ap = pbuf + idx * 32 + ((h ^ ((idx >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a[im][q] = *reinterpret_cast<const f16x8*>(ap + q * PLP);
+          }
+        };
+        auto load_b = [&](const unsigned char* bs, int tp, f16x8 (&b)[TN][2]) {
+#pragma unroll
+          for (int in = 0; in < TN; ++in) {
+            const int row = wn + in * 32 + (lane & 31);
+            const unsigned char* bp = bs + (tp * 2 * BN + row) * 32 + ((h ^ ((row >> 3) & 1)) << 4);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) b[in][q] = *reinterpret_cast<const f16x8*>(bp + q * BN * 32);
+          }
+        };
+        constexpr int NT = R * S, NRD = 2 * (TM + TN), NMF = 3 * TM * TN;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int tp = t % TPS;
+          if (tp == 0) {
+            __syncthreads();           // barrier #gs: this step's weights (and, at t = 0, this chunk's patch) are in LDS
+            if (t == 0) load_a(0, fa[0]);
+            load_b(bslot0 + (gs % NBS) * SBY, 0, fb[t & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const unsigned char* bs = bslot0 + (gs % NBS) * SBY;
+          const bool nxt_a = t + 1 < NT, nxt_b = tp + 1 < TPS;
+          if (nxt_a) load_a(t + 1, fa[(t + 1) & 1]);
+          if (nxt_b) load_b(bs, tp + 1, fb[(t + 1) & 1]);
+          mfma_step_h<TM, TN>(fa[t & 1], fb[t & 1], acc);
+          // one fragment read per matrix instruction while there are reads, then the remaining matrix instructions
+          constexpr int NR_AB = NRD, NR_A = 2 * TM;
+          const int nr = (nxt_a ? NR_A : 0) + (nxt_b ? NR_AB - NR_A : 0);
+#pragma unroll
+          for (int i = 0; i < NMF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (tp == TPS - 1) ++gs;
+        }
+        ++gc;
+        continue;
+      }
 #pragma unroll 1
       for (int st = 0; st < SPC; ++st) {
         __syncthreads();             // barrier #gs: this step's weights (and, at st = 0, this chunk's patch) are in LDS
@@ -619,10 +676,12 @@ extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const
   return check_launch("conv_weight_planes");
 }
 
+static bool patch_pipe() { static const bool v = env_long("EMBNET_PATCH_PIPE", 1) != 0; return v; }   // 0: the plain loop (A/B)
 template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
   static bool once = false;
   if (!once) {
+    (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -631,6 +690,7 @@ static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
   }
   if (planes_f16()) {
     if (p.bn.x) conv_patch_kernel<BN, 3, 3, TPS, NBS, true, true><<<p.grid, 640, lds, st>>>(p);
+    else if (patch_pipe()) conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true, true><<<p.grid, 640, lds, st>>>(p);
     else conv_patch_kernel<BN, 3, 3, TPS, NBS, false, true><<<p.grid, 640, lds, st>>>(p);
     return;
   }
@@ -663,7 +723,7 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
     // (the names rocprofv3 prints: bench.py looks the kernel's measured HBM traffic up by them)
     static thread_local char kname[160];
     snprintf(kname, sizeof kname, "void embnet::patch::conv_patch_kernel<%d, 3, 3, %d, %d, %s%s>(embnet::patch::PatchParams)", pl.bn, pl.tps, pl.nbs,
-             p.bn.x ? "true" : "false", planes_f16() ? ", true" : "");
+             p.bn.x ? "true" : "false", planes_f16() ? ((patch_pipe() && !p.bn.x) ? ", true, true" : ", true") : "");
     EMBNET_TRACE_FLOP(kname,
                       2.0 * M * k * r * s * c,
                       (planes_f16() ? 4.0 : 6.0) * ((double)n * h * wd * c + (double)r * s * c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);

@@ -357,7 +357,7 @@ __device__ __forceinline__ Split4H split4h(const float4 v, float s) {
   return r;
 }
 // (s, 1 / s) for a tensor whose largest |element| is at most `bound`: bound * s lands in [2^14, 2^15).  bound = 0 (an all-zero
-// tensor), infinite or NaN: s = 1 (nothing to scale / the values are poisoned anyway and stay so).  |k| <= 110 keeps s and 1 / s
+// tensor), infinite or NaN: s = 1 (nothing to scale / the values are poisoned anyway and stay so).  |k| <= 126 keeps s and 1 / s
 // normal numbers; consumers multiply their sums by the two operands' 1 / s ONE AFTER THE OTHER (the product of two of them may not
 // be representable although the result is).
 __device__ __forceinline__ int scale_exponent_of(float bound) {
@@ -365,7 +365,7 @@ __device__ __forceinline__ int scale_exponent_of(float bound) {
   const int e = (int)(bits >> 23);                       // bound = f 2^(e - 127), f in [1, 2)  (e = 0: subnormal)
   if (bits == 0u || e >= 255) return 0;
   const int k = 141 - (e > 1 ? e : 1);
-  return k > 110 ? 110 : (k < -110 ? -110 : k);
+  return k > 126 ? 126 : (k < -126 ? -126 : k);
 }
 __device__ __forceinline__ float2 scale_pair(int k) {
   return make_float2(__uint_as_float((uint32_t)(127 + k) << 23), __uint_as_float((uint32_t)(127 - k) << 23));

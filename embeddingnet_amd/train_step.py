@@ -120,13 +120,13 @@ class TripletTrainer:
         self._drops = [m for m in self.model.modules() if isinstance(m, (L.Dropout, L.DropConnect))]
         self._ring_np = self._ring.numpy()                                        # same memory
         self._ring_pos, self._ring_events = 0, [None, None]
-        self._gx = torch.empty_like(images)
+        self._gx = self._inputs_like(images)
         self.opt.coef_dev = self._state
         self.opt.prepare_capture()
         it0, st0 = self.opt.iterations, self.step_no
         drop_steps = [m._step for m in self._drops]
         try:
-            self._gx.copy_(images)
+            self._inputs_copy(images)
             self.step_no += 1
             self._push_state()
             g = torch.cuda.CUDAGraph()
@@ -151,7 +151,7 @@ class TripletTrainer:
                 L.GRAPH_TICK = None
                 if self.reducer is not None:
                     self.reducer.hold(False)
-            self._g_last = (self.last_triplets, self.last_total)     # the replayed step's (static) output tensors
+            self._g_last = (getattr(self, "last_triplets", None), self.last_total)     # the replayed step's (static) output tensors
             self._graph = g
         except Exception as exc:                                                  # stay correct: eager from here on
             self._graph, self._graph_failed, self._state = None, True, None
@@ -167,8 +167,19 @@ class TripletTrainer:
             for m, st in zip(self._drops, drop_steps):
                 m._step = st
 
-    def _replay(self, images):
+    # the step's inputs: one image batch here; SiameseTrainer packs (x1, x2, y)
+    @staticmethod
+    def _inputs_like(images):
+        return torch.empty_like(images)
+
+    def _inputs_copy(self, images):
         self._gx.copy_(images)
+
+    def _inputs_match(self, images):
+        return images.shape == self._gx.shape
+
+    def _replay(self, images):
+        self._inputs_copy(images)
         self.step_no += 1
         self._push_state()
         self.opt.iterations += 1
@@ -242,7 +253,7 @@ class TripletTrainer:
     def step(self, images):
         from . import _lib
         if self.graph_mode and not self._graph_failed and not _lib.trace_is_enabled():
-            if self._graph is not None and images.shape == self._gx.shape:
+            if self._graph is not None and self._inputs_match(images):
                 return self._replay(images)
             if self._graph is None and self.step_no >= self.GRAPH_WARMUP:
                 if self.graph_mode == "auto":
@@ -260,7 +271,7 @@ class TripletTrainer:
                             self.opt.coef_dev = None
                     elif self.reducer is not None:
                         self.graph_mode = False
-                if self._graph is not None and images.shape == self._gx.shape:
+                if self._graph is not None and self._inputs_match(images):
                     return self._replay(images)
         return self._plain_step(images)
 
@@ -313,3 +324,60 @@ class TripletTrainer:
             self.opt.step()
             L.refresh_weight_planes(self.model)     # bf16 planes of the patch convs' kernels, one launch (layers.py)
         return mean.detach()
+
+
+class SiameseTrainer(TripletTrainer):
+    """The Siamese training step (reference models.py:192-236 + tools/train.py:108-119: `model.fit` of SiameseNet.model with
+    contrastive_loss on the first output) with TripletTrainer's machinery: its own step context, the weight-gradient slab sums
+    deferred to one launch per flush, the KerasOptimizer's one-launch update with the kernel planes / ranges refreshed behind it,
+    and — graph=True / 'auto' — the whole step (two branch forwards, pair distance, loss, backward with the two branches' gradient
+    accumulation, optimizer) captured once into a HIP graph and replayed: ResNet50 at 256 pairs is 900 launches per step that the
+    host needs 79 ms to enqueue against 85-89 ms of kernels (profiles/r05_final_bench_c3_kernels.txt) — any faster kernel makes the
+    eager step host-bound.  `graph_probe` (graph='auto') reports the eager step's host work like TripletTrainer's.
+
+    siamese_model: SiameseNet.model ([x1, x2] -> [distance, cls1, cls2]); loss_fn(y_true, distance) -> scalar (contrastive_loss).
+    step(x1, x2, y) -> the loss of the step (detached)."""
+
+    def __init__(self, siamese_model, optimizer, loss_fn=None, seed=0, reducer=None, graph=None):
+        from .optimizers import KerasOptimizer
+        env = os.environ.get("EMBNET_GRAPH", "0")
+        self.graph_mode = ({"1": True, "auto": "auto"}.get(env, False)) if graph is None else (graph if graph == "auto" else bool(graph))
+        self._graph, self._graph_failed = None, False
+        self.model, self.opt = siamese_model, optimizer
+        self.seed, self.step_no, self.reducer = int(seed), 0, reducer
+        self.ctx = L.StepContext(f"SiameseTrainer@{id(self):x}")
+        self.fused_loss = False
+        self.last_triplets = None
+        if loss_fn is None:
+            from .losses_and_accuracies import contrastive_loss as loss_fn
+        self.loss_fn = loss_fn
+        self._keras_opt = isinstance(optimizer, KerasOptimizer)
+        if self._keras_opt:
+            optimizer.set_l2(L.regularized_kernels(siamese_model))
+            if reducer is not None:
+                reducer.direct(False)         # two gradient contributions per shared parameter: autograd accumulates, no in-place sinks
+
+    def loss(self, inputs):
+        x1, x2, y = inputs
+        mean = self.loss_fn(y, self.model([x1, x2])[0])
+        reg = L.regularization_loss(self.model, with_grad=not self._keras_opt)
+        return (mean if reg is None else mean + reg), mean, None
+
+    def _graph_supported(self, inputs):
+        if not self._keras_opt:
+            return False
+        return self.opt.rule != "radam" or self.opt.iterations >= 6
+
+    @staticmethod
+    def _inputs_like(inputs):
+        return tuple(torch.empty_like(t) for t in inputs)
+
+    def _inputs_copy(self, inputs):
+        for d, t in zip(self._gx, inputs):
+            d.copy_(t)
+
+    def _inputs_match(self, inputs):
+        return len(inputs) == len(self._gx) and all(a.shape == b.shape for a, b in zip(inputs, self._gx))
+
+    def step(self, x1, x2, y):
+        return super().step((x1, x2, y))

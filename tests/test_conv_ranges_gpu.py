@@ -308,8 +308,10 @@ def test_resnet18_step_runs_its_gather_convs_on_three_products(dev):
     assert sum("conv_fwd_h_kernel" in s for s in h) >= 8, (h, six)
     assert sum("conv_wgrad_h_kernel" in s for s in h) >= 8 and sum("conv_dgrad_h_kernel" in s for s in h) >= 7, (h, six)
     assert not any("conv_fwd_kernel" in s for s in six), six
-    for a, b in zip(l3, l6):
-        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (l3, l6)
+    # same start: the first two losses agree to fp32 rounding; from the third on two Adam updates (sign-like for gradients near
+    # zero) separate the trajectories of ANY two arithmetics that differ in the last bits
+    for i, (a, b) in enumerate(zip(l3, l6)):
+        assert abs(a - b) <= (2e-5 if i < 2 else 2e-4) * max(abs(b), 1e-3), (l3, l6)
 
 
 def test_optimizer_step_leaves_kernel_ranges_and_planes_current(dev):
