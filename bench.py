@@ -139,7 +139,14 @@ def cpu_baseline(args):
         what = (f"oracle/step.py ReferenceStep (P predict() calls + f64 distance matrix + Python mining loop + 3-branch "
                 f"fwd/bwd + {args.optimizer}) on torch-CPU fp32, {args.backbone} {args.image}x{args.image}, batch {p}x{k}={unique} "
                 f"unique images/step (the timed GPU step has {args.k_classes}x{k})")
-    run(0)                                                        # warm-up (allocator, thread pool)
+    if args.mode != "siamese" and p > 4:
+        # warm-up (allocator, thread pool) on a 4-class batch: a full-size warm-up step is 20 s of a run that should take minutes
+        warm = ReferenceStep(args.backbone, shape, args.encodings_len, 4, k, args.margin,
+                             args.mining if args.mining != "batch_hard" else "hardest", lr=args.lr, optimizer=args.optimizer)
+        warm.step(x[:4 * k], rng=np.random.RandomState(0))
+        del warm
+    else:
+        run(0)                                                    # warm-up (allocator, thread pool)
     t0, n = time.perf_counter(), 0
     while n < 2 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):     # at least two timed steps
         n += 1

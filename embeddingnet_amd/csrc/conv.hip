@@ -382,12 +382,13 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[G::TM][G::TN],
 // (struct BnSums: conv_geom.h)
 
 __device__ __forceinline__ void bn_sums_add(int act, float4 v, float4 xq, float4 sc, float4 sh, float4 mu, float4 rs,
-                                            float4& s1, float4& s2) {      // the arithmetic of bn_bwd_reduce4_kernel
+                                            float4& s1, float4& s2, float4& s3) {      // the arithmetic of bn_bwd_reduce4_kernel
   float4 dz = v;
   if (act) {
     dz.x = act_grad(act, fmaf(xq.x, sc.x, sh.x), v.x); dz.y = act_grad(act, fmaf(xq.y, sc.y, sh.y), v.y);
     dz.z = act_grad(act, fmaf(xq.z, sc.z, sh.z), v.z); dz.w = act_grad(act, fmaf(xq.w, sc.w, sh.w), v.w);
   }
+  s3.x = fmaxf(s3.x, fabsf(dz.x)); s3.y = fmaxf(s3.y, fabsf(dz.y)); s3.z = fmaxf(s3.z, fabsf(dz.z)); s3.w = fmaxf(s3.w, fabsf(dz.w));
   s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
   s2.x = fmaf(dz.x, (xq.x - mu.x) * rs.x, s2.x); s2.y = fmaf(dz.y, (xq.y - mu.y) * rs.y, s2.y);
   s2.z = fmaf(dz.z, (xq.z - mu.z) * rs.z, s2.z); s2.w = fmaf(dz.w, (xq.w - mu.w) * rs.w, s2.w);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
                                                          const float* __restrict__ bias, int relu,
                                                          const float* __restrict__ residual, float* __restrict__ out,
                                                          float* __restrict__ stats, int stats_rows, const BnSums bsum) {
-  __shared__ float4 red[2][256];
+  __shared__ float4 red[3][256];
   const int cpb = 1024 / wtm, qpb = cpb / 4;              // columns / column quads per workgroup
   const int blocks_per_tile = bm * bn / 1024, col_groups = bn / cpb;
   const int t = blockIdx.x / blocks_per_tile, bi = blockIdx.x % blocks_per_tile;
@@ -422,17 +423,18 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
     *reinterpret_cast<float4*>(out + row * cols + col) = a;
   }
   if (bsum.x) {                                            // a data gradient's fix-up: the BatchNorm-backward sums of its tile rows
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
     if (in)
       bn_sums_add(bsum.act, a, *reinterpret_cast<const float4*>(bsum.x + row * cols + col),
                   *reinterpret_cast<const float4*>(bsum.scale + col), *reinterpret_cast<const float4*>(bsum.shift + col),
-                  *reinterpret_cast<const float4*>(bsum.mean + col), *reinterpret_cast<const float4*>(bsum.rstd + col), s1, s2);
-    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+                  *reinterpret_cast<const float4*>(bsum.mean + col), *reinterpret_cast<const float4*>(bsum.rstd + col), s1, s2, s3);
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = s3;
     stats = bsum.partial; stats_rows = bsum.rows;
   } else {
     if (!stats) return;
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+    red[2][threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   for (int s = wtm / 2; s >= 1; s >>= 1) {                // fixed tree over the band's rows
@@ -443,6 +445,9 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
         float4& d = red[w][threadIdx.x];
         d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w;
       }
+      const float4 o = red[2][threadIdx.x + s * qpb];
+      float4& d = red[2][threadIdx.x];
+      d.x = fmaxf(d.x, o.x); d.y = fmaxf(d.y, o.y); d.z = fmaxf(d.z, o.z); d.w = fmaxf(d.w, o.w);
     }
     __syncthreads();
   }
@@ -453,6 +458,11 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
     float* d2 = d1 + (long)cols * P;
     d1[0] = s1.x; d1[P] = s1.y; d1[2 * P] = s1.z; d1[3 * P] = s1.w;
     d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
+    if (bsum.x && bsum.kinds == 3) {
+      const float4 s3 = red[2][threadIdx.x];
+      float* d3 = d2 + (long)cols * P;
+      d3[0] = s3.x; d3[P] = s3.y; d3[2 * P] = s3.z; d3[3 * P] = s3.w;
+    }
   }
 }
 
@@ -609,7 +619,7 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
         if (p.accumulate || bnon) res[im][j] = *reinterpret_cast<const float4*>(pre + base[im][j] + (cok ? ecol : 0));
       }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 bsc = z4, bsh = z4, bmu = z4, brs = z4, s1 = z4, s2 = z4;
+    float4 bsc = z4, bsh = z4, bmu = z4, brs = z4, s1 = z4, s2 = z4, s3 = z4;
     if (bnon && cok) {
       bsc = *reinterpret_cast<const float4*>(p.bn.scale + ecol); bsh = *reinterpret_cast<const float4*>(p.bn.shift + ecol);
       bmu = *reinterpret_cast<const float4*>(p.bn.mean + ecol); brs = *reinterpret_cast<const float4*>(p.bn.rstd + ecol);
@@ -624,7 +634,7 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
     auto emit = [&](int im, int j, int col, float4 v) {
       if (p.accumulate) { const float4 o = res[im][j]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       *reinterpret_cast<float4*>(p.dx + base[im][j] + col) = v;
-      if (bnon) bn_sums_add(p.bn.act, v, res[im][j], bsc, bsh, bmu, brs, s1, s2);
+      if (bnon) bn_sums_add(p.bn.act, v, res[im][j], bsc, bsh, bmu, brs, s1, s2, s3);
     };
     if (m0 + G::BM <= M && n0 + G::BN <= p.g.C) {          // interior tile (wave-uniform): straight-line stores, no edge tests
       for_each_acc_row4_idx<G>(acc, smem, [&](int im, int j, int, int c, float4 v) { emit(im, j, n0 + c, v); });
@@ -635,7 +645,7 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
     }
     if (bnon) {                                            // partial (tile_m * WAVES_M + wave_m) of [2][C][rows], as the forward statistics
       constexpr int LPR = G::WTN / 4;
-      s1 = colquad_sum<LPR>(s1); s2 = colquad_sum<LPR>(s2);
+      s1 = colquad_sum<LPR>(s1); s2 = colquad_sum<LPR>(s2); s3 = colquad_max<LPR>(s3);
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int col = n0 + (wave % G::WAVES_N) * G::WTN + lane * 4;
       if (lane < LPR && col < p.g.C) {
@@ -644,6 +654,10 @@ __device__ __forceinline__ void conv_dgrad_body(const ConvDgradParams& p) {
         float* d2 = d1 + (long)p.g.C * P;
         d1[0] = s1.x; d1[P] = s1.y; d1[2 * P] = s1.z; d1[3 * P] = s1.w;
         d2[0] = s2.x; d2[P] = s2.y; d2[2 * P] = s2.z; d2[3 * P] = s2.w;
+        if (p.bn.kinds == 3) {                               // max |dz| of the band: the bound of the BatchNorm backward's dx
+          float* d3 = d2 + (long)p.g.C * P;
+          d3[0] = s3.x; d3[P] = s3.y; d3[2 * P] = s3.z; d3[3 * P] = s3.w;
+        }
       }
     }
     stamp(5);
@@ -1300,7 +1314,7 @@ static int conv2d_dgrad_bnsums_impl(const float* dy, const float* w, float* dx, 
                                     int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
                                     const float* bn_x, const float* bn_scale, const float* bn_shift,
                                     const float* bn_mean, const float* bn_rstd, int bn_act, float* bn_partial,
-                                    int bn_rows, void* workspace, size_t workspace_bytes, void* stream, const Ranges rg) {
+                                    int bn_rows, void* workspace, size_t workspace_bytes, void* stream, const Ranges rg, int kinds = 2) {
   EMBNET_CHECK_ARG(bn_x && bn_scale && bn_shift && bn_mean && bn_rstd && bn_partial, "conv2d_dgrad_bnsums: null pointer");
   EMBNET_CHECK_ARG(bn_rows > 0 && bn_rows == embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride),
                    "conv2d_dgrad_bnsums: rows %d for this geometry (see embnet_conv2d_dgrad_bnsums_rows)", bn_rows);
@@ -1308,7 +1322,7 @@ static int conv2d_dgrad_bnsums_impl(const float* dy, const float* w, float* dx, 
                    aligned16(dy) && aligned16(w), "conv2d_dgrad_bnsums: operands must be 16-byte aligned");
   EMBNET_CHECK_ARG(bn_act >= 0 && bn_act <= 2, "conv2d_dgrad_bnsums: activation code %d", bn_act);
   return conv2d_dgrad_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, 0, nullptr, workspace, workspace_bytes,
-                           stream, BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows}, rg);
+                           stream, BnSums{bn_x, bn_scale, bn_shift, bn_mean, bn_rstd, bn_act, bn_partial, bn_rows, kinds}, rg);
 }
 extern "C" int embnet_conv2d_dgrad_bnsums_f32(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r,
                                               int s, int k, int stride, int pad_t, int pad_l, int oh, int ow,
@@ -1326,7 +1340,7 @@ extern "C" int embnet_conv2d_dgrad_bnsums_f32_ex(const float* dy, const float* w
                                                  const uint32_t* dy_range, const uint32_t* w_range, void* stream) {
   (void)take_ranges();
   return conv2d_dgrad_bnsums_impl(dy, w, dx, n, h, wd, c, r, s, k, stride, pad_t, pad_l, oh, ow, bn_x, bn_scale, bn_shift, bn_mean,
-                                  bn_rstd, bn_act, bn_partial, bn_rows, workspace, workspace_bytes, stream, Ranges{dy_range, w_range});
+                                  bn_rstd, bn_act, bn_partial, bn_rows, workspace, workspace_bytes, stream, Ranges{dy_range, w_range}, 3);
 }
 
 // wgrad tiling: rows = R*S*C, cols = K; split the (n,oh,ow) reduction so the grid covers the chip

@@ -35,7 +35,9 @@ __device__ __forceinline__ void split_k(int kk, const FastDiv& dinner, const Fas
 
 // BatchNorm-backward sums riding on a data gradient (conv.hip's conv_dgrad_kernel / tail_fixup_kernel, conv_patch.hip's
 // epilogue): see the comment at conv.hip's bn_sums_add.  x == NULL: off.
-struct BnSums { const float* x; const float* scale; const float* shift; const float* mean; const float* rstd; int act; float* partial; int rows; };
+// kinds: 3 = partial has a THIRD plane [C][rows]: max |dz| per row band (the bound of the BatchNorm backward's dx, nn_kernels.hip
+// dx_channel_bound); 0 / 2 = the two sums only
+struct BnSums { const float* x; const float* scale; const float* shift; const float* mean; const float* rstd; int act; float* partial; int rows; int kinds; };
 
 // conv.hip: fix-up pass over left-over tiles computed as K-split partial tiles (used by conv.hip and conv_patch.hip)
 void launch_tail_fixup(const float* ws, int parts, int bm, int bn, int wtm, int n_full, int rem, int tiles_n, long m, int cols,

@@ -850,6 +850,16 @@ __device__ __forceinline__ float4 colquad_sum(float4 v) {
   return v;
 }
 
+template <int LPR>
+__device__ __forceinline__ float4 colquad_max(float4 v) {
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    v.x = fmaxf(v.x, __shfl_xor(v.x, o, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, o, 64));
+    v.z = fmaxf(v.z, __shfl_xor(v.z, o, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, o, 64));
+  }
+  return v;
+}
+
 // blockIdx.x -> (tile_m, tile_n) keeping the workgroups that share an XCD (ids equal mod 8)
 // on neighbouring tiles so they reuse operand panels in that XCD's L2.  Bijective for any count.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

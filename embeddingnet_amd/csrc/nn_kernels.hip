@@ -160,21 +160,28 @@ struct NoPrep { __device__ __forceinline__ int operator()(int) const { return 0;
 // F(row, quad, const K& k, float4& a, float4& b) with k = prep(quad): the per-channel constants of a column are fetched ONCE
 // per thread and column block, not once per row (bn_bwd_reduce4 issued four 16-byte constant loads beside the two data
 // loads of every element: 3.9 TB/s where the apply pass, two constant loads per element, reached 5.3)
-template <class P, class F>
-__device__ __forceinline__ void col_reduce2_v4p(long m, int c4, ColGeom g, float* __restrict__ partial, P prep, F f) {
-  __shared__ float4 sh4[2][256];
+template <class P, class F, bool MAX3 = false>
+__device__ __forceinline__ void col_reduce2_v4p(long m, int c4, ColGeom g, float* __restrict__ partial, P prep, F f,
+                                                float* __restrict__ pmax = nullptr) {
+  // MAX3: F takes a third accumulator, a running per-element MAXIMUM (>= 0); the block's maxima go to pmax[block][c]
+  __shared__ float4 sh4[MAX3 ? 3 : 2][256];
   const int ci = threadIdx.x % g.cl, ri = threadIdx.x / g.cl;
   const long r0 = (long)blockIdx.x * g.rows_per_block;
   const long r1 = min(r0 + g.rows_per_block, m);
   for (int q0 = 0; q0 < c4; q0 += g.cl) {
     const int q = q0 + ci;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, mx = a;
     if (q < c4) {                     // four rows per trip (same accumulation order): 8 x 16-byte loads in flight per lane
       const auto k = prep(q);
       long r = r0 + ri;
       const long rl = g.rl;
-      for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, k, a, b); f(r + rl, q, k, a, b); f(r + 2 * rl, q, k, a, b); f(r + 3 * rl, q, k, a, b); }
-      for (; r < r1; r += rl) f(r, q, k, a, b);
+      if constexpr (MAX3) {
+        for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, k, a, b, mx); f(r + rl, q, k, a, b, mx); f(r + 2 * rl, q, k, a, b, mx); f(r + 3 * rl, q, k, a, b, mx); }
+        for (; r < r1; r += rl) f(r, q, k, a, b, mx);
+      } else {
+        for (; r + 3 * rl < r1; r += 4 * rl) { f(r, q, k, a, b); f(r + rl, q, k, a, b); f(r + 2 * rl, q, k, a, b); f(r + 3 * rl, q, k, a, b); }
+        for (; r < r1; r += rl) f(r, q, k, a, b);
+      }
     }
     // row-lanes of one wave first (xor butterfly over the lane bits above the column bits), then the <= 4 per-wave
     // (or per-row-lane, when a wave is one row-lane) sums through LDS: 2 LDS round trips instead of rl - 1 serial ones
@@ -183,22 +190,36 @@ __device__ __forceinline__ void col_reduce2_v4p(long m, int c4, ColGeom g, float
       for (int o = g.cl; o < 64; o <<= 1) {
         a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
         b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+        if constexpr (MAX3) {
+          mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
+          mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
+        }
       }
       groups = 4;
-      if ((threadIdx.x & 63) < g.cl) { sh4[0][(threadIdx.x >> 6) * g.cl + ci] = a; sh4[1][(threadIdx.x >> 6) * g.cl + ci] = b; }
+      if ((threadIdx.x & 63) < g.cl) {
+        sh4[0][(threadIdx.x >> 6) * g.cl + ci] = a; sh4[1][(threadIdx.x >> 6) * g.cl + ci] = b;
+        if constexpr (MAX3) sh4[2][(threadIdx.x >> 6) * g.cl + ci] = mx;
+      }
     } else {
       sh4[0][threadIdx.x] = a; sh4[1][threadIdx.x] = b;
+      if constexpr (MAX3) sh4[2][threadIdx.x] = mx;
     }
     __syncthreads();
     if (ri == 0 && q < c4) {
       a = sh4[0][ci]; b = sh4[1][ci];
+      if constexpr (MAX3) mx = sh4[2][ci];
       for (int k = 1; k < groups; ++k) {
         const float4 oa = sh4[0][k * g.cl + ci], ob = sh4[1][k * g.cl + ci];
         a.x += oa.x; a.y += oa.y; a.z += oa.z; a.w += oa.w;
         b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
+        if constexpr (MAX3) {
+          const float4 om = sh4[2][k * g.cl + ci];
+          mx.x = fmaxf(mx.x, om.x); mx.y = fmaxf(mx.y, om.y); mx.z = fmaxf(mx.z, om.z); mx.w = fmaxf(mx.w, om.w);
+        }
       }
       reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 0) * c4 * 4)[q] = a;
       reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 1) * c4 * 4)[q] = b;
+      if constexpr (MAX3) reinterpret_cast<float4*>(pmax + (long)blockIdx.x * c4 * 4)[q] = mx;
     }
     __syncthreads();
   }
@@ -217,17 +238,19 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* __restrict_
   });
 }
 
+// pmax [blocks][c]: the block's max |dz| per channel — what bounds the dx of the apply pass before it runs (dx_channel_bound)
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              long m, int c4, ColGeom g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int relu,
-                                                             float* __restrict__ partial, const DropArg drop) {
+                                                             float* __restrict__ partial, const DropArg drop, float* __restrict__ pmax) {
   struct K4 { float4 sc, sh, mu, rs; };
   const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
-  col_reduce2_v4p(m, c4, g, partial, [&](int q) {
+  auto prep = [&](int q) {
     return K4{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q],
               reinterpret_cast<const float4*>(mean)[q], reinterpret_cast<const float4*>(rstd)[q]};
-  }, [&](long r, int q, const K4& k, float4& a, float4& b) {
+  };
+  auto body = [&](long r, int q, const K4& k, float4& a, float4& b, float4& mx) {
     const float4 xv = reinterpret_cast<const float4*>(x)[r * c4 + q];
     float4 dz = reinterpret_cast<const float4*>(dy)[r * c4 + q];
     if (drop.thr) dz = drop4(drop, dseed, r * c4 + q, dz);   // dy of the Dropout behind this layer -> dy of the layer
@@ -239,13 +262,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
     a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
     b.x = fmaf(dz.x, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(dz.y, (xv.y - mu.y) * rs.y, b.y);
     b.z = fmaf(dz.z, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(dz.w, (xv.w - mu.w) * rs.w, b.w);
-  });
+    mx.x = fmaxf(mx.x, fabsf(dz.x)); mx.y = fmaxf(mx.y, fabsf(dz.y)); mx.z = fmaxf(mx.z, fabsf(dz.z)); mx.w = fmaxf(mx.w, fabsf(dz.w));
+  };
+  if (pmax) col_reduce2_v4p<decltype(prep), decltype(body), true>(m, c4, g, partial, prep, body, pmax);
+  else {
+    auto body2 = [&](long r, int q, const K4& k, float4& a, float4& b) { float4 mx = make_float4(0.f, 0.f, 0.f, 0.f); body(r, q, k, a, b, mx); };
+    col_reduce2_v4p(m, c4, g, partial, prep, body2);
+  }
 }
 
 // MODE 0: as described.  MODE 1: dx_planes in the two-piece fp16 format, scaled by the s the slot holds.  MODE 2: the dry run in front
 // of MODE 1 — the same arithmetic, nothing stored but the workgroup's max |dx| (floats 2 + blockIdx.x behind the slot); the scale
 // kernel below turns the maxima into s.  (8 bytes per element read once more: the price of an exact range for the gradient's planes.)
 // MODE 3: MODE 0 + the range of dx into `range_slot` (common.h range_emit) for the three-product gather convs that read dx (conv.hip Ranges).
+// MODE 4: MODE 1 without the dry run: the planes' scale from `dx_bound` [c] (bn_bwd_finalize_kernel's dx_channel_bound), + the range of
+// dx_add (`add_range`: the bound of the identity shortcut's gradient) where one is added; workgroup 0 leaves (s, 1 / s) in the planes'
+// slot and — range_slot != NULL — the bound in the range slot of the fp32 dx.
 template <int MODE = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             long total4, int c4, float inv_m, const float* __restrict__ mean,
@@ -253,7 +285,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ shift, const float* __restrict__ dbeta,
                                                             const float* __restrict__ dgamma, int relu, int training,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx,
-                                                            unsigned short* __restrict__ dx_planes, uint32_t* __restrict__ range_slot = nullptr) {
+                                                            unsigned short* __restrict__ dx_planes, uint32_t* __restrict__ range_slot = nullptr,
+                                                            const float* __restrict__ dx_bound = nullptr, const uint32_t* __restrict__ add_range = nullptr) {
   const long stride = (long)gridDim.x * 256;
   // (the launcher makes the stride a multiple of c4 whenever c4 divides a power of two, so a thread keeps its channel
   // quad and the six per-channel constants are loaded once; otherwise they are re-read per element)
@@ -269,7 +302,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
   };
   if (fixed) consts((int)(((long)blockIdx.x * 256 + threadIdx.x) % c4));
   float amax = 0.f;
-  const float pscale = MODE == 1 ? planes_scale_slot(dx_planes, total4 * 4)[0] : 1.f;
+  float pscale = MODE == 1 ? planes_scale_slot(dx_planes, total4 * 4)[0] : 1.f;
+  if (MODE == 4) {
+    float b = tensor_bound(dx_bound, 4 * c4);
+    if (dx_add) b += __uint_as_float(*add_range);
+    const float2 sp = scale_pair(scale_exponent_of(b));
+    pscale = sp.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      float* sl = planes_scale_slot(dx_planes, total4 * 4); sl[0] = sp.x; sl[1] = sp.y;
+      if (range_slot) *range_slot = __float_as_uint(b);
+    }
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     if (!fixed) consts((int)(i % c4));
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
@@ -297,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
     if (dx_planes) {                                     // the same values as bf16 pieces, chunk-major: dy operand of the
       const long pix = i / c4; const int q = (int)(i - pix * c4);      // patch data gradient of the convolution in front
       const long e = ((long)(q >> 2) * (total4 / c4) + pix) * 16 + 4 * (q & 3);
-      if (MODE == 1) {
+      if (MODE == 1 || MODE == 4) {
         const Split4H s = split4h(o, pscale);
 #pragma unroll
         for (int k = 0; k < 2; ++k) *reinterpret_cast<uint2*>(dx_planes + k * total4 * 4 + e) = s.p[k];
@@ -584,7 +627,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ moving_mean,
                                                           float* __restrict__ moving_var, int by_channel,
-                                                          float* __restrict__ bound = nullptr) {
+                                                          float* __restrict__ bound = nullptr, float* __restrict__ xhat_bound = nullptr) {
   const int col = blockIdx.x;
   double s, ss;
   float qmax;
@@ -599,6 +642,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const float sh = (beta ? beta[col] : 0.f) - (float)mean * sc;
   scale[col] = sc; shift[col] = sh;
   if (bound) bound[col] = channel_bound(sc, sh, qmax);     // |act(scale x + shift)| of this channel (see channel_bound)
+  if (xhat_bound) xhat_bound[col] = (sqrtf(qmax) + fabsf((float)mean)) * rstd * 1.0009765625f;   // |x - mean| rstd <= this (backward: dx_channel_bound)
   if (moving_mean) moving_mean[col] = momentum * moving_mean[col] + (1.f - momentum) * (float)mean;
   if (moving_var) moving_var[col] = momentum * moving_var[col] + (1.f - momentum) * (float)var;
 }
@@ -670,12 +714,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   });
 }
 
+// The range of a BatchNorm backward's dx, known before its apply pass runs (replaces round 5's dry run of the pass):
+//     dx = scale_c (dz - dbeta_c / m - xhat dgamma_c / m)   =>   |dx| <= |scale_c| (max |dz| + |dbeta_c| / m + max |xhat| |dgamma_c| / m)
+// with max |dz| of channel c from the reduction pass (its third accumulator / the data-gradient epilogue's third plane) and
+// max |xhat| from the forward statistics (bn_finalize_kernel's xhat_bound).  Above the true maximum by the two correction terms'
+// share (they are O(1 / sqrt(m)) of the first for a gradient that does not correlate with the batch): typically within a binade.
+__device__ __forceinline__ float dx_channel_bound(float sc, float mz, float db, float dg, float xh, float inv_m, int training) {
+  const float corr = training ? (fabsf(db) + xh * fabsf(dg)) * inv_m : 0.f;
+  return fabsf(sc) * (mz + corr) * 1.0009765625f;
+}
+// pmax (optional): max |dz| partials — [blocks][c] behind the own reduction's sums (by_channel = 0) or the third plane [c][blocks] of
+// a data-gradient epilogue's partials (by_channel = 1); dx_bound [c] receives dx_channel_bound
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                              int by_channel = 0, uint32_t* __restrict__ zero_slot = nullptr) {
+                                                              int by_channel = 0, uint32_t* __restrict__ zero_slot = nullptr,
+                                                              const float* __restrict__ pmax = nullptr, const float* __restrict__ scale = nullptr,
+                                                              const float* __restrict__ xhat_bound = nullptr, float inv_m = 0.f,
+                                                              int training = 1, float* __restrict__ dx_bound = nullptr) {
   const int col = blockIdx.x;
   double s, ss;
   block_partial_sums(partial, blocks, c, col, s, ss, by_channel != 0);
+  if (dx_bound) {
+    __shared__ float redm[4];
+    float mz = 0.f;
+    if (by_channel) for (int b = threadIdx.x; b < blocks; b += 256) mz = fmaxf(mz, pmax[(long)col * blocks + b]);
+    else for (int b = threadIdx.x; b < blocks; b += 256) mz = fmaxf(mz, pmax[(long)b * c + col]);
+    mz = wave_max(mz);
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mz;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      dx_bound[col] = dx_channel_bound(scale[col], fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])), (float)s, (float)ss,
+                                       xhat_bound ? xhat_bound[col] : 0.f, inv_m, training && xhat_bound);
+  }
   if (threadIdx.x == 0) { dbeta[col] = (float)s; dgamma[col] = (float)ss; }
   if (zero_slot && col == 0)                                           // the apply pass behind this kernel emits dx's range there
     for (int i = threadIdx.x; i < 1 + RANGE_PARTIALS; i += 256) zero_slot[i] = 0u;
@@ -1404,14 +1474,17 @@ static inline int ew_blocks_c4(long total4, int c4) {
 
 extern "C" size_t embnet_bn_workspace_bytes(long m, int c) {
   if (m <= 0 || c <= 0) return 0;
-  return (size_t)col_geom(m, c).blocks * 2 * c * sizeof(float);
+  // per block: the two sums and (backward, four-channel kernels) the max |dz| row; + one row of per-channel dx bounds
+  int blocks = col_geom(m, c).blocks;
+  if ((c & 3) == 0) { const int b4 = col_geom(m, c / 4).blocks; if (b4 > blocks) blocks = b4; }
+  return ((size_t)blocks * 3 * c + c) * sizeof(float);
 }
 
 static int bn_train_fwd_impl(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
                              float momentum, int relu, float* y, float* save_mean, float* save_rstd,
                              float* scale, float* shift, float* moving_mean, float* moving_var,
                              const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
-                             float* y_bound, uint32_t* y_range, void* stream) {
+                             float* y_bound, uint32_t* y_range, void* stream, float* xhat_bound = nullptr) {
   EMBNET_CHECK_ARG(x && save_mean && save_rstd && scale && shift && workspace, "bn_train_fwd: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0, "bn_train_fwd: m=%ld c=%d", m, c);
   EMBNET_CHECK_ARG(!y_range || (y_bound && y && !(reinterpret_cast<uintptr_t>(y_range) & 3)),
@@ -1432,7 +1505,7 @@ static int bn_train_fwd_impl(const float* x, long m, int c, const float* gamma, 
     { EMBNET_TRACE("embnet::bn_stats_kernel", TRACE_BYTES, 4.0 * m * c, stream); bn_stats_kernel<<<g.blocks, 256, 0, S(stream)>>>(x, m, c, g, (float*)workspace); }
   }
   { EMBNET_TRACE("embnet::bn_finalize_kernel", TRACE_BYTES, 8.0 * nblocks * c, stream); bn_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, nblocks, m, c, gamma, beta, eps, momentum, save_mean,
-                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr, y_bound); }
+                                                          save_rstd, scale, shift, moving_mean, moving_var, partial_in != nullptr, y_bound, xhat_bound); }
   if (y)                                    // y == NULL: statistics + scale/shift only (a fused consumer applies them)
     { EMBNET_TRACE("embnet::affine_act_kernel", TRACE_BYTES, 8.0 * m * c, stream); affine_act_kernel<<<((c & 3) ? ew_blocks(m * c / 4 + 1) : ew_blocks_c4(m * c / 4, c / 4)), 256, 0, S(stream)>>>(x, m * c, c, scale, shift, relu, y, DropArg{0, nullptr, 0u, 1.f}, y_bound, y_range); }
   return check_launch("bn_train_fwd");
@@ -1449,9 +1522,9 @@ extern "C" int embnet_bn_train_fwd_ex(const float* x, long m, int c, const float
                                       float momentum, int relu, float* y, float* save_mean, float* save_rstd,
                                       float* scale, float* shift, float* moving_mean, float* moving_var,
                                       const float* partial_in, int partial_rows, void* workspace, size_t workspace_bytes,
-                                      float* y_bound, uint32_t* y_range, void* stream) {
+                                      float* y_bound, uint32_t* y_range, float* xhat_bound, void* stream) {
   return bn_train_fwd_impl(x, m, c, gamma, beta, eps, momentum, relu, y, save_mean, save_rstd, scale, shift, moving_mean, moving_var,
-                           partial_in, partial_rows, workspace, workspace_bytes, y_bound, y_range, stream);
+                           partial_in, partial_rows, workspace, workspace_bytes, y_bound, y_range, stream, xhat_bound);
 }
 
 extern "C" int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
@@ -1481,6 +1554,21 @@ extern "C" int embnet_affine_act_dropout(const float* x, long m, int c, const fl
   return check_launch("affine_act_dropout");
 }
 
+// The range slot of a tensor y with |y| <= factor * max_c bound_c (+ the range of another tensor): the outputs of the fused
+// BatchNorm passes that are not plain applies — act(BN(x)) * gate (gate in (0, 1)), skip + drop_factor * BN(x) — for the
+// three-product gather convs that read them (EfficientNet's project / expand convs, reference backbones.py:84-98).
+__global__ __launch_bounds__(256) void range_from_bound_kernel(const float* __restrict__ bound, int c, float factor,
+                                                               const uint32_t* __restrict__ add_range, uint32_t* __restrict__ out) {
+  const float b = tensor_bound(bound, c) * factor + (add_range ? __uint_as_float(*add_range) : 0.f);
+  if (threadIdx.x == 0) *out = __float_as_uint(b);
+}
+extern "C" int embnet_range_from_bound(const float* bound, int c, float factor, const uint32_t* add_range, uint32_t* out, void* stream) {
+  EMBNET_CHECK_ARG(bound && out && c > 0 && factor >= 0.f && !((reinterpret_cast<uintptr_t>(add_range) | reinterpret_cast<uintptr_t>(out)) & 3),
+                   "range_from_bound: bad argument");
+  range_from_bound_kernel<<<1, 256, 0, S(stream)>>>(bound, c, factor, add_range, out);
+  return check_launch("range_from_bound");
+}
+
 static int affine_act_planes_impl(const float* x, long m, int c, const float* scale, const float* shift, int act, float* y,
                                   void* planes, const float* y_bound, uint32_t* y_range, void* stream) {
   EMBNET_CHECK_ARG(x && scale && shift && planes, "affine_act_planes: null pointer");
@@ -1494,6 +1582,10 @@ static int affine_act_planes_impl(const float* x, long m, int c, const float* sc
   if (!planes_f16()) {
     EMBNET_TRACE("void embnet::affine_act_planes_kernel<false>", TRACE_BYTES, ((y ? 8.0 : 4.0) + 6.0) * m * c, stream);
     affine_act_planes_kernel<false><<<blocks, 256, 0, S(stream)>>>(x, m, c / 4, scale, shift, act, y, pl);
+    if (y_range) {                                          // (the three-piece planes need no scale; the fp32 y's readers want its range)
+      EMBNET_CHECK_ARG(y_bound, "affine_act_planes: y_range without y_bound in the three-piece (bf16) planes format");
+      range_from_bound_kernel<<<1, 256, 0, S(stream)>>>(y_bound, c, 1.f, nullptr, y_range);
+    }
     return check_launch("affine_act_planes");
   }
   if (y_bound) {                                            // the range is known before the pass (bn_finalize_kernel's bounds)
@@ -1522,11 +1614,16 @@ extern "C" int embnet_affine_act_planes_ex(const float* x, long m, int c, const 
 static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                                  const float* scale, const float* shift, const float* dbeta, const float* dgamma, int relu,
                                  int training, const float* dx_add, float* dx, void* dx_planes, hipStream_t st,
-                                 uint32_t* range_slot = nullptr) {
+                                 uint32_t* range_slot = nullptr, const float* dx_bound = nullptr, const uint32_t* add_range = nullptr) {
   const long total4 = m * c / 4;
   const int blocks = ew_blocks_c4(total4, c / 4);
   const float inv_m = 1.f / (float)m;
   unsigned short* pl = (unsigned short*)dx_planes;
+  if (dx_planes && planes_f16() && dx_bound) {              // the range is known before the pass (bn_bwd_finalize_kernel's bounds): no dry run
+    bn_bwd_apply4_kernel<4><<<blocks, 256, 0, st>>>(dy, x, total4, c / 4, inv_m, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu,
+                                                   training, dx_add, dx, pl, range_slot, dx_bound, add_range);
+    return;
+  }
   if (dx_planes && planes_f16()) {
     float* slot = planes_scale_slot(dx_planes, total4 * 4);
     // (the third plane's space — 2 * total4 floats, >= 8 — holds the slot and the dry run's workgroup maxima: fewer workgroups for a tiny tensor)
@@ -1551,7 +1648,8 @@ static void launch_bn_bwd_apply4(const float* dy, const float* x, long m, int c,
 static int bn_bwd_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
                        const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                        const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
-                       size_t workspace_bytes, uint32_t* emit, void* stream) {
+                       size_t workspace_bytes, uint32_t* emit, void* stream, const float* xhat_bound = nullptr,
+                       const uint32_t* dx_add_range = nullptr) {
   EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || planes_f16()) && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd &&
                              !(reinterpret_cast<uintptr_t>(emit) & 3)),
                    "bn_bwd: a range of dx was requested but this call cannot emit one (an fp32 dx — beside planes only in the two-piece "
@@ -1568,11 +1666,20 @@ static int bn_bwd_impl(const float* dy, const float* x, long m, int c, const flo
   // inference-mode statistics: xhat uses the moving stats folded in scale/shift; dgamma then needs them too.
   // We only support parameter gradients in training mode; frozen BN returns dgamma = dbeta sums with xhat from
   // save_mean/save_rstd when given, else zeros.
+  // planes in the two-piece format need dx's range before the apply pass: from the bound (the reduction's max |dz|, the forward's
+  // max |xhat|, the range of what is added) where all of it is at hand, else from a dry run of the pass (launch_bn_bwd_apply4)
+  static const bool no_dry = env_long("EMBNET_BN_BWD_BOUND", 1) != 0;          // 0: round 5's dry run (A/B)
+  const bool bound = no_dry && dx_planes && planes_f16() && (c & 3) == 0 && !bn_scalar() && save_mean && save_rstd &&
+                     (xhat_bound || !training) && (!dx_add || dx_add_range);
+  float* dx_bound = nullptr;
   if (save_mean && save_rstd) {
     if ((c & 3) == 0 && !bn_scalar()) {
       const ColGeom g4 = col_geom(m, c / 4);
-      { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, DropArg{0, nullptr, 0u, 1.f}); }
-      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma, 0, emit);
+      float* pmax = bound ? partial + (size_t)g4.blocks * 2 * c : nullptr;
+      if (bound) dx_bound = pmax + (size_t)g4.blocks * c;
+      { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, DropArg{0, nullptr, 0u, 1.f}, pmax); }
+      bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma, 0, bound ? nullptr : emit, pmax, scale, xhat_bound,
+                                                       1.f / (float)m, training, dx_bound);
     } else {
       { EMBNET_TRACE("embnet::bn_bwd_reduce_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, x, m, c, g, save_mean, save_rstd, scale, shift, relu, partial); }
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
@@ -1582,8 +1689,8 @@ static int bn_bwd_impl(const float* dy, const float* x, long m, int c, const flo
     (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
   }
   if ((c & 3) == 0 && !bn_scalar())
-    { EMBNET_TRACE(emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
-      launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream), emit); }
+    { EMBNET_TRACE(dx_bound ? "void embnet::bn_bwd_apply4_kernel<4>" : emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() && !dx_bound ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+      launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, training, dx_add, dx, dx_planes, S(stream), emit, dx_bound, dx_add_range); }
   else
     { EMBNET_TRACE("embnet::bn_bwd_apply_kernel", TRACE_BYTES, (dx_add ? 16.0 : 12.0) * m * c, stream); bn_bwd_apply_kernel<<<ew_blocks(m * c), 256, 0, S(stream)>>>(dy, x, m * c, c, 1.f / (float)m, save_mean, save_rstd,
                                                                  scale, shift, dbeta, dgamma, relu, training, dx_add, dx); }
@@ -1599,10 +1706,11 @@ extern "C" int embnet_bn_bwd(const float* dy, const float* x, long m, int c, con
 extern "C" int embnet_bn_bwd_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
                                 const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                                 const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* workspace,
-                                size_t workspace_bytes, uint32_t* dx_range, void* stream) {
+                                size_t workspace_bytes, uint32_t* dx_range, const float* xhat_bound, const uint32_t* dx_add_range,
+                                void* stream) {
   (void)take_emit_slot();
   return bn_bwd_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dx_add, dx, dgamma, dbeta, dx_planes, workspace,
-                     workspace_bytes, dx_range, stream);
+                     workspace_bytes, dx_range, stream, xhat_bound, dx_add_range);
 }
 
 static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
@@ -1618,7 +1726,7 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
   float* partial = (float*)workspace;
   const ColGeom g4 = col_geom(m, c / 4);
   if (save_mean && save_rstd) {
-    { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, drop); }
+    { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, drop, nullptr); }
     bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
   } else {
     (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
@@ -1690,15 +1798,22 @@ extern "C" int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const
 static int bn_bwd_partials_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
                                 const float* save_rstd, const float* scale, const float* shift, int relu,
                                 const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
-                                float* dbeta, void* dx_planes, uint32_t* emit, void* stream) {
+                                float* dbeta, void* dx_planes, uint32_t* emit, void* stream, int partial_kinds = 2,
+                                const float* xhat_bound = nullptr, const uint32_t* dx_add_range = nullptr) {
   EMBNET_CHECK_ARG(!emit || (dx && (!dx_planes || planes_f16()) && !(reinterpret_cast<uintptr_t>(emit) & 3)),
                    "bn_bwd_partials: a range of dx was requested but this call cannot emit one (see embnet_bn_bwd_ex)");
   EMBNET_CHECK_ARG(dy && x && save_mean && save_rstd && scale && shift && partials && (dx || dx_planes) && dgamma && dbeta, "bn_bwd_partials: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0 && rows > 0, "bn_bwd_partials: m=%ld c=%d rows=%d (c %% 4 == 0)", m, c, rows);
   EMBNET_CHECK_ARG(!dx_planes || ((c & 15) == 0 && (size_t)m * c * 2 < 0x7FFFFFF0ull / 3), "bn_bwd_partials: dx_planes needs c %% 16 == 0");
-  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1, emit);
-  { EMBNET_TRACE(emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
-    launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream), emit); }
+  // the planes' scale from the bound where the partials carry the max |dz| plane (the per-channel bounds live behind the planes' slot)
+  static const bool no_dry = env_long("EMBNET_BN_BWD_BOUND", 1) != 0;
+  const long total4 = m * c / 4;
+  const bool bound = no_dry && dx_planes && planes_f16() && partial_kinds == 3 && xhat_bound && (!dx_add || dx_add_range) && 2 * total4 >= 2 + c;
+  float* dx_bound = bound ? planes_scale_slot(dx_planes, total4 * 4) + 2 : nullptr;
+  bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partials, rows, c, dbeta, dgamma, 1, bound ? nullptr : emit,
+                                                   bound ? partials + (size_t)2 * c * rows : nullptr, scale, xhat_bound, 1.f / (float)m, 1, dx_bound);
+  { EMBNET_TRACE(dx_bound ? "void embnet::bn_bwd_apply4_kernel<4>" : emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() && !dx_bound ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
+    launch_bn_bwd_apply4(dy, x, m, c, save_mean, save_rstd, scale, shift, dbeta, dgamma, relu, 1, dx_add, dx, dx_planes, S(stream), emit, dx_bound, dx_add_range); }
   return check_launch("bn_bwd_partials");
 }
 extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean,
@@ -1711,10 +1826,12 @@ extern "C" int embnet_bn_bwd_partials(const float* dy, const float* x, long m, i
 extern "C" int embnet_bn_bwd_partials_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
                                          const float* save_rstd, const float* scale, const float* shift, int relu,
                                          const float* partials, int rows, const float* dx_add, float* dx, float* dgamma,
-                                         float* dbeta, void* dx_planes, uint32_t* dx_range, void* stream) {
+                                         float* dbeta, void* dx_planes, uint32_t* dx_range, int partial_kinds, const float* xhat_bound,
+                                         const uint32_t* dx_add_range, void* stream) {
   (void)take_emit_slot();
+  EMBNET_CHECK_ARG(partial_kinds == 2 || partial_kinds == 3, "bn_bwd_partials: partial_kinds %d (2: the sums; 3: + max |dz|)", partial_kinds);
   return bn_bwd_partials_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, partials, rows, dx_add, dx, dgamma, dbeta, dx_planes,
-                              dx_range, stream);
+                              dx_range, stream, partial_kinds, xhat_bound, dx_add_range);
 }
 
 extern "C" int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean,

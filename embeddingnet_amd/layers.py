@@ -759,7 +759,7 @@ class _Conv2dFn(torch.autograd.Function):
                 rows = lib.embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride) if bn_src is not None else 0
                 if rows > 0:
                     bn_x, bn_stats, bn_act = bn_src
-                    partial = torch.empty((2, c, rows), device=x.device, dtype=torch.float32)
+                    partial = torch.empty((3, c, rows), device=x.device, dtype=torch.float32)      # sums, and max |dz| per band
                     sp = bn_stats.data_ptr()
                     check(lib.embnet_conv2d_dgrad_bnsums_f32_ex(
                         ptr(dz), ptr(w), ptr(dx), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, ptr(bn_x), sp + 8 * c, sp + 12 * c,
@@ -1057,9 +1057,10 @@ class Conv2D(nn.Module):
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
-        if torch.is_grad_enabled() and (w_range is not None or (residual is not None and getattr(residual, "_wants_dy_range", False))):
-            # the BatchNormalization reading y leaves the range of its dx in DY_RANGE (backward) — for this conv, or for the conv
-            # behind the fused Add (the projection shortcut), which receives the same gradient tensor
+        if torch.is_grad_enabled() and (w_range is not None or residual is not None):
+            # the BatchNormalization reading y leaves the range of its dx in DY_RANGE (backward) — for this conv, for the conv behind
+            # the fused Add (the projection shortcut), which receives the same gradient tensor, or for the BatchNormalization at the
+            # head of an identity shortcut, which adds that gradient to its own dx and bounds the sum with it (no dry run)
             y._wants_dy_range = True
         if planes is not None and not self.relu:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
@@ -1071,6 +1072,8 @@ class Conv2D(nn.Module):
         if (self.relu and self.bias is not None and (FUSE_RELU_BN[0] or FUSE_RELU_POOL[0]) and self.kernel.shape[3] % 4 == 0
                 and residual is None):
             y._relu_conv = (self.bias,)        # see RELU_DONE
+        if with_skip and _range_of(x) is not None:
+            out[1]._range = _range_of(x)       # the pass-through copy is the same tensor: same range
         return (y, out[1]) if with_skip else y
 
     def planes_only_input(self, x_shape):
@@ -1222,7 +1225,8 @@ def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mea
     """embnet_bn_train_fwd_ex; partials [2,C,P] = sums / sums of squares of x by row band from the producing conv's
     epilogue (Conv2D(..., emit_stats=True)), which then replace the statistics pass over x.
     stats with >= 5 rows: row 4 receives the per-channel bounds of |act(BN(x))| (nn_kernels.hip channel_bound); with_range (needs a
-    sixth row and y): the apply pass folds them into the range slot of y — the first word of row 5 (_stats_range)."""
+    sixth row and y): the apply pass folds them into the range slot of y — the first word of row 5 (_stats_range); a seventh row
+    receives the per-channel bounds of |xhat| (what the backward needs to bound its dx without a dry run)."""
     lib = _lib.lib()
     ws = workspace(lib.embnet_bn_workspace_bytes(m, c), x.device)
     if partials is not None and tuple(partials.shape[:2]) != (2, c):
@@ -1230,10 +1234,11 @@ def _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, y, stats, moving_mea
     sp, sc = stats.data_ptr(), stats.shape[1]
     bound = sp + 16 * sc if stats.shape[0] >= 5 else None
     yr = sp + 20 * sc if (with_range and y is not None and stats.shape[0] >= 6) else None
+    xh = sp + 24 * sc if stats.shape[0] >= 7 else None
     check(lib.embnet_bn_train_fwd_ex(ptr(x), m, c, ptr(gamma), ptr(beta), eps, momentum, int(act), ptr(y),
                                      sp, sp + 4 * sc, sp + 8 * sc, sp + 12 * sc,
                                      ptr(moving_mean), ptr(moving_var), ptr(partials),
-                                     partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, bound, yr, stream()))
+                                     partials.shape[2] if partials is not None else 0, ptr(ws), ws.numel() * 4, bound, yr, xh, stream()))
 
 
 def _stats_range(stats):
@@ -1282,7 +1287,7 @@ class _BatchNormFn(torch.autograd.Function):
         y = _placeholder(x.shape, x.device) if planes_only else torch.empty_like(x)
         # mean, rstd, scale, shift; in training also row 4 = the per-channel bounds of |y| and row 5 = y's range slot (first word)
         ranged = bool(training and c % 4 == 0 and not dropout and not _BN_SCALAR)
-        stats = torch.empty((6 if ranged else 4, c), device=x.device, dtype=torch.float32)
+        stats = torch.empty((7 if ranged else 4, c), device=x.device, dtype=torch.float32)     # (row 6: the bounds of |xhat|, for backward)
         yk = None if (emit_planes or dropout) else y                         # planes / dropout: statistics first, then one pass
         if training:
             _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, relu, yk, stats, moving_mean, moving_var, partials, with_range=ranged)
@@ -1330,8 +1335,13 @@ class _BatchNormFn(torch.autograd.Function):
         m = x.numel() // c
         dy = _c(dy)
         dskip = _c(dskip) if dskip is not None else None
+        dskip_range = None
         if dskip is not None and DY_RANGE:
-            DY_RANGE.pop(dskip.data_ptr(), None)      # (the identity shortcut ends here: nobody else will claim that gradient's range)
+            # the identity shortcut ends here: nobody else will claim that gradient's range — it bounds what this pass adds to its dx
+            e = DY_RANGE.pop(dskip.data_ptr(), None)
+            if e is not None and e[1].shape == dskip.shape:
+                dskip_range = e[0]
+        xh = (stats.data_ptr() + 24 * c) if stats.shape[0] >= 7 else None     # bounds of |xhat| from the forward statistics
         only = getattr(ctx, "dx_planes_only", False) and dskip is None
         dx = _placeholder(x.shape, x.device) if only else torch.empty_like(x)
         dxp = None if only else ptr(dx)
@@ -1356,7 +1366,7 @@ class _BatchNormFn(torch.autograd.Function):
                 dxr = _emit_dx_range(dx)
             check(lib.embnet_bn_bwd_partials_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c),
                                                 int(ctx.relu), ptr(hit[0]), hit[1], ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes),
-                                                ptr(dxr), stream()))
+                                                ptr(dxr), int(hit[0].shape[0]), xh, ptr(dskip_range), stream()))
             dgamma, dbeta = finish()
             return (dx, dgamma, dbeta) + (None,) * 15
         if drop is not None and not inrelu:      # the Dropout's backward as a pass of its own in front of the BN backward
@@ -1385,7 +1395,7 @@ class _BatchNormFn(torch.autograd.Function):
                 dxr = _emit_dx_range(dx)
             check(lib.embnet_bn_bwd_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]), (stats.data_ptr() + 12 * stats.shape[1]),
                                        int(ctx.relu), int(ctx.training), ptr(dskip), dxp, ptr(tg), ptr(tb), ptr(planes), ptr(ws),
-                                       ws.numel() * 4, ptr(dxr), stream()))
+                                       ws.numel() * 4, ptr(dxr), xh, ptr(dskip_range), stream()))
         dgamma, dbeta = finish()
         return (dx, dgamma, dbeta) + (None,) * 15
 
@@ -1480,7 +1490,7 @@ class _BNPoolFn(torch.autograd.Function):
         lib = _lib.lib()
         n, c = x.shape[0], x.shape[-1]
         m = x.numel() // c
-        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        stats = torch.empty((6 if c % 4 == 0 else 4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift [, bound of |act(BN(x))|, range word]
         _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, act, None, stats, moving_mean, moving_var, partials)
         g = torch.empty((n, c), device=x.device, dtype=torch.float32)
         check(lib.embnet_affine_act_gap(ptr(x), n, m // n, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(act),
@@ -1524,6 +1534,9 @@ class _BNScaleFn(torch.autograd.Function):
         y = torch.empty_like(x)
         sp = stats.data_ptr()
         check(_lib.lib().embnet_affine_act_scale(ptr(x), n, hw, c, sp + 8 * c, sp + 12 * c, int(act), ptr(s), ptr(y), stream()))
+        if stats.shape[0] >= 6:              # |act(BN(x)) * gate| <= the BatchNorm's output bound (the gate is a sigmoid): y's range slot
+            check(_lib.lib().embnet_range_from_bound(sp + 16 * c, c, 1.0, None, sp + 20 * c, stream()))
+            _ACT_RANGE[y.data_ptr()] = _stats_range(stats)
         ctx.act, ctx.token = int(act), token
         ctx.save_for_backward(x, s, stats)
         return y
@@ -1549,17 +1562,22 @@ class _BNDropAddFn(torch.autograd.Function):
     the output gradient (embnet_bn_bwd_gap with gate = factor, dpool = 0); the skip's gradient IS the output gradient."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, partials, skip, rate, seed):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, partials, skip, rate, seed, skip_range=None):
+        """skip_range: the range slot of `skip` (layers._range_of) -> the output gets one too: |y| <= |skip| + |BN(x)| / (1 - rate)."""
         x, skip = _c(x), _c(skip)
         lib = _lib.lib()
         n, c = x.shape[0], x.shape[-1]
         m = x.numel() // c
-        stats = torch.empty((4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift
+        stats = torch.empty((6 if skip_range is not None else 4, c), device=x.device, dtype=torch.float32)   # mean, rstd, scale, shift [, bound, range word]
         _bn_train_fwd(x, m, c, gamma, beta, eps, momentum, 0, None, stats, moving_mean, moving_var, partials)
         y = torch.empty_like(x)
         factor = torch.empty((n, c), device=x.device, dtype=torch.float32)
         check(lib.embnet_affine_drop_add(ptr(x), n, m // n, c, stats.data_ptr() + 8 * c, stats.data_ptr() + 12 * c, float(rate), seed,
                                          GRAPH_TICK, ptr(skip), ptr(y), ptr(factor), stream()))
+        if skip_range is not None:
+            sp = stats.data_ptr()
+            check(lib.embnet_range_from_bound(sp + 16 * c, c, 1.0 / (1.0 - float(rate)), _rptr(skip_range), sp + 20 * c, stream()))
+            _ACT_RANGE[y.data_ptr()] = _stats_range(stats)
         ctx.has_gamma, ctx.gamma_ref, ctx.beta_ref = gamma is not None, gamma, beta
         ctx.save_for_backward(x, stats, factor)
         return y
@@ -1579,7 +1597,7 @@ class _BNDropAddFn(torch.autograd.Function):
         check(lib.embnet_bn_bwd_gap(ptr(dy), ptr(zero), ptr(factor), n, m // n, ptr(x), c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, 0,
                                     ptr(dx), ptr(tg), ptr(tb), ptr(ws), ws.numel() * 4, stream()))
         dgamma, dbeta = finish()
-        return dx, dgamma, dbeta, None, None, None, None, None, dy, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, dy, None, None, None
 
 
 class Deferred:
@@ -1678,8 +1696,12 @@ class BatchNormalization(nn.Module):
             if drop is not None and drop.training and drop.enabled and drop.rate > 0:
                 drop._step += 1
                 rate, seed = drop.rate, (drop.seed << 32) + drop._step
-            return _BNDropAddFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps, self.momentum,
-                                      _partials_of(x, True), skip, rate, seed)
+            y = _BNDropAddFn.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.eps, self.momentum,
+                                   _partials_of(x, True), skip, rate, seed, _range_of(skip))
+            rng = _ACT_RANGE.pop(y.data_ptr(), None)
+            if rng is not None:
+                y._range = rng
+            return y
         y = self(x)
         if drop is not None:
             y = drop(y)
@@ -1773,7 +1795,11 @@ def _se_gate(bn, x, gate_fn):
                                  _partials_of(x, True), token)
         bn_x, stats, act = _BN_FWD_STATS.pop(pooled.data_ptr())
         s = gate_fn(pooled)
-        return _BNScaleFn.apply(bn_x, s.reshape(x.shape[0], c), stats, act, token)
+        y = _BNScaleFn.apply(bn_x, s.reshape(x.shape[0], c), stats, act, token)
+        rng = _ACT_RANGE.pop(y.data_ptr(), None)
+        if rng is not None:
+            y._range = rng
+        return y
     y, g = bn(x, emit_gap=True, lazy_scale=True)
     return channel_scale(y, gate_fn(g), lazy=True)
 

@@ -113,7 +113,7 @@ class TripletTrainer:
         self._ring_pos += 1
 
     def _capture(self, images):
-        dev = images.device
+        dev = (images[0] if isinstance(images, (tuple, list)) else images).device
         self._state = torch.zeros(12, dtype=torch.float32, device=dev)           # lr, b1, b2, eps, c1, c2 | seed (uint64) | steps since capture (uint64) | pad
         self._ring = torch.zeros((256, 12), dtype=torch.float32).pin_memory()
         self._since_capture = 0

@@ -253,6 +253,9 @@ int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream
  * DEPRECATED, kept for one round: embnet_range_emit(slot) and embnet_conv2d_ranges(a, b) arm the same slots for the NEXT non-_ex
  * call of the calling thread (ABI 20) — hidden per-thread state: a binding in another language, a second stream on one thread or
  * an exception between the two calls gets the wrong arithmetic silently.  Every conv / bn_bwd entry point clears the request. */
+/* out = the range slot of a tensor y with |y| <= factor * max_c bound[c] (+ the range in add_range, or NULL): for the outputs of
+ * the fused BatchNorm passes that are not plain applies (act(BN(x)) * gate; skip + drop_factor * BN(x)); bound from embnet_bn_train_fwd_ex. */
+int embnet_range_from_bound(const float* bound, int c, float factor, const uint32_t* add_range, uint32_t* out, void* stream);
 int embnet_range_slot_words(void);
 int embnet_range_emit(uint32_t* slot);
 int embnet_range_chunk_elems(void);
@@ -267,6 +270,7 @@ int embnet_conv2d_dgrad_f32_ex(const float* dy, const float* w, float* dx, int n
                                int k, int stride, int pad_t, int pad_l, int oh, int ow, int accumulate, const float* dx_add,
                                void* workspace, size_t workspace_bytes, const uint32_t* dy_range, const uint32_t* w_range,
                                void* stream);
+/* (the _ex form of dgrad_bnsums writes bn_partial as [3][c][bn_rows]: the two sums and max |dz| per row band) */
 int embnet_conv2d_dgrad_bnsums_f32_ex(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int r, int s,
                                       int k, int stride, int pad_t, int pad_l, int oh, int ow, const float* bn_x,
                                       const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_rstd,
@@ -408,12 +412,13 @@ int embnet_bn_train_fwd(const float* x, long m, int c, const float* gamma, const
                         float* shift, float* moving_mean, float* moving_var, const float* partial_in,
                         int partial_rows, void* workspace, size_t workspace_bytes, void* stream);
 /* _ex: y_bound (NULL or [c]) receives, per channel, an upper bound of |act(scale_c x + shift_c)| over the batch (RANGE SLOT above);
- * y_range (NULL or a range slot; needs y_bound and y): their maximum, as the range slot of y. */
+ * y_range (NULL or a range slot; needs y_bound and y): their maximum, as the range slot of y;  xhat_bound (NULL or [c]): an upper
+ * bound of |x - mean_c| rstd_c — what embnet_bn_bwd_ex needs to bound its dx without a dry run. */
 int embnet_bn_train_fwd_ex(const float* x, long m, int c, const float* gamma, const float* beta, float eps,
                            float momentum, int relu, float* y, float* save_mean, float* save_rstd, float* scale,
                            float* shift, float* moving_mean, float* moving_var, const float* partial_in,
                            int partial_rows, void* workspace, size_t workspace_bytes, float* y_bound, uint32_t* y_range,
-                           void* stream);
+                           float* xhat_bound, void* stream);
 int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const float* beta,
                         const float* moving_mean, const float* moving_var, float eps, int relu, float* y,
                         float* scale, float* shift, void* stream);
@@ -422,11 +427,17 @@ int embnet_bn_infer_fwd(const float* x, long m, int c, const float* gamma, const
 int embnet_bn_bwd(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                   const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                   float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, void* stream);
-/* _ex: dx_range (NULL or a range slot of embnet_range_slot_words() words) receives the exact max |dx| of the fp32 dx (RANGE SLOT). */
+/* _ex: dx_range (NULL or a range slot of embnet_range_slot_words() words) receives max |dx| of the fp32 dx (RANGE SLOT) — exact, or,
+ * where dx is also written as planes from a bound, that bound.
+ * xhat_bound ([c] from embnet_bn_train_fwd_ex, or NULL), dx_add_range (the range slot of dx_add, or NULL): with dx_planes in the
+ * two-piece format the planes' scale then comes from an upper bound of |dx| —
+ *   |scale_c| (max |dz| + |dbeta_c| / m + xhat_bound_c |dgamma_c| / m)  [+ the range of dx_add],
+ * max |dz| per channel being a third output of the reduction pass — instead of from a DRY RUN of the apply pass (8 B per element
+ * read once more: round 5's form, still taken when either pointer is missing; EMBNET_BN_BWD_BOUND=0 forces it). */
 int embnet_bn_bwd_ex(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                      const float* scale, const float* shift, int relu, int training, const float* dx_add, float* dx,
                      float* dgamma, float* dbeta, void* dx_planes, void* workspace, size_t workspace_bytes, uint32_t* dx_range,
-                     void* stream);
+                     const float* xhat_bound, const uint32_t* dx_add_range, void* stream);
 /* BatchNorm backward of a layer whose output is also globally average-pooled (the squeeze-and-excite block of the EfficientNet
  * MBConv, reference backbones.py:84-98): the output gradient is dy[n,p,c] + dpool[n,c] / hw; both passes form it on the fly with
  * embnet_gap_bwd's arithmetic (the result of embnet_gap_bwd(dx_add = dy) followed by embnet_bn_bwd to the last bits), so the
@@ -452,10 +463,12 @@ int embnet_bn_bwd_gap_sums(const float* dy, const float* dpool, const float* gat
 int embnet_bn_bwd_partials(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                            const float* scale, const float* shift, int relu, const float* partials, int rows,
                            const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, void* stream);
+/* _ex: partial_kinds = 3: partials is [3][c][rows], the third plane holding max |dz| per row band (what
+ * embnet_conv2d_dgrad_bnsums_f32_ex writes): with xhat_bound / dx_add_range as for embnet_bn_bwd_ex, no dry run. */
 int embnet_bn_bwd_partials_ex(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                               const float* scale, const float* shift, int relu, const float* partials, int rows,
                               const float* dx_add, float* dx, float* dgamma, float* dbeta, void* dx_planes, uint32_t* dx_range,
-                              void* stream);
+                              int partial_kinds, const float* xhat_bound, const uint32_t* dx_add_range, void* stream);
 /* BatchNorm backward for a BN whose input x is the output of a layer with a fused ReLU (conv -> ReLU -> BN, the small
  * backbones' block): dz = d(x) * [x > 0] (the gradient the producer's data / weight gradients consume, ReLU backward
  * included) and dbias[c] = column sums of dz (the producer's bias gradient), in the pass that computes d(x).  c % 4 == 0. */

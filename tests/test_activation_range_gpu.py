@@ -47,7 +47,7 @@ def bn_forward(x2d, gamma, beta, act, partial=None, y=True, planes=False, use_bo
     lib = _lib.lib()
     m, c = x2d.shape
     dev = x2d.device
-    stats = torch.empty((6, c), device=dev)
+    stats = torch.empty((7, c), device=dev)
     sp = stats.data_ptr()
     ws = torch.empty(max(lib.embnet_bn_workspace_bytes(m, c) // 4, 4), device=dev)
     yt = torch.full((m, c), float("nan"), device=dev) if y else None
@@ -55,8 +55,8 @@ def bn_forward(x2d, gamma, beta, act, partial=None, y=True, planes=False, use_bo
     _lib.check(lib.embnet_bn_train_fwd_ex(x2d.data_ptr(), m, c, _lib.ptr(gamma), _lib.ptr(beta), eps, 0.99, act,
                                           None if planes else _lib.ptr(yt), sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, None, None,
                                           _lib.ptr(partial), partial.shape[2] if partial is not None else 0, ws.data_ptr(), ws.numel() * 4,
-                                          sp + 16 * c, rng.data_ptr() if (y and not planes) else None, _lib.stream()))
-    out = dict(y=yt, stats=stats, bound=stats[4], range=rng)
+                                          sp + 16 * c, rng.data_ptr() if (y and not planes) else None, sp + 24 * c, _lib.stream()))
+    out = dict(y=yt, stats=stats, bound=stats[4], range=rng, xhat_bound=stats[6])
     if planes:
         p = torch.zeros(3 * m * c, dtype=torch.int16, device=dev)
         _lib.check(lib.embnet_affine_act_planes_ex(x2d.data_ptr(), m, c, sp + 8 * c, sp + 12 * c, act, _lib.ptr(yt), p.data_ptr(),
@@ -198,6 +198,100 @@ def test_batchnorm_planes_through_patch_conv_and_planes_weight_gradient_vs_float
     e_wg = np.abs(dw.cpu().numpy() - wantw).max() / np.abs(wantw).max()
     print(f"amplitude {amp:g}: forward {e_fwd:.2e}, weight gradient {e_wg:.2e}")
     assert e_fwd < 1.5e-6 and e_wg < 1.5e-6, (e_fwd, e_wg)
+
+
+# ---- the BatchNorm backward's planes without a dry run -----------------------------------------------------------------
+@pytest.mark.parametrize("m,c,gmag,add", [(8 * 28 * 28, 64, 1e-3, False), (4 * 14 * 14, 256, 1e-8, True), (37, 16, 3.0, True),
+                                          (16 * 56 * 56, 64, 1e-5, True)])
+def test_bn_backward_planes_take_their_scale_from_a_bound(dev, m, c, gmag, add):
+    """dx as planes (+ fp32) with the scale from |scale| (max |dz| + |dbeta| / m + max |xhat| |dgamma| / m) [+ the range of dx_add]:
+    the bound is never below max |dx| and within 4x of it, the planes decode to the fp32 dx, the fp32 dx and the parameter gradients
+    are bit for bit those of the dry-run form, and the trace shows ONE apply pass."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=g) * torch.logspace(-1, 1, c) + 0.3).to(dev)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(c, generator=g) * 0.1).to(dev)
+    fwd = bn_forward(x, gamma, beta, 1)
+    st, sp = fwd["stats"], fwd["stats"].data_ptr()
+    dy = (torch.randn(m, c, generator=g) * gmag * torch.exp(torch.randn(m, c, generator=g))).to(dev)
+    dx_add = (torch.randn(m, c, generator=g) * gmag * 3).to(dev) if add else None
+    add_range = range_of(dx_add) if add else None
+    ws = torch.empty(max(lib.embnet_bn_workspace_bytes(m, c) // 4, 4), device=dev)
+
+    def run(xhat, addr):
+        dx = torch.full((m, c), float("nan"), device=dev)
+        planes = torch.zeros(3 * m * c, dtype=torch.int16, device=dev)
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        slot = torch.full((lib.embnet_range_slot_words(),), -1, dtype=torch.int32, device=dev)
+        _lib.trace_reset(); _lib.trace_enable(True)
+        try:
+            _lib.check(lib.embnet_bn_bwd_ex(dy.data_ptr(), x.data_ptr(), m, c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, 1, 1, _lib.ptr(dx_add),
+                                            dx.data_ptr(), dg.data_ptr(), db.data_ptr(), planes.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                            slot.data_ptr(), xhat, addr, _lib.stream()))
+            names = [r[0] for r in _lib.trace_records()]
+        finally:
+            _lib.trace_enable(False)
+        return dx, planes, dg, db, slot, names
+
+    dx, planes, dg, db, slot, names = run(sp + 24 * c, _lib.ptr(add_range))
+    dx0, planes0, dg0, db0, slot0, names0 = run(None, None)                       # no bound at hand: the dry run
+    assert any("bn_bwd_apply4_kernel<4>" in s for s in names) and not any("bn_bwd_apply4_kernel<1>" in s for s in names), names
+    assert any("bn_bwd_apply4_kernel<1>" in s for s in names0), names0
+    assert torch.equal(dx, dx0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+    top = float(dx.abs().max())
+    B, B0 = fbits(slot[:1]), fbits(slot0[:1])
+    assert B0 == np.float32(top)                                                # the dry run's exact maximum
+    assert top <= B <= 4 * top, (top, B)
+    got, s = decode(planes, m, c)
+    want = dx.cpu().numpy().astype(np.float64)
+    assert 2.0 ** 14 <= B * s < 2.0 ** 15
+    assert (np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -25 / s)).all()
+
+
+def test_data_gradient_epilogue_hands_the_bound_its_third_plane(dev):
+    """embnet_conv2d_dgrad_bnsums_f32_ex writes [3][c][rows]: the two BatchNorm-backward sums and max |dz| per row band;
+    embnet_bn_bwd_partials_ex (partial_kinds = 3) then scales its dx planes without a dry run."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(21)
+    n, h, c, k = 8, 14, 64, 256                                                  # a bottleneck's conv3 (1x1) behind bn3
+    m = n * h * h
+    e = (torch.randn(m, c, generator=g) + 0.2).to(dev)                          # bn3's input
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev)
+    fwd = bn_forward(e, gamma, beta, 1)
+    sp = fwd["stats"].data_ptr()
+    w = (torch.randn(1, 1, c, k, generator=g) * 0.1).to(dev)
+    dy = (torch.randn(n, h, h, k, generator=g) * 1e-4).to(dev)
+    rows = lib.embnet_conv2d_dgrad_bnsums_rows(n, h, h, c, 1, 1, k, 1)
+    assert rows > 0
+    part = torch.full((3, c, rows), float("nan"), device=dev)
+    da = torch.empty((n, h, h, c), device=dev)                                   # d(conv3 input) = d(act(bn3(e)))
+    ws = torch.empty(max(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, h, c, 1, 1, k, 1) // 4, 4), device=dev)
+    _lib.check(lib.embnet_conv2d_dgrad_bnsums_f32_ex(dy.data_ptr(), w.data_ptr(), da.data_ptr(), n, h, h, c, 1, 1, k, 1, 0, 0, h, h,
+                                                     e.data_ptr(), sp + 8 * c, sp + 12 * c, sp, sp + 4 * c, 1, part.data_ptr(), rows,
+                                                     ws.data_ptr(), ws.numel() * 4, None, None, _lib.stream()))
+    torch.cuda.synchronize()
+    z = e * fwd["stats"][2] + fwd["stats"][3]
+    dz = torch.where(z > 0, da.view(m, c), torch.zeros_like(z))
+    assert torch.isfinite(part).all()
+    assert float(part[2].amax()) == float(dz.abs().max())                        # the bands' maxima cover every element, exactly
+    dx = torch.empty((m, c), device=dev)
+    planes = torch.zeros(3 * m * c, dtype=torch.int16, device=dev)
+    dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    _lib.trace_reset(); _lib.trace_enable(True)
+    try:
+        _lib.check(lib.embnet_bn_bwd_partials_ex(da.data_ptr(), e.data_ptr(), m, c, sp, sp + 4 * c, sp + 8 * c, sp + 12 * c, 1, part.data_ptr(), rows,
+                                                 None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), planes.data_ptr(), None, 3, sp + 24 * c, None,
+                                                 _lib.stream()))
+        names = [r[0] for r in _lib.trace_records()]
+    finally:
+        _lib.trace_enable(False)
+    assert any("bn_bwd_apply4_kernel<4>" in s for s in names) and not any("bn_bwd_apply4_kernel<1>" in s for s in names), names
+    got, s = decode(planes, m, c)
+    want = dx.cpu().numpy().astype(np.float64)
+    top = np.abs(want).max()
+    assert 2.0 ** 12 <= top * s < 2.0 ** 15                                      # the bound is within 4x of the maximum
+    assert (np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -25 / s)).all()
 
 
 # ---- the C ABI's explicit ranges ---------------------------------------------------------------------------------------------------
