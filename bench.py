@@ -213,7 +213,7 @@ def roofline_from_trace(records, traced_steps, ms_per_step, workload, conv_terms
                 traced_kernel_ms_per_step=round(total_ms, 3))
     # measured HBM bytes per launch (PMC counters, separate rocprofv3 passes): only from a profile of THIS workload
     roof["traffic"] = None
-    for tfile in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # newest profile that has this workload and kernel
+    for tfile in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # newest profile that has this workload and kernel
         tpath = os.path.join(ROOT, "profiles", tfile)
         if not os.path.exists(tpath):
             continue

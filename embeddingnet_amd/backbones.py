@@ -156,6 +156,9 @@ class ResidualUnit(nn.Module):
             self.conv2 = _rn_conv(filters, filters, 3, stride, 1, gen)
             self.bn3 = L.BatchNormalization(filters, epsilon=RN_EPS, relu=True)
             self.conv3 = _rn_conv(filters, cout, 1, 1, 0, gen)
+            # conv3 reads the unit's THIN tensor (filters = cout / 4 channels): bn3 writes it as planes too (+ 4 B per element of the
+            # small tensor) and conv3's forward runs the 1x1 planes GEMM (layers.CONV1X1_PLANES; DESIGN 3.14 prices the other 1x1 convs)
+            self.conv3.planes1x1 = True
         self.out_channels = cout
 
     def forward(self, x):
@@ -178,7 +181,7 @@ class ResidualUnit(nn.Module):
         if self.kind == "basic":
             return self.conv2(y, residual=sc, emit_stats=st)   # the unit's Add runs in the last conv's epilogue
         # bottleneck: bn3 is conv2's only reader (owns_input: its dx may be planes only when conv2 is a stride-1 patch conv)
-        return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d, owns_input=True), residual=sc, emit_stats=st)
+        return self.conv3(self.bn3(self.conv2(y, emit_stats=st), defer=d, owns_input=True, planes_for=self.conv3), residual=sc, emit_stats=st)
 
 
 class ResNet(nn.Module):

@@ -64,10 +64,10 @@ __device__ __forceinline__ kargp kargs() {
 
 struct Item { int m0, n0, cc_b, cc_e, tile_m; float* part; };
 
-template <int BN>
+template <int BN, int CCH = 16>      // CCH: channels per reduction unit `cc` (a 16-channel chunk; the 1x1 kernel walks groups of chunks)
 __device__ __forceinline__ Item work_item(int item, int n_mine) {
   kargp pp = kargs();
-  const int b = blockIdx.x, NCC = pp->g.C / 16, tiles_n = (pp->g.K + BN - 1) / BN;
+  const int b = blockIdx.x, NCC = pp->g.C / CCH, tiles_n = (pp->g.K + BN - 1) / BN;
   Item t; int id;
   if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr; }
   else {
@@ -108,6 +108,109 @@ __device__ __forceinline__ void step_planes(const bf16x8 (&a)[G::TM][NP], const 
 // 64 extra epilogue registers and scalar spills cost the plain kernel ~10 % when both forms share one body
 // F16: the planes hold two fp16 pieces + a scale (gemm_engine.h, EMBNET_PLANES_F16): NP = 2 planes are fetched, held in LDS and read,
 // three matrix products per step instead of six, the accumulators x 1 / (s_x s_w) in the epilogue
+// The epilogue of one output tile, straight from the accumulators (shared by the 3x3 patch kernel and the 1x1 planes kernel):
+// 1 / (s_x s_w) (F16), then a raw partial tile (K-split left-overs) or bias / ReLU / residual / BatchNorm statistics / backward sums.
+template <class G, int BN, bool BNS, bool F16>
+__device__ __forceinline__ void patch_epilogue(const PatchParams& p, const Item& cur, f32x16 (&acc)[G::TM][G::TN], int M, int K,
+                                               int wave, int lane, int h, int wm, int wn) {
+  constexpr int TM = G::TM, TN = G::TN;
+  // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
+  // lane & 31, so a store instruction writes two 128-byte row segments
+  if (F16) {                                           // 1 / (s_x s_w): powers of two, exact
+    // (one after the other: each factor is a normal number, their product need not be — gemm_engine.h scale_exponent_of)
+    const float osx = planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1], osw = planes_scale_slot(p.wp, (long)(p.w_plane_bytes >> 1))[1];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[im][in][rr] = (acc[im][in][rr] * osw) * osx;
+  }
+  if (cur.part) {
+    float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+          part[(im * 32 + (rr & 3) + 8 * (rr >> 2)) * BN + in * 32] = acc[im][in][rr];
+  } else {
+    const bool inner = cur.m0 + 256 <= M && cur.n0 + BN <= K;      // wave-uniform: no edge tests on interior tiles
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = cur.n0 + wn + in * 32 + (lane & 31);
+      const bool cok = col < K;
+      const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+      // BNS — data gradient: the outputs are d(act(BN(e))): the BatchNorm-backward sums  sum dz, sum dz * ehat  of this row band
+      // (dz = v * act'(scale e + shift)), e read here at 4 bytes per element (conv.hip's BnSums; the arithmetic of bn_sums_add).
+      // All of the column block's e values are requested BEFORE the first store (the stores may alias them as far as hipcc
+      // knows, and one exposed memory latency per 16 values costs 10 us per tile)
+      constexpr bool bnm = BNS;
+      float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
+      float ev[BNS ? TM : 1][16];
+      if (BNS) {
+        if (cok) { bsc = p.bn.scale[col]; bsh = p.bn.shift[col]; bmu = p.bn.mean[col]; brs = p.bn.rstd[col]; }
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+          const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            ev[BNS ? im : 0][rr] = (inner || (row < M && cok)) ? p.bn.x[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int im = 0; im < TM; ++im) {
+        const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
+        float v[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) { v[rr] = acc[im][in][rr] + bv; if (p.relu) v[rr] = fmaxf(v[rr], 0.f); }
+        if (inner) {
+          if (p.residual) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) v[rr] += p.residual[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K];
+          }
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            p.y[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] = v[rr];
+            if (BNS) {
+              const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
+              s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
+            } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            if (row < M && cok) {
+              const long o = o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K;
+              if (p.residual) v[rr] += p.residual[o];
+              p.y[o] = v[rr];
+              if (BNS) {
+                const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
+                s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
+              } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
+            }
+          }
+        }
+      }
+      if (p.stats || bnm) {             // BatchNorm statistics of the layer that follows (as conv.hip's epilogue) / backward sums
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0 && cok) {
+          float* const dst = bnm ? p.bn.partial : p.stats;
+          const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = bnm ? p.bn.rows : p.stats_rows;
+          dst[(long)col * P + prow] = s1;
+          dst[((long)K + col) * P + prow] = s2;
+        }
+      }
+    }
+  }
+
+}
+
 // PIPE (F16 only): the MFMA waves read the fragments of tap t + 1 while the matrix pipe works on tap t (two fragment sets in
 // registers, reads and MFMAs interleaved one to one by sched_group_barrier), across the step barriers too for the patch fragments
 // (the patch of a chunk stays put for its nine taps; only the weights of a step become valid at its barrier).  The plain loop reads
@@ -337,100 +440,161 @@ __global__ __launch_bounds__(640) void conv_patch_kernel(const PatchParams p) {
       }
       ++gc;
     }
-    // epilogue straight from the accumulators: register rr of a 32x32 block holds row (rr&3) + 8*(rr>>2) + 4*h, column
-    // lane & 31, so a store instruction writes two 128-byte row segments
-    if (F16) {                                           // 1 / (s_x s_w): powers of two, exact
-      // (one after the other: each factor is a normal number, their product need not be — gemm_engine.h scale_exponent_of)
-      const float osx = planes_scale_slot(p.xp, (long)(p.x_plane_bytes >> 1))[1], osw = planes_scale_slot(p.wp, (long)(p.w_plane_bytes >> 1))[1];
+    patch_epilogue<G, BN, BNS, F16>(p, cur, acc, M, K, wave, lane, h, wm, wn);
+  }
+}
+
+// ---- 1x1 convolutions on the planes ("planes GEMM"; VERDICT r03-r05 #2a) ---------------------------------------------------------
+// y[m][k] = sum_c a[pix(m)][c] w[c][k] for the ResNets' 1x1 convs (reference backbones.py:99-104: the bottleneck's conv1 / conv3 and the
+// projection shortcuts): the operands the patch kernel reads — activation planes [2][C/16][pixels][16], kernel planes
+// [2][C/16][K][16] (embnet_conv_weight_planes with r = s = 1: flip 0 forward, flip 1 data gradient) — by LDS-DMA, no register
+// staging and no split arithmetic in the loop.  A 1x1 conv has one ninth of the 3x3's matrix work per operand byte, so what shapes
+// the kernel is the LOAD stream, not the matrix pipe:
+//  * a STEP is G = 2 chunks (32 channels) of both operands: A 256 pixels x 32 B x 2 planes x G = 32 KB, B BN x 32 B x 2 x G; a ring
+//    of NS = 3 stages (144 KB at BN = 128), requested two steps ahead, one s_barrier per step (24 MFMAs per wave at BN = 128);
+//  * THREE loader waves: wave 8 the kernel planes (16 DMA instructions per step), waves 9 and 10 one chunk of the pixels each (16
+//    each) — one wave issuing all 48 would need ~4 000 cycles per step against ~800 of matrix work;
+//  * output pixel m reads input pixel (n, oh * stride, ow * stride): the per-lane DMA offset does the strided gather (shortcuts);
+//  * the workgroup walks its tiles persistently, left-over tiles are cut along the channel groups (work_item<BN, 16 * G>), the
+//    epilogue is the patch kernel's (patch_epilogue: bias / ReLU / residual / statistics / partial tiles).
+template <int BN, int G, int NS, bool F16>
+__global__ __launch_bounds__(704) void conv1x1_planes_kernel(const PatchParams p) {
+  using GP = GeomP<BN>;
+  static_assert(F16, "the 1x1 planes kernel is built for the two-piece fp16 format");
+  constexpr int NP = 2, TM = GP::TM, TN = GP::TN, D = NS - 1;
+  constexpr int A_BYTES = G * NP * 256 * 32, B_BYTES = G * NP * BN * 32, STAGE = A_BYTES + B_BYTES;
+  constexpr int NBI_B = G * NP * (BN / 32), NBI_A = NP * 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int n_mine = b < p.n_full ? (p.n_full - b + p.grid - 1) / p.grid : 0;
+  const int n_items = n_mine + (b < p.n_pieces ? 1 : 0);
+  if (n_items == 0) return;
+  const int dhalf = (lane & 1) ^ ((lane >> 4) & 1);      // logical 16-byte half this lane's DMA piece holds
+  int total = 0;                                         // steps (channel groups) of this workgroup
+  for (int i = 0; i < n_items; ++i) { const Item q = work_item<BN, 16 * G>(i, n_mine); total += q.cc_e - q.cc_b; }
+
+  if (wave >= 8) {
+    // ---- loaders: stage (gs % NS) <- operands of step gs, D steps ahead of the MFMA waves ----------------------------------
+    const bool is_b = wave == 8;
+    const int tp = wave - 9;                                      // an A loader's chunk of the group
+    const __amdgpu_buffer_rsrc_t rs = is_b
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wp), 0, 3u * p.w_plane_bytes, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xp), 0, 3u * p.x_plane_bytes, 0x00020000);
+    const int K = p.g.K;
+    const unsigned wpb = p.w_plane_bytes, xpb = p.x_plane_bytes, chunk_bytes = 32u * (unsigned)(p.g.N * p.g.H * p.g.W);
+    int it = 0; Item t = work_item<BN, 16 * G>(0, n_mine);        // the step being REQUESTED: (it, cg)
+    int cg = t.cc_b; bool live = true;
+    unsigned off[8];                                              // per lane: B rows (BN / 32 groups) or A pixels (8 groups): constant per tile
+    auto tile_offsets = [&]() {
+      if (is_b) {
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int in = 0; in < TN; ++in)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) acc[im][in][rr] = (acc[im][in][rr] * osw) * osx;
-    }
-    if (cur.part) {
-      float* part = cur.part + (wm + 4 * h) * BN + wn + (lane & 31);
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int in = 0; in < TN; ++in)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr)
-            part[(im * 32 + (rr & 3) + 8 * (rr >> 2)) * BN + in * 32] = acc[im][in][rr];
-    } else {
-      const bool inner = cur.m0 + 256 <= M && cur.n0 + BN <= K;      // wave-uniform: no edge tests on interior tiles
-#pragma unroll
-      for (int in = 0; in < TN; ++in) {
-        const int col = cur.n0 + wn + in * 32 + (lane & 31);
-        const bool cok = col < K;
-        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-        // BNS — data gradient: the outputs are d(act(BN(e))): the BatchNorm-backward sums  sum dz, sum dz * ehat  of this row band
-        // (dz = v * act'(scale e + shift)), e read here at 4 bytes per element (conv.hip's BnSums; the arithmetic of bn_sums_add).
-        // All of the column block's e values are requested BEFORE the first store (the stores may alias them as far as hipcc
-        // knows, and one exposed memory latency per 16 values costs 10 us per tile)
-        constexpr bool bnm = BNS;
-        float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
-        float ev[BNS ? TM : 1][16];
-        if (BNS) {
-          if (cok) { bsc = p.bn.scale[col]; bsh = p.bn.shift[col]; bmu = p.bn.mean[col]; brs = p.bn.rstd[col]; }
-#pragma unroll
-          for (int im = 0; im < TM; ++im) {
-            const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-              ev[BNS ? im : 0][rr] = (inner || (row < M && cok)) ? p.bn.x[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] : 0.f;
-            }
-          }
+        for (int gb = 0; gb < BN / 32; ++gb) {
+          const int row = t.n0 + gb * 32 + (lane >> 1);
+          off[gb] = row < K ? 32u * (unsigned)row + 16u * dhalf : OOB;
         }
+      } else {
+        kargp pp = kargs();
+        FastDiv dOHW, dOW;
+        dOHW.mul = pp->g.dOHW.mul; dOHW.shift = pp->g.dOHW.shift; dOHW.d = pp->g.dOHW.d;
+        dOW.mul = pp->g.dOW.mul; dOW.shift = pp->g.dOW.shift; dOW.d = pp->g.dOW.d;
+        const int M = pp->g.N * pp->g.OH * pp->g.OW, st = pp->g.stride, H = pp->g.H, W = pp->g.W;
 #pragma unroll
-        for (int im = 0; im < TM; ++im) {
-          const long o0 = (long)(cur.m0 + wm + im * 32 + 4 * h) * K + col;
-          float v[16];
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) { v[rr] = acc[im][in][rr] + bv; if (p.relu) v[rr] = fmaxf(v[rr], 0.f); }
-          if (inner) {
-            if (p.residual) {
-#pragma unroll
-              for (int rr = 0; rr < 16; ++rr) v[rr] += p.residual[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K];
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              p.y[o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K] = v[rr];
-              if (BNS) {
-                const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
-                s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
-              } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
-            }
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              const int row = cur.m0 + wm + im * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-              if (row < M && cok) {
-                const long o = o0 + (long)((rr & 3) + 8 * (rr >> 2)) * K;
-                if (p.residual) v[rr] += p.residual[o];
-                p.y[o] = v[rr];
-                if (BNS) {
-                  const float e = ev[BNS ? im : 0][rr], dz = act_grad(p.bn.act, fmaf(e, bsc, bsh), v[rr]);
-                  s1 += dz; s2 = fmaf(dz, (e - bmu) * brs, s2);
-                } else { s1 += v[rr]; s2 = fmaf(v[rr], v[rr], s2); }
-              }
-            }
-          }
-        }
-        if (p.stats || bnm) {             // BatchNorm statistics of the layer that follows (as conv.hip's epilogue) / backward sums
-          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-          if (h == 0 && cok) {
-            float* const dst = bnm ? p.bn.partial : p.stats;
-            const long prow = (long)cur.tile_m * G::WAVES_M + wave / G::WAVES_N, P = bnm ? p.bn.rows : p.stats_rows;
-            dst[(long)col * P + prow] = s1;
-            dst[((long)K + col) * P + prow] = s2;
-          }
+        for (int gI = 0; gI < 8; ++gI) {
+          const int m = t.m0 + 32 * gI + (lane >> 1);
+          uint32_t n, rem, oh, ow;
+          dOHW.divmod((uint32_t)min(m, M - 1), n, rem); dOW.divmod(rem, oh, ow);
+          off[gI] = m < M ? 32u * (unsigned)(((int)n * H + (int)oh * st) * W + (int)ow * st) + 16u * dhalf : OOB;
         }
       }
+    };
+    tile_offsets();
+    auto issue = [&](int gs) {
+      unsigned char* stage = smem + (gs % NS) * STAGE;
+      if (is_b) {
+#pragma unroll
+        for (int c2 = 0; c2 < G; ++c2)
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int gb = 0; gb < BN / 32; ++gb)
+              dma16(rs, stage + A_BYTES + ((c2 * NP + q) * BN + gb * 32) * 32, live ? off[gb] : OOB,
+                    q * wpb + 32u * (unsigned)((cg * G + c2) * K));
+      } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+          for (int gI = 0; gI < 8; ++gI)
+            dma16(rs, stage + ((tp * NP + q) * 256 + gI * 32) * 32, live ? off[gI] : OOB, q * xpb + (unsigned)(cg * G + tp) * chunk_bytes);
+      }
+      if (live && ++cg == t.cc_e) {
+        if (++it < n_items) { t = work_item<BN, 16 * G>(it, n_mine); cg = t.cc_b; tile_offsets(); } else live = false;
+      }
+    };
+    for (int gs = 0; gs < D; ++gs) issue(gs);
+    for (int gs = 0; gs < total; ++gs) {
+      // the D - 1 youngest requests may still be in flight: step gs has landed.  (Past the last step the loaders keep issuing
+      // out-of-range requests — zeros into stages nobody reads — so the count stays a constant.)
+      if (is_b) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NBI_B) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * NBI_A) : "memory");
+      __builtin_amdgcn_s_barrier();                              // #gs: step gs - 1 is done everywhere -> its stage is free
+      issue(gs + D);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ---- MFMA waves ---------------------------------------------------------------------------------------------------
+  const int wm = (wave / GP::WAVES_N) * GP::WTM, wn = (wave % GP::WAVES_N) * GP::WTN;
+  const int K = p.g.K, M = p.g.N * p.g.OH * p.g.OW;
+  int aoff[TM], boff[TN];                                // byte offsets of this lane's fragment rows inside a (chunk, plane) image
+#pragma unroll
+  for (int im = 0; im < TM; ++im) { const int row = wm + im * 32 + (lane & 31); aoff[im] = row * 32 + ((h ^ ((row >> 3) & 1)) << 4); }
+#pragma unroll
+  for (int in = 0; in < TN; ++in) { const int row = wn + in * 32 + (lane & 31); boff[in] = row * 32 + ((h ^ ((row >> 3) & 1)) << 4); }
+  int gs = 0;
+  f32x16 acc[TM][TN];
+  for (int item = 0; item < n_items; ++item) {
+    const Item cur = work_item<BN, 16 * G>(item, n_mine);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+    for (int cg = cur.cc_b; cg < cur.cc_e; ++cg) {
+      __syncthreads();                 // barrier #gs: this step's operands are in LDS
+      const unsigned char* sa = smem + (gs % NS) * STAGE;
+      const unsigned char* sb = sa + A_BYTES;
+      f16x8 fa[2][TM][2], fb[2][TN][2];
+      auto load = [&](int c2, f16x8 (&a)[TM][2], f16x8 (&bb)[TN][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int im = 0; im < TM; ++im) a[im][q] = *reinterpret_cast<const f16x8*>(sa + (c2 * NP + q) * 256 * 32 + aoff[im]);
+#pragma unroll
+          for (int in = 0; in < TN; ++in) bb[in][q] = *reinterpret_cast<const f16x8*>(sb + (c2 * NP + q) * BN * 32 + boff[in]);
+        }
+      };
+      load(0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c2 = 0; c2 < G; ++c2) {
+        if (c2 + 1 < G) load(c2 + 1, fa[(c2 + 1) & 1], fb[(c2 + 1) & 1]);
+        mfma_step_h<TM, TN>(fa[c2 & 1], fb[c2 & 1], acc);
+        constexpr int NMF = 3 * TM * TN, NRD = 2 * (TM + TN);
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (c2 + 1 < G && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++gs;
+    }
+    patch_epilogue<GP, BN, false, F16>(p, cur, acc, M, K, wave, lane, h, wm, wn);
   }
 }
 
@@ -583,7 +747,34 @@ static int patch_rows(int n, int oh, int ow, int r, int s) {                 // 
 
 struct Plan { int bn, tps, nbs, LR, tiles, n_full, parts, cc_part, n_pieces, grid; size_t lds, ws_bytes; };
 
+// the 1x1 planes GEMM (conv1x1_planes_kernel): G = 2 chunks per step, a ring of three stages; reduction units are 32-channel groups
+constexpr int ONE_G = 2, ONE_NS = 3;
+static bool make_plan1(int n, int c, int k, int stride, int oh, int ow, Plan& pl) {
+  pl = Plan{};
+  if (!planes_f16() || (stride != 1 && stride != 2) || (c % (16 * ONE_G)) || (k & 3) || n <= 0 || oh <= 0 || ow <= 0) return false;
+  const size_t in_pix = (size_t)n * ((size_t)(oh - 1) * stride + 1) * ((size_t)(ow - 1) * stride + 1);
+  if (in_pix * 32 >= 0x7FFFFFF0ull || (size_t)n * oh * ow * k * 4 >= 0x7FFFFFF0ull) return false;
+  pl.bn = k >= 128 ? 128 : 64;
+  pl.tps = ONE_G; pl.nbs = ONE_NS; pl.LR = 256;
+  pl.lds = (size_t)ONE_NS * ONE_G * 2 * 32 * (256 + pl.bn);
+  const long M = (long)n * oh * ow;
+  pl.tiles = cdiv(M, 256) * cdiv(k, pl.bn);
+  pl.grid = 256;
+  const int ncc = c / (16 * ONE_G);
+  pl.n_full = pl.tiles / pl.grid * pl.grid;
+  const int rem = pl.tiles - pl.n_full;
+  pl.parts = 1; pl.cc_part = ncc; pl.n_pieces = 0; pl.ws_bytes = 0;
+  if (rem > 0) {
+    int parts = pl.grid / rem; if (parts > ncc) parts = ncc; if (parts < 1) parts = 1;
+    pl.cc_part = cdiv(ncc, parts); pl.parts = cdiv(ncc, pl.cc_part);
+    if (pl.parts == 1) { pl.n_full = pl.tiles; }
+    else { pl.n_pieces = rem * pl.parts; pl.ws_bytes = (size_t)pl.n_pieces * 256 * pl.bn * 4; }
+  }
+  return true;
+}
+
 static bool make_plan(int n, int c, int r, int s, int k, int stride, int oh, int ow, Plan& pl) {
+  if (r == 1 && s == 1) return make_plan1(n, c, k, stride, oh, ow, pl);
   static const int enabled = (int)env_long("EMBNET_CONV_PATCH", 1);
   if (!enabled || stride != 1 || r != 3 || s != 3 || (c & 15) || (k & 3) || n <= 0 || oh <= 0 || ow <= 0) return false;
   if ((size_t)n * (oh + 2) * (ow + 2) * 32 >= 0x7FFFFFF0ull || (size_t)n * oh * ow * c * 2 >= 0x7FFFFFF0ull / 3) return false;
@@ -703,6 +894,7 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
                              const float* residual, float* stats, const BnSums& bsum, void* workspace, size_t workspace_bytes,
                              void* stream) {
   EMBNET_CHECK_ARG(xp && wp && y, "conv2d_patch: null pointer");
+  EMBNET_CHECK_ARG(r == 3 && s == 3, "conv2d_patch: 3x3 kernels (1x1: embnet_conv2d_planes1x1_f32)");
   Plan pl;
   EMBNET_CHECK_ARG(make_plan(n, c, r, s, k, 1, oh, ow, pl), "conv2d_patch: unsupported geometry (see embnet_conv2d_patch_supported)");
   PatchParams p{(const unsigned short*)xp, (const unsigned short*)wp, y, bias, residual, stats, 0, relu};
@@ -743,6 +935,49 @@ extern "C" int embnet_conv2d_patch_f32(const void* xp, const void* wp, const flo
                                        void* stream) {
   return conv2d_patch_impl(xp, wp, bias, y, n, h, wd, c, r, s, k, pad_t, pad_l, oh, ow, relu, residual, stats,
                            BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0}, workspace, workspace_bytes, stream);
+}
+
+// 1x1 convolution on the planes (conv1x1_planes_kernel): y[n,oh,ow,k] = sum_c x[n, oh*stride, ow*stride, c] w[c,k]; x planes
+// [.][c/16][n*h*wd][16], kernel planes of a [1,1,c,k] kernel (flip 0) — or, with dy planes and flip-1 planes, c and k swapped, the
+// stride-1 data gradient.  Epilogue options as embnet_conv2d_patch_f32.
+template <int BN>
+static void launch_1x1(const PatchParams& p, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)conv1x1_planes_kernel<BN, ONE_G, ONE_NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  conv1x1_planes_kernel<BN, ONE_G, ONE_NS, true><<<p.grid, 704, lds, st>>>(p);
+}
+extern "C" int embnet_conv2d_planes1x1_f32(const void* xp, const void* wp, const float* bias, float* y, int n, int h, int wd, int c,
+                                           int k, int stride, int oh, int ow, int relu, const float* residual, float* stats,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  EMBNET_CHECK_ARG(xp && wp && y, "conv2d_planes1x1: null pointer");
+  Plan pl;
+  EMBNET_CHECK_ARG(make_plan1(n, c, k, stride, oh, ow, pl), "conv2d_planes1x1: unsupported geometry (embnet_conv2d_patch_supported with r = s = 1)");
+  PatchParams p{(const unsigned short*)xp, (const unsigned short*)wp, y, bias, residual, stats, 0, relu};
+  if (int rc = make_geom(p.g, n, h, wd, c, 1, 1, k, stride, 0, 0, oh, ow, "conv2d_planes1x1")) return rc;
+  const long M = (long)n * oh * ow;
+  p.x_plane_bytes = (unsigned)((size_t)n * h * wd * c * 2);
+  p.w_plane_bytes = (unsigned)((size_t)c * k * 2);
+  p.PH = oh; p.PW = ow; p.dPHW = FastDiv::make(oh * ow); p.dPW = FastDiv::make(ow);
+  p.LR = 256;
+  p.stats_rows = cdiv(M, 256) * 4;
+  p.bn = BnSums{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0};
+  p.grid = pl.grid;
+  if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
+  p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    static thread_local char kname[160];
+    snprintf(kname, sizeof kname, "void embnet::patch::conv1x1_planes_kernel<%d, %d, %d, true>(embnet::patch::PatchParams)", pl.bn, ONE_G, ONE_NS);
+    EMBNET_TRACE_FLOP(kname, 2.0 * M * k * c, 4.0 * ((double)M * c + (double)c * k) + 4.0 * (double)M * k * (residual ? 2 : 1), st);
+    if (pl.bn == 128) launch_1x1<128>(p, pl.lds, st); else launch_1x1<64>(p, pl.lds, st);
+  }
+  if (p.n_pieces > 0)
+    launch_tail_fixup(p.ws, p.parts, 256, pl.bn, 64, p.n_full, pl.tiles - p.n_full, cdiv(k, pl.bn), M, k, bias, relu, residual, y,
+                      stats, p.stats_rows, p.bn, st);
+  return check_launch("conv2d_planes1x1");
 }
 
 // The patch kernel as a stride-1 DATA GRADIENT (xp: planes of dy [n,h,wd,c], wp: the flipped kernel planes, y: the gradient

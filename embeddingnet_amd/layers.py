@@ -242,12 +242,15 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
     # (only for a leaf kernel: the gradient of a derived one — the channel-padded kernel of an image conv — is consumed by the
     # next backward node at once)
-    if SLAB_DEFER[0] and w.grad_fn is None and \
+    if SLAB_DEFER[0] and _SLAB_PENDING and any(e[4] is w for e in _SLAB_PENDING):
+        # the same kernel a second time in one backward (a shared layer: the two branches of a Siamese step): the first gradient's
+        # slab sum is still queued and autograd is about to ADD this one to that buffer — finish the queue first, compute this
+        # gradient in place (round 5 reached this branch only with a gradient sink: with a plain .grad the queued sum later
+        # overwrote the accumulated gradient, dropping the second branch's half — found by tests/test_siamese_trainer_gpu.py)
+        flush_slab_reduces()
+    elif SLAB_DEFER[0] and w.grad_fn is None and \
             (getattr(w, "grad", None) is None or (GRAD_SINKS and w.data_ptr() in GRAD_SINKS)):
-        if any(e[4] is w for e in _SLAB_PENDING):               # the same kernel a second time in one backward (shared layer):
-            flush_slab_reduces()                                # finish the first gradient, compute this one in place
-            splits = 1
-        elif planes:
+        if planes:
             splits = lib.embnet_conv2d_wgrad_planes_splits(n, h, wd, c, k)
         else:
             splits = lib.embnet_conv2d_wgrad_splits(n, c, r, s, k, oh, ow)
@@ -363,6 +366,12 @@ FUSE_RELU_BN = [_os.environ.get("EMBNET_FUSE_RELU_BN", "1") != "0"]
 FUSE_RELU_POOL = [_os.environ.get("EMBNET_FUSE_RELU_POOL", "1") != "0"]
 RELU_DONE = _CtxDict("relu_done")
 PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: every conv on the gather kernels (A/B)
+# 1x1 convs marked `planes1x1` (backbones: the bottleneck's conv3, whose input is the thin tensor) run their FORWARD on the planes GEMM
+# (csrc/conv_patch.hip conv1x1_planes_kernel).  OFF by default: back to back the kernel beats the ranged gather kernel on every
+# stride-1 ResNet50 layer (profiles/r06_exp_conv1x1_planes.txt: 1024 -> 256 at 14x14 150 -> 81 us), but in the step the
+# BatchNormalization in front must write the planes BESIDE the fp32 copy the gather weight gradient still reads: C3 86.8 -> 87.8 ms
+# (profiles/r06_exp_conv1x1_step.txt).  It pays once a 1x1 planes weight gradient lets that tensor exist as planes only.
+CONV1X1_PLANES = [_os.environ.get("EMBNET_CONV_1X1_PLANES", "0") != "0"]
 DY_PLANES = _CtxDict("dy_planes")
 _ACT_PLANES = _CtxDict("act_planes")
 _ACT_RANGE = _CtxDict("act_range")
@@ -658,7 +667,11 @@ class _Conv2dFn(torch.autograd.Function):
                 raise _lib.EmbnetError(f"Add: shapes differ {(n, oh, ow, k)} vs {tuple(residual.shape)}")
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         lib = _lib.lib()
-        if planes is not None:
+        if planes is not None and r == 1:           # 1x1 on the planes (csrc/conv_patch.hip conv1x1_planes_kernel): forward only —
+            ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, c, 1, 1, k, oh, ow), x.device)   # backward stays on the ranged gather kernels
+            check(lib.embnet_conv2d_planes1x1_f32(ptr(planes), ptr(weight_planes(w, 0)), ptr(bias), ptr(y), n, h, wd, c, k, stride,
+                                                  oh, ow, int(relu), ptr(residual), ptr(out_stats), ptr(ws), ws.numel() * 4, stream()))
+        elif planes is not None:
             ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
             check(lib.embnet_conv2d_patch_f32(ptr(planes), ptr(weight_planes(w, 0)), ptr(bias), ptr(y), n, h, wd, c, r, s, k,
                                               pt, pl, oh, ow, int(relu), ptr(residual), ptr(out_stats), ptr(ws),
@@ -670,10 +683,11 @@ class _Conv2dFn(torch.autograd.Function):
                 ptr(x), ptr(w), ptr(bias), ptr(y), n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, int(relu), ptr(residual),
                 in_scale, in_shift, int(in_act), ptr(out_stats), ptr(ws), ws.numel() * 4,
                 _rptr(x_range) if fr else None, _rptr(w_range) if fr else None, stream()))
-        ctx.patch = planes is not None
-        ctx.w_range = w_range if (planes is None and in_stats is None) else None
-        ctx.x_range = x_range if (planes is None and in_stats is None) else None
-        ctx.x_planes = planes                # kept for the weight gradient (conv_wgrad)
+        one = planes is not None and r == 1         # (a 1x1 planes forward: data and weight gradient run the gather kernels, on their ranges)
+        ctx.patch = planes is not None and not one
+        ctx.w_range = w_range if ((planes is None or one) and in_stats is None) else None
+        ctx.x_range = x_range if ((planes is None or one) and in_stats is None) else None
+        ctx.x_planes = None if one else planes   # kept for the weight gradient (conv_wgrad)
         ctx.bn_src = bn_src
         ctx.geom, ctx.relu, ctx.has_bias, ctx.has_res = geom, relu, bias is not None, residual is not None
         ctx.in_act = int(in_act)
@@ -993,7 +1007,7 @@ class Conv2D(nn.Module):
     def range_for(self, x, planes, in_stats):
         """The kernel's range slot when this conv, on that input, runs the gather kernels on three products; else None (among
         the reasons: the input carries no range — nobody vouches for its magnitude, so six exact bf16 terms it is)."""
-        if not (CONV_F16[0] and getattr(self, "f16", False)) or planes is not None or in_stats is not None or self.relu:
+        if not (CONV_F16[0] and getattr(self, "f16", False)) or (planes is not None and self.k != 1) or in_stats is not None or self.relu:
             return None
         if _range_of(x) is None:
             return None
@@ -1062,7 +1076,7 @@ class Conv2D(nn.Module):
             # the fused Add (the projection shortcut), which receives the same gradient tensor, or for the BatchNormalization at the
             # head of an identity shortcut, which adds that gradient to its own dx and bounds the sum with it (no dry run)
             y._wants_dy_range = True
-        if planes is not None and not self.relu:
+        if planes is not None and not self.relu and self.k != 1:
             y._wants_dy_planes = True          # the BatchNormalization reading y writes its dx also as planes (backward)
             # ... and ONLY as planes when this conv takes both of its gradients from them and the BatchNormalization is told
             # that nobody else reads its dx (BatchNormalization.forward(owns_input=True))
@@ -1079,7 +1093,7 @@ class Conv2D(nn.Module):
     def planes_only_input(self, x_shape):
         """True when no pass of this conv reads an fp32 copy of its input: forward on the patch kernel, weight gradient on the
         planes kernel (the data gradient never reads the input)."""
-        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.patch_capable(x_shape)):
+        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.k == 3 and self.patch_capable(x_shape)):
             return False
         n, h, w, c = x_shape
         stride, pt, pl, oh, ow = self.geometry(h, w)
@@ -1088,7 +1102,7 @@ class Conv2D(nn.Module):
     def planes_only_gradient(self, x_shape, geom=None):
         """True when this conv's backward reads NO fp32 copy of its output gradient: data gradient on the patch kernel, weight
         gradient on the planes kernel, no bias gradient, no fused ReLU."""
-        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.bias is None and not self.relu and self.patch_capable(x_shape)):
+        if not (PLANES_ONLY[0] and WGRAD_PLANES[0] and self.bias is None and not self.relu and self.k == 3 and self.patch_capable(x_shape)):
             return False
         n, h, w, c = x_shape
         stride, pt, pl, oh, ow = geom if geom is not None else self.geometry(h, w)
@@ -1098,9 +1112,16 @@ class Conv2D(nn.Module):
     def patch_capable(self, x_shape):
         """True when this conv on an input of that shape runs the patch kernel (csrc/conv_patch.hip): 3x3, stride 1,
         C % 16 == 0, K % 4 == 0 and an LDS budget the library checks."""
-        if self.k != 3 or self.stride != 1 or len(x_shape) != 4 or not PATCH_CONV[0]:
+        if len(x_shape) != 4 or not PATCH_CONV[0]:
             return False
         n, h, w, c = x_shape
+        if self.k == 1:          # the planes GEMM (forward only): where a BatchNormalization was told to write this conv's input as planes
+            if not (CONV1X1_PLANES[0] and getattr(self, "planes1x1", False)) or self.padding not in ("valid", "same", 0):
+                return False
+            _, _, _, oh, ow = self.geometry(h, w)
+            return patch_ok(n, h, w, c, 1, 1, self.kernel.shape[3], self.stride, oh, ow)
+        if self.k != 3 or self.stride != 1:
+            return False
         _, _, _, oh, ow = self.geometry(h, w)
         return patch_ok(n, h, w, c, 3, 3, self.kernel.shape[3], 1, oh, ow)
 

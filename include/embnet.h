@@ -337,6 +337,15 @@ int embnet_conv2d_patch_stats_rows(int n, int oh, int ow);
 int embnet_conv2d_patch_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
                             int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu, const float* residual,
                             float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* 1x1 convolutions on the planes (ABI 21; csrc/conv_patch.hip conv1x1_planes_kernel): the bottleneck units' conv1 / conv3 and the
+ * projection shortcuts (backbones.py:99-104) as a GEMM whose operands arrive by LDS-DMA from the planes — x planes of [n,h,wd,c],
+ * kernel planes of a [1,1,c,k] kernel (embnet_conv_weight_planes; flip 1 and dy planes give the stride-1 data gradient) —
+ * y[n,oh,ow,k] = sum_c x[n, oh*stride, ow*stride, c] w[c,k], epilogue options and workspace as embnet_conv2d_patch_f32
+ * (embnet_conv2d_patch_supported / _workspace_bytes / _stats_rows with r = s = 1: c % 32 == 0, k % 4 == 0, stride 1 or 2, the
+ * two-piece planes format). */
+int embnet_conv2d_planes1x1_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
+                                int k, int stride, int oh, int ow, int relu, const float* residual, float* stats,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* The patch kernel as a stride-1 data gradient (dy planes, flip-1 kernel planes, c and k swapped as above) whose epilogue ALSO
  * emits the BatchNorm-backward sums of the BatchNormalization in front of the conv — the conv's input was
  * act(bn_scale * bn_x + bn_shift): embnet_conv2d_dgrad_bnsums_f32's contract on this kernel, bn_partial [2][k][bn_rows] with

@@ -21,6 +21,7 @@ def dev():
 
 def _net(dev, distance_type="l2", backbone="resnet18", image=64, enc=32, seed=4):
     from embeddingnet_amd.models import SiameseNet
+    torch.manual_seed(11)            # (the heads' Dense layers draw from torch's global generator)
     return SiameseNet({"model": dict(input_shape=[image, image, 3], encodings_len=enc, mode="siamese", distance_type=distance_type,
                                      backbone_name=backbone, backbone_weights=None, freeze_backbone=False,
                                      embeddings_normalization=True, device=dev, seed=seed),
