@@ -81,7 +81,7 @@ def test_bn_backward_emits_the_range_of_its_dx(dev):
         slot = torch.full((lib.embnet_range_slot_words(),), 0x7F000000, dtype=torch.int32, device=dev)   # (stale content: zeroed by the call)
         _lib.check(lib.embnet_bn_bwd_ex(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                         1, 1, _lib.ptr(dx_add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), None, ws.data_ptr(),
-                                        ws.numel() * 4, slot.data_ptr(), _lib.stream()))
+                                        ws.numel() * 4, slot.data_ptr(), None, None, _lib.stream()))
         assert bits(slot[0]) == bits(dx.abs().max())
         # the deprecated per-thread request (ABI 20) gives the same, once
         slot.fill_(0x7F000000)
@@ -108,7 +108,8 @@ def test_a_range_request_that_cannot_be_met_fails_loudly(dev):
     ws = torch.empty(max(lib.embnet_bn_workspace_bytes(m, c) // 4, 4), device=dev)
     slot = torch.zeros(lib.embnet_range_slot_words(), dtype=torch.int32, device=dev)
     rc = lib.embnet_bn_bwd_ex(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, 1,
-                              None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), ws.numel() * 4, slot.data_ptr(), _lib.stream())
+                              None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), ws.numel() * 4, slot.data_ptr(), None, None,
+                              _lib.stream())
     assert rc != 0 and b"range" in lib.embnet_last_error()
     _lib.check(lib.embnet_range_emit(slot.data_ptr()))
     rc = lib.embnet_bn_bwd(dy.data_ptr(), x.data_ptr(), m, c, mean.data_ptr(), rstd.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, 1,

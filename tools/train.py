@@ -186,9 +186,15 @@ def main():
                                                          if isinstance(v, torch.nn.Parameter)})
             print(f'resumed optimizer state from {opt_path} (iterations {opt.iterations}, saved after epoch {int(extra.get("epoch", 0))})')
     reducer = GradReducer(params) if world > 1 else None
-    trainer = None if siamese else TripletTrainer(
-        model.base_model, opt, gen_kw['k_classes'], p_gen['k_samples'], margin=p_gen['margin'],
-        negatives_selection_mode=p_gen['negatives_selection_mode'], seed=rank, reducer=reducer)
+    if siamese:
+        # the Siamese step (reference train.py:108-119: fit of SiameseNet.model with contrastive_loss) as a trainer: its own step
+        # context, one-launch optimizer, and a captured step where the host cannot keep up (EMBNET_GRAPH=auto)
+        from embeddingnet_amd.train_step import SiameseTrainer
+        trainer = SiameseTrainer(model.model, opt, contrastive_loss, seed=rank, reducer=reducer)
+    else:
+        trainer = TripletTrainer(
+            model.base_model, opt, gen_kw['k_classes'], p_gen['k_samples'], margin=p_gen['margin'],
+            negatives_selection_mode=p_gen['negatives_selection_mode'], seed=rank, reducer=reducer)
     plateau = Plateau(persistent=bool(p_train.get('plateau_persistent', False)))
     history = {'loss': [], 'val_loss': []}
     n_epochs = min(p_train['n_epochs'], args.max_epochs or p_train['n_epochs'])
@@ -211,14 +217,8 @@ def main():
         for _ in range(len(train_gen)):
             if siamese:
                 (x1, x2), y = train_gen[0]
-                opt.zero_grad(set_to_none=True) if reducer is None else reducer.zero()
-                out = model.model([torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)])[0]
-                loss = contrastive_loss(torch.from_numpy(y).to(dev), out)
-                loss.backward()
-                if reducer is not None:
-                    reducer.finish()
-                opt.step()
-                losses.append(loss.detach())
+                losses.append(trainer.step(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev),
+                                           torch.from_numpy(np.asarray(y, dtype=np.float32)).to(dev).reshape(-1, 1)))
             else:
                 xb = feeder.next()
                 n_images += xb.shape[0]
