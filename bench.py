@@ -371,10 +371,13 @@ def main():
     # A traced C2 step costs ~1.4 ms more than a plain one (13 121 images/s timed with three of 50 steps traced vs 13 235 in
     # the untraced leg), so the number of traced steps follows the length of the timed region: 1 below 40 steps, 2 below
     # 80, else 3 — spread evenly, never the first step.
-    # Round 6: never fewer than three traced steps (a per-kernel average over ONE step is one box's one moment); at
-    # --steps 20 they cost ~2 % of `value`, which is then an under-statement, not an over-statement.
-    n_traced = min(3, max(args.steps - 1, 1))
+    # Round 6: never fewer than three traced steps in all (a per-kernel average over ONE step is one box's one moment)
+    # — but a traced step is slower than a plain one (+ ~1.4 ms on C2; on a graph-replayed config it runs eagerly: 2.0 vs 0.9 ms on
+    # C1), so only as many of them sit inside the timed region as its length carries (1 below 40 steps, 2 below 80, else 3) and the
+    # rest are taken in the sustained leg behind it, which is not part of `value`.
+    n_traced = min(1 if args.steps < 40 else 2 if args.steps < 80 else 3, max(args.steps - 1, 1))
     traced_at = {(j + 1) * args.steps // (n_traced + 1) for j in range(n_traced)}
+    n_traced_sustained = max(0, 3 - n_traced) if args.sustain_seconds > 0 else 0
     if trace:
         _lib.trace_reset()
     # liveness record of the timed region, kept on the device (no host sync inside a step): every step's loss and number
@@ -402,13 +405,17 @@ def main():
     value = n_local * world * args.steps / elapsed
     # sustained leg (not part of `value`): the chip lowers its clock under sustained matrix load, so a 0.2-0.6 s timed
     # region is a short-burst number; keep stepping and report what the step time settles at
-    sustained = None
+    sustained, sus_traced = None, set()
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(args.sustain_seconds * 1e3 / max(ms_per_step, 1e-3)) + 1)
+        sus_traced = {(j + 1) * n_sus // (n_traced_sustained + 1) for j in range(n_traced_sustained)} if trace else set()
         barrier()
         s0 = time.perf_counter()
-        for _ in range(n_sus):
+        for i in range(n_sus):
+            if sus_traced:
+                _lib.trace_enable(i in sus_traced)
             step()
+        _lib.trace_enable(False)
         barrier()
         sus = time.perf_counter() - s0
         if world > 1:
@@ -491,8 +498,10 @@ def main():
         + f", step {ms_per_step:.2f} ms ({'GPU' if host_work < 0.9 * ms_per_step else 'host'}-bound)")
     roofline = None
     if trace:
-        roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at), ms_per_step, args.config,
+        roofline, _ = roofline_from_trace(_lib.trace_records(), len(traced_at) + (len(sus_traced) if sustained else 0), ms_per_step, args.config,
                                           _lib.lib().embnet_conv_mfma_terms(), _lib.lib().embnet_conv_planes_mfma_terms())
+        if roofline is not None:
+            roofline["traced_steps"] = {"in_timed_region": len(traced_at), "in_sustained_leg": len(sus_traced) if sustained else 0}
         if roofline is not None and args.backbone in FWD_GMAC and args.image == 224:
             # the whole step's algorithmic FLOP against (a) the fp32-MFMA ceiling SURVEY 8(d) names — it can exceed 1: the convs
             # execute as 16-bit MFMA terms — and (b) the peak of the instruction they execute on, x the terms executed per product

@@ -916,6 +916,9 @@ using G128x64 = Geom<128, 64, 2, 2>;
 using G128x32 = Geom<128, 32, 4, 1>;
 using G64x64 = Geom<64, 64, 2, 2>;
 using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 576 = 3*192 rows (4.5 tiles of 128)
+// three-product wgrad only: a gradient of 129 .. 256 rows x <= 64 filters as ONE row tile — the ResNet stem's 7x7x4 x 64 = 196 rows
+// took two 128-row tiles, each streaming all of dy: 1 136 MB per launch against 514 MB algorithmic (profiles/r05_pmc_traffic_c2.txt)
+using G256x64 = Geom<256, 64, 4, 1>;
 
 
 // pick the widest N tile that the channel count fills, shrink M tile when the grid would not cover the chip
@@ -952,12 +955,12 @@ static int pick_tile(long m, int ncols, bool strided_dgrad = false, long kdepth 
   if (!strided_dgrad && kdepth >= 32 * BK && cdiv(m, 64) * cdiv(ncols, 64) < 512) return 1;
   return (cdiv(m, 128) * cdiv(ncols, 64) >= need) ? 1 : 3;
 }
-static const int TILE_BM[5] = {128, 128, 128, 64, 192}, TILE_BN[5] = {128, 64, 32, 64, 64}, TILE_WTM[5] = {64, 64, 32, 32, 96};
+static const int TILE_BM[6] = {128, 128, 128, 64, 192, 256}, TILE_BN[6] = {128, 64, 32, 64, 64, 64}, TILE_WTM[6] = {64, 64, 32, 32, 96, 64};
 // workgroups of each tile type a CU holds at once (registers / LDS; measured with in-kernel stamps)
 #if EMBNET_CONV_SPLIT
-static const int TILE_RESIDENT[5] = {2, 3, 4, 4, 2};
+static const int TILE_RESIDENT[6] = {2, 3, 4, 4, 2, 2};
 #else
-static const int TILE_RESIDENT[5] = {3, 4, 5, 7, 3};
+static const int TILE_RESIDENT[6] = {3, 4, 5, 7, 3, 3};
 #endif
 // Progress-ordered priority (gemm_engine.h: `fair`) for launches whose workgroups are all resident at once.  Measured
 // A/B, one process (tools/exp/ab_conv.py, ResNet18 layers at batch 128): 64x64-tile forward / data-gradient launches
@@ -1028,7 +1031,7 @@ static void plan_tail(long tiles, int kt, int bm, int bn, size_t ws_bytes, Split
 }
 
 // kernel name as rocprofv3 prints it, for the trace log (and embnet_conv2d_kernel_name)
-static const char* GEOM_NAME[5] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2", "192, 64, 2, 2"};
+static const char* GEOM_NAME[6] = {"128, 128, 2, 2", "128, 64, 2, 2", "128, 32, 4, 1", "64, 64, 2, 2", "192, 64, 2, 2", "256, 64, 4, 1"};
 static const char* conv_kernel_name(const char* kernel, const char* params, int tile, const char* flags) {
   static thread_local char buf[160];
   snprintf(buf, sizeof buf, "void embnet::%s<embnet::Geom<%s>, %s>(embnet::%s)", kernel, GEOM_NAME[tile], flags, params);
@@ -1053,6 +1056,7 @@ static const char* conv_kernel_name(const char* kernel, const char* params, int 
 #define LAUNCH_WGRAD_H(KERNEL, tile, grid, st, p)          /* + the 192-row tile only the weight gradient plans */ \
   switch (tile) {                                                                     \
     case 4: KERNEL<G192x64><<<grid, 256, 0, st>>>(p); break;                          \
+    case 5: KERNEL<G256x64><<<grid, 256, 0, st>>>(p); break;                          \
     default: LAUNCH_TILED_H(KERNEL, tile, grid, st, p)                                \
   }
 static const char* conv_h_kernel_name(const char* kernel, const char* params, int tile) {
@@ -1440,7 +1444,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     }
     return check_launch("conv2d_wgrad");
   }
-  const dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
+  dim3 grid(cdiv(rows, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]) * ((p.splits + 7) / 8 * 8));
   p.fair_from = fair_from(grid.x, tile, true);
   const bool va = (c & 3) == 0 && aligned16(x), vb = (k & 3) == 0 && aligned16(dy);
   EMBNET_CHECK_ARG(!in_scale == !in_shift, "conv2d_wgrad: in_scale and in_shift go together");
@@ -1455,6 +1459,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     const bool k32 = wgrad_k32() && tile != 1;
     const bool hform = ranged && va && vb && !in_scale && !(k32 && !p.xcd_order);
     p.rg = rg;
+    // one 256-row tile where two 128-row tiles would each stream all of dy (three-product kernels only; the split count — the slab
+    // layout every caller planned with — stays the plan's)
+    static const bool no256 = env_long("EMBNET_WGRAD_NO256", 0) != 0;
+    if (hform && tile == 1 && rows > 128 && rows <= 256 && !no256) {
+      tile = 5;
+      grid = dim3(cdiv(k, TILE_BN[5]) * ((p.splits + 7) / 8 * 8));
+      p.fair_from = fair_from(grid.x, tile, true);
+    }
     char k32name[160];
     snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);
     if (in_scale) snprintf(k32name, sizeof k32name, "void embnet::conv_wgrad_k32_tf_kernel<embnet::Geom<%s> >(embnet::ConvWgradParams)", GEOM_NAME[tile]);

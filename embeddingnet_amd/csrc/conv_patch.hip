@@ -50,6 +50,7 @@ struct PatchParams {
   int PH, PW; FastDiv dPHW, dPW;
   int LR;                        // LDS patch rows (multiple of 32)
   int n_full, parts, cc_part, n_pieces, grid; float* ws;
+  int xcd_rows;                  // work_item: the column tiles of a tile row on one XCD (EMBNET_PATCH_XCD_ROWS, default on)
   BnSums bn;                     // data-gradient use: the BatchNorm-backward sums of the layer in front (bn.x == NULL: off)
 };
 
@@ -69,7 +70,19 @@ __device__ __forceinline__ Item work_item(int item, int n_mine) {
   kargp pp = kargs();
   const int b = blockIdx.x, NCC = pp->g.C / CCH, tiles_n = (pp->g.K + BN - 1) / BN;
   Item t; int id;
-  if (item < n_mine) { id = b + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr; }
+  if (item < n_mine) {
+    // whole rounds of `grid` tiles.  Workgroups b, b + 8, b + 16 ... share an XCD (observed placement; speed only): where a row
+    // of tiles has T = 2, 4, ... column tiles (256 / 512 filters) they go to T consecutive workgroups OF ONE XCD, so the input
+    // patch they all read is fetched into one L2 once instead of into T of them (profiles/r05_pmc_traffic_c2.txt: 1.58 x the
+    // algorithmic bytes per launch).  A bijection of the round's positions when T divides grid / 8; other T keep the plain order.
+    int pos = b;
+    const int per_xcd = pp->grid >> 3;
+    if (pp->xcd_rows && tiles_n > 1 && (pp->grid & 7) == 0 && per_xcd % tiles_n == 0) {
+      const int xcd = b & 7, slot = b >> 3;
+      pos = ((slot / tiles_n) * 8 + xcd) * tiles_n + slot % tiles_n;
+    }
+    id = pos + item * pp->grid; t.cc_b = 0; t.cc_e = NCC; t.part = nullptr;
+  }
   else {
     id = pp->n_full + b / pp->parts;
     t.cc_b = (b % pp->parts) * pp->cc_part; t.cc_e = min(NCC, t.cc_b + pp->cc_part);
@@ -867,6 +880,7 @@ extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const
   return check_launch("conv_weight_planes");
 }
 
+static int patch_xcd_rows() { static const int v = env_long("EMBNET_PATCH_XCD_ROWS", 1) != 0; return v; }
 static bool patch_pipe() { static const bool v = env_long("EMBNET_PATCH_PIPE", 1) != 0; return v; }   // 0: the plain loop (A/B)
 template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {
@@ -910,6 +924,7 @@ static int conv2d_patch_impl(const void* xp, const void* wp, const float* bias, 
   p.grid = pl.grid;
   if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
   p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
+  p.xcd_rows = patch_xcd_rows();
   hipStream_t st = (hipStream_t)stream;
   {
     // (the names rocprofv3 prints: bench.py looks the kernel's measured HBM traffic up by them)
@@ -967,6 +982,7 @@ extern "C" int embnet_conv2d_planes1x1_f32(const void* xp, const void* wp, const
   p.grid = pl.grid;
   if (pl.n_pieces > 0 && (pl.ws_bytes > workspace_bytes || !workspace)) { pl.n_full = pl.tiles; pl.n_pieces = 0; pl.parts = 1; }
   p.n_full = pl.n_full; p.parts = pl.parts; p.cc_part = pl.cc_part; p.n_pieces = pl.n_pieces; p.ws = (float*)workspace;
+  p.xcd_rows = patch_xcd_rows();
   hipStream_t st = (hipStream_t)stream;
   {
     static thread_local char kname[160];

@@ -172,7 +172,10 @@ class TripletsDataGenerator(ENDataGenerator):
 
     def load_plan_u8(self, plan, out=None):
         """The planned batch as DECODED uint8 [P*K,H,W,3] (BGR, resized; augmentations applied), class-contiguous — what the
-        input pipeline's worker threads run (embeddingnet_amd/input_pipeline.py); file-backed datasets only."""
+        input pipeline's worker threads run (embeddingnet_amd/input_pipeline.py); file-backed datasets only.
+        NB with augmentations the worker threads draw from the library's global random state concurrently with this thread's plan
+        draws, `depth` batches ahead: the PLANS keep the reference's order (they are drawn on the training thread), the
+        augmentation draws do not — a seeded run with augmentations is reproducible only with workers=1, depth=1."""
         classes, idxs = plan
         h, w = self.input_shape[1], self.input_shape[0]     # get_image resizes to (input_shape[0], input_shape[1]) = (width, height)
         if out is None:
@@ -186,6 +189,12 @@ class TripletsDataGenerator(ENDataGenerator):
                 img = get_image(src[int(i)], self.input_shape)
                 if self.augmentations is not None:
                     img = self.augmentations(image=img)['image']
+                    # (an augmentation that returns floats — Normalize, ToFloat — would be truncated by the uint8 store below:
+                    # refuse it here; sample_batch() / load_plan() take the float path for such pipelines — ADVICE r05)
+                    if getattr(img, "dtype", None) != np.uint8 or img.shape != out[row].shape:
+                        raise TypeError(f"load_plan_u8: the augmentation pipeline returned {getattr(img, 'dtype', type(img))} "
+                                        f"{getattr(img, 'shape', None)}; the uint8 input pipeline needs uint8 {out[row].shape} "
+                                        "(EMBNET_IMAGE_STORE=0 and the Feeder's float path, or drop the float transform)")
                 out[row] = img
                 row += 1
         return out

@@ -151,6 +151,14 @@ class DecodeProcesses:
                 p.terminate()
             except OSError:
                 pass
+        for p in self.procs:                 # reap them: a terminated child that nobody waits for stays a zombie
+            try:
+                p.wait(timeout=5)
+            except Exception:                # noqa: BLE001
+                try:
+                    p.kill(); p.wait(timeout=5)
+                except Exception:            # noqa: BLE001
+                    pass
         self.procs = []
         try:
             os.unlink(self.path)
@@ -263,7 +271,7 @@ class BatchPrefetcher:
         return out
 
     def close(self):
-        if not self._closed:
+        if not getattr(self, "_closed", True):      # (a half-constructed object has no _closed: nothing to release)
             self._closed = True
             self.pool.shutdown(wait=True, cancel_futures=True)
             if self.procs is not None:

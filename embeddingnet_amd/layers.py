@@ -84,6 +84,7 @@ class StepContext:
         for n in self.DICTS:
             setattr(self, n, {})
         self.slab_pending = []
+        self.slab_seen = set()              # kernels (storage addresses) that already produced a weight gradient in the running backward
         self.unclaimed = {}                 # dict name -> entries dropped at the end of a backward, over the context's life
         self._armed = -1
 
@@ -92,6 +93,7 @@ class StepContext:
 
     def end_of_backward(self):
         self._armed = -1
+        self.slab_seen.clear()
         for n in self.BACKWARD:
             d = getattr(self, n)
             if d:
@@ -102,6 +104,7 @@ class StepContext:
         for n in self.DICTS:
             getattr(self, n).clear()
         self.slab_pending.clear()
+        self.slab_seen.clear()
 
 
 _CONTEXTS = [StepContext("default")]
@@ -242,14 +245,18 @@ def conv_wgrad(lib, x, dz, dw, w, n, h, wd, c, r, s, k, stride, pt, pl, oh, ow, 
     # (an existing .grad means autograd will ADD dw to it at once — unless dw IS the parameter's gradient sink, which autograd never sees)
     # (only for a leaf kernel: the gradient of a derived one — the channel-padded kernel of an image conv — is consumed by the
     # next backward node at once)
-    if SLAB_DEFER[0] and _SLAB_PENDING and any(e[4] is w for e in _SLAB_PENDING):
-        # the same kernel a second time in one backward (a shared layer: the two branches of a Siamese step): the first gradient's
-        # slab sum is still queued and autograd is about to ADD this one to that buffer — finish the queue first, compute this
-        # gradient in place (round 5 reached this branch only with a gradient sink: with a plain .grad the queued sum later
-        # overwrote the accumulated gradient, dropping the second branch's half — found by tests/test_siamese_trainer_gpu.py)
-        flush_slab_reduces()
+    seen = current_context().slab_seen if SLAB_DEFER[0] else None
+    if seen is not None and w.data_ptr() in seen:
+        # the same kernel a second time in one backward (a shared layer: the two branches of a Siamese step).  Autograd holds the
+        # first gradient in the node's input buffer and is about to ADD this one to it (the parameter's .grad stays None until both
+        # have arrived): the first must be final by then and this one must be complete when it is returned — finish the queue if
+        # the first is still in it, and never defer a second gradient.  (Round 5 deferred it: the add consumed an unreduced buffer
+        # and the late slab sum then replaced the accumulated gradient — found by tests/test_siamese_trainer_gpu.py.)
+        if any(e[4] is w for e in _SLAB_PENDING):
+            flush_slab_reduces()
     elif SLAB_DEFER[0] and w.grad_fn is None and \
             (getattr(w, "grad", None) is None or (GRAD_SINKS and w.data_ptr() in GRAD_SINKS)):
+        seen.add(w.data_ptr())
         if planes:
             splits = lib.embnet_conv2d_wgrad_planes_splits(n, h, wd, c, k)
         else:

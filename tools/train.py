@@ -203,69 +203,71 @@ def main():
     # role of Keras' fit_generator enqueuer, reference train.py:172-177)
     feeder = None if siamese else train_gen.feeder(dev, log=(print if rank == 0 else None))
     import time
-    for epoch in range(n_epochs):
-        t_epoch, n_images = time.perf_counter(), 0
-        # LearningRateScheduler.on_epoch_begin (reference train.py:80-81): sets the rate outright, which discards the
-        # previous epoch's ReduceLROnPlateau reduction (see Plateau) unless TRAIN.plateau_persistent is set
-        lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size'])
-        if plateau.persistent:
-            lr *= plateau.scale
-        for g in opt.param_groups:
-            g['lr'] = lr
-        trainable.train()
-        losses = []
-        for _ in range(len(train_gen)):
-            if siamese:
-                (x1, x2), y = train_gen[0]
-                losses.append(trainer.step(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev),
-                                           torch.from_numpy(np.asarray(y, dtype=np.float32)).to(dev).reshape(-1, 1)))
-            else:
-                xb = feeder.next()
-                n_images += xb.shape[0]
-                losses.append(trainer.step(xb))
-        epoch_loss = all_reduce_mean(float(torch.stack(losses).mean().item()))     # mean over ranks (logging + monitor)
-        history['loss'].append(epoch_loss)
-        msg = f'Epoch {epoch + 1}/{n_epochs} - lr {lr:.3g} - loss {epoch_loss:.4f}'
-        if n_images:                                  # (the .item() above waited for the epoch's last step)
-            msg += f' - {n_images * world / (time.perf_counter() - t_epoch):.0f} images/s'
-        value = epoch_loss
-        if val_gen is not None:
-            trainable.eval()
-            vals = []
-            with torch.no_grad():
-                for _ in range(len(val_gen)):
-                    xs, y = val_gen[0]
-                    xs = [torch.from_numpy(a).to(dev) for a in xs]
-                    if siamese:
-                        out = model.model(xs)[0]
-                        vals.append(contrastive_loss(torch.from_numpy(y).to(dev), out))
-                    else:
-                        vals.append(triplet_loss(p_gen['margin'])(None, model.model(xs)).mean())
-            value = all_reduce_mean(float(torch.stack(vals).mean().item()))
-            history['val_loss'].append(value)
-            msg += f' - val_loss {value:.4f}'
-        if rank == 0:
-            print(msg, flush=True)
-        improved, stop, lr_end = plateau.update(value, lr)   # `value` is the all-reduced mean: same decisions on every rank
-        for g in opt.param_groups:                    # ReduceLROnPlateau.on_epoch_end (until the scheduler's next epoch begin)
-            g['lr'] = lr_end
-        if improved:
-            average_buffers(trainable)                # BN moving statistics: mean over the ranks' local batches
-        if improved and rank == 0:
-            path = os.path.join(paths['weights'], f'epoch_{epoch + 1:03d}.npz')
-            model.save_weights(path)
-            from embeddingnet_amd.backbones import keras_weights
-            from embeddingnet_amd.optimizers import save_optimizer_state
-            os.makedirs(os.path.dirname(_optimizer_state_path(path)), exist_ok=True)
-            save_optimizer_state(_optimizer_state_path(path), opt,
-                                 {k: v for k, v in keras_weights(trainable).items() if isinstance(v, torch.nn.Parameter)},
-                                 extra={'epoch': epoch + 1})
-            print(f'{monitor} improved to {value:.5f}, saving model to {path}')
-        if stop:
-            print('EarlyStopping')
-            break
-    if feeder is not None:
-        feeder.close()                                # decode worker processes, staging file in /dev/shm
+    try:        # (the feeder owns worker processes and a staging file in /dev/shm: released on ANY exit)
+        for epoch in range(n_epochs):
+            t_epoch, n_images = time.perf_counter(), 0
+            # LearningRateScheduler.on_epoch_begin (reference train.py:80-81): sets the rate outright, which discards the
+            # previous epoch's ReduceLROnPlateau reduction (see Plateau) unless TRAIN.plateau_persistent is set
+            lr = lr0 * p_train['decay_factor'] ** np.floor(epoch / p_train['step_size'])
+            if plateau.persistent:
+                lr *= plateau.scale
+            for g in opt.param_groups:
+                g['lr'] = lr
+            trainable.train()
+            losses = []
+            for _ in range(len(train_gen)):
+                if siamese:
+                    (x1, x2), y = train_gen[0]
+                    losses.append(trainer.step(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev),
+                                               torch.from_numpy(np.asarray(y, dtype=np.float32)).to(dev).reshape(-1, 1)))
+                else:
+                    xb = feeder.next()
+                    n_images += xb.shape[0]
+                    losses.append(trainer.step(xb))
+            epoch_loss = all_reduce_mean(float(torch.stack(losses).mean().item()))     # mean over ranks (logging + monitor)
+            history['loss'].append(epoch_loss)
+            msg = f'Epoch {epoch + 1}/{n_epochs} - lr {lr:.3g} - loss {epoch_loss:.4f}'
+            if n_images:                                  # (the .item() above waited for the epoch's last step)
+                msg += f' - {n_images * world / (time.perf_counter() - t_epoch):.0f} images/s'
+            value = epoch_loss
+            if val_gen is not None:
+                trainable.eval()
+                vals = []
+                with torch.no_grad():
+                    for _ in range(len(val_gen)):
+                        xs, y = val_gen[0]
+                        xs = [torch.from_numpy(a).to(dev) for a in xs]
+                        if siamese:
+                            out = model.model(xs)[0]
+                            vals.append(contrastive_loss(torch.from_numpy(y).to(dev), out))
+                        else:
+                            vals.append(triplet_loss(p_gen['margin'])(None, model.model(xs)).mean())
+                value = all_reduce_mean(float(torch.stack(vals).mean().item()))
+                history['val_loss'].append(value)
+                msg += f' - val_loss {value:.4f}'
+            if rank == 0:
+                print(msg, flush=True)
+            improved, stop, lr_end = plateau.update(value, lr)   # `value` is the all-reduced mean: same decisions on every rank
+            for g in opt.param_groups:                    # ReduceLROnPlateau.on_epoch_end (until the scheduler's next epoch begin)
+                g['lr'] = lr_end
+            if improved:
+                average_buffers(trainable)                # BN moving statistics: mean over the ranks' local batches
+            if improved and rank == 0:
+                path = os.path.join(paths['weights'], f'epoch_{epoch + 1:03d}.npz')
+                model.save_weights(path)
+                from embeddingnet_amd.backbones import keras_weights
+                from embeddingnet_amd.optimizers import save_optimizer_state
+                os.makedirs(os.path.dirname(_optimizer_state_path(path)), exist_ok=True)
+                save_optimizer_state(_optimizer_state_path(path), opt,
+                                     {k: v for k, v in keras_weights(trainable).items() if isinstance(v, torch.nn.Parameter)},
+                                     extra={'epoch': epoch + 1})
+                print(f'{monitor} improved to {value:.5f}, saving model to {path}')
+            if stop:
+                print('EarlyStopping')
+                break
+    finally:
+        if feeder is not None:
+            feeder.close()                            # decode worker processes, staging file in /dev/shm
     if rank == 0:
         np.savez(os.path.join(paths['plots'], 'history.npz'), **{k: np.asarray(v) for k, v in history.items()})
     dump = os.environ.get('EMBNET_DUMP_FINAL_WEIGHTS')     # diagnostics: EVERY rank's final weights -> <prefix><rank>.npz
