@@ -916,8 +916,9 @@ using G128x64 = Geom<128, 64, 2, 2>;
 using G128x32 = Geom<128, 32, 4, 1>;
 using G64x64 = Geom<64, 64, 2, 2>;
 using G192x64 = Geom<192, 64, 2, 2>;        // wgrad only: 3x3xC64 kernels have 576 = 3*192 rows (4.5 tiles of 128)
-// three-product wgrad only: a gradient of 129 .. 256 rows x <= 64 filters as ONE row tile — the ResNet stem's 7x7x4 x 64 = 196 rows
-// took two 128-row tiles, each streaming all of dy: 1 136 MB per launch against 514 MB algorithmic (profiles/r05_pmc_traffic_c2.txt)
+// three-product wgrad only (EMBNET_WGRAD_256=1, measured slower, off): a gradient of 129 .. 256 rows x <= 64 filters as ONE row tile —
+// the ResNet stem's 7x7x4 x 64 = 196 rows takes two 128-row tiles, each streaming all of dy: 1 136 MB per launch against 514 MB
+// algorithmic (profiles/r05_pmc_traffic_c2.txt)
 using G256x64 = Geom<256, 64, 4, 1>;
 
 
@@ -1460,9 +1461,11 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, void* workspac
     const bool hform = ranged && va && vb && !in_scale && !(k32 && !p.xcd_order);
     p.rg = rg;
     // one 256-row tile where two 128-row tiles would each stream all of dy (three-product kernels only; the split count — the slab
-    // layout every caller planned with — stays the plan's)
-    static const bool no256 = env_long("EMBNET_WGRAD_NO256", 0) != 0;
-    if (hform && tile == 1 && rows > 128 && rows <= 256 && !no256) {
+    // layout every caller planned with — stays the plan's).  EMBNET_WGRAD_256=1; OFF by default: the stem's weight gradient moves half
+    // the bytes (1 130 -> 554 MB per launch, profiles/r06_pmc_traffic_c2_xcd0.txt) and takes 256 -> 321-330 us: half as many
+    // workgroups, and the loop is bound by its gather round trips, not by bytes (profiles/r06_exp_xcd_rows.txt)
+    static const bool use256 = env_long("EMBNET_WGRAD_256", 0) != 0;
+    if (hform && tile == 1 && rows > 128 && rows <= 256 && use256) {
       tile = 5;
       grid = dim3(cdiv(k, TILE_BN[5]) * ((p.splits + 7) / 8 * 8));
       p.fair_from = fair_from(grid.x, tile, true);

@@ -50,7 +50,7 @@ struct PatchParams {
   int PH, PW; FastDiv dPHW, dPW;
   int LR;                        // LDS patch rows (multiple of 32)
   int n_full, parts, cc_part, n_pieces, grid; float* ws;
-  int xcd_rows;                  // work_item: the column tiles of a tile row on one XCD (EMBNET_PATCH_XCD_ROWS, default on)
+  int xcd_rows;                  // work_item: the column tiles of a tile row on one XCD (EMBNET_PATCH_XCD_ROWS=1; off by default)
   BnSums bn;                     // data-gradient use: the BatchNorm-backward sums of the layer in front (bn.x == NULL: off)
 };
 
@@ -77,7 +77,7 @@ __device__ __forceinline__ Item work_item(int item, int n_mine) {
     // algorithmic bytes per launch).  A bijection of the round's positions when T divides grid / 8; other T keep the plain order.
     int pos = b;
     const int per_xcd = pp->grid >> 3;
-    if (pp->xcd_rows && tiles_n > 1 && (pp->grid & 7) == 0 && per_xcd % tiles_n == 0) {
+    if (pp->xcd_rows && tiles_n > 1 && (pp->grid & 7) == 0 && per_xcd % tiles_n == 0 && (item + 1) * pp->grid <= pp->n_full) {   // (whole rounds only)
       const int xcd = b & 7, slot = b >> 3;
       pos = ((slot / tiles_n) * 8 + xcd) * tiles_n + slot % tiles_n;
     }
@@ -880,7 +880,9 @@ extern "C" int embnet_conv_weight_planes(const void* table, int n_tensors, const
   return check_launch("conv_weight_planes");
 }
 
-static int patch_xcd_rows() { static const int v = env_long("EMBNET_PATCH_XCD_ROWS", 1) != 0; return v; }
+// (off: measured on C2, three alternating pairs — 85.5 us either way, FETCH + WRITE 117.0 -> 109.2 MB per launch: the layers with several
+// column tiles per row have fewer tiles than the grid, i.e. no whole round; profiles/r06_exp_xcd_rows.txt)
+static int patch_xcd_rows() { static const int v = env_long("EMBNET_PATCH_XCD_ROWS", 0) != 0; return v; }
 static bool patch_pipe() { static const bool v = env_long("EMBNET_PATCH_PIPE", 1) != 0; return v; }   // 0: the plain loop (A/B)
 template <int BN, int TPS, int NBS>
 static void launch_patch(const PatchParams& p, size_t lds, hipStream_t st) {

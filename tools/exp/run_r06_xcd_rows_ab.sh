@@ -11,8 +11,8 @@ for rep in 1 2 3; do
 done
 for rep in 1 2; do
   for v in 1 0; do
-    echo "== C2 EMBNET_WGRAD_NO256=$v rep $rep" >> $out
-    EMBNET_WGRAD_NO256=$v python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-batch-hard --sustain-seconds 0 2>&1 | grep -E "enqueue loop|conv_wgrad_h_kernel|traced kernels|\"metric\"" | cut -c1-230 >> $out
+    echo "== C2 EMBNET_WGRAD_256=$v rep $rep" >> $out
+    EMBNET_WGRAD_256=$v python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-batch-hard --sustain-seconds 0 2>&1 | grep -E "enqueue loop|conv_wgrad_h_kernel|traced kernels|\"metric\"" | cut -c1-230 >> $out
   done
 done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
