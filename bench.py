@@ -459,11 +459,14 @@ def main():
     # a dead problem (hinge 0 on the reference's fallback triplet, datagenerators.py:246-250: every gradient exactly zero)
     # is not a training step: refuse to report a throughput for it — on every rank (each mines its own shard)
     losses, counts = loss_log.tolist(), count_log.tolist()
+    # (isolated dead steps — semihard mining on a batch where no negative falls inside the margin band — happen in live training
+    # too and run the same kernels: the run is refused when more than one step in twenty is dead)
+    dead_steps = sum(1 for i, l in enumerate(losses) if l <= 0.0 or (args.mode != "siamese" and counts[i] <= 1))
     live = dict(loss_first_timed=losses[0], loss_last_timed=losses[-1], loss_min_timed=min(losses),
                 active_triplets_min=(min(counts) if args.mode != "siamese" else None),
                 active_triplets_mean=(round(sum(counts) / len(counts), 1) if args.mode != "siamese" else None),
-                resident_batches=pool)
-    dead = min(losses) <= 0.0 or (args.mode != "siamese" and min(counts) <= 1)
+                dead_steps=dead_steps, resident_batches=pool)
+    dead = dead_steps > len(losses) // 20
     if world > 1:
         t = torch.tensor([1.0 if dead else 0.0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

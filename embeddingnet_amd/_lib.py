@@ -59,7 +59,7 @@ def lib():
                 continue
             fn = getattr(l, name)          # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, argtypes
-        if l.embnet_abi_version() != 21 and not lax:
+        if l.embnet_abi_version() != 22 and not lax:
             raise EmbnetError("libembnet_hip.so ABI version mismatch")
         _lib = l
     return _lib

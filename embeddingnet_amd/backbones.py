@@ -99,12 +99,28 @@ class Seq(nn.Module):
         return x
 
 
+def _three_products(seq):
+    """The small backbones' convs on three products per fp32 product (layers.CONV_F16 note): every operand with a range —
+      kernels: their exact maximum; the image: exact, from the pass that widens it to four channels (where that pass runs);
+      activations: `simple` has no BatchNormalization — each MaxPool2D leaves the exact max of what it writes; `simple2`: the bound
+        a training-mode BatchNormalization derives from its statistics (x 1 / (1 - rate) behind a fused Dropout);
+      gradients: the exact max |dz| from the pass that applies the fused ReLU's mask (MaxPool2D / BatchNormalization backward,
+        embnet_relu_bwd_colsum_ex for the last conv).
+    A pass without both ranges (c or k % 4 != 0, an inference-mode BatchNormalization) runs the six-term kernels."""
+    for m in seq.modules():
+        if isinstance(m, L.Conv2D):
+            m.f16 = True
+        elif isinstance(m, L.MaxPool2D):
+            m.emit_range = True
+    return seq
+
+
 def _simple(gen):
-    return Seq(
+    return _three_products(Seq(
         conv1=L.Conv2D(3, 64, 10, activation="relu", l2=2e-4, gen=gen), pool1=L.MaxPool2D(),
         conv2=L.Conv2D(64, 128, 7, activation="relu", l2=2e-4, gen=gen), pool2=L.MaxPool2D(),
         conv3=L.Conv2D(128, 128, 4, activation="relu", l2=2e-4, gen=gen), pool3=L.MaxPool2D(),
-        conv4=L.Conv2D(128, 256, 4, activation="relu", l2=2e-4, gen=gen), flatten=L.Flatten())
+        conv4=L.Conv2D(128, 256, 4, activation="relu", l2=2e-4, gen=gen), flatten=L.Flatten()))
 
 
 def _simple2(gen):
@@ -117,7 +133,7 @@ def _simple2(gen):
     mods.update(cbr(4, 32, 64, 3)); mods.update(cbr(5, 64, 64, 3)); mods.update(cbr(6, 64, 64, 5, 2, "same"))
     mods["drop2"] = L.Dropout(0.4, seed=2)
     mods.update(cbr(7, 64, 128, 4))
-    return Seq(**mods)
+    return _three_products(Seq(**mods))
 
 
 RN_EPS = 2e-5
@@ -156,9 +172,12 @@ class ResidualUnit(nn.Module):
             self.conv2 = _rn_conv(filters, filters, 3, stride, 1, gen)
             self.bn3 = L.BatchNormalization(filters, epsilon=RN_EPS, relu=True)
             self.conv3 = _rn_conv(filters, cout, 1, 1, 0, gen)
-            # conv3 reads the unit's THIN tensor (filters = cout / 4 channels): bn3 writes it as planes too (+ 4 B per element of the
-            # small tensor) and conv3's forward runs the 1x1 planes GEMM (layers.CONV1X1_PLANES; DESIGN 3.14 prices the other 1x1 convs)
-            self.conv3.planes1x1 = True
+            # layers.CONV1X1_PLANES (off by default): the 1x1 convs whose FORWARD on the planes GEMM gains more, back to back
+            # (profiles/r06_exp_conv1x1_planes.txt), than writing their input as planes beside the fp32 copy costs — conv3 from 128
+            # filters (it reads the unit's thin tensor; the 56x56 layers sit on their HBM floor either way), conv1 of the identity units
+            # from 1 024 input channels (14x14 / 7x7: 150 -> 81 us against 40 us of planes written)
+            self.conv3.planes1x1 = filters >= 128
+            self.conv1.planes1x1 = (not post) and cin >= 1024
         self.out_channels = cout
 
     def forward(self, x):

@@ -582,10 +582,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_inrelu4_kernel(const float* 
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                                    int relu, int training, float* __restrict__ dz_out,
-                                                                   float* __restrict__ partial, const DropArg drop) {
+                                                                   float* __restrict__ partial, const DropArg drop,
+                                                                   uint32_t* __restrict__ range_slot) {
   struct K6 { float4 sc, sh, mu, rs, db, dg; };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const uint64_t dseed = drop.thr ? drop_seed(drop) : 0ull;
+  float amax = 0.f;                                     // max |dz| of this thread's elements (range_slot: conv.hip Ranges)
   col_reduce2_v4p(m, c4, g, partial, [&](int q) {
     K6 k{reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q], z4, z4, z4, z4};
     if (training) {
@@ -614,7 +616,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_inrelu4_kernel(const float* 
     o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f; o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
     reinterpret_cast<float4*>(dz_out)[r * c4 + q] = o;
     a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    amax = amax4(amax, o);
   });
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
 
 // (A one-launch BatchNorm backward — sums, two spin barriers across a co-resident 1024-workgroup grid, then dx from the
@@ -750,6 +754,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (zero_slot && col == 0)                                           // the apply pass behind this kernel emits dx's range there
     for (int i = threadIdx.x; i < 1 + RANGE_PARTIALS; i += 256) zero_slot[i] = 0u;
 }
+__global__ __launch_bounds__(256) void range_zero_kernel(uint32_t* __restrict__ slot) {
+  for (int i = threadIdx.x; i < 1 + RANGE_PARTIALS; i += 256) slot[i] = 0u;
+}
+// (instead of hipMemsetAsync: a memset node inside a captured HIP graph did not zero a range slot on replay — round 6, ROCm 7.2 —
+// so nothing a captured step may run uses one)
+__global__ __launch_bounds__(256) void zero2_kernel(float* __restrict__ a, float* __restrict__ b, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { a[i] = 0.f; if (b) b[i] = 0.f; }
+}
 // word 0 of a range slot = the maximum of the workgroup partials behind it (common.h range_emit_block)
 __global__ __launch_bounds__(256) void range_fold_kernel(uint32_t* __restrict__ slot) {
   uint32_t m = 0u;
@@ -846,31 +858,38 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // Four channels per thread (C % 4 == 0): 16-byte loads/stores, 4-byte arg-max words.
 __global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, int n, int h, int w, int c4,
                                                            int k, int stride, int pad, int oh, int ow,
-                                                           float* __restrict__ y, uint8_t* __restrict__ argmax) {
+                                                           float* __restrict__ y, uint8_t* __restrict__ argmax,
+                                                           uint32_t* __restrict__ range_slot) {
   const long total = (long)n * oh * ow * c4;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int col = (int)(i % c4);
-  long t = i / c4;
-  const int x_o = (int)(t % ow); t /= ow;
-  const int y_o = (int)(t % oh);
-  const int b = (int)(t / oh);
-  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  int bi[4] = {255, 255, 255, 255};
-  for (int dy = 0; dy < k; ++dy)
-    for (int dx = 0; dx < k; ++dx) {
-      const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
-      const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) v = reinterpret_cast<const float4*>(x)[(((long)b * h + ih) * w + iw) * c4 + col];
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      const int tap = in ? dy * k + dx : 255;
+  float amax = 0.f;
+  if (i < total) {
+    const int col = (int)(i % c4);
+    long t = i / c4;
+    const int x_o = (int)(t % ow); t /= ow;
+    const int y_o = (int)(t % oh);
+    const int b = (int)(t / oh);
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {255, 255, 255, 255};
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const int ih = y_o * stride + dy - pad, iw = x_o * stride + dx - pad;
+        const bool in = (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = reinterpret_cast<const float4*>(x)[(((long)b * h + ih) * w + iw) * c4 + col];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const int tap = in ? dy * k + dx : 255;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; }
-    }
-  reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
-  reinterpret_cast<uint32_t*>(argmax)[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) |
-                                           ((uint32_t)bi[3] << 24);
+        for (int j = 0; j < 4; ++j) if (vv[j] > best[j]) { best[j] = vv[j]; bi[j] = tap; }
+      }
+    const float4 o = make_float4(best[0], best[1], best[2], best[3]);
+    reinterpret_cast<float4*>(y)[i] = o;
+    reinterpret_cast<uint32_t*>(argmax)[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) |
+                                             ((uint32_t)bi[3] << 24);
+    amax = amax4(0.f, o);
+  }
+  // the exact max |y| of the pooled tensor for the three-product conv that reads it (conv.hip Ranges; `simple`: conv -> ReLU -> pool)
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ argmax,
@@ -910,7 +929,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restri
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_colsum4_kernel(
     const float* __restrict__ dy, const uint8_t* __restrict__ argmax, const float* __restrict__ y, long m, int h, int w,
     DivU dw, DivU dh, int c4, int k, int stride, int pad, int oh, int ow, ColGeom g, float* __restrict__ dz,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, uint32_t* __restrict__ range_slot) {
+  float amax = 0.f;                                     // max |dz| of this thread's elements (range_slot: conv.hip Ranges)
   col_reduce2_v4(m, c4, g, partial, [&](long r, int q, float4& a, float4& b) {
     const uint32_t t = divu((uint32_t)r, dw);
     const int iw = (int)((uint32_t)r - t * (uint32_t)w);
@@ -934,7 +954,9 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_colsum4_kernel(
                                  yv.w > 0.f ? gr[3] : 0.f);
     reinterpret_cast<float4*>(dz)[r * c4 + q] = v;
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    amax = amax4(amax, v);
   });
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
 
 // ---------------------------------------------------------------- BN-apply + activation + max-pool, fused
@@ -1198,12 +1220,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // dz = dy * [y > 0] AND the column sums of dz (the bias gradient of a Conv2D / Dense with a fused ReLU) in one pass over
 // the tensor: the separate relu_bwd + colsum pair read dz back (12 + 4 bytes per element -> 12)
 __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, long m, int c,
-                                                              ColGeom g, float* __restrict__ dz, float* __restrict__ partial) {
+                                                              ColGeom g, float* __restrict__ dz, float* __restrict__ partial,
+                                                              uint32_t* __restrict__ range_slot) {
+  float amax = 0.f;
   col_reduce2(m, c, g, partial, [&](long r, int col, float& a, float& b) {
     const long i = r * c + col;
     const float v = y[i] > 0.f ? dy[i] : 0.f;
     dz[i] = v; a += v;
+    amax = fmaxf(amax, fabsf(v));
   });
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);
 }
 
 // Sum over several tensors of alpha_t * sum(x_t^2) — all the kernel_regularizer=l2(lambda) terms of a model
@@ -1323,14 +1349,18 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // y[p, 0:cin] = x[p, :], y[p, cin:cout] = 0 — widens a 3-channel image batch to 4 channels so the stem
 // convolution gathers 16 bytes per pixel (the zero channel adds no MACs that matter: 196 vs 147 taps*ch).
 __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ x, long pixels, int cin, int cout,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, uint32_t* __restrict__ range_slot) {
   const long total = pixels * cout;
   const long stride = (long)gridDim.x * 256;
+  float amax = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const long p = i / cout;
     const int c = (int)(i - p * cout);
-    y[i] = c < cin ? x[p * cin + c] : 0.f;
+    const float v = c < cin ? x[p * cin + c] : 0.f;
+    y[i] = v;
+    amax = fmaxf(amax, fabsf(v));
   }
+  if (range_slot) range_emit_block(range_slot + 1 + blockIdx.x % RANGE_PARTIALS, amax);     // the image's exact max |x| (conv.hip Ranges)
 }
 
 // sum of squares -> partial per block (double finalize on one thread)
@@ -1446,12 +1476,19 @@ __global__ void sum_finalize_kernel(const float* __restrict__ partial, int n, fl
   *out = (float)(alpha * s);
 }
 
+// fold_slot: a range slot whose workgroup partials the pass in front of this kernel filled — column 0's workgroup folds them into
+// the slot's first word on the way (range_fold_kernel's job, without its launch)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int blocks, int c,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, uint32_t* __restrict__ fold_slot = nullptr) {
   const int col = blockIdx.x;
   double s, unused;
   block_partial_sums(partial, blocks, c, col, s, unused);
   if (threadIdx.x == 0) out[col] = (float)s;
+  if (fold_slot && col == 0) {
+    uint32_t m = 0u;
+    for (int i = threadIdx.x; i < RANGE_PARTIALS; i += 256) m = max(m, fold_slot[1 + i]);
+    range_emit_block(fold_slot, __uint_as_float(m));
+  }
 }
 
 }  // namespace embnet
@@ -1685,8 +1722,7 @@ static int bn_bwd_impl(const float* dy, const float* x, long m, int c, const flo
       bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g.blocks, c, dbeta, dgamma);
     }
   } else {
-    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
-    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+    zero2_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(dbeta, dgamma, c);
   }
   if ((c & 3) == 0 && !bn_scalar())
     { EMBNET_TRACE(dx_bound ? "void embnet::bn_bwd_apply4_kernel<4>" : emit && !dx_planes ? "void embnet::bn_bwd_apply4_kernel<3>" : dx_planes && planes_f16() ? "void embnet::bn_bwd_apply4_kernel<1>" : "void embnet::bn_bwd_apply4_kernel<0>", TRACE_BYTES, ((dx_add ? 16.0 : 12.0) + (dx_planes && planes_f16() && !dx_bound ? 8.0 : 0.0)) * m * c, stream);   // (<1>: + the dry run <2>; the names rocprofv3 prints)
@@ -1713,11 +1749,23 @@ extern "C" int embnet_bn_bwd_ex(const float* dy, const float* x, long m, int c, 
                      workspace_bytes, dx_range, stream, xhat_bound, dx_add_range);
 }
 
+// A range slot (embnet_range_slot_words() words) filled by an elementwise pass: zeroed in front, the workgroup partials folded into word 0
+// behind (the BatchNorm passes zero theirs in their finalize kernels).
+static void range_begin(uint32_t* slot, void* stream) {      // (a kernel, not hipMemsetAsync: these passes run inside captured HIP graphs)
+  if (slot) range_zero_kernel<<<1, 256, 0, S(stream)>>>(slot);
+}
+static void range_end(uint32_t* slot, void* stream) {
+  if (slot) range_fold_kernel<<<1, 256, 0, S(stream)>>>(slot);
+}
+#define EMBNET_RANGE_ARG(slot, what) \
+  EMBNET_CHECK_ARG(!(reinterpret_cast<uintptr_t>(slot) & 3), what ": the range slot is 4-byte aligned")
+
 static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, const float* save_mean,
                               const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                               float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                              size_t workspace_bytes, void* stream, const DropArg drop) {
-  EMBNET_CHECK_ARG(!take_emit_slot(), "bn_bwd_inrelu: this pass cannot emit the range requested by embnet_range_emit");
+                              size_t workspace_bytes, void* stream, const DropArg drop, uint32_t* dz_range = nullptr) {
+  EMBNET_CHECK_ARG(!take_emit_slot(), "bn_bwd_inrelu: the deprecated embnet_range_emit request is not served here: pass dz_range to the _ex form");
+  EMBNET_RANGE_ARG(dz_range, "bn_bwd_inrelu");
   EMBNET_CHECK_ARG(dy && x && scale && shift && dz && dgamma && dbeta && dbias && workspace, "bn_bwd_inrelu: null pointer");
   EMBNET_CHECK_ARG(m > 0 && c > 0 && (c & 3) == 0, "bn_bwd_inrelu: m=%ld c=%d (c %% 4 == 0 required)", m, c);
   EMBNET_CHECK_ARG(!training || (save_mean && save_rstd), "bn_bwd_inrelu: training needs saved statistics");
@@ -1727,15 +1775,15 @@ static int bn_bwd_inrelu_impl(const float* dy, const float* x, long m, int c, co
   const ColGeom g4 = col_geom(m, c / 4);
   if (save_mean && save_rstd) {
     { EMBNET_TRACE("embnet::bn_bwd_reduce4_kernel", TRACE_BYTES, 8.0 * m * c, stream); bn_bwd_reduce4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, save_mean, save_rstd, scale, shift, relu, partial, drop, nullptr); }
-    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma);
+    bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbeta, dgamma, 0, dz_range);     // (zeroes the range slot)
   } else {
-    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
-    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+    zero2_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(dbeta, dgamma, c);
+    range_begin(dz_range, stream);
   }
   { EMBNET_TRACE("embnet::bn_bwd_apply_inrelu4_kernel", TRACE_BYTES, 12.0 * m * c, stream);
     bn_bwd_apply_inrelu4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, x, m, c / 4, g4, 1.f / (float)m, save_mean, save_rstd, scale, shift,
-                                                               dbeta, dgamma, relu, training, dz, partial, drop); }
-  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias);
+                                                               dbeta, dgamma, relu, training, dz, partial, drop, dz_range); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>(partial, g4.blocks, c, dbias, dz_range);                     // (and folds it)
   return check_launch("bn_bwd_inrelu");
 }
 
@@ -1851,20 +1899,45 @@ extern "C" int embnet_bn_bwd_inrelu_dropout(const float* dy, const float* x, lon
   return bn_bwd_inrelu_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dz, dgamma, dbeta, dbias, workspace,
                             workspace_bytes, stream, drop_arg(rate, seed, seed_add_dev));
 }
+// ABI 22: the same two with `dz_range` (NULL or a RANGE SLOT): the exact max |dz| is left in its first word
+extern "C" int embnet_bn_bwd_inrelu_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                       const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                       float* dz, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                                       size_t workspace_bytes, uint32_t* dz_range, void* stream) {
+  return bn_bwd_inrelu_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dz, dgamma, dbeta, dbias, workspace,
+                            workspace_bytes, stream, DropArg{0, nullptr, 0u, 1.f}, dz_range);
+}
+extern "C" int embnet_bn_bwd_inrelu_dropout_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                               const float* save_rstd, const float* scale, const float* shift, int relu,
+                                               int training, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* dz,
+                                               float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes,
+                                               uint32_t* dz_range, void* stream) {
+  EMBNET_CHECK_ARG(rate >= 0.f && rate < 1.f, "bn_bwd_inrelu_dropout: rate %f outside [0,1)", rate);
+  return bn_bwd_inrelu_impl(dy, x, m, c, save_mean, save_rstd, scale, shift, relu, training, dz, dgamma, dbeta, dbias, workspace,
+                            workspace_bytes, stream, drop_arg(rate, seed, seed_add_dev), dz_range);
+}
 
-extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,
-                                  int ow, float* y, uint8_t* argmax, void* stream) {
+extern "C" int embnet_maxpool_fwd_ex(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,
+                                     int ow, float* y, uint8_t* argmax, uint32_t* y_range, void* stream) {
   EMBNET_CHECK_ARG(x && y && argmax, "maxpool_fwd: null pointer");
+  EMBNET_RANGE_ARG(y_range, "maxpool_fwd");
+  EMBNET_CHECK_ARG(!y_range || (c & 3) == 0, "maxpool_fwd: the range of y needs c %% 4 == 0 (c = %d)", c);
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && k <= 15 && stride > 0 && pad >= 0 && oh > 0 && ow > 0,
                    "maxpool_fwd: bad geometry");
   EMBNET_CHECK_ARG((oh - 1) * stride - pad + k <= h + pad && (ow - 1) * stride - pad + k <= w + pad,
                    "maxpool_fwd: window leaves the padded image");
   const long total = (long)n * oh * ow * c;
+  range_begin(y_range, stream);
   if ((c & 3) == 0)
-    { EMBNET_TRACE("embnet::maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 5.0 * total, stream); maxpool_fwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, k, stride, pad, oh, ow, y, argmax); }
+    { EMBNET_TRACE("embnet::maxpool_fwd4_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 5.0 * total, stream); maxpool_fwd4_kernel<<<cdiv(total / 4, 256), 256, 0, S(stream)>>>(x, n, h, w, c / 4, k, stride, pad, oh, ow, y, argmax, y_range); }
   else
     { EMBNET_TRACE("embnet::maxpool_fwd_kernel", TRACE_BYTES, 4.0 * n * h * w * c + 5.0 * total, stream); maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax); }
+  range_end(y_range, stream);
   return check_launch("maxpool_fwd");
+}
+extern "C" int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh,
+                                  int ow, float* y, uint8_t* argmax, void* stream) {
+  return embnet_maxpool_fwd_ex(x, n, h, w, c, k, stride, pad, oh, ow, y, argmax, nullptr, stream);
 }
 
 extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k,
@@ -1879,10 +1952,11 @@ extern "C" int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n,
   return check_launch("maxpool_bwd");
 }
 
-extern "C" int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w,
-                                              int c, int k, int stride, int pad, int oh, int ow, float* dz, float* dbias,
-                                              void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int embnet_maxpool_relu_bwd_colsum_ex(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w,
+                                                 int c, int k, int stride, int pad, int oh, int ow, float* dz, float* dbias,
+                                                 void* workspace, size_t workspace_bytes, uint32_t* dz_range, void* stream) {
   EMBNET_CHECK_ARG(dy && argmax && y && dz && dbias && workspace, "maxpool_relu_bwd_colsum: null pointer");
+  EMBNET_RANGE_ARG(dz_range, "maxpool_relu_bwd_colsum");
   EMBNET_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0 && pad >= 0,
                    "maxpool_relu_bwd_colsum: bad geometry");
   EMBNET_CHECK_ARG((c & 3) == 0, "maxpool_relu_bwd_colsum: channel count %d not a multiple of 4 (use maxpool_bwd + relu_bwd_colsum)", c);
@@ -1893,11 +1967,18 @@ extern "C" int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* ar
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "maxpool_relu_bwd_colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g4 = col_geom(m, c / 4);
+  range_begin(dz_range, stream);
   { EMBNET_TRACE("embnet::maxpool_relu_bwd_colsum4_kernel", TRACE_BYTES, 8.0 * m * c + 5.0 * n * oh * ow * c, stream);
     maxpool_relu_bwd_colsum4_kernel<<<g4.blocks, 256, 0, S(stream)>>>(dy, argmax, y, m, h, w, make_divu((uint32_t)w), make_divu((uint32_t)h),
-                                                                       c / 4, k, stride, pad, oh, ow, g4, dz, (float*)workspace); }
-  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbias);
+                                                                       c / 4, k, stride, pad, oh, ow, g4, dz, (float*)workspace, dz_range); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbias, dz_range);     // (folds the range partials)
   return check_launch("maxpool_relu_bwd_colsum");
+}
+extern "C" int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w,
+                                              int c, int k, int stride, int pad, int oh, int ow, float* dz, float* dbias,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  return embnet_maxpool_relu_bwd_colsum_ex(dy, argmax, y, n, h, w, c, k, stride, pad, oh, ow, dz, dbias, workspace, workspace_bytes,
+                                           nullptr, stream);
 }
 
 extern "C" int embnet_bn_act_maxpool_fwd(const float* x, int n, int h, int w, int c, const float* scale, const float* shift,
@@ -1939,8 +2020,7 @@ static int bn_act_maxpool_bwd_impl(const float* dy, const uint8_t* argmax, const
                                                                  save_mean, save_rstd, scale, shift, act, xwin, (float*)workspace); }
     bn_bwd_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g4.blocks, c, dbeta, dgamma, 0, emit);
   } else {
-    (void)hipMemsetAsync(dbeta, 0, c * sizeof(float), S(stream));
-    (void)hipMemsetAsync(dgamma, 0, c * sizeof(float), S(stream));
+    zero2_kernel<<<cdiv(c, 256), 256, 0, S(stream)>>>(dbeta, dgamma, c);
   }
   const long total = (long)n * h * w * (c / 4);
   { EMBNET_TRACE("embnet::pool_bn_bwd_apply4_kernel", TRACE_BYTES, 32.0 * total + 5.0 * mp * c, stream); pool_bn_bwd_apply4_kernel<<<cdiv(total, 256), 256, 0, S(stream)>>>(dy, argmax, x, n, h, w, c / 4, k, stride, pad, oh, ow,
@@ -2107,16 +2187,22 @@ extern "C" int embnet_colsum(const float* x, long m, int c, float* out, void* wo
   return check_launch("colsum");
 }
 
-extern "C" int embnet_relu_bwd_colsum(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+extern "C" int embnet_relu_bwd_colsum_ex(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
+                                         size_t workspace_bytes, uint32_t* dz_range, void* stream) {
   EMBNET_CHECK_ARG(dy && y && dz && dbias && workspace && m > 0 && c > 0, "relu_bwd_colsum: bad argument");
+  EMBNET_RANGE_ARG(dz_range, "relu_bwd_colsum");
   if (workspace_bytes < embnet_bn_workspace_bytes(m, c))
     return fail(EMBNET_EWORKSPACE, "relu_bwd_colsum: workspace %zu < %zu", workspace_bytes, embnet_bn_workspace_bytes(m, c));
   const ColGeom g = col_geom(m, c);
+  range_begin(dz_range, stream);
   { EMBNET_TRACE("embnet::relu_bwd_colsum_kernel", TRACE_BYTES, 12.0 * m * c, stream);
-    relu_bwd_colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, y, m, c, g, dz, (float*)workspace); }
-  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, dbias);
+    relu_bwd_colsum_kernel<<<g.blocks, 256, 0, S(stream)>>>(dy, y, m, c, g, dz, (float*)workspace, dz_range); }
+  colsum_finalize_kernel<<<c, 256, 0, S(stream)>>>((const float*)workspace, g.blocks, c, dbias, dz_range);      // (folds the range partials)
   return check_launch("relu_bwd_colsum");
+}
+extern "C" int embnet_relu_bwd_colsum(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  return embnet_relu_bwd_colsum_ex(dy, y, m, c, dz, dbias, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int embnet_add(const float* a, const float* b, long total, float* y, void* stream) {
@@ -2181,8 +2267,8 @@ extern "C" int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, in
   EMBNET_CHECK_ARG(make_tap_border(g, oh, ow, k, r, s, stride, pad_t, pad_l, h, w), "tap_border_sums: border rows not contiguous");
   const int nlines = tap_border_lines(g);
   if (nlines == 0) {                                       // no padding at all: every tap sums the whole (zero-sum) map
-    hipError_t e = hipMemsetAsync(taps, 0, (size_t)r * s * k * sizeof(float), S(stream));
-    return e == hipSuccess ? 0 : fail(EMBNET_ELAUNCH, "tap_border_sums: memset: %s", hipGetErrorString(e));
+    zero2_kernel<<<cdiv(r * s * k, 256), 256, 0, S(stream)>>>(taps, nullptr, r * s * k);
+    return check_launch("tap_border_sums");
   }
   const size_t need = embnet_tap_border_sums_workspace_bytes(n, oh, ow, k, r, s, stride, pad_t, pad_l, h, w);
   EMBNET_CHECK_ARG(workspace, "tap_border_sums: null workspace");
@@ -2203,10 +2289,16 @@ extern "C" int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, in
   return check_launch("tap_border_sums");
 }
 
-extern "C" int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream) {
+extern "C" int embnet_pad_channels_ex(const float* x, long pixels, int cin, int cout, float* y, uint32_t* y_range, void* stream) {
   EMBNET_CHECK_ARG(x && y && pixels > 0 && cin > 0 && cout >= cin, "pad_channels: bad argument");
-  { EMBNET_TRACE("embnet::pad_channels_kernel", TRACE_BYTES, 4.0 * pixels * (cin + cout), stream); pad_channels_kernel<<<ew_blocks(pixels * cout), 256, 0, S(stream)>>>(x, pixels, cin, cout, y); }
+  EMBNET_RANGE_ARG(y_range, "pad_channels");
+  range_begin(y_range, stream);
+  { EMBNET_TRACE("embnet::pad_channels_kernel", TRACE_BYTES, 4.0 * pixels * (cin + cout), stream); pad_channels_kernel<<<ew_blocks(pixels * cout), 256, 0, S(stream)>>>(x, pixels, cin, cout, y, y_range); }
+  range_end(y_range, stream);
   return check_launch("pad_channels");
+}
+extern "C" int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream) {
+  return embnet_pad_channels_ex(x, pixels, cin, cout, y, nullptr, stream);
 }
 
 extern "C" int embnet_sumsq_chunk_elems(void) { return 4096; }

@@ -718,19 +718,25 @@ class _Conv2dFn(torch.autograd.Function):
         dskip = _c(dskip) if dskip is not None else None
         dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        w_range = getattr(ctx, "w_range", None)
+        dz_range = None                      # (fused ReLU) the range of dz, from the pass that applied the mask
         done = RELU_DONE.pop(dy.data_ptr(), None) if (ctx.relu and RELU_DONE) else None
         if done is not None and done[0].shape == dy.shape:
-            dz = dy                          # the BatchNormalization behind this conv already applied the ReLU mask ...
+            dz = dy                          # the BatchNormalization / MaxPool2D behind this conv already applied the ReLU mask ...
             if want_db:                      # ... and summed the bias gradient (into the bias' sink when it has one)
                 db = _done(done[1], done[2])
                 want_db = False
+            if w_range is not None:          # ... and left the range of dz (the conv's output was tagged `_wants_dy_range`)
+                dz_range = _take_dy_range(dy)
         elif ctx.relu:
             dz = torch.empty_like(dy)
-            if want_db:                      # dz and its column sums (the bias gradient) in one pass
+            if want_db:                      # dz and its column sums (the bias gradient) in one pass — and its range when wanted
                 db, db_note = _sink(ctx.bias_ref)
                 ws = workspace(lib.embnet_colsum_workspace_bytes(dy.numel() // k, k), x.device)
-                check(lib.embnet_relu_bwd_colsum(ptr(dy), ptr(y), dy.numel() // k, k, ptr(dz), ptr(db), ptr(ws),
-                                                 ws.numel() * 4, stream()))
+                if w_range is not None:
+                    dz_range = _new_range_slot(x.device)
+                check(lib.embnet_relu_bwd_colsum_ex(ptr(dy), ptr(y), dy.numel() // k, k, ptr(dz), ptr(db), ptr(ws),
+                                                    ws.numel() * 4, ptr(dz_range), stream()))
                 db = _done(db, db_note)
                 want_db = False
             else:
@@ -743,8 +749,10 @@ class _Conv2dFn(torch.autograd.Function):
         # planes of dy left by the BatchNormalization behind this conv (only usable when dz IS dy: no fused ReLU)
         dy_planes = _take_dy_planes(dy) if (ctx.patch and not ctx.relu) else None
         # ... or its range, for the three-product gather kernels (same condition)
-        w_range = getattr(ctx, "w_range", None)
-        dy_range = _take_dy_range(dy, keep=ctx.has_res) if (w_range is not None and not ctx.relu and not dy_only_planes) else None
+        if ctx.relu:
+            dy_range = dz_range
+        else:
+            dy_range = _take_dy_range(dy, keep=ctx.has_res) if (w_range is not None and not dy_only_planes) else None
         if dy_only_planes and dy_planes is None:
             raise _lib.EmbnetError("conv2d backward: the gradient exists only as planes and they are gone (DY_PLANES)")
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -981,12 +989,20 @@ class _PadKernelFn(torch.autograd.Function):
         return dwp[:, :, :ctx.c, :].contiguous(), None
 
 
-def pad_channels(x, cp):
-    """NHWC image batch with C channels -> the same with zero channels appended up to cp (no gradient)."""
+def _new_range_slot(device):
+    return torch.empty(_lib.lib().embnet_range_slot_words(), dtype=torch.int32, device=device)
+
+
+def pad_channels(x, cp, with_range=False):
+    """NHWC image batch with C channels -> the same with zero channels appended up to cp (no gradient).
+    with_range: the copy carries its exact range (`_range`, layers.CONV_F16 note) — the pass reads every value anyway."""
     x = _c(x.detach())
     n, h, w, c = x.shape
     xp = torch.empty((n, h, w, cp), device=x.device, dtype=torch.float32)
-    check(_lib.lib().embnet_pad_channels(ptr(x), n * h * w, c, cp, ptr(xp), stream()))
+    slot = _new_range_slot(x.device) if with_range else None
+    check(_lib.lib().embnet_pad_channels_ex(ptr(x), n * h * w, c, cp, ptr(xp), ptr(slot), stream()))
+    if slot is not None:
+        xp._range = slot
     return xp
 
 
@@ -1011,14 +1027,18 @@ class Conv2D(nn.Module):
         self.bias = nn.Parameter(torch.zeros(filters)) if use_bias else None
         self.f16 = False          # True: three-product gather kernels where the operands' ranges are known (layers.CONV_F16 note)
 
-    def range_for(self, x, planes, in_stats):
+    def range_for(self, x, planes, in_stats, kernel=None):
         """The kernel's range slot when this conv, on that input, runs the gather kernels on three products; else None (among
-        the reasons: the input carries no range — nobody vouches for its magnitude, so six exact bf16 terms it is)."""
-        if not (CONV_F16[0] and getattr(self, "f16", False)) or (planes is not None and self.k != 1) or in_stats is not None or self.relu:
+        the reasons: the input carries no range — nobody vouches for its magnitude, so six exact bf16 terms it is).
+        kernel: the tensor the kernels read when it is not self.kernel (the channel-padded copy of a first-layer kernel: its
+        range is self.kernel's — the padding is zeros).  A fused ReLU is no obstacle: the gradient behind the mask comes with
+        its range from the pass that applies the mask (MaxPool2D / BatchNormalization backward, embnet_relu_bwd_colsum_ex)."""
+        if not (CONV_F16[0] and getattr(self, "f16", False)) or (planes is not None and self.k != 1) or in_stats is not None:
             return None
         if _range_of(x) is None:
             return None
-        if self.kernel.shape[2] % 4 or self.kernel.shape[3] % 4 or x.shape[-1] % 4 or _BN_SCALAR:
+        kernel = self.kernel if kernel is None else kernel
+        if kernel.shape[2] % 4 or kernel.shape[3] % 4 or x.shape[-1] % 4 or _BN_SCALAR:
             return None
         return weight_range(self.kernel)
 
@@ -1054,7 +1074,7 @@ class Conv2D(nn.Module):
                 and (kernel.shape[0] * kernel.shape[1] * kernel.shape[2] >= 128 or x.numel() // x.shape[-1] >= (1 << 20))
                 and residual is None and not with_skip):
             cp = (x.shape[-1] + 3) // 4 * 4           # image input, large kernel: 4-channel copy, 16-byte gathers
-            x = pad_channels(x, cp)
+            x = pad_channels(x, cp, with_range=bool(CONV_F16[0] and getattr(self, "f16", False) and not _BN_SCALAR))
             kernel = _PadKernelFn.apply(kernel, cp)
         planes = getattr(x, "_planes", None) if in_stats is None else None
         if planes is not None and not self.patch_capable(x.shape):
@@ -1072,7 +1092,7 @@ class Conv2D(nn.Module):
         if not (FUSE_BN_SUMS[0] and bn_src is not None and in_stats is None and self.stride == 1 and not with_skip
                 and torch.is_grad_enabled() and x.requires_grad and kernel is self.kernel):
             bn_src = None
-        w_range = self.range_for(x, planes, in_stats)      # (a channel-padded kernel has its source's range: the padding is zeros)
+        w_range = self.range_for(x, planes, in_stats, kernel)
         out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
                               planes, bn_src, w_range, _range_of(x) if w_range is not None else None)
         y = out[0] if with_skip else out
@@ -1314,7 +1334,7 @@ class _BatchNormFn(torch.autograd.Function):
         planes_only = bool(planes_only and emit_planes and not dropout)
         y = _placeholder(x.shape, x.device) if planes_only else torch.empty_like(x)
         # mean, rstd, scale, shift; in training also row 4 = the per-channel bounds of |y| and row 5 = y's range slot (first word)
-        ranged = bool(training and c % 4 == 0 and not dropout and not _BN_SCALAR)
+        ranged = bool(training and c % 4 == 0 and not _BN_SCALAR)
         stats = torch.empty((7 if ranged else 4, c), device=x.device, dtype=torch.float32)     # (row 6: the bounds of |xhat|, for backward)
         yk = None if (emit_planes or dropout) else y                         # planes / dropout: statistics first, then one pass
         if training:
@@ -1330,14 +1350,17 @@ class _BatchNormFn(torch.autograd.Function):
                                                   (stats.data_ptr() + 16 * c) if ranged else None,
                                                   (stats.data_ptr() + 20 * c) if (ranged and not planes_only) else None, stream()))
             _ACT_PLANES[y.data_ptr()] = planes
-        if ranged and not planes_only:
-            _ACT_RANGE[y.data_ptr()] = _stats_range(stats)
         ctx.dropout = None
         if dropout:
             rate, seed = dropout
             ctx.dropout = (rate, seed, GRAPH_TICK)
             check(lib.embnet_affine_act_dropout(ptr(x), m, c, (stats.data_ptr() + 8 * c), (stats.data_ptr() + 12 * c), int(relu),
                                                 rate, seed, GRAPH_TICK, ptr(y), stream()))
+            if ranged:       # |dropout(a)| <= |a| / (1 - rate): the range word from the channel bounds (no apply pass folded them)
+                check(lib.embnet_range_from_bound(stats.data_ptr() + 16 * c, c, 1.0 / (1.0 - float(rate)), None,
+                                                  stats.data_ptr() + 20 * c, stream()))
+        if ranged and not planes_only:
+            _ACT_RANGE[y.data_ptr()] = _stats_range(stats)
         if training and FUSE_BN_SUMS[0] and c % 4 == 0 and not dropout:
             if len(_BN_FWD_STATS) > 64:
                 _BN_FWD_STATS.clear()
@@ -1405,15 +1428,17 @@ class _BatchNormFn(torch.autograd.Function):
             # x is the output of a conv with a fused ReLU: its backward (mask + bias gradient) rides on this pass
             (bias,) = ctx.in_relu_bias
             db, db_note = _sink(bias)
+            # (the conv in front tagged its output `_wants_dy_range`: the exact range of dz rides on the pass, for its two gradients)
+            dzr = _emit_dx_range(dx) if getattr(ctx, "emit_dx_range", False) else None
             if drop is not None:
-                check(lib.embnet_bn_bwd_inrelu_dropout(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
-                                                       (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training),
-                                                       drop[0], drop[1], drop[2], ptr(dx), ptr(tg), ptr(tb), ptr(db), ptr(ws),
-                                                       ws.numel() * 4, stream()))
+                check(lib.embnet_bn_bwd_inrelu_dropout_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
+                                                          (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training),
+                                                          drop[0], drop[1], drop[2], ptr(dx), ptr(tg), ptr(tb), ptr(db), ptr(ws),
+                                                          ws.numel() * 4, ptr(dzr), stream()))
             else:
-                check(lib.embnet_bn_bwd_inrelu(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
-                                               (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training), ptr(dx),
-                                               ptr(tg), ptr(tb), ptr(db), ptr(ws), ws.numel() * 4, stream()))
+                check(lib.embnet_bn_bwd_inrelu_ex(ptr(dy), ptr(x), m, c, mean, rstd, (stats.data_ptr() + 8 * stats.shape[1]),
+                                                  (stats.data_ptr() + 12 * stats.shape[1]), int(ctx.relu), int(ctx.training), ptr(dx),
+                                                  ptr(tg), ptr(tb), ptr(db), ptr(ws), ws.numel() * 4, ptr(dzr), stream()))
             if len(RELU_DONE) > 64:
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
@@ -1965,9 +1990,11 @@ def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
 # ----------------------------------------------------------------------------- pooling
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, stride, pad, relu_bias=None):
+    def forward(ctx, x, k, stride, pad, relu_bias=None, y_range=None, want_dz_range=False):
         """relu_bias: the bias of the Conv2D (fused ReLU) whose output x is, when that conv's ReLU backward and bias gradient
-        are to ride on this layer's backward (FUSE_RELU_POOL) — x is then kept for backward (the conv keeps it anyway)."""
+        are to ride on this layer's backward (FUSE_RELU_POOL) — x is then kept for backward (the conv keeps it anyway).
+        y_range: a range slot that receives the exact max |y| (MaxPool2D.emit_range); want_dz_range (with relu_bias): backward
+        leaves the range of dz in DY_RANGE for the conv in front (it tagged x `_wants_dy_range`)."""
         x = _c(x)
         n, h, w, c = x.shape
         oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -1975,9 +2002,10 @@ class _MaxPoolFn(torch.autograd.Function):
             raise _lib.EmbnetError(f"MaxPool {k}x{k}/{stride} does not fit a {h}x{w} input")
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
         arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
-        check(_lib.lib().embnet_maxpool_fwd(ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(y), ptr(arg), stream()))
+        check(_lib.lib().embnet_maxpool_fwd_ex(ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(y), ptr(arg), ptr(y_range), stream()))
         ctx.cfg = (n, h, w, c, k, stride, pad, oh, ow)
         ctx.relu_bias = relu_bias
+        ctx.want_dz_range = bool(want_dz_range) and relu_bias is not None
         if relu_bias is not None:
             ctx.save_for_backward(arg, x)
         else:
@@ -1997,14 +2025,15 @@ class _MaxPoolFn(torch.autograd.Function):
             x = ctx.saved_tensors[1]
             db, db_note = _sink(ctx.relu_bias)
             ws = workspace(lib.embnet_bn_workspace_bytes(n * h * w, c), dy.device)
-            check(lib.embnet_maxpool_relu_bwd_colsum(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), ptr(db),
-                                                     ptr(ws), ws.numel() * 4, stream()))
+            dzr = _emit_dx_range(dx) if getattr(ctx, "want_dz_range", False) else None
+            check(lib.embnet_maxpool_relu_bwd_colsum_ex(ptr(dy), ptr(arg), ptr(x), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), ptr(db),
+                                                        ptr(ws), ws.numel() * 4, ptr(dzr), stream()))
             if len(RELU_DONE) > 64:
                 RELU_DONE.clear()
             RELU_DONE[dx.data_ptr()] = (dx.detach(), db, db_note)
-            return dx, None, None, None, None
+            return (dx,) + (None,) * 6
         check(lib.embnet_maxpool_bwd(ptr(dy), ptr(arg), n, h, w, c, k, stride, pad, oh, ow, ptr(dx), stream()))
-        return dx, None, None, None, None
+        return (dx,) + (None,) * 6
 
 
 class MaxPool2D(nn.Module):
@@ -2013,12 +2042,23 @@ class MaxPool2D(nn.Module):
     def __init__(self, pool_size=2, strides=None, zero_pad=0):
         super().__init__()
         self.k, self.s, self.p = pool_size, strides or pool_size, zero_pad
+        # True: the output carries its exact range (`_range`) for a three-product conv behind it — set by the model builder where
+        # no BatchNormalization bounds the activation (the `simple` backbone's conv -> ReLU -> pool blocks)
+        self.emit_range = False
 
     def forward(self, x):
         rc = getattr(x, "_relu_conv", None) if (FUSE_RELU_POOL[0] and torch.is_grad_enabled() and x.requires_grad) else None
-        if rc is not None and x.shape[3] % 4 == 0 and x.shape[0] * x.shape[1] * x.shape[2] < 2 ** 31:
-            return _MaxPoolFn.apply(x, self.k, self.s, self.p, rc[0])
-        return _MaxPoolFn.apply(x, self.k, self.s, self.p)
+        fused = rc is not None and x.shape[3] % 4 == 0 and x.shape[0] * x.shape[1] * x.shape[2] < 2 ** 31
+        slot = None
+        if _range_of(x) is None and self.emit_range and CONV_F16[0] and x.shape[3] % 4 == 0 and not _BN_SCALAR:
+            slot = _new_range_slot(x.device)
+        want = bool(fused and getattr(x, "_wants_dy_range", False))
+        y = _MaxPoolFn.apply(x, self.k, self.s, self.p, rc[0] if fused else None, slot, want)
+        # (zero padding: a window's maximum is one of x's values or a padding zero, so max |y| <= max |x|)
+        rng = slot if slot is not None else _range_of(x)
+        if rng is not None:
+            y._range = rng
+        return y
 
 
 class _BNActMaxPoolFn(torch.autograd.Function):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMBNET_ABI_VERSION 21
+#define EMBNET_ABI_VERSION 22
 
 enum {
   EMBNET_MINE_SEMIHARD = 0,    /* datagenerators.py:196-199 */
@@ -484,6 +484,11 @@ int embnet_bn_bwd_partials_ex(const float* dy, const float* x, long m, int c, co
 int embnet_bn_bwd_inrelu(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
                          const float* scale, const float* shift, int relu, int training, float* dz, float* dgamma,
                          float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 22 — the same with `dz_range` (NULL or a RANGE SLOT): the exact max |dz| in its first word, for the producer's data and
+ * weight gradient on three products */
+int embnet_bn_bwd_inrelu_ex(const float* dy, const float* x, long m, int c, const float* save_mean, const float* save_rstd,
+                            const float* scale, const float* shift, int relu, int training, float* dz, float* dgamma,
+                            float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, uint32_t* dz_range, void* stream);
 /* dx_planes (NULL, or 3*m*c bf16, c % 16 == 0): dx ALSO as the pre-split planes embnet_conv2d_patch_f32 takes (below) —
  * the gradient of the convolution output in front of this BatchNormalization, i.e. that convolution's data-gradient operand.
  * With dx_planes given, dx may be NULL (embnet_bn_bwd, embnet_bn_bwd_partials; c % 4 == 0): the fp32 tensor is not written —
@@ -499,6 +504,11 @@ int embnet_affine_act(const float* x, long m, int c, const float* scale, const f
  * image read 0 and take no gradient.  argmax[n,oh,ow,c] (uint8) is kept for backward. */
 int embnet_maxpool_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh, int ow,
                        float* y, uint8_t* argmax, void* stream);
+/* ABI 22 — the same with `y_range` (NULL, or a RANGE SLOT of embnet_range_slot_words() words, c % 4 == 0): the exact max |y| of the
+ * pooled tensor is left in its first word, for the three-product conv that reads y (the `simple` backbone's conv -> ReLU -> pool
+ * blocks have no BatchNormalization whose statistics could bound the activation; reference backbones.py:21-31). */
+int embnet_maxpool_fwd_ex(const float* x, int n, int h, int w, int c, int k, int stride, int pad, int oh, int ow,
+                          float* y, uint8_t* argmax, uint32_t* y_range, void* stream);
 int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
                        int pad, int oh, int ow, float* dx, void* stream);
 /* embnet_maxpool_bwd followed by embnet_relu_bwd_colsum in one pass, for the conv -> ReLU -> MaxPool blocks of the
@@ -509,6 +519,11 @@ int embnet_maxpool_bwd(const float* dy, const uint8_t* argmax, int n, int h, int
 int embnet_maxpool_relu_bwd_colsum(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w, int c,
                                    int k, int stride, int pad, int oh, int ow, float* dz, float* dbias, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* ABI 22 — the same with `dz_range` (NULL or a RANGE SLOT): the exact max |dz| in its first word, for the conv's data and
+ * weight gradient on three products. */
+int embnet_maxpool_relu_bwd_colsum_ex(const float* dy, const uint8_t* argmax, const float* y, int n, int h, int w, int c,
+                                      int k, int stride, int pad, int oh, int ow, float* dz, float* dbias, void* workspace,
+                                      size_t workspace_bytes, uint32_t* dz_range, void* stream);
 
 /* BatchNorm-apply + activation + ZeroPadding2D(pad) + MaxPool(k,stride) in one pass (the zoo ResNet stem
  * bn0 -> relu -> pad -> pool, reference backbones.py:99-104 via image-classifiers).  scale/shift come from
@@ -555,6 +570,9 @@ int embnet_relu_bwd(const float* dy, const float* y, long total, float* dz, void
  * workspace >= embnet_colsum_workspace_bytes(m, c) */
 int embnet_relu_bwd_colsum(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* ABI 22 — the same with `dz_range` (NULL or a RANGE SLOT): the exact max |dz| in its first word */
+int embnet_relu_bwd_colsum_ex(const float* dy, const float* y, long m, int c, float* dz, float* dbias, void* workspace,
+                              size_t workspace_bytes, uint32_t* dz_range, void* stream);
 size_t embnet_colsum_workspace_bytes(long m, int c);
 int embnet_colsum(const float* x, long m, int c, float* out, void* workspace, size_t workspace_bytes,
                   void* stream);                                                                /* bias grads */
@@ -574,6 +592,8 @@ int embnet_tap_border_sums(const float* dy, int n, int oh, int ow, int k, int r,
                            int h, int w, float* tap_sums, void* workspace, size_t workspace_bytes, void* stream);
 /* y[pixels,cout] = [x[pixels,cin] | 0]: widens 3-channel images to 4 channels for 16-byte stem gathers. */
 int embnet_pad_channels(const float* x, long pixels, int cin, int cout, float* y, void* stream);
+/* ABI 22 — the same with `y_range` (NULL or a RANGE SLOT): the exact max |x| of the image batch in its first word */
+int embnet_pad_channels_ex(const float* x, long pixels, int cin, int cout, float* y, uint32_t* y_range, void* stream);
 /* Dropout (backbones.py:53,64,73): inverted scaling, counter-based mask from (seed, index). */
 int embnet_dropout(const float* x, long total, float rate, uint64_t seed, const uint64_t* seed_add_dev, float* y,
                    void* stream);   /* seed_add_dev (NULL or device uint64): added to seed — a replayed HIP graph draws a new mask per step */
@@ -587,6 +607,11 @@ int embnet_bn_bwd_inrelu_dropout(const float* dy, const float* x, long m, int c,
                                  const float* save_rstd, const float* scale, const float* shift, int relu, int training,
                                  float rate, uint64_t seed, const uint64_t* seed_add_dev, float* dz, float* dgamma,
                                  float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+int embnet_bn_bwd_inrelu_dropout_ex(const float* dy, const float* x, long m, int c, const float* save_mean,
+                                    const float* save_rstd, const float* scale, const float* shift, int relu, int training,
+                                    float rate, uint64_t seed, const uint64_t* seed_add_dev, float* dz, float* dgamma,
+                                    float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, uint32_t* dz_range,
+                                    void* stream);                                         /* ABI 22: + dz_range, as above */
 /* ---- EfficientNet MBConv pieces (backbones.py:84-98, `efficientnet` zoo package) and the siamese 'l1' head ---- */
 /* DepthwiseConv2D: x[n,h,w,c], w[r,s,c] (Keras depthwise_kernel [r,s,c,1]), y[n,oh,ow,c]; padding as conv2d. */
 int embnet_dwconv2d_fwd_f32(const float* x, const float* w, float* y, int n, int h, int wd, int c, int r, int s,

@@ -144,8 +144,8 @@ def test_bench_sizes_vs_gather_kernel_and_repeatable(dev, n, h, c, k, stride):
     assert err < 2e-6, err
 
 
-def test_bottleneck_unit_with_conv3_on_the_planes_gemm(dev):
-    """layers.CONV1X1_PLANES on: bn3 writes its output also as planes and conv3's forward runs the planes GEMM (trace); outputs and
+def test_bottleneck_unit_with_its_1x1_convs_on_the_planes_gemm(dev):
+    """layers.CONV1X1_PLANES on: bn1 / bn3 write their outputs also as planes and conv1 / conv3 run their forward on the planes GEMM (trace); outputs and
     every gradient agree with the default wiring (gather kernels) to fp32 rounding; nothing is left in the step context."""
     from embeddingnet_amd.backbones import ResidualUnit
 
@@ -153,10 +153,10 @@ def test_bottleneck_unit_with_conv3_on_the_planes_gemm(dev):
         old = L.CONV1X1_PLANES[0]
         L.CONV1X1_PLANES[0] = on
         try:
-            unit = ResidualUnit(256, 64, 1, False, "bottleneck", torch.Generator().manual_seed(5)).to(dev).train()
+            unit = ResidualUnit(1024, 256, 1, False, "bottleneck", torch.Generator().manual_seed(5)).to(dev).train()   # conv1 AND conv3 marked
             g = torch.Generator(device=dev).manual_seed(6)
-            x = torch.randn((8, 14, 14, 256), device=dev, generator=g).requires_grad_(True)
-            dy = torch.randn((8, 14, 14, 256), device=dev, generator=g) * 1e-3
+            x = torch.randn((8, 14, 14, 1024), device=dev, generator=g).requires_grad_(True)
+            dy = torch.randn((8, 14, 14, 1024), device=dev, generator=g) * 1e-3
             _lib.trace_reset(); _lib.trace_enable(True)
             try:
                 y = unit(x)
@@ -171,7 +171,7 @@ def test_bottleneck_unit_with_conv3_on_the_planes_gemm(dev):
 
     y1, dx1, g1, n1 = run(True)
     y0, dx0, g0, n0 = run(False)
-    assert any("conv1x1_planes_kernel" in s for s in n1) and not any("conv1x1_planes_kernel" in s for s in n0), (n1, n0)
+    assert sum("conv1x1_planes_kernel" in s for s in n1) == 2 and not any("conv1x1_planes_kernel" in s for s in n0), (n1, n0)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     assert rel(y1, y0) < 2e-6 and rel(dx1, dx0) < 2e-5
     for a, b in zip(g1, g0):

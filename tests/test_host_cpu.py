@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in protos if not hasattr(lib, n)]
     assert not missing, missing
     bound = _lib.lib()                      # sets argtypes/restype from the header, checks the ABI version
-    assert bound.embnet_abi_version() == 21
+    assert bound.embnet_abi_version() == 22
     assert bound.embnet_mine_max_triplets(32, 4) == 192
     assert bound.embnet_pairwise_workspace_bytes(128, 256) == 512          # row norms only: short reduction, no K split
     # the reference's default encodings_len = 4096 at a 128-row batch: 4 tiles x 128 K tiles -> K split, partial Gram slabs
