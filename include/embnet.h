@@ -225,7 +225,7 @@ int embnet_conv2d_wgrad_splits(int n, int c, int r, int s, int k, int oh, int ow
  * captured graph.  slabs and out 16-byte aligned when n % 4 == 0. */
 int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream);
 
-/* ---- three products per fp32 product for the implicit-GEMM ("gather") convolutions above (ABI 21; csrc/conv.hip "Ranges") -------
+/* ---- three products per fp32 product for the implicit-GEMM ("gather") convolutions above (ABI 21 / 22; csrc/conv.hip "Ranges") -------
  * The layers of backbones.py:99-104 the patch kernels do not take — the 7x7 stem, the stride-2 3x3 convs, every 1x1 conv — split
  * their fp32 operands inside the kernel.  Given the RANGE of BOTH operands they use the planes kernels' arithmetic (below: two fp16
  * pieces of x s, three products, the sums x 1 / s x 1 / s') instead of three bf16 pieces and six products: half the matrix
@@ -245,6 +245,11 @@ int embnet_slab_reduce_multi(const void* host_table, int n_tensors, void* stream
  *                the apply pass runs — per channel |scale_c| sqrt(q_c) + |shift_c| with q_c the largest per-band sum of squares
  *                among the statistics partials (>= max x^2), folded over the channels; above the true maximum by at most
  *                sqrt(rows per band) (3.3 binades for a conv epilogue's bands), never below it.
+ *   without a BatchNormalization (ABI 22; the `simple` / `simple2` backbones, reference backbones.py:19-81): the exact maximum of what
+ *                the pass writes, a slot of embnet_range_slot_words() words as for gradients — `y_range` of embnet_pad_channels_ex
+ *                (the image batch) and embnet_maxpool_fwd_ex (pooled activations), `dz_range` of embnet_maxpool_relu_bwd_colsum_ex,
+ *                embnet_relu_bwd_colsum_ex and embnet_bn_bwd_inrelu[_dropout]_ex (the gradient behind a fused ReLU's mask).  These
+ *                passes zero the slot with a KERNEL: a hipMemsetAsync node did not zero it when a captured HIP graph was replayed.
  * Who reads it: the last two pointer arguments (in front of `stream`) of embnet_conv2d_{fwd, dgrad, dgrad_bnsums, wgrad,
  * wgrad_slabs}_f32_ex — the ranges of the call's first and second tensor argument (x, w | dy, w | x, dy); NULL = unknown.  The
  * scale of a tensor puts B into [2^14, 2^15).  The scalar-load kernels (c or k % 4 != 0), a fused input transform and the thin
