@@ -379,6 +379,15 @@ PATCH_CONV = [_os.environ.get("EMBNET_CONV_PATCH", "1") != "0"]      # [False]: 
 # BatchNormalization in front must write the planes BESIDE the fp32 copy the gather weight gradient still reads: C3 86.8 -> 87.8 ms
 # (profiles/r06_exp_conv1x1_step.txt).  It pays once a 1x1 planes weight gradient lets that tensor exist as planes only.
 CONV1X1_PLANES = [_os.environ.get("EMBNET_CONV_1X1_PLANES", "0") != "0"]
+# 1x1 convs whose operands both carry a range: the activation operand read as fp32 by LDS-DMA and split in the matrix waves
+# (csrc/conv_patch.hip conv1x1_a32_kernel) instead of the gather loop — forward, and the stride-1 data gradients that do not carry
+# BatchNorm-backward sums; output width >= 128.  Built, tested (tests/test_conv1x1_dma_gpu.py), OFF: 1.1 - 1.3 x the gather kernel
+# back to back, 86.0 -> 86.2 ms in the C3 step (profiles/r06_exp_conv1x1_dma_step.txt) — ResNet50's 1x1 layers are HBM-bound there.
+CONV1X1_DMA = [int(_os.environ.get("EMBNET_CONV_1X1_DMA_MODE", "0"))]
+
+
+def _dma1x1_ok(n, h, wd, c, k, stride, oh, ow):
+    return bool(CONV1X1_DMA[0]) and k >= 128 and bool(_lib.lib().embnet_conv2d_dma1x1_supported(n, h, wd, c, k, stride, oh, ow))
 DY_PLANES = _CtxDict("dy_planes")
 _ACT_PLANES = _CtxDict("act_planes")
 _ACT_RANGE = _CtxDict("act_range")
@@ -648,7 +657,7 @@ def same_pad(n, k, s):
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, relu, residual=None, in_stats=None, in_act=0, out_stats=None, with_skip=False,
-                planes=None, bn_src=None, w_range=None, x_range=None):
+                planes=None, bn_src=None, w_range=None, x_range=None, dma=False):
         """planes: the input's pre-split planes (layers.DY_PLANES note above) -> the patch kernel computes the forward.
         bn_src = (bn_x, bn_stats, bn_act): x is act(BatchNorm(bn_x)) — the data gradient also emits that layer's backward sums.
         w_range: the kernel's range slot (weight_range), x_range: the input's (layers._range_of) -> the gather kernels multiply
@@ -683,6 +692,10 @@ class _Conv2dFn(torch.autograd.Function):
             check(lib.embnet_conv2d_patch_f32(ptr(planes), ptr(weight_planes(w, 0)), ptr(bias), ptr(y), n, h, wd, c, r, s, k,
                                               pt, pl, oh, ow, int(relu), ptr(residual), ptr(out_stats), ptr(ws),
                                               ws.numel() * 4, stream()))
+        elif dma:                                   # 1x1, both ranges known: x by LDS-DMA as fp32, the kernel planes (Conv2D.forward decided)
+            ws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, c, 1, 1, k, oh, ow), x.device)
+            check(lib.embnet_conv2d_dma1x1_f32(ptr(x), ptr(weight_planes(w, 0)), ptr(bias), ptr(y), n, h, wd, c, k, stride, oh, ow,
+                                               int(relu), ptr(residual), ptr(out_stats), _rptr(x_range), ptr(ws), ws.numel() * 4, stream()))
         else:
             ws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, c, r, s, k, oh, ow), x.device)
             fr = w_range is not None and x_range is not None and in_stats is None
@@ -781,6 +794,15 @@ class _Conv2dFn(torch.autograd.Function):
             if dy_planes is not None and patch_ok(n, oh, ow, k, r, s, c, 1, h, wd):
                 _patch_dgrad(dy_planes, w, dx, n, h, wd, c, r, s, k, pt, pl, oh, ow, dskip,
                              getattr(ctx, "bn_src", None) if dskip is None else None)
+            elif (r == 1 and s == 1 and stride == 1 and dy_range is not None and w_range is not None and w.shape[3] % 16 == 0
+                  and _dma1x1_ok(n, oh, ow, k, c, 1, h, wd)
+                  and (dskip is not None or getattr(ctx, "bn_src", None) is None
+                       or lib.embnet_conv2d_dgrad_bnsums_rows(n, h, wd, c, r, s, k, stride) <= 0)):
+                # 1x1 stride-1 data gradient without BatchNorm sums: dz by LDS-DMA as fp32 against the flipped kernel planes (c and k
+                # swap roles)
+                dws = workspace(lib.embnet_conv2d_patch_workspace_bytes(n, k, 1, 1, c, h, wd), x.device)
+                check(lib.embnet_conv2d_dma1x1_f32(ptr(dz), ptr(weight_planes(w, 1)), None, ptr(dx), n, oh, ow, k, c, 1, h, wd, 0,
+                                                   ptr(dskip), None, _rptr(dy_range), ptr(dws), dws.numel() * 4, stream()))
             else:
                 # its own scratch: with OVERLAP_WGRAD the wgrad slabs are in flight on the side stream's buffer
                 dws = workspace(lib.embnet_conv2d_dgrad_workspace_bytes(n, h, wd, c, r, s, k, stride), x.device)
@@ -817,7 +839,7 @@ class _Conv2dFn(torch.autograd.Function):
             # (the residual branch would receive a placeholder — three uninitialised floats behind zero strides)
             raise _lib.EmbnetError("conv2d backward: a conv with a fused Add received its gradient as planes only; the Add's other "
                                    "branch needs the fp32 gradient (BatchNormalization(owns_input=True) behind conv(residual=...))")
-        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None, None
 
 
 class _ConvPairFn(torch.autograd.Function):
@@ -1079,10 +1101,13 @@ class Conv2D(nn.Module):
         planes = getattr(x, "_planes", None) if in_stats is None else None
         if planes is not None and not self.patch_capable(x.shape):
             planes = None
+        w_range = self.range_for(x, planes, in_stats, kernel)
+        dma = bool(self.k == 1 and planes is None and w_range is not None and kernel is self.kernel
+                   and _dma1x1_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], kernel.shape[3], geom[0], geom[3], geom[4]))
         out_stats = None
         if emit_stats:
             r, s, c, k = kernel.shape
-            if planes is not None:
+            if planes is not None or dma:
                 rows = _lib.lib().embnet_conv2d_patch_stats_rows(x.shape[0], geom[3], geom[4])
             else:
                 rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], c, r, s, k, geom[3], geom[4])
@@ -1092,9 +1117,8 @@ class Conv2D(nn.Module):
         if not (FUSE_BN_SUMS[0] and bn_src is not None and in_stats is None and self.stride == 1 and not with_skip
                 and torch.is_grad_enabled() and x.requires_grad and kernel is self.kernel):
             bn_src = None
-        w_range = self.range_for(x, planes, in_stats, kernel)
         out = _Conv2dFn.apply(x, kernel, self.bias, geom, self.relu, residual, in_stats, in_act, out_stats, with_skip,
-                              planes, bn_src, w_range, _range_of(x) if w_range is not None else None)
+                              planes, bn_src, w_range, _range_of(x) if w_range is not None else None, dma)
         y = out[0] if with_skip else out
         if out_stats is not None:
             y._bn_partials = out_stats
@@ -2233,7 +2257,13 @@ class Dropout(nn.Module):
         if not self.active():
             return x
         self._step += 1
-        return _DropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)
+        y = _DropoutFn.apply(x, self.rate, (self.seed << 32) + self._step)
+        r = _range_of(x)
+        if r is not None:          # |dropout(x)| <= |x| / (1 - rate): the input's range, scaled (as a BatchNormalization with a fused Dropout does)
+            slot = _new_range_slot(x.device)
+            check(_lib.lib().embnet_range_from_bound(_rptr(r), 1, 1.0 / (1.0 - float(self.rate)), None, ptr(slot), stream()))
+            y._range = slot
+        return y
 
 
 # ----------------------------------------------------------------------------- MBConv pieces

@@ -351,6 +351,17 @@ int embnet_conv2d_patch_f32(const void* x_planes, const void* w_planes, const fl
 int embnet_conv2d_planes1x1_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
                                 int k, int stride, int oh, int ow, int relu, const float* residual, float* stats,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 22 — the same 1x1 product with the ACTIVATION operand read as fp32 (csrc/conv_patch.hip conv1x1_a32_kernel): no planes of x
+ * have to exist.  x fp32 [n,h,wd,c] reaches LDS by DMA (16-byte pieces, one 128-byte line per pixel and 32-channel step, three stages
+ * in flight) and is split into its two fp16 pieces by the matrix waves; x_range: x's RANGE SLOT (required — its scale); wp: the kernel
+ * planes of embnet_conv_weight_planes (r = s = 1; flip 0).  With dy, dy's range slot, the flip-1 planes and c, k swapped (stride 1) the
+ * call is the DATA GRADIENT (residual = a gradient to add).  c % 32 == 0, k % 4 == 0, stride 1 or 2, the tensor below 4 GiB:
+ * embnet_conv2d_dma1x1_supported.  Workspace: embnet_conv2d_patch_workspace_bytes(n, c, 1, 1, k, oh, ow).  The Python layers leave it
+ * off by default (layers.CONV1X1_DMA; DESIGN 3.14: 1.1 - 1.3 x the gather kernel back to back, no gain inside the HBM-bound C3 step). */
+int embnet_conv2d_dma1x1_supported(int n, int h, int wd, int c, int k, int stride, int oh, int ow);
+int embnet_conv2d_dma1x1_f32(const float* x, const void* wp, const float* bias, float* y, int n, int h, int wd, int c, int k,
+                             int stride, int oh, int ow, int relu, const float* residual, float* stats, const uint32_t* x_range,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* The patch kernel as a stride-1 data gradient (dy planes, flip-1 kernel planes, c and k swapped as above) whose epilogue ALSO
  * emits the BatchNorm-backward sums of the BatchNormalization in front of the conv — the conv's input was
  * act(bn_scale * bn_x + bn_shift): embnet_conv2d_dgrad_bnsums_f32's contract on this kernel, bn_partial [2][k][bn_rows] with

@@ -46,7 +46,7 @@ def timed(fn, reps):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-print(f"{'layer':28s} {'planes us':>10s} {'TF/s':>7s} {'gather us':>10s} {'TF/s':>7s} {'HBM floor us':>13s}")
+print(f"{'layer':28s} {'planes us':>10s} {'TF/s':>7s} {'fp32-DMA us':>12s} {'TF/s':>7s} {'gather us':>10s} {'TF/s':>7s} {'HBM floor us':>13s} {'dma vs gather':>14s}")
 for name, h, c, k, stride, res in LAYERS:
     oh = (h - 1) // stride + 1
     m = N * oh * oh
@@ -78,8 +78,15 @@ for name, h, c, k, stride, res in LAYERS:
                                                 _lib.ptr(rs[j]), None, None, 0, None, ws.data_ptr(), ws.numel() * 4, rx[j].data_ptr(), rw.data_ptr(),
                                                 _lib.stream()))
 
-    tp, tg = timed(planes, 20), timed(gather, 20)
+    def dma(i):
+        j = i % copies
+        _lib.check(lib.embnet_conv2d_dma1x1_f32(xs[j].data_ptr(), wp.data_ptr(), None, ys[j].data_ptr(), N, h, h, c, k, stride, oh, oh, 0,
+                                                _lib.ptr(rs[j]), None, rx[j].data_ptr(), ws.data_ptr(), ws.numel() * 4, _lib.stream()))
+
+    gather(0); ref = ys[0].clone(); dma(0)
+    err = float((ys[0] - ref).abs().max()) / float(ref.abs().max())
+    tp, td, tg = timed(planes, 20), timed(dma, 20), timed(gather, 20)
     flop = 2.0 * m * c * k
-    print(f"{name:28s} {tp:10.1f} {flop / tp / 1e6:7.1f} {tg:10.1f} {flop / tg / 1e6:7.1f} {bytes_io / 5.2e6:13.1f}")
+    print(f"{name:28s} {tp:10.1f} {flop / tp / 1e6:7.1f} {td:12.1f} {flop / td / 1e6:7.1f} {tg:10.1f} {flop / tg / 1e6:7.1f} {bytes_io / 5.2e6:13.1f} {err:14.2e}")
     del xs, ys, rs, xps
     torch.cuda.empty_cache()
