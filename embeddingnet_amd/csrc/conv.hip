@@ -1162,9 +1162,17 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     if (can) return launch_thin_gemm(x, w, 0, M, c, k, y, stats, bias, relu, residual, stride, n, h, wd, oh, ow, st);
     EMBNET_CHECK_ARG(!stats, "conv2d_fwd: epilogue statistics of a thin 1x1 conv go with pad 0 and no input transform");
   }
-  const int tile = pick_tile(M, k, false, (long)r * s * c);
-  const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   const bool vec = (c & 3) == 0 && (k & 3) == 0 && aligned16(x) && aligned16(w) && (!bias || aligned16(bias));
+  const bool hform = ranged && vec && !in_scale;
+  int tile = pick_tile(M, k, false, (long)r * s * c);
+  // EMBNET_FWD_256=1 (experiment, off): a short reduction into <= 64 filters over very many pixels (the zoo ResNets' 7x7x4 stem: 7 K
+  // tiles, 12 544 tiles of 128 x 64 at batch 128) on 256 x 64 tiles — if the launch were (rounds) x (K tiles) x (a gather round trip),
+  // half the rounds would halve it; measured 244 -> 271 us: it is the rate at which the L1 takes the 49 16-byte requests per output
+  // pixel, and fewer, fatter workgroups hide less of it.  Only the three-product form has the instantiation; M % 256 == 0 keeps the
+  // statistics' row count what embnet_conv2d_fwd_stats_rows says.
+  static const int fwd256 = (int)env_long("EMBNET_FWD_256", 0);     // measured slower (244 -> 271 us, profiles/r06_exp_fwd256.txt): off
+  if (fwd256 && hform && tile == 1 && k <= 64 && M % 256 == 0 && cdiv((long)r * s * c, BK) <= 8 && M / 256 >= 4 * 512) tile = 5;
+  const long tiles = (long)cdiv(M, TILE_BM[tile]) * cdiv(k, TILE_BN[tile]);
   EMBNET_CHECK_ARG(!in_scale || (vec && aligned16(in_scale) && aligned16(in_shift)),
                    "conv2d_fwd: the fused input transform needs channel counts that are multiples of 4 and aligned pointers");
   EMBNET_CHECK_ARG(!stats || (vec && aligned16(stats)),
@@ -1177,14 +1185,14 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
   const int grid = p.tail.n_full + (int)(tiles - p.tail.n_full) * p.tail.parts;
   p.fair_from = fair_from(grid, tile, false);
   const double flop = 2.0 * M * k * r * s * c;
-  const bool hform = ranged && vec && !in_scale;
   p.rg = rg;
   {
     EMBNET_TRACE_FLOP(hform ? conv_h_kernel_name("conv_fwd_h_kernel", "ConvFwdParams", tile) :
                       conv_kernel_name(in_scale ? "conv_fwd_tf_kernel" : "conv_fwd_kernel", "ConvFwdParams", tile,
                                        (vec || in_scale) ? "true" : "false"), flop,
                       4.0 * ((double)n * h * wd * c + (double)r * s * c * k + (double)M * k * (residual ? 2 : 1)), st);
-    if (hform) { LAUNCH_TILED_H(conv_fwd_h_kernel, tile, grid, st, p) }
+    if (hform && tile == 5) conv_fwd_h_kernel<G256x64><<<grid, 256, 0, st>>>(p);
+    else if (hform) { LAUNCH_TILED_H(conv_fwd_h_kernel, tile, grid, st, p) }
     else if (in_scale) { LAUNCH_TILED(conv_fwd_tf_kernel, true, tile, grid, st, p) }
     else if (vec) { LAUNCH_TILED(conv_fwd_kernel, true, tile, grid, st, p) }
     else { LAUNCH_TILED(conv_fwd_kernel, false, tile, grid, st, p) }
