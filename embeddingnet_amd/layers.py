@@ -41,6 +41,7 @@ def _side_stream(device):
 
 
 _WS_RETIRED = []
+_WS_POISON = _os.environ.get("EMBNET_WS_POISON", "0") == "1"
 
 
 def workspace(nbytes, device):
@@ -54,6 +55,8 @@ def workspace(nbytes, device):
             _WS_RETIRED.append(buf)
         buf = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
         _WS[key] = buf
+    if _WS_POISON:             # debug aid (EMBNET_WS_POISON=1): a kernel that reads scratch it did not write sees NaN, not a neighbour's leftovers
+        buf.fill_(float("nan"))
     return buf
 
 
@@ -384,6 +387,7 @@ CONV1X1_PLANES = [_os.environ.get("EMBNET_CONV_1X1_PLANES", "0") != "0"]
 # BatchNorm-backward sums; output width >= 128.  Built, tested (tests/test_conv1x1_dma_gpu.py), OFF: 1.1 - 1.3 x the gather kernel
 # back to back, 86.0 -> 86.2 ms in the C3 step (profiles/r06_exp_conv1x1_dma_step.txt) — ResNet50's 1x1 layers are HBM-bound there.
 CONV1X1_DMA = [int(_os.environ.get("EMBNET_CONV_1X1_DMA_MODE", "0"))]
+STEM_CONV = [_os.environ.get("EMBNET_STEM_CONV", "1") != "0"]        # [False]: the ResNet stem's forward on the gather kernel (A/B)
 
 
 def _dma1x1_ok(n, h, wd, c, k, stride, oh, ow):
@@ -1891,8 +1895,10 @@ class _InputBNConvFn(torch.autograd.Function):
     _ones = {}
 
     @staticmethod
-    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False, w_range=None):
-        """w_range: the kernel's range slot (_Conv2dFn.forward); the channel-padded copy has the same range."""
+    def forward(ctx, x, beta, moving_mean, moving_var, w, eps, momentum, geom, out_stats=None, zero_sum_dy=False, w_range=None,
+                stem=False):
+        """w_range: the kernel's range slot (_Conv2dFn.forward); the channel-padded copy has the same range.
+        stem: the forward runs csrc/conv_stem.hip (input_bn_conv decided: 7x7 / 2, 4 -> 64 channels, both ranges known)."""
         x, w = _c(x), _c(w)
         lib = _lib.lib()
         n, h, wd, c = x.shape
@@ -1929,10 +1935,16 @@ class _InputBNConvFn(torch.autograd.Function):
             moving_mean.copy_(mm_p[:c])
             moving_var.copy_(mv_p[:c])
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
-        check(lib.embnet_conv2d_fwd_f32_ex(
-            ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
-            ptr(out_stats), ptr(cws), cws.numel() * 4, _rptr(a_range), _rptr(w_range) if a_range is not None else None, stream()))
+        if stem:
+            if a_range is None:
+                raise _lib.EmbnetError("input_bn_conv: the stem kernel needs the ranges of both operands")
+            check(lib.embnet_conv2d_stem_f32(ptr(a), ptr(w_p), ptr(y), n, h, wd, pt, pl, oh, ow, ptr(out_stats), _rptr(a_range),
+                                             _rptr(w_range), stream()))
+        else:
+            cws = workspace(lib.embnet_conv2d_fwd_workspace_bytes(n, cp, r, s, k, oh, ow), x.device)
+            check(lib.embnet_conv2d_fwd_f32_ex(
+                ptr(a), ptr(w_p), None, ptr(y), n, h, wd, cp, r, s, k, stride, pt, pl, oh, ow, 0, None, None, None, 0,
+                ptr(out_stats), ptr(cws), cws.numel() * 4, _rptr(a_range), _rptr(w_range) if a_range is not None else None, stream()))
         ctx.w_range = w_range
         ctx.a_range = a_range
         ctx.geom, ctx.c, ctx.zero_sum_dy = geom, c, bool(zero_sum_dy)
@@ -1979,7 +1991,7 @@ class _InputBNConvFn(torch.autograd.Function):
                 None, None, 0, stream()))
         dbeta, db_note = _sink(ctx.beta_ref)
         check(lib.embnet_tap_contract(ptr(w), ptr(taps), r * s, c, k, ptr(dbeta), stream()))
-        return None, _done(dbeta, db_note), None, None, dw, None, None, None, None, None, None
+        return None, _done(dbeta, db_note), None, None, dw, None, None, None, None, None, None, None
 
 
 def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
@@ -1992,18 +2004,26 @@ def input_bn_conv(x, bn, conv, emit_stats=False, zero_sum_dy=False):
     if not fusable:
         return conv(bn(x), emit_stats=emit_stats)
     geom = conv.geometry(x.shape[1], x.shape[2])
-    out_stats = None
-    if emit_stats:
-        r, s, c, k = conv.kernel.shape
-        cp = c if c % 4 == 0 else c + 4 - c % 4                     # the fused stem pads the image channels
-        rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], cp, r, s, k, geom[3], geom[4])
-        if rows > 0:
-            out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
+    r, s, c, k = conv.kernel.shape
+    cp = c if c % 4 == 0 else c + 4 - c % 4                         # the fused stem pads the image channels
     w_range = None
     if CONV_F16[0] and getattr(conv, "f16", False) and conv.kernel.shape[3] % 4 == 0 and not _BN_SCALAR:
         w_range = weight_range(conv.kernel)
+    # the zoo ResNets' 7x7 / 2 stem on its own kernel (csrc/conv_stem.hip: every input pixel once per tile instead of 49 gathers per
+    # output pixel) when both operands carry a range
+    stem = bool(STEM_CONV[0] and w_range is not None
+                and _lib.lib().embnet_conv2d_stem_supported(x.shape[0], x.shape[1], x.shape[2], cp, r, s, k, geom[0], geom[1], geom[2],
+                                                            geom[3], geom[4]))
+    out_stats = None
+    if emit_stats:
+        if stem:
+            rows = _lib.lib().embnet_conv2d_stem_stats_rows(x.shape[0], geom[3], geom[4])
+        else:
+            rows = _lib.lib().embnet_conv2d_fwd_stats_rows(x.shape[0], cp, r, s, k, geom[3], geom[4])
+        if rows > 0:
+            out_stats = torch.empty((2, k, rows), device=x.device, dtype=torch.float32)
     y = _InputBNConvFn.apply(x, bn.beta, bn.moving_mean, bn.moving_variance, conv.kernel, bn.eps, bn.momentum, geom,
-                             out_stats, zero_sum_dy, w_range)
+                             out_stats, zero_sum_dy, w_range, stem)
     if out_stats is not None:
         y._bn_partials = out_stats
     if w_range is not None:

@@ -342,6 +342,16 @@ int embnet_conv2d_patch_stats_rows(int n, int oh, int ow);
 int embnet_conv2d_patch_f32(const void* x_planes, const void* w_planes, const float* bias, float* y, int n, int h, int wd, int c,
                             int r, int s, int k, int pad_t, int pad_l, int oh, int ow, int relu, const float* residual,
                             float* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* ABI 22 — the zoo ResNets' stem (7x7, stride 2, 4 -> 64 channels; reference backbones.py:99-104 via image-classifiers) forward as a
+ * kernel of its own (csrc/conv_stem.hip): x fp32 [n,h,wd,4] (the image widened to four channels), w fp32 [7,7,4,64], y [n,oh,ow,64];
+ * taps outside the image read zeros (pad_t / pad_l: where output (0, 0)'s window starts above / left of the image).  Every input
+ * pixel reaches LDS once per 16 x 16 output tile (LDS-DMA), the kernel is split into its fp16 pieces by each workgroup, the products
+ * are the three-term form: BOTH range slots are required.  stats (NULL or [2][64][embnet_conv2d_stem_stats_rows(n, oh, ow)]): the
+ * BatchNorm statistics partials of the layer behind, as embnet_conv2d_fwd_f32's.  The gather kernel's result to fp32 rounding. */
+int embnet_conv2d_stem_supported(int n, int h, int wd, int c, int r, int s, int k, int stride, int pad_t, int pad_l, int oh, int ow);
+int embnet_conv2d_stem_stats_rows(int n, int oh, int ow);
+int embnet_conv2d_stem_f32(const float* x, const float* w, float* y, int n, int h, int wd, int pad_t, int pad_l, int oh, int ow,
+                           float* stats, const uint32_t* x_range, const uint32_t* w_range, void* stream);
 /* 1x1 convolutions on the planes (ABI 21; csrc/conv_patch.hip conv1x1_planes_kernel): the bottleneck units' conv1 / conv3 and the
  * projection shortcuts (backbones.py:99-104) as a GEMM whose operands arrive by LDS-DMA from the planes — x planes of [n,h,wd,c],
  * kernel planes of a [1,1,c,k] kernel (embnet_conv_weight_planes; flip 1 and dy planes give the stride-1 data gradient) —

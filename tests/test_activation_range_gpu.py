@@ -399,7 +399,7 @@ def test_resnet18_with_small_gammas_vs_oracle(dev):
         names = [r[0] for r in _lib.trace_records()]
     finally:
         _lib.trace_enable(False)
-    assert sum("_h_kernel" in s for s in names) >= 20, names
+    assert sum("_h_kernel" in s or "conv_stem_kernel" in s for s in names) >= 20, names
     assert not any(s.startswith("void embnet::conv_fwd_kernel") for s in names), [s for s in names if "conv_fwd_kernel" in s]
     params = {k: v.detach().cpu().double().requires_grad_(v.requires_grad) for k, v in B.keras_weights(base).items()}
     ctx = OB.Ctx(params, training=True)

@@ -304,9 +304,11 @@ def test_resnet18_step_runs_its_gather_convs_on_three_products(dev):
     h = [s for s in names3 if "_h_kernel" in s]
     six = [s for s in names3 if ("conv_fwd_kernel" in s or "conv_dgrad_kernel" in s or "conv_wgrad_kernel" in s)]
     assert not any("_h_kernel" in s for s in names6)
-    # forward: stem + 3 stride-2 3x3 + 4 shortcuts = 8 launches; backward: their data / weight gradients (the stem has no data gradient)
+    # forward: stem (its own three-product kernel, csrc/conv_stem.hip) + 3 stride-2 3x3 + 4 shortcuts = 8 launches; backward: their
+    # data / weight gradients (the stem has no data gradient)
     # (at 64x64 the last stages' maps are too small for the patch kernel: their 3x3 convs are gather launches too)
-    assert sum("conv_fwd_h_kernel" in s for s in h) >= 8, (h, six)
+    assert sum("conv_fwd_h_kernel" in s for s in h) + sum("conv_stem_kernel" in s for s in names3) >= 8, (h, six)
+    assert sum("conv_stem_kernel" in s for s in names3) == 1 and not any("conv_stem_kernel" in s for s in names6)
     assert sum("conv_wgrad_h_kernel" in s for s in h) >= 8 and sum("conv_dgrad_h_kernel" in s for s in h) >= 7, (h, six)
     assert not any("conv_fwd_kernel" in s for s in six), six
     # same start: the first two losses agree to fp32 rounding; from the third on two Adam updates (sign-like for gradients near
