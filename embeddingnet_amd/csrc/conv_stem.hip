@@ -7,8 +7,8 @@
 // takes those requests (244 us at batch 128, 0.16 of what the matrix pipe could do), and neither more resident workgroups nor fatter
 // tiles help (EMBNET_FWD_256).  Here every input pixel is fetched ONCE per tile:
 //  * a workgroup (persistent) takes 16 x 16 output pixels of one image x all 64 filters; the input PATCH those outputs read
-//    (37 x 37 pixels x 16 B, fp32, zero outside the image) reaches LDS by LDS-DMA from a loader wave, one tile ahead (two buffers,
-//    one s_barrier per tile);
+//    (37 x 37 pixels x 16 B, fp32, zero outside the image) reaches LDS by LDS-DMA from a loader wave, two tiles ahead (three
+//    buffers, one s_barrier per tile);
 //  * the kernel — 7 x (7 + 1 zero tap) x 4 channels = 224 reduction elements x 64 filters — is split into its two fp16 pieces by the
 //    workgroup itself, once, into LDS (56 KB; planes-kernel row layout), so there is no weight-planes tensor to keep current;
 //  * a k-step of the 32x32x16 matrix instruction is (kernel row r, four taps, four channels): a lane's eight reduction elements are
@@ -20,6 +20,14 @@
 //    fp32 product, the sums x 1 / s_w x 1 / s_x in the epilogue; the epilogue also leaves the BatchNorm statistics of the layer
 //    behind (sum, sum of squares per filter and 32-pixel band) like the other conv epilogues.
 // Algorithmic work 2 * M * 196 * 64 (the zero tap and the pad channel are not counted); HBM: the image once + the output once.
+// Where its time goes (batch 128, back to back with the statistics, tools/exp/stem_bench.py on build variants; in the C2 step the
+// kernel takes 171 us against 244 for the gather loop): 61 us with neither the matrix loop nor the output stores (the loader's
+// round trips), + 67 us for the stores (411 MB: the HBM write rate), + 108 us for the matrix loop with its LDS reads and splits —
+// and the three ADD UP (227 us): the eight waves of a workgroup run loop and epilogue one after the other, in step with each other.
+// Tried to overlap them, measured, not kept (tools/exp/conv_stem_two_groups.diff): two groups of four waves on alternate tiles
+// half a tile apart (233 us: one multiplying wave per SIMD leaves the matrix pipe 60 % idle, and its issue slots compete with the
+// storing wave's); two workgroups per CU on 8 x 16 tiles with one patch buffer each (255 us); a bare s_barrier instead of
+// __syncthreads() (which also waits for the stores' acknowledgement) and branch-free interior-tile stores are in (230 -> 222 us).
 #include "gemm_engine.h"
 #include "conv_geom.h"
 #include "../../include/embnet.h"
@@ -39,7 +47,8 @@ constexpr int PIECES = (PR * PWL + 63) / 64;                  // 64-pixel DMA pi
 constexpr int PATCH_BYTES = PIECES * 64 * 16;
 constexpr int STEPS = R * 2;                                  // k-steps: (kernel row, taps 0..3 | 4..6 + a zero tap)
 constexpr int W_BYTES = STEPS * 2 * K * 32;
-constexpr int LDS_BYTES = W_BYTES + 2 * PATCH_BYTES;
+constexpr int NBUF = 3;                                       // patch buffers: the loader runs two tiles ahead
+constexpr int LDS_BYTES = W_BYTES + NBUF * PATCH_BYTES;
 
 struct StemParams {
   const float* x; const float* w; float* y; float* stats;
@@ -74,27 +83,39 @@ __global__ __launch_bounds__(576) void conv_stem_kernel(const StemParams p) {
   __syncthreads();
 
   if (wave == 8) {
-    // ---- patch loader: buffer (i & 1) <- the patch of this workgroup's tile i, one tile ahead of the matrix waves ---------------
+    // ---- patch loader: buffer (i % 3) <- the patch of this workgroup's tile i, TWO tiles ahead of the matrix waves (a DMA round
+    // trip is ~2.5 us under load, a tile ~4) ------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    int rel[PIECES], rc[PIECES];                                 // per lane and piece: pixel offset inside the patch window, (row, column) packed
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) {
+      const int slot = pc * 64 + lane, prow = slot / PWL, pcl = flip(slot - prow * PWL);
+      const bool in = prow < PR && pcl < PC;
+      rel[pc] = prow * p.W + pcl;
+      rc[pc] = in ? (prow << 16) | pcl : -1;
+    }
     auto issue = [&](int i) {
       const int tile = (int)blockIdx.x + i * (int)gridDim.x;
       const int n = tile / (p.tiles_x * p.tiles_y), rem = tile - n * (p.tiles_x * p.tiles_y);
       const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
       const int ih0 = 2 * TH * ty - p.pad_t, iw0 = 2 * TW * tx - p.pad_l;
-      unsigned char* buf = patch0 + (i & 1) * PATCH_BYTES;
+      const int base = (n * p.H + ih0) * p.W + iw0;
+      unsigned char* buf = patch0 + (i % NBUF) * PATCH_BYTES;
 #pragma unroll
       for (int pc = 0; pc < PIECES; ++pc) {
-        const int slot = pc * 64 + lane, prow = slot / PWL, pp = slot - prow * PWL;
-        const int ih = ih0 + prow, iw = iw0 + flip(pp);
-        const bool ok = prow < PR && flip(pp) < PC && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        dma16(xr, buf + pc * 1024, ok ? 16u * (unsigned)((n * p.H + ih) * p.W + iw) : OOB);
+        const int ih = ih0 + (rc[pc] >> 16), iw = iw0 + (rc[pc] & 0xffff);
+        const bool ok = rc[pc] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        dma16(xr, buf + pc * 1024, ok ? 16u * (unsigned)(base + rel[pc]) : OOB);
       }
     };
     issue(0);
+    if (n_mine > 1) issue(1);
     for (int i = 0; i < n_mine; ++i) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the patch of tile i has landed
-      __builtin_amdgcn_s_barrier();                              // #i: the matrix waves are done with tile i - 1 (buffer (i + 1) & 1)
-      if (i + 1 < n_mine) issue(i + 1);
+      // the patch of tile i has landed (the next tile's pieces may be in flight)
+      if (i + 1 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                              // #i: the matrix waves are done with tile i - 1 (buffer (i + 2) % 3)
+      if (i + 2 < n_mine) issue(i + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
@@ -112,8 +133,11 @@ __global__ __launch_bounds__(576) void conv_stem_kernel(const StemParams p) {
 #pragma unroll
   for (int in = 0; in < 2; ++in) { const int f = in * 32 + pl; boff[in] = f * 32 + ((h ^ ((f >> 3) & 1)) << 4); }
   for (int i = 0; i < n_mine; ++i) {
-    __syncthreads();                                     // barrier #i: the patch of tile i is in LDS
-    const unsigned char* buf = patch0 + (i & 1) * PATCH_BYTES + rowb;
+    // barrier #i: the patch of tile i is in LDS.  (A bare s_barrier: __syncthreads() would also wait for the acknowledgement of
+    // this wave's output stores; what must be complete is its LDS reads of the previous patch, and the matrix instructions consumed them.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* buf = patch0 + (i % NBUF) * PATCH_BYTES + rowb;
     f32x16 acc[1][2];
 #pragma unroll
     for (int in = 0; in < 2; ++in)
@@ -138,36 +162,54 @@ __global__ __launch_bounds__(576) void conv_stem_kernel(const StemParams p) {
     };
     load(0, fb[0]);
     split(fa[0]);
+#ifndef STEM_NO_MFMA                                         // (STEM_NO_*: timing variants for tools/exp/stem_bench.py, never in the library)
 #pragma unroll
     for (int t = 0; t < STEPS; ++t) {
       if (t + 1 < STEPS) load(t + 1, fb[(t + 1) & 1]);
       mfma_step_h<1, 2>(fa[t & 1], fb[t & 1], acc);
       if (t + 1 < STEPS) split(fa[(t + 1) & 1]);
     }
+#endif
     // ---- epilogue: 1 / (s_w s_x), the outputs, the statistics of this wave's 32-pixel band -------------------------------------
+    // register rr of a 32x32 block holds block row (rr & 3) + 8 (rr >> 2) + 4 h = output row (rr >> 3), column
+    // 8 ((rr >> 2) & 1) + 4 h + (rr & 3) of this wave's two output rows; lanes 0..31 are 32 consecutive filters (128 B per store)
     const int tile = (int)blockIdx.x + i * (int)gridDim.x;
     const int n = tile / (p.tiles_x * p.tiles_y), rem = tile - n * (p.tiles_x * p.tiles_y);
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int oy0 = TH * ty + 2 * wave, ox0 = TW * tx;
+    const bool full = oy0 + 2 <= p.OH && ox0 + TW <= p.OW;          // (wave-uniform) no edge tests on interior tiles
+    float* const yb = p.y + ((long)(n * p.OH + oy0) * p.OW + ox0 + 4 * h) * K + pl;
 #pragma unroll
     for (int in = 0; in < 2; ++in) {
-      const int col = in * 32 + pl;
       float s1 = 0.f, s2 = 0.f;
+      if (full) {
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int prow = (rr & 3) + 8 * (rr >> 2) + 4 * h;         // row of the 32x32 block this register holds
-        const int oy = TH * ty + 2 * wave + (prow >> 4), ox = TW * tx + (prow & 15);
-        const float v = (acc[0][in][rr] * sw.y) * sa.y;
-        if (oy < p.OH && ox < p.OW) {
-          p.y[((long)(n * p.OH + oy) * p.OW + ox) * K + col] = v;
+        for (int rr = 0; rr < 16; ++rr) {
+          const float v = (acc[0][in][rr] * sw.y) * sa.y;
+#ifndef STEM_NO_STORE
+          yb[((long)(rr >> 3) * p.OW + 8 * ((rr >> 2) & 1) + (rr & 3)) * K + in * 32] = v;
+#endif
           s1 += v; s2 = fmaf(v, v, s2);
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int oy = oy0 + (rr >> 3), ox = ox0 + 8 * ((rr >> 2) & 1) + 4 * h + (rr & 3);
+          const float v = (acc[0][in][rr] * sw.y) * sa.y;
+          if (oy < p.OH && ox < p.OW) {
+#ifndef STEM_NO_STORE
+            yb[((long)(rr >> 3) * p.OW + 8 * ((rr >> 2) & 1) + (rr & 3)) * K + in * 32] = v;
+#endif
+            s1 += v; s2 = fmaf(v, v, s2);
+          }
         }
       }
       if (p.stats) {
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
         if (h == 0) {
           const long prow = (long)tile * 8 + wave, P = p.stats_rows;
-          p.stats[(long)col * P + prow] = s1;
-          p.stats[((long)K + col) * P + prow] = s2;
+          p.stats[(long)(in * 32 + pl) * P + prow] = s1;
+          p.stats[((long)K + in * 32 + pl) * P + prow] = s2;
         }
       }
     }
