@@ -52,3 +52,28 @@ def timed(fn, reps=30):
 ts, tg = timed(stem), timed(gather)
 flop = 2.0 * n * 112 * 112 * 147 * 64
 print(f"stem kernel {ts:7.1f} us ({flop / ts / 1e6:6.1f} TFLOP/s on 3 channels; output {4e-6 * n * 112 * 112 * 64 / ts:5.2f} TB/s)   gather {tg:7.1f} us")
+
+# ---- the weight gradient (needs tools/exp/conv_stem_wgrad.diff applied: the kernel is not in the library)
+if not hasattr(lib, "embnet_conv2d_stem_wgrad_f32"):
+    sys.exit(0)
+dys = [torch.randn((n, 112, 112, 64), device=dev, generator=g) * 1e-4 for _ in range(3)]
+rd = [slot(d) for d in dys]
+dw = torch.empty((7, 7, 4, 64), device=dev)
+wsw = torch.empty(lib.embnet_conv2d_stem_wgrad_workspace_bytes() // 4, device=dev)
+wsg = torch.empty(max(lib.embnet_conv2d_wgrad_workspace_bytes(n, 4, 7, 7, 64, 112, 112) // 4, 4), device=dev)
+
+
+def stem_w(i):
+    j = i % 3
+    _lib.check(lib.embnet_conv2d_stem_wgrad_f32(xs[j].data_ptr(), dys[j].data_ptr(), dw.data_ptr(), n, h, h, 3, 3, 112, 112, wsw.data_ptr(),
+                                                wsw.numel() * 4, rx[j].data_ptr(), rd[j].data_ptr(), _lib.stream()))
+
+
+def gather_w(i):
+    j = i % 3
+    _lib.check(lib.embnet_conv2d_wgrad_f32_ex(xs[j].data_ptr(), dys[j].data_ptr(), dw.data_ptr(), wsg.data_ptr(), wsg.numel() * 4, n, h, h, 4, 7, 7, 64,
+                                              2, 3, 3, 112, 112, None, None, 0, rx[j].data_ptr(), rd[j].data_ptr(), _lib.stream()))
+
+
+ts, tg = timed(stem_w), timed(gather_w)
+print(f"stem weight gradient {ts:7.1f} us ({flop / ts / 1e6:6.1f} TFLOP/s; dy read at {4e-6 * n * 112 * 112 * 64 / ts:5.2f} TB/s)   gather {tg:7.1f} us")
