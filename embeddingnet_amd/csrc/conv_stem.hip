@@ -27,7 +27,9 @@
 // Tried to overlap them, measured, not kept (tools/exp/conv_stem_two_groups.diff): two groups of four waves on alternate tiles
 // half a tile apart (233 us: one multiplying wave per SIMD leaves the matrix pipe 60 % idle, and its issue slots compete with the
 // storing wave's); two workgroups per CU on 8 x 16 tiles with one patch buffer each (255 us); a bare s_barrier instead of
-// __syncthreads() (which also waits for the stores' acknowledgement) and branch-free interior-tile stores are in (230 -> 222 us).
+// __syncthreads() (which also waits for the stores' acknowledgement) and branch-free interior-tile stores are in (230 -> 222 us);
+// the previous tile's stores issued four per k-step behind the next tile's matrix instructions (tools/exp/conv_stem_store_behind.diff):
+// 245 us — a store in the loop holds the wave's issue slot longer than it saves.
 #include "gemm_engine.h"
 #include "conv_geom.h"
 #include "../../include/embnet.h"
