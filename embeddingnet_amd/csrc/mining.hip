@@ -25,6 +25,9 @@ __device__ __forceinline__ void decode_pair(int q, int k, int& ii, int& jj) {
   ii = i; jj = i + 1 + rem;
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0u;
+}
 __global__ __launch_bounds__(256) void mine_select_kernel(
     const float* __restrict__ D, int n, int p, int k, float margin, int mode, uint64_t seed,
     int* __restrict__ selected, uint32_t* __restrict__ cand_mask, int mask_words) {
@@ -340,9 +343,9 @@ extern "C" int embnet_mine_triplets(const float* dist, int p, int k, float margi
   hipStream_t s = (hipStream_t)stream;
   const int n = p * k, npairs = p * (k * (k - 1) / 2);
   const int mask_words = (n - k + 31) / 32;
-  if (cand_mask) {
-    hipError_t e = hipMemsetAsync(cand_mask, 0, (size_t)npairs * mask_words * 4, s);
-    if (e != hipSuccess) return fail(EMBNET_ELAUNCH, "mine_triplets: memset: %s", hipGetErrorString(e));
+  if (cand_mask) {      // (a kernel, not hipMemsetAsync: a memset node did not zero its target when a captured HIP graph was replayed — DESIGN 3.14)
+    const long words = (long)npairs * mask_words;
+    zero_words_kernel<<<(int)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024), 256, 0, s>>>(cand_mask, words);
   }
   const int by_anchor = (int)env_long("EMBNET_MINE_BY_ANCHOR", 1);      // read per call: tests compare the two forms in one process
   if (mode == EMBNET_MINE_HARDEST && by_anchor && k - 1 <= 7 && n >= 1024) {
